@@ -1,0 +1,393 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product package (x_clip_amd).
+
+A CPU restatement of the lucidrains/x-clip contrastive-training hot path
+(`CLIP.forward(text, image, return_loss=True)`, reference x_clip/x_clip.py:597-875) written as pure
+functions over a flat `state_dict` (reference key names).  Arithmetic is plain
+torch on the CPU in whatever dtype the state dict / inputs carry (fp32 or fp64); gradients come from
+torch autograd over these functions, plus an independent closed-form numpy statement of the
+similarity/InfoNCE/DCL head in `simloss_closed_form`.
+
+Parity pin: `tests/test_oracle_golden.py` checks every function here against golden vectors that
+`oracle/make_golden.py` produced by importing and running the *reference itself* in the build container
+(committed under tests/golden/).  Only tests/, `__graft_entry__.smoke()` and bench.py's cpu_baseline
+leg may import this module.
+
+Each function cites the reference lines it restates.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field, asdict
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------------------
+# configuration = the reference constructor's keyword arguments (x_clip.py:413-456) that reach the
+# hot path.  Defaults are the reference's defaults.
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class ClipConfig:
+    dim_text: int = 512
+    dim_image: int = 512
+    dim_latent: int = 512
+    num_text_tokens: int = 10000
+    text_enc_depth: int = 6
+    text_seq_len: int = 256
+    text_heads: int = 8
+    text_dim_head: int = 64
+    text_has_cls_token: bool = True
+    text_pad_id: int = 0
+    visual_enc_depth: int = 6
+    visual_heads: int = 8
+    visual_dim_head: int = 64
+    visual_image_size: int = 256
+    visual_patch_size: int = 32
+    visual_has_cls_token: bool = True
+    channels: int = 3
+    use_all_token_embeds: bool = False
+    decoupled_contrastive_learning: bool = False
+    extra_latent_projection: bool = False
+    multiview_loss_weight: float = 0.1
+
+    @property
+    def num_patches(self) -> int:
+        return (self.visual_image_size // self.visual_patch_size) ** 2
+
+    def ctor_kwargs(self) -> dict:
+        """kwargs for the reference / product constructor (patch dropout is passed separately)."""
+        return asdict(self)
+
+
+# --------------------------------------------------------------------------------------------------
+# row ops
+# --------------------------------------------------------------------------------------------------
+def layer_norm(x: Tensor, g: Tensor) -> Tensor:
+    """Gain-only LayerNorm with a dtype dependent epsilon (x_clip.py:112-121):
+    biased variance, eps 1e-5 for fp32 (we also use it for fp64), 1e-3 for every other dtype."""
+    eps = 1e-5 if x.dtype in (torch.float32, torch.float64) else 1e-3
+    mu = x.mean(dim=-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(dim=-1, keepdim=True)
+    return xc * torch.rsqrt(var + eps) * g
+
+
+def geglu(y: Tensor) -> Tensor:
+    """GEGLU (x_clip.py:180-183): first half of the last dim is the value, second half the gate;
+    exact (erf) GELU on the gate."""
+    half = y.shape[-1] // 2
+    val, gate = y[..., :half], y[..., half:]
+    return val * (0.5 * gate * (1.0 + torch.erf(gate / math.sqrt(2.0))))
+
+
+def l2_normalize(x: Tensor) -> Tensor:
+    """F.normalize(dim=-1) (x_clip.py:54-55): x / max(||x||, 1e-12)."""
+    n = torch.sqrt((x * x).sum(dim=-1, keepdim=True))
+    return x / n.clamp_min(1e-12)
+
+
+# --------------------------------------------------------------------------------------------------
+# transformer block stack (x_clip.py:201-291)
+# --------------------------------------------------------------------------------------------------
+def attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: int,
+              key_mask: Optional[Tensor]) -> Tensor:
+    """Attention.forward (x_clip.py:213-245): bias-free fused qkv projection, q scaled by
+    dim_head**-0.5, key padding mask, softmax in fp32 (or wider), bias-free out projection followed by a
+    LayerNorm."""
+    b, n, _ = x.shape
+    qkv = x @ sd[pfx + "to_qkv.weight"].t()                     # [b, n, 3*h*d]
+    qkv = qkv.view(b, n, 3, heads, dim_head).permute(2, 0, 3, 1, 4)   # [3, b, h, n, d]
+    q, k, v = qkv[0] * (dim_head ** -0.5), qkv[1], qkv[2]
+    scores = q @ k.transpose(-1, -2)                            # [b, h, n, n]
+    if key_mask is not None:
+        scores = scores.masked_fill(~key_mask[:, None, None, :], -torch.finfo(scores.dtype).max)
+    sm_dtype = torch.float32 if scores.dtype != torch.float64 else torch.float64
+    probs = torch.softmax(scores.to(sm_dtype), dim=-1).to(scores.dtype)
+    o = (probs @ v).permute(0, 2, 1, 3).reshape(b, n, heads * dim_head)
+    o = o @ sd[pfx + "to_out.0.weight"].t()
+    return layer_norm(o, sd[pfx + "to_out.1.g"])
+
+
+def feed_forward(x: Tensor, sd: Dict[str, Tensor], pfx: str) -> Tensor:
+    """FeedForward (x_clip.py:185-199): Linear(D, 8D) -> GEGLU -> LayerNorm(4D) -> Linear(4D, D), no
+    biases (dropout prob is 0)."""
+    y = x @ sd[pfx + "net.0.weight"].t()
+    h = layer_norm(geglu(y), sd[pfx + "net.2.g"])
+    return h @ sd[pfx + "net.4.weight"].t()
+
+
+def transformer(x: Tensor, sd: Dict[str, Tensor], pfx: str, depth: int, heads: int, dim_head: int,
+                key_mask: Optional[Tensor]) -> Tensor:
+    """Transformer.forward (x_clip.py:274-291): norm_in, pre-norm residual attention + feed-forward
+    blocks, norm_out."""
+    x = layer_norm(x, sd[pfx + "norm_in.g"])
+    for l in range(depth):
+        a = f"{pfx}layers.{l}.0."
+        f = f"{pfx}layers.{l}.1."
+        x = attention(layer_norm(x, sd[a + "norm.g"]), sd, a + "fn.", heads, dim_head, key_mask) + x
+        x = feed_forward(layer_norm(x, sd[f + "norm.g"]), sd, f + "fn.") + x
+    return layer_norm(x, sd[pfx + "norm_out.g"])
+
+
+# --------------------------------------------------------------------------------------------------
+# encoders
+# --------------------------------------------------------------------------------------------------
+def encode_text(sd: Dict[str, Tensor], cfg: ClipConfig, tokens: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """TextTransformer.forward (x_clip.py:317-338): token embedding + absolute positions, learned CLS
+    prepended (its mask slot is True), then the block stack.  Returns [b, n+1, dim_text]."""
+    pfx = "text_transformer."
+    b, n = tokens.shape
+    x = sd[pfx + "token_emb.weight"][tokens] + sd[pfx + "abs_pos_emb.weight"][:n][None]
+    cls = sd[pfx + "cls_token"].expand(b, 1, -1)
+    x = torch.cat([cls, x], dim=1)
+    if mask is not None:
+        mask = torch.cat([torch.ones(b, 1, dtype=torch.bool), mask], dim=1)
+    return transformer(x, sd, pfx + "transformer.", cfg.text_enc_depth, cfg.text_heads,
+                       cfg.text_dim_head, mask)
+
+
+def patchify(image: Tensor, p: int) -> Tensor:
+    """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (x_clip.py:357)."""
+    b, c, H, W = image.shape
+    x = image.view(b, c, H // p, p, W // p, p)           # b c h p1 w p2
+    x = x.permute(0, 2, 4, 3, 5, 1)                      # b h w p1 p2 c
+    return x.reshape(b, (H // p) * (W // p), p * p * c)
+
+
+def encode_image(sd: Dict[str, Tensor], cfg: ClipConfig, image: Tensor,
+                 keep_idx: Optional[Tensor] = None) -> Tensor:
+    """VisionTransformer.forward (x_clip.py:372-390): patch embedding (Linear with bias) + position
+    table, optional patch dropout expressed as an explicit kept-index set `keep_idx` [b, n_keep]
+    (x_clip.py:140-151 draws it from randn().topk; the oracle takes it as an input so both sides can
+    share it), block stack, CLS = Linear(mean over tokens) prepended.  Returns [b, 1+n_keep, dim]."""
+    pfx = "visual_transformer."
+    x = patchify(image, cfg.visual_patch_size) @ sd[pfx + "to_tokens.1.weight"].t() \
+        + sd[pfx + "to_tokens.1.bias"]
+    x = x + sd[pfx + "pos_emb.weight"][None, : x.shape[1]]
+    if keep_idx is not None:
+        x = torch.gather(x, 1, keep_idx[..., None].expand(-1, -1, x.shape[-1]))
+    out = transformer(x, sd, pfx + "transformer.", cfg.visual_enc_depth, cfg.visual_heads,
+                      cfg.visual_dim_head, None)
+    cls = out.mean(dim=1) @ sd[pfx + "to_cls_tokens.1.weight"].t()
+    return torch.cat([cls[:, None], out], dim=1)
+
+
+# --------------------------------------------------------------------------------------------------
+# contrastive head
+# --------------------------------------------------------------------------------------------------
+def _info_nce(t2i: Tensor, i2t: Tensor, dcl: bool) -> Tensor:
+    """InfoNCE / DCL tail (x_clip.py:821-847) for stacked [P, B, B] logits.  No max subtraction, the
+    `+1e-20` inside the logs is kept."""
+    B = t2i.shape[-1]
+    e1, e2 = t2i.exp(), i2t.exp()
+    pos1 = torch.diagonal(e1, dim1=-2, dim2=-1)
+    pos2 = torch.diagonal(e2, dim1=-2, dim2=-1)
+    if dcl:
+        off = ~torch.eye(B, dtype=torch.bool)
+        e1, e2 = e1 * off, e2 * off
+    l1 = (-(pos1 + 1e-20).log() + (e1.sum(-1) + 1e-20).log()).mean(-1)
+    l2 = (-(pos2 + 1e-20).log() + (e2.sum(-1) + 1e-20).log()).mean(-1)
+    return (l1 + l2) / 2
+
+
+def contrastive_loss(cfg: ClipConfig, temperature: Tensor,
+                     t_lat: Tensor, i_lat: Tensor,
+                     t_lat_x: Optional[Tensor], i_lat_x: Optional[Tensor],
+                     text_mask: Optional[Tensor], m: int, n: int) -> Tensor:
+    """x_clip.py:736,750-755,797-868.  `t_lat` is [(m b), d] (CLS mode) or [(m b), nt, d] (FILIP);
+    `i_lat` likewise with n views.  `*_x` are the CLOOB extra-projection latents or None."""
+    temp = temperature.exp()
+    tl = t_lat.view(m, -1, *t_lat.shape[1:])
+    il = i_lat.view(n, -1, *i_lat.shape[1:])
+    tlx = tl if t_lat_x is None else t_lat_x.view(m, -1, *t_lat_x.shape[1:])
+    ilx = il if i_lat_x is None else i_lat_x.view(n, -1, *i_lat_x.shape[1:])
+    if cfg.use_all_token_embeds:
+        # fine-grained (FILIP) similarity, x_clip.py:799-811
+        s1 = torch.einsum("mxtd,nyid->mnxyti", tl, il) * temp
+        s2 = s1 if t_lat_x is None else torch.einsum("mxtd,nyid->mnxyti", tlx, ilx) * temp
+        tm = text_mask.view(m, -1, text_mask.shape[-1])                  # [m, b, t]
+        w = tm[:, None, :, None, :]                                      # m 1 b 1 t
+        t2i_tok = s1.max(dim=-1).values                                  # m n x y t
+        t2i = (t2i_tok * w).sum(-1) / w.sum(-1).clamp(min=1e-6)
+        masked = s2.masked_fill(~w[..., None], -torch.finfo(s2.dtype).max)
+        i2t = masked.max(dim=-2).values.mean(dim=-1)                     # m n x y
+    else:
+        t2i = torch.einsum("mtd,nid->mnti", tl, il) * temp
+        if t_lat_x is None:
+            i2t = t2i.transpose(-1, -2)
+        else:
+            i2t = torch.einsum("mtd,nid->mnit", tlx, ilx) * temp
+    B = t2i.shape[-1]
+    losses = _info_nce(t2i.reshape(m * n, B, B), i2t.reshape(m * n, B, B),
+                       cfg.decoupled_contrastive_learning)
+    multiview = (m > 1) or (n > 1)
+    w_mv = cfg.multiview_loss_weight if multiview else 0.0
+    loss = losses[0] * (1.0 - w_mv)
+    if multiview:
+        loss = loss + losses[1:].mean() * w_mv
+    return loss
+
+
+def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Tensor,
+                 aug_text: Sequence[Tensor] = (), aug_image: Sequence[Tensor] = (),
+                 keep_idx: Optional[Tensor] = None, return_latents: bool = False):
+    """CLIP.forward(return_loss=True) (x_clip.py:597-875) without the SSL side losses."""
+    m, n = 1 + len(aug_text), 1 + len(aug_image)
+    text = torch.cat([text, *aug_text], dim=0)
+    image = torch.cat([image, *aug_image], dim=0)
+    text_mask = text != cfg.text_pad_id                                   # x_clip.py:614
+    enc_t = encode_text(sd, cfg, text, text_mask)
+    enc_i = encode_image(sd, cfg, image, keep_idx)
+    if cfg.use_all_token_embeds:                                          # x_clip.py:702-709
+        et = enc_t[:, 1:] if cfg.text_has_cls_token else enc_t
+        ei = enc_i[:, 1:] if cfg.visual_has_cls_token else enc_i
+    else:
+        et, ei = enc_t[:, 0], enc_i[:, 0]
+    tl = l2_normalize(et @ sd["to_text_latent.weight"].t())               # x_clip.py:713-715
+    il = l2_normalize(ei @ sd["to_visual_latent.weight"].t())
+    tlx = ilx = None
+    if cfg.extra_latent_projection:                                       # x_clip.py:720-724
+        tlx = l2_normalize(et @ sd["to_text_latent_extra.weight"].t())
+        ilx = l2_normalize(ei @ sd["to_visual_latent_extra.weight"].t())
+    if return_latents:
+        return (tl, il) if tlx is None else (tl, il, tlx, ilx)
+    return contrastive_loss(cfg, sd["temperature"], tl, il, tlx, ilx, text_mask, m, n)
+
+
+# --------------------------------------------------------------------------------------------------
+# closed form of the CLS-mode head in numpy/fp64, independent of autograd
+# --------------------------------------------------------------------------------------------------
+def simloss_closed_form(T: np.ndarray, I: np.ndarray, tau: float, dcl: bool,
+                        Tx: Optional[np.ndarray] = None, Ix: Optional[np.ndarray] = None):
+    """Loss and gradients of  L = 1/2 [ mean_i(lse_j S_ij - S_ii) + mean_j(lse_i S'_ij - S'_jj) ]
+    with S = e^tau T I^T and S' = S (or e^tau Tx Ix^T with the CLOOB extra latents); DCL drops the diagonal
+    from both log-sum-exps (x_clip.py:813-847).  Returns dict(loss, dT, dI, dTx, dIx, dtau, lse_row,
+    lse_col) in fp64."""
+    T = np.asarray(T, np.float64); I = np.asarray(I, np.float64)
+    B = T.shape[0]
+    temp = math.exp(tau)
+    S1 = temp * T @ I.T
+    extra = Tx is not None
+    S2 = temp * np.asarray(Tx, np.float64) @ np.asarray(Ix, np.float64).T if extra else S1
+    eye = np.eye(B, dtype=bool)
+
+    def lse(S, axis):
+        E = np.exp(S)
+        if dcl:
+            E = np.where(eye, 0.0, E)
+        return np.log(E.sum(axis=axis))
+
+    lse_row = lse(S1, 1)           # over images j for each text i
+    lse_col = lse(S2, 0)           # over texts i for each image j
+    loss = 0.5 * ((lse_row - np.diag(S1)).mean() + (lse_col - np.diag(S2)).mean())
+    off = (~eye) if dcl else np.ones_like(eye)
+    G1 = np.exp(S1 - lse_row[:, None]) * off / (2 * B) - eye / (2 * B)     # dL/dS1
+    G2 = np.exp(S2 - lse_col[None, :]) * off / (2 * B) - eye / (2 * B)     # dL/dS2
+    out = dict(loss=loss, lse_row=lse_row, lse_col=lse_col)
+    if extra:
+        Tx = np.asarray(Tx, np.float64); Ix = np.asarray(Ix, np.float64)
+        out.update(dT=temp * G1 @ I, dI=temp * G1.T @ T, dTx=temp * G2 @ Ix, dIx=temp * G2.T @ Tx,
+                   dtau=(G1 * S1).sum() + (G2 * S2).sum())
+    else:
+        G = G1 + G2
+        out.update(dT=temp * G @ I, dI=temp * G.T @ T, dTx=None, dIx=None, dtau=(G * S1).sum())
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# deterministic, platform independent parameter / input generation shared by the fixture generator
+# and the tests (numpy legacy RandomState streams are frozen across numpy versions)
+# --------------------------------------------------------------------------------------------------
+def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
+    """Key -> shape map of the default-built reference model."""
+    shapes: Dict[str, Tuple[int, ...]] = {"temperature": ()}
+
+    def tower(pfx, dim, depth, heads, dim_head):
+        inner = heads * dim_head
+        for l in range(depth):
+            a, f = f"{pfx}layers.{l}.0.", f"{pfx}layers.{l}.1."
+            shapes[a + "norm.g"] = (dim,)
+            shapes[a + "fn.to_qkv.weight"] = (3 * inner, dim)
+            shapes[a + "fn.to_out.0.weight"] = (dim, inner)
+            shapes[a + "fn.to_out.1.g"] = (dim,)
+            shapes[f + "norm.g"] = (dim,)
+            shapes[f + "fn.net.0.weight"] = (8 * dim, dim)
+            shapes[f + "fn.net.2.g"] = (4 * dim,)
+            shapes[f + "fn.net.4.weight"] = (dim, 4 * dim)
+        shapes[pfx + "norm_in.g"] = (dim,)
+        shapes[pfx + "norm_out.g"] = (dim,)
+
+    t = "text_transformer."
+    shapes[t + "cls_token"] = (cfg.dim_text,)
+    shapes[t + "token_emb.weight"] = (cfg.num_text_tokens, cfg.dim_text)
+    shapes[t + "abs_pos_emb.weight"] = (cfg.text_seq_len, cfg.dim_text)
+    tower(t + "transformer.", cfg.dim_text, cfg.text_enc_depth, cfg.text_heads, cfg.text_dim_head)
+    v = "visual_transformer."
+    pd = cfg.channels * cfg.visual_patch_size ** 2
+    shapes[v + "to_tokens.1.weight"] = (cfg.dim_image, pd)
+    shapes[v + "to_tokens.1.bias"] = (cfg.dim_image,)
+    shapes[v + "pos_emb.weight"] = (cfg.num_patches, cfg.dim_image)
+    tower(v + "transformer.", cfg.dim_image, cfg.visual_enc_depth, cfg.visual_heads, cfg.visual_dim_head)
+    shapes[v + "to_cls_tokens.1.weight"] = (cfg.dim_image, cfg.dim_image)
+    for k, d in (("to_text_latent", cfg.dim_text), ("to_visual_latent", cfg.dim_image)):
+        shapes[k + ".weight"] = (cfg.dim_latent, d)
+        shapes[k + "_extra.weight"] = (cfg.dim_latent, d)
+    return shapes
+
+
+def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str, Tensor]:
+    """Seeded synthetic parameters with reference-like scales: linear weights U(-1/sqrt(fan_in), +),
+    embeddings / cls N(0, 1), LayerNorm gains 1 + 0.1 N(0, 1) (so gain gradients are exercised),
+    temperature 1.0.  Keys are generated in sorted order from one RandomState stream."""
+    rs = np.random.RandomState(seed)
+    sd: Dict[str, Tensor] = {}
+    for key, shape in sorted(state_dict_shapes(cfg).items()):
+        if key == "temperature":
+            a = np.array(1.0)
+        elif key.endswith(".g"):
+            a = 1.0 + 0.1 * rs.standard_normal(shape)
+        elif key.endswith(".bias"):
+            a = rs.uniform(-0.05, 0.05, shape)
+        elif "emb" in key or key.endswith("cls_token"):
+            a = rs.standard_normal(shape)
+        else:
+            bound = 1.0 / math.sqrt(shape[-1])
+            a = rs.uniform(-bound, bound, shape)
+        sd[key] = torch.tensor(a, dtype=torch.float64).to(dtype)
+    return sd
+
+
+def make_inputs(cfg: ClipConfig, batch: int, seed: int, n_aug_text: int = 0, n_aug_image: int = 0,
+                pad_tail: int = 3):
+    """Seeded synthetic batch: randint tokens (a few trailing pad ids so the key mask is live) and
+    N(0,1) images (fp64, cast by the caller)."""
+    rs = np.random.RandomState(seed)
+
+    def toks():
+        t = rs.randint(1, cfg.num_text_tokens, size=(batch, cfg.text_seq_len))
+        for r in range(batch):
+            k = (r * 7 + 1) % (pad_tail + 1)
+            if k:
+                t[r, -k:] = cfg.text_pad_id
+        return torch.tensor(t, dtype=torch.int64)
+
+    def img():
+        return torch.tensor(rs.standard_normal((batch, cfg.channels, cfg.visual_image_size,
+                                                cfg.visual_image_size)), dtype=torch.float64)
+
+    text, image = toks(), img()
+    aug_t = [toks() for _ in range(n_aug_text)]
+    aug_i = [img() for _ in range(n_aug_image)]
+    return text, image, aug_t, aug_i
+
+
+CFG1 = ClipConfig(dim_text=64, dim_image=64, dim_latent=64, num_text_tokens=1000, text_enc_depth=2,
+                  text_seq_len=32, text_heads=4, visual_enc_depth=2, visual_image_size=64,
+                  visual_patch_size=32, visual_heads=4)
+"""BASELINE.json configs[0] (SURVEY.md 8(d) cfg1): the reference's CPU-runnable plumbing case."""

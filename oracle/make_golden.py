@@ -1,0 +1,189 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Golden-vector generator.
+
+Runs the *unmodified reference* (lucidrains/x-clip, imported from /root/reference) on the CPU in the build
+container and writes its outputs as small JSON fixtures under tests/golden/.  /root/reference does not
+exist on the GPU box, so nothing but this script (run by hand here) ever imports it; the committed
+fixtures are what travels.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.json
+
+What is recorded per case: the constructor kwargs, the seeds (parameters and inputs are regenerated
+from numpy RandomState streams by oracle/clip_oracle.py: make_state_dict / make_inputs, so fixtures stay
+tiny), the reference's fp32 loss, latents, d(temperature), and for every parameter the L2 norm plus the
+first 8 entries of its gradient.
+
+The reference needs two work-arounds that do not touch the hot path:
+  * `torchvision` (only used by the out-of-scope visual_ssl.py) is stubbed in sys.modules;
+  * x_clip/distributed.py references `F` and `exists` without defining them; for the 2-rank case they
+    are injected into that module's namespace before use.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REFERENCE = "/root/reference"
+
+sys.path.insert(0, ROOT)
+from oracle.clip_oracle import CFG1, ClipConfig, make_inputs, make_state_dict  # noqa: E402
+
+
+def import_reference():
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    import x_clip  # the reference package
+    assert os.path.realpath(x_clip.__file__).startswith(REFERENCE), x_clip.__file__
+    return x_clip
+
+
+CASES = {
+    # name: (config overrides, batch, n_aug_text, n_aug_image, patch_dropout)
+    "cfg1_infonce": (dict(), 4, 0, 0, 0.0),
+    "cfg1_dcl": (dict(decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
+    "cfg1_extra_dcl": (dict(decoupled_contrastive_learning=True, extra_latent_projection=True), 4, 0, 0, 0.0),
+    "cfg1_multiview": (dict(), 4, 1, 1, 0.0),
+    "cfg1_multiview_m3n1": (dict(), 4, 2, 0, 0.0),
+    "cfg1_filip": (dict(use_all_token_embeds=True), 4, 0, 0, 0.0),
+    "cfg1_filip_dcl": (dict(use_all_token_embeds=True, decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
+    "cfg1_patchdrop": (dict(), 4, 0, 0, 0.5),
+    "p16_heads2": (dict(dim_text=48, dim_image=80, dim_latent=40, text_heads=2, text_dim_head=32,
+                        visual_heads=3, visual_dim_head=16, visual_image_size=48, visual_patch_size=16,
+                        text_seq_len=19, text_enc_depth=1, visual_enc_depth=3, num_text_tokens=257),
+                   6, 0, 0, 0.0),
+}
+PARAM_SEED = 20240901
+INPUT_SEED = 1234
+
+
+def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropout, want_latents=True):
+    torch.manual_seed(0)
+    ref = x_clip.CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=patch_dropout)
+    sd = make_state_dict(cfg, PARAM_SEED)
+    ref.load_state_dict(sd, strict=True)          # strict: pins the key/shape map of Appendix A
+    ref.train()
+    text, image, aug_t, aug_i = make_inputs(cfg, batch, INPUT_SEED, n_aug_t, n_aug_i)
+    image = image.float()
+    aug_i = [a.float() for a in aug_i]
+    keep_idx = None
+    drop_seed = 777
+    if patch_dropout > 0:
+        # reproduce the draw PatchDropout.forward will make (x_clip.py:148-149) so it can be recorded
+        n = cfg.num_patches
+        keep = max(1, int(n * (1 - patch_dropout)))
+        torch.manual_seed(drop_seed)
+        keep_idx = torch.randn(batch * (1 + n_aug_i), n).topk(keep, dim=-1).indices
+        torch.manual_seed(drop_seed)
+    kw = {}
+    if aug_t:
+        kw["aug_text"] = tuple(aug_t)
+    if aug_i:
+        kw["aug_image"] = tuple(aug_i)
+    loss = ref(text, image, return_loss=True, **kw)
+    loss.backward()
+    out = dict(loss=float(loss))
+    grads = {k: p.grad for k, p in ref.named_parameters()}
+    out["dtau"] = float(grads["temperature"])
+    out["grad_norm"] = {k: (float(g.double().norm()) if g is not None else None) for k, g in grads.items()}
+    out["grad_head"] = {k: (g.flatten()[:8].double().tolist() if g is not None else None)
+                        for k, g in grads.items()}
+    if want_latents and not (n_aug_t or n_aug_i) and patch_dropout == 0:
+        with torch.no_grad():
+            lat = ref(text, image, return_latents=True)
+        names = ["text_latents", "image_latents", "text_latents_extra", "image_latents_extra"]
+        for nme, l in zip(names, lat):
+            out[nme] = l.double().flatten().tolist()
+            out[nme + "_shape"] = list(l.shape)
+    if keep_idx is not None:
+        out["keep_idx"] = keep_idx.tolist()
+    return out
+
+
+def _dist_worker(rank, world, port, cfg_kwargs, sizes, q):
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x_clip = import_reference()
+    import x_clip.distributed as xd
+    xd.F = F
+    xd.exists = lambda v: v is not None
+    cfg = ClipConfig(**cfg_kwargs)
+    ref = x_clip.CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)      # group exists -> requires_all_gather
+    ref.load_state_dict(make_state_dict(cfg, PARAM_SEED), strict=True)
+    ref.train()
+    text, image, _, _ = make_inputs(cfg, sum(sizes), INPUT_SEED)
+    lo = sum(sizes[:rank]); hi = lo + sizes[rank]
+    loss = ref(text[lo:hi], image[lo:hi].float(), return_loss=True)
+    loss.backward()
+    gn = {k: p.grad.double() for k, p in ref.named_parameters() if p.grad is not None}
+    q.put((rank, float(loss), {k: v.numpy() for k, v in gn.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_reference_distributed(cfg: ClipConfig, sizes):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = len(sizes)
+    port = 29611
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, cfg.ctor_kwargs(), sizes, q))
+             for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=600) for _ in range(world)]
+    [p.join() for p in procs]
+    res.sort(key=lambda r: r[0])
+    losses = [r[1] for r in res]
+    summed = {}
+    for _, _, g in res:
+        for k, v in g.items():
+            summed[k] = summed.get(k, 0) + v
+    return dict(rank_losses=losses,
+                grad_sum_norm={k: float(np.linalg.norm(v)) for k, v in summed.items()},
+                grad_sum_head={k: v.flatten()[:8].tolist() for k, v in summed.items()})
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    x_clip = import_reference()
+    for name, (over, batch, nat, nai, pdrop) in CASES.items():
+        cfg = ClipConfig(**{**CFG1.ctor_kwargs(), **over})
+        out = run_reference(x_clip, cfg, batch, nat, nai, pdrop)
+        rec = dict(case=name, config=cfg.ctor_kwargs(), batch=batch, n_aug_text=nat, n_aug_image=nai,
+                   visual_patch_dropout=pdrop, param_seed=PARAM_SEED, input_seed=INPUT_SEED,
+                   reference="lucidrains/x-clip v0.14.4 (x_clip/x_clip.py), fp32, torch %s CPU" % torch.__version__,
+                   **out)
+        with open(os.path.join(GOLDEN, name + ".json"), "w") as f:
+            json.dump(rec, f, indent=0)
+        print(f"{name}: loss={out['loss']:.9f} dtau={out['dtau']:+.9f}")
+
+    # 2-rank distributed intent (uneven 5+3 split) vs. the single-process global batch
+    for name, over in (("dist2_infonce", dict()), ("dist2_dcl", dict(decoupled_contrastive_learning=True))):
+        cfg = ClipConfig(**{**CFG1.ctor_kwargs(), **over})
+        sizes = [5, 3]
+        d = run_reference_distributed(cfg, sizes)
+        single = run_reference(x_clip, cfg, sum(sizes), 0, 0, 0.0, want_latents=False)
+        rec = dict(case=name, config=cfg.ctor_kwargs(), sizes=sizes, param_seed=PARAM_SEED, input_seed=INPUT_SEED,
+                   single_process=single, **d)
+        with open(os.path.join(GOLDEN, name + ".json"), "w") as f:
+            json.dump(rec, f, indent=0)
+        print(f"{name}: rank losses {d['rank_losses']} single {single['loss']:.9f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""Pins oracle/clip_oracle.py against golden vectors produced by the reference itself
+(oracle/make_golden.py, run in the build container where /root/reference exists)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.clip_oracle import (ClipConfig, clip_forward, make_inputs, make_state_dict,
+                                simloss_closed_form, state_dict_shapes)
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.json")) if not os.path.basename(p).startswith("dist"))
+
+
+def load(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def run_oracle(rec, dtype):
+    cfg = ClipConfig(**rec["config"])
+    sd = {k: v.clone().requires_grad_(True) for k, v in make_state_dict(cfg, rec["param_seed"], dtype).items()}
+    text, image, aug_t, aug_i = make_inputs(cfg, rec["batch"], rec["input_seed"], rec["n_aug_text"], rec["n_aug_image"])
+    keep = torch.tensor(rec["keep_idx"]) if "keep_idx" in rec else None
+    # fixtures were produced from fp32 images: round through fp32 first
+    image = image.float().to(dtype)
+    aug_i = [a.float().to(dtype) for a in aug_i]
+    loss = clip_forward(sd, cfg, text, image, aug_t, aug_i, keep)
+    loss.backward()
+    return cfg, sd, loss, (text, image)
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[:-5])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["fp32", "fp64"])
+def test_oracle_matches_reference(path, dtype):
+    rec = load(path)
+    cfg, sd, loss, (text, image) = run_oracle(rec, dtype)
+    # the reference ran in fp32; both oracle precisions must sit within fp32 round-off of it
+    assert abs(float(loss.detach()) - rec["loss"]) < 2e-6 * max(1.0, abs(rec["loss"]))
+    assert abs(float(sd["temperature"].grad) - rec["dtau"]) < 5e-6
+    for k, ref_norm in rec["grad_norm"].items():
+        g = sd[k].grad
+        if ref_norm is None:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        assert g is not None, k
+        got = float(g.double().norm())
+        assert abs(got - ref_norm) <= 2e-4 * ref_norm + 1e-7, (k, got, ref_norm)
+        head = np.asarray(rec["grad_head"][k])
+        np.testing.assert_allclose(g.flatten()[:8].double().numpy(), head, rtol=2e-3, atol=2e-6 + 1e-4 * ref_norm / max(1, g.numel()) ** 0.5, err_msg=k)
+    if "text_latents" in rec:
+        sdd = {k: v.detach() for k, v in sd.items()}
+        lat = clip_forward(sdd, cfg, text, image, return_latents=True)
+        names = ["text_latents", "image_latents", "text_latents_extra", "image_latents_extra"]
+        for nme, l in zip(names, lat):
+            np.testing.assert_allclose(l.double().flatten().numpy(), np.asarray(rec[nme]), atol=3e-6, err_msg=nme)
+
+
+def test_state_dict_keys_match_reference_fixture():
+    rec = load(os.path.join(GOLDEN, "cfg1_infonce.json"))
+    cfg = ClipConfig(**rec["config"])
+    assert set(state_dict_shapes(cfg)) == set(rec["grad_norm"])
+
+
+@pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl"])
+def test_closed_form_head_matches_reference(name):
+    """The numpy closed form against the reference's loss / dtau, fed with the
+    reference's own latents."""
+    rec = load(os.path.join(GOLDEN, name + ".json"))
+    shp = rec["text_latents_shape"]
+    T = np.asarray(rec["text_latents"]).reshape(shp)
+    I = np.asarray(rec["image_latents"]).reshape(shp)
+    extra = rec["config"]["extra_latent_projection"]
+    Tx = np.asarray(rec["text_latents_extra"]).reshape(shp) if extra else None
+    Ix = np.asarray(rec["image_latents_extra"]).reshape(shp) if extra else None
+    out = simloss_closed_form(T, I, 1.0, rec["config"]["decoupled_contrastive_learning"], Tx, Ix)
+    assert abs(out["loss"] - rec["loss"]) < 2e-6
+    assert abs(out["dtau"] - rec["dtau"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["dist2_infonce", "dist2_dcl"])
+def test_distributed_fixture_identity(name):
+    """Reference intent for the 2-rank all-gather path (distributed.py with its two missing names
+    injected): every rank's loss equals the single-process global-batch loss and the rank-summed
+    gradient equals the single-process gradient.  The oracle must reproduce the global-batch run."""
+    rec = load(os.path.join(GOLDEN, name + ".json"))
+    single = rec["single_process"]
+    for l in rec["rank_losses"]:
+        assert abs(l - single["loss"]) < 2e-6
+    world = len(rec["sizes"])
+    for k, n in rec["grad_sum_norm"].items():
+        # everything upstream of the gather gets its local slice only (distributed.py:51-54), so the
+        # rank-sum equals the single-process gradient; `temperature` sits downstream of the gather and
+        # every rank computes its full gradient, so its rank-sum is world x the single-process value.
+        want = single["grad_norm"][k] * (world if k == "temperature" else 1)
+        assert abs(n - want) <= 1e-4 * n + 1e-7, k
+    rec2 = dict(rec, batch=sum(rec["sizes"]), n_aug_text=0, n_aug_image=0)
+    cfg, sd, loss, _ = run_oracle(rec2, torch.float64)
+    assert abs(float(loss) - single["loss"]) < 2e-6
+    for k, n in single["grad_norm"].items():
+        assert abs(float(sd[k].grad.norm()) - n) <= 2e-4 * n + 1e-7, k
