@@ -99,6 +99,8 @@ def test_distributed_fixture_identity(name):
         assert abs(n - want) <= 1e-4 * n + 1e-7, k
     rec2 = dict(rec, batch=sum(rec["sizes"]), n_aug_text=0, n_aug_image=0)
     cfg, sd, loss, _ = run_oracle(rec2, torch.float64)
-    assert abs(float(loss) - single["loss"]) < 2e-6
+    assert abs(float(loss.detach()) - single["loss"]) < 2e-6
     for k, n in single["grad_norm"].items():
+        if n is None:          # unused *_extra projections
+            continue
         assert abs(float(sd[k].grad.norm()) - n) <= 2e-4 * n + 1e-7, k
