@@ -1,0 +1,101 @@
+/* xclip.h -- C ABI of libxclip_hip.so, the MI355X (gfx950) kernel library behind x_clip_amd.
+ *
+ * The reference (lucidrains/x-clip) is pure Python/PyTorch and has no FFI of its own; every entry point below
+ * replaces a sequence of ATen calls issued by the reference lines cited next to it.
+ * Conventions:
+ *   - plain pointers + sizes, no torch types.  All tensor pointers are DEVICE pointers, row-major, 16-byte
+ *     aligned, contiguous dims a multiple of the 16-byte chunk (8 bf16 / 4 fp32) unless stated otherwise.
+ *   - the caller owns every buffer (inputs, outputs, workspaces, accumulators); the library never allocates.
+ *   - `dtype`: XCLIP_F32 or XCLIP_BF16 = storage type of activations / parameters; arithmetic is fp32.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous on it and never synchronise.
+ *   - return 0 on success; otherwise a non-zero code and xclip_last_error() describes it (thread local).
+ *   - "accum" outputs are fp32 accumulators the kernel ADDS into (caller zeroes them).
+ */
+#ifndef XCLIP_H
+#define XCLIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
+#define XCLIP_ABI_VERSION 1
+
+int xclip_abi_version(void);
+const char* xclip_last_error(void);
+
+/* ---- LayerNorm family (reference LayerNorm x_clip.py:112-121; GEGLU x_clip.py:180-183) -----------------------
+ * y[r,:] = (v - mean) * rstd * g (+ res[r,:]),  v = x[r,:dim]               (geglu = 0, ldx >= dim)
+ *                                               v = x[r,:dim] * gelu(x[r,dim:2dim])   (geglu = 1, ldx >= 2 dim)
+ * mean/rstd [rows] fp32 are saved for the backward.  eps: 1e-5 for fp32 models, 1e-3 otherwise (x_clip.py:118). */
+int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, float* mean, float* rstd,
+                        int64_t rows, int64_t dim, float eps, int geglu, int dtype, void* stream);
+/* dx [rows, dim] (lddx) -- or [rows, 2 dim] = (d value | d gate) with geglu; dg_accum [dim] fp32 += dy * xhat */
+int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
+                        void* dx, int64_t lddx, float* dg_accum, int64_t rows, int64_t dim, int geglu, int dtype, void* stream);
+
+/* ---- l2 normalisation (reference l2norm = F.normalize, x_clip.py:54-55,715) ------------------------------------ */
+int xclip_l2norm_fwd(const void* x, void* y, float* rnorm, int64_t rows, int64_t dim, int dtype, void* stream);
+int xclip_l2norm_bwd(const void* dy, const void* y, const float* rnorm, void* dx, int64_t rows, int64_t dim, int dtype, void* stream);
+
+/* ---- text embedding (reference TextTransformer.forward x_clip.py:320-335) ---------------------------------------
+ * out[b,0] = cls ; out[b,1+j] = E[tok[b,j]] + P[j].  cls / P may be NULL (no CLS row / no absolute positions). */
+int xclip_text_embed_fwd(const int64_t* tokens, const void* E, const void* P, const void* cls, void* out,
+                         int64_t batch, int64_t n, int64_t dim, int dtype, void* stream);
+/* fp32 accumulators: dE [vocab, dim], dP [n, dim] (may be NULL), dcls [dim] (NULL when has_cls = 0) */
+int xclip_text_embed_bwd(const void* dout, const int64_t* tokens, float* dE_accum, float* dP_accum, float* dcls_accum,
+                         int64_t batch, int64_t n, int64_t dim, int has_cls, int dtype, void* stream);
+
+/* ---- patchify 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (x_clip.py:357) with the PatchDropout keep-set
+ * (x_clip.py:140-151) folded in: out[(b,i), :] = patch keep[b*nkeep + i] of image b (keep NULL: identity, nkeep =
+ * number of patches).  Rows are zero padded from p*p*C up to ldo. */
+int xclip_patchify(const void* image, const int32_t* keep, void* out, int64_t ldo, int64_t batch, int64_t channels,
+                   int64_t height, int64_t width, int64_t patch, int64_t nkeep, int dtype, void* stream);
+
+/* ---- vision CLS pooling: mean over tokens (x_clip.py:366-370) -------------------------------------------------- */
+int xclip_token_mean_fwd(const void* x, void* out, int64_t batch, int64_t n, int64_t dim, int dtype, void* stream);
+int xclip_token_mean_bwd(const void* dout, void* dx, int64_t batch, int64_t n, int64_t dim, int accumulate, int dtype, void* stream);
+
+/* dst[i] = (dtype) (src[i] * scale) : fp32 gradient accumulators -> parameter dtype */
+int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale, int dtype, void* stream);
+
+/* ---- GEMM: every nn.Linear on the path and its dgrad / wgrad (x_clip.py:191-195,209-210,358,368,556,570) --------
+ * C[M,N] = alpha * op(A) op(B) + bias[n] + addrows[rowidx[m], n] + residual[m, n]      (each term optional / NULL)
+ *   a_kmajor = 0: A[m*lda + k]   1: A[k*lda + m]        b_kmajor = 0: B[n*ldb + k] (Linear weight)   1: B[k*ldb + n]
+ * forward (0,0), dgrad (0,1), wgrad (1,1).  `workspace` (fp32 split-K slabs, may be NULL) of
+ * xclip_gemm_workspace_bytes(...) bytes lets long contractions (wgrad) fill the chip. */
+int64_t xclip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype);
+int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+               int64_t M, int64_t N, int64_t K, float alpha, const void* bias, const void* residual, int64_t ldr,
+               const void* addrows, const int32_t* rowidx, int64_t ld_add, void* workspace, int64_t workspace_bytes,
+               int dtype, void* stream);
+
+/* ---- fused attention (reference Attention.forward x_clip.py:213-245; dim_head = 64) -------------------------------
+ * qkv [batch, n, 3, heads, 64] = output of the to_qkv Linear; mask [batch, n] bytes (1 = attend) or NULL;
+ * out [batch, n, heads*64]; lse [batch, heads, n] fp32 saved for the backward.  scale = dim_head^-0.5. */
+int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n,
+                        int64_t heads, float scale, int dtype, void* stream);
+/* delta_ws: [batch, heads, n] fp32 scratch; dqkv [batch, n, 3, heads, 64] fully overwritten */
+int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
+                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int dtype,
+                        void* stream);
+
+/* ---- contrastive head (similarity + InfoNCE / DCL, x_clip.py:813-847) ---------------------------------------------
+ * S = scale * Q K^T, Q [nq, d], K [nk, d].  Row i's positive is column i + diag_off.
+ * fwd: lse[i] = log sum_j exp S_ij (positive excluded when dcl); pos[i] = S_{i,i+diag_off};
+ *      *loss_accum += coef * sum_i (lse[i] - pos[i]).  workspace: xclip_simloss_workspace_bytes(nq, nk) bytes.
+ * grad: G[i,j] = [a exp(S_ij - lse_q[i]) + c exp(S_ij - lse_k[j])] (1 - dcl*[j==i+diag_off]) - e [j==i+diag_off],
+ *      G [nq, ldg] in `dtype` (ldg = nk rounded up to the chunk, padding columns written as 0);
+ *      *dtau_accum += sum_ij G_ij S_ij.   dQ = scale * G K and dK = scale * G^T Q are ordinary xclip_gemm calls. */
+int64_t xclip_simloss_workspace_bytes(int64_t nq, int64_t nk);
+int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, int64_t diag_off, int dcl,
+                      float coef, void* workspace, float* pos, float* lse, float* loss_accum, int dtype, void* stream);
+int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, int64_t diag_off, int dcl,
+                       float a, float c, float e, const float* lse_q, const float* lse_k, void* G, int64_t ldg,
+                       float* dtau_accum, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

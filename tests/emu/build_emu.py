@@ -1,0 +1,33 @@
+"""TEST INFRASTRUCTURE ONLY: builds tests/emu/libxclip_emu.so = the product's C-ABI + kernel sources compiled
+for the HOST against the wave64 emulator header (tests/emu/xc_device.h).  Used by the CPU test-suite."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "x_clip_amd", "csrc")
+OUT = os.path.join(HERE, "libxclip_emu.so")
+
+
+def sources():
+    out = [os.path.join(CSRC, "xclip_api.hip"), os.path.join(HERE, "xc_device.h"), os.path.join(ROOT, "include", "xclip.h")]
+    kdir = os.path.join(CSRC, "kernels")
+    out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir))]
+    return out
+
+
+def build(force=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
+        return OUT
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        cxx = "clang++"
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi",
+           "-I", HERE, "-I", CSRC, os.path.join(CSRC, "xclip_api.hip"), "-o", OUT]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,321 @@
+// xc_device.h (EMULATOR build) -- TEST INFRASTRUCTURE ONLY.
+//
+// Same vocabulary as x_clip_amd/csrc/hw/xc_device.h, implemented on a functional wave64 emulator so
+// that the CPU test-suite (no GPU in the build container) executes the *same kernel sources* the
+// product compiles for gfx950.  One OS thread; every GPU thread of a workgroup is a fibre (ucontext);
+// workgroups run one after another.  Fibres switch only at __syncthreads() and at wave collectives
+// (shuffles, MFMA), waves of a workgroup are scheduled in a seeded random order and the dynamic LDS is
+// poisoned per workgroup, so a missing barrier or a read of unwritten LDS shows up as a wrong result.
+// MFMA follows the operand / accumulator lane maps documented in cdna_hip_programming.md section 3.
+//
+// Built by tests/emu/build_emu.py into tests/emu/libxclip_emu.so with the host clang++; it is never
+// loaded by the x_clip_amd package itself.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define XC_DEV inline
+#define XC_HOST_DEV inline
+#define XC_LDS_DYNAMIC(name) unsigned char* name = xcemu::dyn_lds()
+#define XC_ALLOW_LDS(kernel, bytes) ((void)0)
+
+namespace xcemu {
+
+struct Dim3 {
+    unsigned x, y, z;
+    Dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+constexpr int kStack = 256 * 1024;
+constexpr int kMaxThreads = 1024;
+constexpr int kExBytes = 64;          // bytes one lane may deposit in a wave collective
+
+struct Fiber {
+    ucontext_t ctx;
+    bool done = true;
+    int tid = 0;
+    unsigned coll = 0;                // number of wave collectives this lane has completed
+};
+struct WaveState {
+    alignas(16) unsigned char buf[2][64][kExBytes];
+    unsigned slot_gen[2];
+    int arrived[2];
+    int live;
+};
+struct State {
+    Dim3 threadIdx, blockIdx, blockDim, gridDim;
+    Fiber fibers[kMaxThreads];
+    WaveState waves[kMaxThreads / 64];
+    ucontext_t sched;
+    char* stacks = nullptr;
+    unsigned char* lds = nullptr;
+    int cur = -1, nthreads = 0, live = 0;
+    int bar_arrived = 0;
+    unsigned bar_gen = 0;
+    bool progressed = false;
+    const std::function<void()>* body = nullptr;
+    unsigned rng = 12345u;
+};
+inline State& S() {
+    static State* s = nullptr;
+    if (!s) {
+        s = new State();
+        s->stacks = (char*)aligned_alloc(4096, (size_t)kStack * kMaxThreads);
+        s->lds = (unsigned char*)aligned_alloc(4096, 160 * 1024);
+        const char* e = getenv("XCEMU_SEED");
+        if (e) s->rng = (unsigned)atoi(e) * 2654435761u + 1u;
+    }
+    return *s;
+}
+inline unsigned char* dyn_lds() { return S().lds; }
+inline unsigned next_rand() {
+    State& s = S();
+    s.rng = s.rng * 1664525u + 1013904223u;
+    return s.rng >> 8;
+}
+
+inline void yield() {
+    State& s = S();
+    Fiber& f = s.fibers[s.cur];
+    swapcontext(&f.ctx, &s.sched);
+}
+
+inline void fiber_main() {
+    State& s = S();
+    (*s.body)();
+    Fiber& f = s.fibers[s.cur];
+    f.done = true;
+    s.live--;
+    s.waves[f.tid >> 6].live--;
+    s.progressed = true;
+    // a thread that has exited no longer takes part in barriers (as on the hardware)
+    if (s.live > 0 && s.bar_arrived == s.live) {
+        s.bar_arrived = 0;
+        s.bar_gen++;
+    }
+    swapcontext(&f.ctx, &s.sched);
+}
+
+inline void block_barrier() {
+    State& s = S();
+    unsigned gen = s.bar_gen;
+    s.bar_arrived++;
+    s.progressed = true;
+    if (s.bar_arrived == s.live) {
+        s.bar_arrived = 0;
+        s.bar_gen++;
+        return;
+    }
+    while (s.bar_gen == gen) yield();
+}
+
+// Deposit `bytes` from this lane, wait until every live lane of the wave has deposited, return the table
+// (indexed by lane).  Double buffered: a lane can be at most one collective ahead of its wave mates.
+inline const unsigned char (*wave_exchange(const void* mine, int bytes))[kExBytes] {
+    State& s = S();
+    Fiber& f = s.fibers[s.cur];
+    WaveState& w = s.waves[f.tid >> 6];
+    const int slot = f.coll & 1;
+    if (w.slot_gen[slot] != f.coll) {
+        w.slot_gen[slot] = f.coll;
+        w.arrived[slot] = 0;
+    }
+    memcpy(w.buf[slot][f.tid & 63], mine, bytes);
+    w.arrived[slot]++;
+    s.progressed = true;
+    while (w.arrived[slot] < w.live) yield();
+    f.coll++;
+    return w.buf[slot];
+}
+
+inline void run_block(const std::function<void()>& body, Dim3 grid, Dim3 block, Dim3 bidx) {
+    State& s = S();
+    const int n = block.x * block.y * block.z;
+    if (n > kMaxThreads) { fprintf(stderr, "xcemu: block too large\n"); abort(); }
+    s.body = &body;
+    s.blockIdx = bidx; s.blockDim = block; s.gridDim = grid;
+    s.nthreads = n; s.live = n; s.bar_arrived = 0; s.bar_gen = 0;
+    memset(s.lds, 0xFF, 160 * 1024);                      // poison: bf16/f32 NaN patterns
+    const int nw = (n + 63) / 64;
+    for (int w = 0; w < nw; ++w) {
+        WaveState& ws = s.waves[w];
+        ws.slot_gen[0] = ws.slot_gen[1] = 0xFFFFFFFFu;
+        ws.arrived[0] = ws.arrived[1] = 0;
+        ws.live = (w == nw - 1) ? n - 64 * w : 64;
+    }
+    for (int t = 0; t < n; ++t) {
+        Fiber& f = s.fibers[t];
+        f.done = false; f.tid = t; f.coll = 0;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = s.stacks + (size_t)t * kStack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_main, 0);
+    }
+    std::vector<int> order(nw);
+    for (int w = 0; w < nw; ++w) order[w] = w;
+    while (s.live > 0) {
+        s.progressed = false;
+        for (int i = nw - 1; i > 0; --i) {                // fresh random wave order every sweep
+            int j = next_rand() % (i + 1);
+            int tmp = order[i]; order[i] = order[j]; order[j] = tmp;
+        }
+        for (int oi = 0; oi < nw; ++oi) {
+            const int w = order[oi];
+            const int lanes = (w == nw - 1) ? n - 64 * w : 64;
+            const int rot = next_rand() & 63;
+            for (int li = 0; li < lanes; ++li) {
+                const int t = w * 64 + (li + rot) % lanes;
+                Fiber& f = s.fibers[t];
+                if (f.done) continue;
+                s.cur = t;
+                s.threadIdx = Dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                swapcontext(&s.sched, &f.ctx);
+            }
+        }
+        if (!s.progressed) {
+            fprintf(stderr, "xcemu: deadlock in block (%u,%u,%u): a barrier or wave collective is not reached by all "
+                            "threads (divergent __syncthreads / shuffle / MFMA?)\n", bidx.x, bidx.y, bidx.z);
+            abort();
+        }
+    }
+}
+
+template <class F>
+inline void launch(F&& f, Dim3 grid, Dim3 block) {
+    std::function<void()> body(f);
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) run_block(body, grid, block, Dim3(x, y, z));
+}
+
+}  // namespace xcemu
+
+// ---- HIP surface used by kernels and by the C-ABI launch code ----------------------------------------
+typedef xcemu::Dim3 dim3;
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipPeekAtLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emulator"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline hipError_t hipMemcpyAsyncD2D(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipFuncSetAttributeMaxDynLds(const void*, int) { return 0; }
+#define threadIdx (xcemu::S().threadIdx)
+#define blockIdx (xcemu::S().blockIdx)
+#define blockDim (xcemu::S().blockDim)
+#define gridDim (xcemu::S().gridDim)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    xcemu::launch([=]() { kernel(__VA_ARGS__); }, grid, block)
+inline void __syncthreads() { xcemu::block_barrier(); }
+
+namespace xc {
+
+typedef uint16_t bf16_t;
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVE = 64;
+
+inline float bf2f(bf16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline bf16_t f2bf(float f) {           // round to nearest even, NaN preserved
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+inline int lane_id() { return threadIdx.x & 63; }
+inline int wave_id() { return threadIdx.x >> 6; }
+inline void sync() { xcemu::block_barrier(); }
+
+template <class V>
+inline V shfl_generic(V v, int src_lane) {
+    auto tab = xcemu::wave_exchange(&v, sizeof(V));
+    V out;
+    memcpy(&out, tab[src_lane & 63], sizeof(V));
+    return out;
+}
+inline float shfl_xor(float v, int mask) { return shfl_generic(v, lane_id() ^ mask); }
+inline int shfl_xor(int v, int mask) { return shfl_generic(v, lane_id() ^ mask); }
+inline float shfl(float v, int src) { return shfl_generic(v, src); }
+inline int shfl(int v, int src) { return shfl_generic(v, src); }
+
+inline float wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
+inline float wave_max(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+    return v;
+}
+
+inline f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+    struct Dep { s16x8 a, b; } mine{a, b};
+    auto tab = xcemu::wave_exchange(&mine, sizeof(Dep));
+    const int l = lane_id();
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        const int j = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            Dep da, db;
+            memcpy(&da, tab[i + 32 * (k >> 3)], sizeof(Dep));
+            memcpy(&db, tab[j + 32 * (k >> 3)], sizeof(Dep));
+            acc += bf2f((bf16_t)da.a[k & 7]) * bf2f((bf16_t)db.b[k & 7]);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    struct Dep { float a, b; } mine{a, b};
+    auto tab = xcemu::wave_exchange(&mine, sizeof(Dep));
+    const int l = lane_id();
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        const int j = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            Dep da, db;
+            memcpy(&da, tab[i + 32 * k], sizeof(Dep));
+            memcpy(&db, tab[j + 32 * k], sizeof(Dep));
+            acc = fmaf(da.a, db.b, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
+inline void atomic_add(float* p, float v) { *p += v; }
+inline float fast_exp(float x) { return expf(x); }
+inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
+
+}  // namespace xc
+
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -1,0 +1,263 @@
+"""Per-kernel parity cases, shared by tests/test_kernels_emu.py (CPU, wave64 emulator build of the kernel sources) and
+tests/test_kernels_gpu.py (MI355X, libxclip_hip.so).  Every case calls through the C ABI (x_clip_amd.ops) and
+compares against an fp32/fp64 torch-CPU expression taken from the oracle (oracle/clip_oracle.py).
+
+Tolerances: fp32 storage -> 2e-5 relative to the output scale (fp32 accumulation order differs from ATen's);
+bf16 storage -> the reference is evaluated in fp64 on the bf16-rounded inputs, and the kernel (fp32 arithmetic,
+one rounding on store) must sit within 1.5 bf16 ulps of the output scale (2^-8 * 1.5 ~ 6e-3) -- the per-kernel
+reading of the north-star's "1e-3 bf16 / 1e-5 fp32" given in SURVEY.md section 0.
+"""
+import math
+
+import numpy as np
+import torch
+
+from oracle import clip_oracle as O
+from x_clip_amd import ops
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 6e-3
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def ref64(t):
+    return t.detach().cpu().to(torch.float64)
+
+
+def close(got, want, dtype, name="", scale=None, mult=1.0):
+    got = got.detach().cpu().to(torch.float64)
+    want = want.detach().cpu().to(torch.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    s = float(want.abs().max()) if scale is None else scale
+    err = float((got - want).abs().max())
+    assert math.isfinite(err), name
+    assert err <= tol(dtype) * mult * max(s, 1e-6), f"{name}: max err {err:.3e} vs scale {s:.3e} ({dtype})"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def case_layernorm(dev, dtype, rows, dim, geglu, with_res):
+    width = 2 * dim if geglu else dim
+    x = rnd((rows, width), dtype, 1)
+    g = (1 + 0.1 * rnd((dim,), torch.float32, 2)).to(dtype)
+    res = rnd((rows, dim), dtype, 3) if with_res else None
+    dy = rnd((rows, dim), dtype, 4)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), g.to(dev), None if res is None else res.to(dev), geglu)
+    dx, dg = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, geglu)
+
+    x64 = ref64(x).requires_grad_(True)
+    g64 = ref64(g).requires_grad_(True)
+    eps = ops.ln_eps(dtype)
+    v = O.geglu(x64) if geglu else x64
+    mu = v.mean(-1, keepdim=True)
+    var = ((v - mu) ** 2).mean(-1, keepdim=True)
+    yr = (v - mu) * torch.rsqrt(var + eps) * g64
+    if res is not None:
+        yr = yr + ref64(res)
+    yr.backward(ref64(dy))
+    close(y, yr, dtype, "ln y")
+    close(dx, x64.grad, dtype, "ln dx", mult=2.0)
+    close(dg, g64.grad, dtype, "ln dg", mult=2.0)
+
+
+def case_l2norm(dev, dtype, rows, dim):
+    x = rnd((rows, dim), dtype, 5)
+    dy = rnd((rows, dim), dtype, 6)
+    y, rn = ops.l2norm_fwd(x.to(dev))
+    dx = ops.l2norm_bwd(dy.to(dev), y, rn)
+    x64 = ref64(x).requires_grad_(True)
+    yr = O.l2_normalize(x64)
+    yr.backward(ref64(dy))
+    close(y, yr, dtype, "l2 y")
+    # the backward consumes the (rounded) y the forward stored
+    close(dx, x64.grad, dtype, "l2 dx", mult=3.0)
+
+
+def case_text_embed(dev, dtype, batch, n, dim, vocab, has_pos=True, has_cls=True):
+    g = torch.Generator().manual_seed(7)
+    tok = torch.randint(0, vocab, (batch, n), generator=g)
+    E = rnd((vocab, dim), dtype, 8)
+    P = rnd((n, dim), dtype, 9) if has_pos else None
+    cls = rnd((dim,), dtype, 10) if has_cls else None
+    out = ops.text_embed_fwd(tok.to(dev), E.to(dev), None if P is None else P.to(dev), None if cls is None else cls.to(dev))
+    E64 = ref64(E).requires_grad_(True)
+    P64 = ref64(P).requires_grad_(True) if has_pos else None
+    c64 = ref64(cls).requires_grad_(True) if has_cls else None
+    r = E64[tok]
+    if has_pos:
+        r = r + P64[None]
+    if has_cls:
+        r = torch.cat([c64.expand(batch, 1, dim), r], dim=1)
+    close(out, r, dtype, "embed out")
+    dout = rnd(tuple(r.shape), dtype, 11)
+    r.backward(ref64(dout))
+    dE, dP, dcls = ops.text_embed_bwd(dout.to(dev), tok.to(dev), vocab, has_pos, has_cls)
+    close(dE, E64.grad, torch.float32, "dE", mult=4.0)
+    if has_pos:
+        close(dP, P64.grad, torch.float32, "dP", mult=4.0)
+    if has_cls:
+        close(dcls, c64.grad, torch.float32, "dcls", mult=4.0)
+
+
+def case_patchify(dev, dtype, batch, c, size, p, keep_frac):
+    img = rnd((batch, c, size, size), dtype, 12)
+    npatch = (size // p) ** 2
+    keep = None
+    if keep_frac < 1.0:
+        g = torch.Generator().manual_seed(13)
+        nk = max(1, int(npatch * keep_frac))
+        keep = torch.randn(batch, npatch, generator=g).topk(nk, dim=-1).indices.to(torch.int32)
+    out = ops.patchify(img.to(dev), p, None if keep is None else keep.to(dev))
+    r = O.patchify(img.float(), p)
+    if keep is not None:
+        r = torch.gather(r, 1, keep.long()[..., None].expand(-1, -1, r.shape[-1]))
+    r = r.reshape(-1, r.shape[-1])
+    got = out.cpu().float()
+    assert torch.equal(got[:, : r.shape[1]], r), "patchify is a pure gather: must be bit exact"
+    assert float(got[:, r.shape[1]:].abs().sum()) == 0.0
+
+
+def case_token_mean(dev, dtype, batch, n, dim):
+    x = rnd((batch, n, dim), dtype, 14)
+    out = ops.token_mean_fwd(x.to(dev))
+    close(out, ref64(x).mean(1), dtype, "mean")
+    d = rnd((batch, dim), dtype, 15)
+    dx = ops.token_mean_bwd(d.to(dev), n)
+    close(dx, (ref64(d) / n)[:, None].expand(batch, n, dim), dtype, "mean bwd")
+    base = rnd((batch, n, dim), dtype, 16)
+    acc = ops.token_mean_bwd(d.to(dev), n, into=base.to(dev).clone())
+    close(acc, ref64(base) + (ref64(d) / n)[:, None], dtype, "mean bwd accumulate")
+
+
+def case_gemm(dev, dtype, M, N, K, layout, epilogue=False, alpha=1.0):
+    """layout: 'nt' forward, 'nn' dgrad, 'tn' wgrad"""
+    a_k = layout == "tn"
+    b_k = layout in ("nn", "tn")
+    # asymmetric operands: a transposed / mirrored output cannot pass
+    a = rnd((K, M) if a_k else (M, K), dtype, 17)
+    b = rnd((K, N) if b_k else (N, K), dtype, 18)
+    bias = res = addrows = rowidx = None
+    if epilogue:
+        bias = rnd((N,), dtype, 19)
+        res = rnd((M, N), dtype, 20)
+        addrows = rnd((5, N), dtype, 21)
+        rowidx = (torch.arange(M) * 3 % 5).to(torch.int32)
+    c = ops.gemm(a.to(dev), b.to(dev), M, N, K, a_k, b_k, alpha, None if bias is None else bias.to(dev),
+                 None if res is None else res.to(dev), None if addrows is None else addrows.to(dev),
+                 None if rowidx is None else rowidx.to(dev))
+    A = ref64(a).t() if a_k else ref64(a)
+    B = ref64(b) if b_k else ref64(b).t()
+    r = alpha * (A @ B)
+    scale = float(r.abs().max())
+    if epilogue:
+        r = r + ref64(bias) + ref64(res) + ref64(addrows)[rowidx.long()]
+    close(c, r, dtype, f"gemm {layout} {M}x{N}x{K}", scale=max(scale, float(r.abs().max())))
+
+
+def _attention_ref(qkv64, mask, heads, scale):
+    b, n, _ = qkv64.shape
+    q, k, v = qkv64.view(b, n, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q * scale) @ k.transpose(-1, -2)
+    if mask is not None:
+        s = s.masked_fill(~mask[:, None, None, :], -torch.finfo(s.dtype).max)
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(b, n, heads * 64)
+
+
+def case_attention(dev, dtype, batch, n, heads, masked):
+    qkv = rnd((batch, n, 3 * heads * 64), dtype, 22)
+    dout = rnd((batch, n, heads * 64), dtype, 23)
+    mask = None
+    if masked:
+        mask = torch.ones(batch, n, dtype=torch.bool)
+        for bi in range(batch):
+            k = (bi * 5 + 2) % max(1, n // 2)
+            if k:
+                mask[bi, n - k:] = False
+            if n > 3:
+                mask[bi, 2] = bi % 2 == 0           # a hole in the middle as well
+    scale = 64 ** -0.5
+    out, lse = ops.attention_fwd(qkv.to(dev), None if mask is None else mask.to(dev), heads, scale)
+    q64 = ref64(qkv).requires_grad_(True)
+    r = _attention_ref(q64, mask, heads, scale)
+    r.backward(ref64(dout))
+    close(out, r, dtype, "attn out")
+    dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale)
+    close(dqkv, q64.grad, dtype, "attn dqkv", mult=3.0)
+
+
+def case_attention_spike(dev, dtype):
+    """forces the online-softmax rescale: one key scores far above everything in a LATER tile (guide rule 26)"""
+    batch, n, heads = 1, 150, 1
+    qkv = rnd((batch, n, 3 * 64), dtype, 24, scale=0.3)
+    v = qkv.view(batch, n, 3, 64)
+    v[0, :, 0, :] = v[0, :, 0, :] + 0.0
+    v[0, 140, 1, :] = v[0, 5, 0, :] * 40.0           # key 140 (third tile) aligned with query 5
+    v[0, 70, 1, :] = v[0, 5, 0, :] * 15.0            # and a smaller spike in the second tile
+    scale = 64 ** -0.5
+    out, lse = ops.attention_fwd(qkv.to(dev), None, heads, scale)
+    r = _attention_ref(ref64(qkv), None, heads, scale)
+    close(out, r, dtype, "attn spike")
+
+
+def case_simloss(dev, dtype, nq, nk, d, dcl, diag_off=0, tau=1.3):
+    T = O.l2_normalize(rnd((nq, d), torch.float32, 25)).to(dtype)
+    I = O.l2_normalize(rnd((nk, d), torch.float32, 26)).to(dtype)
+    temp = math.exp(tau)
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    lse, pos = ops.simloss_fwd(T.to(dev), I.to(dev), temp, diag_off, dcl, 0.5, loss)
+    S = temp * ref64(T) @ ref64(I).t()
+    rows = torch.arange(nq)
+    diag = torch.zeros(nq, nk, dtype=torch.bool)
+    valid = (rows + diag_off < nk) & (rows + diag_off >= 0)
+    diag[rows[valid], (rows + diag_off)[valid]] = True
+    E = S.exp()
+    if dcl:
+        E = E.masked_fill(diag, 0.0)
+    lse_r = E.sum(1).log()
+    close(lse, lse_r, dtype, "lse", scale=float(lse_r.abs().max()))
+    pos_r = torch.zeros(nq, dtype=torch.float64)
+    pos_r[valid] = S[diag]
+    close(pos, pos_r, dtype, "pos", scale=float(S.abs().max()))
+    close(loss.reshape(1), (0.5 * (lse_r - pos_r).sum()).reshape(1), dtype, "loss", mult=2.0)
+
+    # gradient factor G and dtau with arbitrary coefficients
+    a, c, e = 0.013, 0.021, 0.05
+    g = torch.Generator().manual_seed(27)
+    lse_k = (torch.rand(nk, generator=g) * 2 + float(S.max())).float()
+    dtau = torch.zeros((), dtype=torch.float32, device=dev)
+    G = ops.simloss_grad(T.to(dev), I.to(dev), temp, diag_off, dcl, a, c, e, lse.detach(), lse_k.to(dev), dtau)
+    lq = lse.detach().cpu().double()
+    off = (~diag).double() if dcl else torch.ones_like(S)
+    Gr = (a * (S - lq[:, None]).exp() + c * (S - lse_k.double()[None, :]).exp()) * off - e * diag.double()
+    close(G[:, :nk], Gr, dtype, "G", mult=2.0)
+    assert float(G[:, nk:].abs().sum()) == 0.0
+    close(dtau.reshape(1), (Gr * S).sum().reshape(1), dtype, "dtau", scale=float((Gr * S).abs().sum()), mult=2.0)
+
+
+def case_simloss_closed_form(dev, dtype, B, d, dcl):
+    """full head (two LSE passes + G + two GEMMs) against the numpy closed form of SURVEY Appendix C"""
+    T = O.l2_normalize(rnd((B, d), torch.float32, 28)).to(dtype)
+    I = O.l2_normalize(rnd((B, d), torch.float32, 29)).to(dtype)
+    tau = 0.7
+    temp = math.exp(tau)
+    w = 1.0 / (2 * B)
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    lse_r, _ = ops.simloss_fwd(T.to(dev), I.to(dev), temp, 0, dcl, w, loss)
+    lse_c, _ = ops.simloss_fwd(I.to(dev), T.to(dev), temp, 0, dcl, w, loss)
+    dtau = torch.zeros((), dtype=torch.float32, device=dev)
+    G = ops.simloss_grad(T.to(dev), I.to(dev), temp, 0, dcl, w, w, 1.0 / B, lse_r, lse_c, dtau)
+    dT = ops.gemm(G[:, :B], I.to(dev), B, d, B, False, True, temp)
+    dI = ops.gemm(G[:, :B], T.to(dev), B, d, B, True, True, temp)
+    want = O.simloss_closed_form(T.double().numpy(), I.double().numpy(), tau, dcl)
+    close(loss.reshape(1), torch.tensor([want["loss"]]), dtype, "loss", mult=2.0)
+    close(dtau.reshape(1), torch.tensor([want["dtau"]]), dtype, "dtau", scale=1.0, mult=2.0)
+    sc = float(np.abs(want["dT"]).max())
+    close(dT, torch.tensor(want["dT"]), dtype, "dT", scale=sc, mult=4.0)
+    close(dI, torch.tensor(want["dI"]), dtype, "dI", scale=sc, mult=4.0)

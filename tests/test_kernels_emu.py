@@ -1,0 +1,90 @@
+"""CPU run of every kernel: the product's kernel sources + C ABI compiled for the host against the wave64 emulator
+(tests/emu), driven through the same Python wrappers (x_clip_amd.ops) and checked against the oracle expressions.
+Sizes are kept small (the emulator executes every GPU thread as a fibre)."""
+import os
+import sys
+
+import pytest
+import torch
+
+from x_clip_amd import _lib
+
+sys.path.insert(0, os.path.dirname(__file__))
+import kernel_cases as K  # noqa: E402
+from emu.build_emu import build  # noqa: E402
+
+DEV = torch.device("cpu")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulator_library():
+    path = build()
+    _lib._use_library_for_tests(path)
+    yield
+    _lib._use_library_for_tests(None)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,dim,geglu,res", [(5, 64, False, False), (9, 512, False, True), (6, 256, True, False),
+                                                (3, 2048, True, False), (2, 1096, False, False)])
+def test_layernorm(dtype, rows, dim, geglu, res):
+    K.case_layernorm(DEV, dtype, rows, dim, geglu, res)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_l2norm(dtype):
+    K.case_l2norm(DEV, dtype, 7, 64)
+    K.case_l2norm(DEV, dtype, 3, 512)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_text_embed(dtype):
+    K.case_text_embed(DEV, dtype, 3, 9, 64, 50)
+    K.case_text_embed(DEV, dtype, 2, 5, 72, 11, has_pos=False, has_cls=False)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_patchify(dtype):
+    K.case_patchify(DEV, dtype, 2, 3, 64, 32, 1.0)
+    K.case_patchify(DEV, dtype, 3, 3, 32, 8, 0.5)
+    K.case_patchify(DEV, dtype, 1, 3, 28, 14, 1.0)      # 588-wide rows: zero padded to the chunk
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_token_mean(dtype):
+    K.case_token_mean(DEV, dtype, 3, 5, 64)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_layouts(dtype, layout):
+    K.case_gemm(DEV, dtype, 136, 72, 96, layout)            # ragged M / N tiles, K tail
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_gemm_epilogue_and_splitk(dtype):
+    K.case_gemm(DEV, dtype, 40, 136, 64, "nt", epilogue=True, alpha=0.5)
+    K.case_gemm(DEV, dtype, 64, 64, 1536, "tn")             # long contraction -> split-K slabs + reduce
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("n,masked", [(33, False), (70, True), (97, True)])
+def test_attention(dtype, n, masked):
+    K.case_attention(DEV, dtype, 2, n, 2, masked)
+
+
+def test_attention_rescale_spike():
+    K.case_attention_spike(DEV, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dcl", [False, True])
+def test_simloss(dtype, dcl):
+    K.case_simloss(DEV, dtype, 12, 12, 64, dcl)
+    K.case_simloss(DEV, dtype, 20, 140, 32, dcl, diag_off=100)       # a rank's row block of a larger global batch
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dcl", [False, True])
+def test_simloss_closed_form(dtype, dcl):
+    K.case_simloss_closed_form(DEV, dtype, 12, 64, dcl)

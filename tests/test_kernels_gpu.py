@@ -1,0 +1,93 @@
+"""MI355X run of every kernel through the C ABI of libxclip_hip.so (same cases as the emulator suite, larger
+shapes incl. the BASELINE cfg2 widths)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+import kernel_cases as K  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+IDS = ["fp32", "bf16"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_library():
+    from x_clip_amd import _lib
+    _lib._use_library_for_tests(None)
+    assert not _lib.is_emulator()
+    _lib.lib()          # raises if libxclip_hip.so is missing -- no fallback
+    yield
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,dim,geglu,res", [(5, 64, False, False), (1031, 512, False, True), (517, 2048, True, False),
+                                                (66, 4096, True, False), (130, 768, False, False), (9000, 512, False, False)])
+def test_layernorm(dtype, rows, dim, geglu, res):
+    K.case_layernorm(DEV, dtype, rows, dim, geglu, res)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_l2norm(dtype):
+    K.case_l2norm(DEV, dtype, 1027, 512)
+    K.case_l2norm(DEV, dtype, 33, 64)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_text_embed(dtype):
+    K.case_text_embed(DEV, dtype, 37, 256, 512, 1000)
+    K.case_text_embed(DEV, dtype, 2, 5, 72, 11, has_pos=False, has_cls=False)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_patchify(dtype):
+    K.case_patchify(DEV, dtype, 5, 3, 256, 32, 0.5)
+    K.case_patchify(DEV, dtype, 3, 3, 224, 16, 1.0)
+    K.case_patchify(DEV, dtype, 2, 3, 28, 14, 1.0)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_token_mean(dtype):
+    K.case_token_mean(DEV, dtype, 33, 32, 512)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K_", [(136, 72, 96), (1000, 1536, 512), (515, 512, 2048)])
+def test_gemm_layouts(dtype, layout, M, N, K_):
+    K.case_gemm(DEV, dtype, M, N, K_, layout)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_gemm_epilogue_and_splitk(dtype):
+    K.case_gemm(DEV, dtype, 1030, 520, 3072, "nt", epilogue=True, alpha=0.5)
+    K.case_gemm(DEV, dtype, 1536, 512, 33000, "tn")          # wgrad shape: long token contraction, split-K
+    K.case_gemm(DEV, dtype, 64, 64, 1536, "tn")
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("n,heads,masked", [(33, 2, False), (70, 2, True), (257, 8, True), (32, 8, False), (197, 3, True)])
+def test_attention(dtype, n, heads, masked):
+    K.case_attention(DEV, dtype, 3, n, heads, masked)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_attention_rescale_spike(dtype):
+    K.case_attention_spike(DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("dcl", [False, True])
+def test_simloss(dtype, dcl):
+    K.case_simloss(DEV, dtype, 12, 12, 64, dcl)
+    K.case_simloss(DEV, dtype, 300, 1100, 512, dcl, diag_off=600)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("dcl", [False, True])
+def test_simloss_closed_form(dtype, dcl):
+    K.case_simloss_closed_form(DEV, dtype, 12, 64, dcl)
+    K.case_simloss_closed_form(DEV, dtype, 520, 512, dcl)

@@ -1,0 +1,85 @@
+// xc_device.h (gfx950 build) -- the thin vocabulary every kernel in csrc/kernels is written in.
+//
+// This is the only header that names HIP/CDNA4 builtins.  tests/emu/xc_device.h provides the same
+// vocabulary on top of a wave64 fibre emulator so the CPU test-suite can execute the very same kernel
+// sources; the include path (-I csrc/hw  vs  -I tests/emu) selects which one a build sees.  The product
+// library (libxclip_hip.so) is only ever built from THIS header by hipcc --offload-arch=gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define XC_DEV __device__ __forceinline__
+#define XC_HOST_DEV __host__ __device__ __forceinline__
+// dynamic LDS carve base, 16-byte aligned (cdna_hip_programming.md Guideline 17)
+#define XC_LDS_DYNAMIC(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+// kernels that carve more than the default 64 KiB of dynamic LDS must opt in once per function
+#define XC_ALLOW_LDS(kernel, bytes)                                                                          \
+    do {                                                                                                     \
+        static bool done_ = false;                                                                           \
+        if (!done_) {                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));             \
+            done_ = true;                                                                                    \
+        }                                                                                                    \
+    } while (0)
+
+namespace xc {
+
+typedef uint16_t bf16_t;                                            // raw bfloat16 bits
+typedef short s16x8 __attribute__((ext_vector_type(8)));            // 8 x bf16  (MFMA A/B operand, 4 VGPR)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));          // 32x32 MFMA accumulator
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));     // one 16-byte global/LDS transaction
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVE = 64;
+
+XC_DEV float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even; clang lowers the __bf16 conversion to v_cvt_pk_bf16_f32 on gfx950
+XC_DEV bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+XC_DEV int lane_id() { return threadIdx.x & 63; }
+XC_DEV int wave_id() { return threadIdx.x >> 6; }
+XC_DEV void sync() { __syncthreads(); }
+
+// ---- wave-level data exchange (64 lanes) ---------------------------------------------------------
+XC_DEV float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+XC_DEV int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+XC_DEV float shfl(float v, int src) { return __shfl(v, src, 64); }
+XC_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
+
+XC_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+XC_DEV float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// ---- matrix cores ---------------------------------------------------------------------------------
+// D = A*B + C, one wave.  32x32x16 bf16: lane l supplies A[i = l&31][k = 8*(l>>5) + 0..7] and
+// B[k = 8*(l>>5) + 0..7][j = l&31]; D/C: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16)
+// (cdna_hip_programming.md section 3).
+XC_DEV f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// 32x32x2 f32 (exact fp32 fma chain): lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31].
+XC_DEV f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+XC_DEV void atomic_add(float* p, float v) { atomicAdd(p, v); }
+
+XC_DEV float fast_exp(float x) { return __expf(x); }
+XC_DEV float fast_rsqrt(float x) { return rsqrtf(x); }
+
+}  // namespace xc

@@ -1,0 +1,263 @@
+// rows.h -- HBM-bound row kernels: gain-only LayerNorm (plain / +residual / fused GEGLU prologue) and
+// l2-normalisation, forward and backward.
+//
+// Layout: one wave64 per row, the whole row held in registers (lane owns the 16-byte chunks
+// c = lane + 64*i), every global access a coalesced 16-byte transaction, all reductions are wave
+// shuffles -- no LDS in the forward kernels.  Algorithmic HBM traffic: forward 2 x rows x D x e
+// (+ residual read), backward 3 x rows x D x e.
+//
+// Semantics follow the reference LayerNorm (x_clip.py:112-121: biased variance, gain only, the caller
+// passes eps = 1e-5 for fp32 and 1e-3 otherwise), GEGLU (x_clip.py:180-183: value = first half, gate =
+// second half, erf GELU) and F.normalize (x_clip.py:54-55, eps 1e-12).  Arithmetic is fp32 whatever the
+// storage type.
+#pragma once
+#include "common.h"
+
+namespace xc {
+
+// ---- row <-> registers --------------------------------------------------------------------------------
+// Loads row `xr` (width D); with GEGLU the source row is [value(D) | gate(D)] and the loaded value is
+// value * gelu(gate) (u/gt return the raw halves for the backward).
+template <typename T, int MAXC, bool GEGLU>
+XC_DEV void load_row(const T* xr, int D, int lane, float (&v)[MAXC][Elem<T>::VEC]) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int nch = D / VEC;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            load_vec<T>(xr + c * VEC, v[i]);
+            if (GEGLU) {
+                float gt[VEC];
+                load_vec<T>(xr + D + c * VEC, gt);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[i][j] *= gelu_erf(gt[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[i][j] = 0.f;
+        }
+    }
+}
+
+template <typename T, int MAXC>
+XC_DEV void row_stats(const float (&v)[MAXC][Elem<T>::VEC], int D, int lane, float& mean, float& var) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int nch = D / VEC;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s += v[i][j];            // padding chunks hold zeros
+    mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    var = wave_sum(q) / (float)D;
+}
+
+// ---- LayerNorm forward:  y = (x - mean) * rstd * g (+ res) ---------------------------------------------
+template <typename T, int MAXC, bool GEGLU>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ g,
+                                                     const T* __restrict__ res, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int rows, int D, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= rows) return;                       // whole wave leaves together; no barriers below
+    const int nch = D / VEC;
+    float v[MAXC][VEC];
+    load_row<T, MAXC, GEGLU>(x + row * ldx, D, lane, v);
+    float mean, var;
+    row_stats<T, MAXC>(v, D, lane, mean, var);
+    const float rstd = fast_rsqrt(var + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float gv[VEC], o[VEC];
+            load_vec<T>(g + c * VEC, gv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * gv[j];
+            if (res != nullptr) {
+                float rv[VEC];
+                load_vec<T>(res + row * (long)D + c * VEC, rv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] += rv[j];
+            }
+            store_vec<T>(y + row * (long)D + c * VEC, o);
+        }
+    }
+    if (lane == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+}
+
+// ---- LayerNorm backward --------------------------------------------------------------------------------
+// xhat = (x - mean) rstd ; dyg = dy g ; dx = rstd (dyg - mean(dyg) - xhat mean(dyg xhat)) ; dg += dy xhat.
+// With GEGLU the LayerNorm input was a = u gelu(t): du = da gelu(t), dt = da u gelu'(t), written to the
+// [rows, 2D] gradient of the FF1 output.  Waves walk the rows grid-stride and keep their dg partials in
+// registers; one LDS fold + one fp32 atomic per column per work-group at the end.
+template <typename T, int MAXC, bool GEGLU>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long ldx,
+                                                     const T* __restrict__ g, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, T* __restrict__ dx, long lddx,
+                                                     float* __restrict__ dg_accum, int rows, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    XC_LDS_DYNAMIC(lds);
+    float* red = reinterpret_cast<float*>(lds);            // [3][D]
+    const int lane = lane_id(), wave = wave_id();
+    const int nch = D / VEC;
+    float gv[MAXC][VEC], dgacc[MAXC][VEC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { gv[i][j] = 0.f; dgacc[i][j] = 0.f; }
+        if (c < nch) load_vec<T>(g + c * VEC, gv[i]);
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xh[MAXC][VEC], dyv[MAXC][VEC];
+        load_row<T, MAXC, GEGLU>(x + row * ldx, D, lane, xh);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                load_vec<T>(dy + row * (long)D + c * VEC, dyv[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    xh[i][j] = (xh[i][j] - mean) * rstd;
+                    dgacc[i][j] += dyv[i][j] * xh[i][j];
+                    dyv[i][j] *= gv[i][j];                         // dyg
+                    s1 += dyv[i][j];
+                    s2 += dyv[i][j] * xh[i][j];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D;
+        const float c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float da[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) da[j] = rstd * (dyv[i][j] - c1 - xh[i][j] * c2);
+                if (GEGLU) {
+                    float u[VEC], t[VEC], du[VEC], dt[VEC];
+                    load_vec<T>(x + row * ldx + c * VEC, u);
+                    load_vec<T>(x + row * ldx + D + c * VEC, t);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        du[j] = da[j] * gelu_erf(t[j]);
+                        dt[j] = da[j] * u[j] * gelu_erf_grad(t[j]);
+                    }
+                    store_vec<T>(dx + row * lddx + c * VEC, du);
+                    store_vec<T>(dx + row * lddx + D + c * VEC, dt);
+                } else {
+                    store_vec<T>(dx + row * lddx + c * VEC, da);
+                }
+            }
+        }
+    }
+    // fold the 4 waves' dg partials, then one atomic per column
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) red[(wave - 1) * D + c * VEC + j] = dgacc[i][j];
+        }
+    }
+    sync();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int col = c * VEC + j;
+                    atomic_add(dg_accum + col, dgacc[i][j] + red[col] + red[D + col] + red[2 * D + col]);
+                }
+        }
+    }
+}
+
+// ---- l2 normalisation -------------------------------------------------------------------------------------
+// y = x / max(||x||, 1e-12) ; rnorm saved for the backward: dx = (dy - y <y, dy>) rnorm.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                         float* __restrict__ rnorm_out, int rows, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= rows) return;
+    const int nch = D / VEC;
+    float v[MAXC][VEC];
+    load_row<T, MAXC, false>(x + row * (long)D, D, lane, v);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) q += v[i][j] * v[i][j];
+    const float nrm = sqrtf(wave_sum(q));
+    const float rn = 1.0f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = v[i][j] * rn;
+            store_vec<T>(y + row * (long)D + c * VEC, o);
+        }
+    }
+    if (lane == 0) rnorm_out[row] = rn;
+}
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                         const float* __restrict__ rnorm, T* __restrict__ dx,
+                                                         int rows, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= rows) return;
+    const int nch = D / VEC;
+    float yv[MAXC][VEC], dv[MAXC][VEC];
+    load_row<T, MAXC, false>(y + row * (long)D, D, lane, yv);
+    load_row<T, MAXC, false>(dy + row * (long)D, D, lane, dv);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dot += yv[i][j] * dv[i][j];
+    dot = wave_sum(dot);
+    const float rn = rnorm[row];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = (dv[i][j] - yv[i][j] * dot) * rn;
+            store_vec<T>(dx + row * (long)D + c * VEC, o);
+        }
+    }
+}
+
+}  // namespace xc

@@ -1,0 +1,147 @@
+// simloss.h -- the contrastive head: similarity matrix + InfoNCE / DCL (reference x_clip.py:813-847), forward
+// and backward, without ever materialising the logits.
+//
+// One primitive covers text->image, image->text, the CLOOB extra-projection variant, multiview pairs and the
+// rank-sharded row/column blocks of the multi-GPU path:
+//
+//   forward   S = scale * Q K^T   (Q: [nq, d] "own" latents, K: [nk, d] the other modality, scale = exp(tau))
+//             lse_i = log sum_j exp(S_ij)      (j = i + diag_off left out when dcl)
+//             pos_i = S_{i, i + diag_off}
+//             loss += coef * sum_i (lse_i - pos_i)
+//   backward  G_ij = [a exp(S_ij - lse_q[i]) + c exp(S_ij - lse_k[j])] (1 - dcl * delta) - e * delta     (delta = [j == i + diag_off])
+//             G is written once (storage dtype) and consumed by two ordinary GEMMs:
+//             dQ = scale * G K ("NN"),  dK = scale * G^T Q ("TN");   dtau += sum_ij G_ij S_ij.
+//
+// The S tile is produced by the GEMM main loop (128x128 per work-group, MFMA, fp32 in LDS); the forward
+// epilogue reduces each tile row to an online-softmax partial (max, sum) -- two threads per row -- and a second
+// tiny kernel folds the per-tile partials.  Algorithmic HBM traffic of the forward: (nq + nk) * d * e read,
+// 2 * nq * tiles_n * 4 written; the backward adds nq * nk * e for G (written once, read twice).
+#pragma once
+#include "gemm.h"
+
+namespace xc {
+
+struct SimParams {
+    const void* Q; const void* K;
+    int nq, nk, d;
+    float scale;
+    int diag_off, dcl;
+    int tiles_m, tiles_n;
+    // forward
+    float* part_m; float* part_l;          // [tiles_n][nq]
+    float* pos;                            // [nq]
+    // backward
+    const float* lse_q; const float* lse_k;
+    float a, c, e;
+    void* G; long ldg;
+    float* dtau;                           // scalar accumulator
+};
+
+constexpr float SIM_NEG = -3.0e38f;
+
+template <typename T>
+__global__ __launch_bounds__(256) void sim_lse_partial_kernel(SimParams p) {
+    constexpr int LDC = GemmCfg<T>::LDC;
+    XC_LDS_DYNAMIC(lds);
+    const float* Cs = reinterpret_cast<const float*>(lds);
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tn = tile % p.tiles_n;
+    const int m0 = (tile / p.tiles_n) * GEMM_BM, n0 = tn * GEMM_BN;
+    gemm_mainloop<T, false, false>(reinterpret_cast<const T*>(p.Q), p.d, reinterpret_cast<const T*>(p.K), p.d, p.nq, p.nk,
+                                   m0, n0, 0, p.d, lds);
+    // two threads per row, 64 columns each, then one shuffle to merge the pair
+    const int row = tid >> 1, half = tid & 1;
+    const int gm = m0 + row;
+    const int dcol = gm + p.diag_off;
+    float m = SIM_NEG, l = 0.f;
+    for (int c4 = 0; c4 < 16; ++c4) {
+        const int col = half * 64 + c4 * 4;
+        float v[4];
+        load_vec<float>(Cs + row * LDC + col, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gn = n0 + col + k;
+            const float s = v[k] * p.scale;
+            if (gn < p.nk) {
+                if (gn == dcol && gm < p.nq) p.pos[gm] = s;
+                if (!(p.dcl && gn == dcol)) {
+                    if (s > m) {
+                        l = l * fast_exp(m - s) + 1.0f;
+                        m = s;
+                    } else {
+                        l += fast_exp(s - m);
+                    }
+                }
+            }
+        }
+    }
+    const float m2 = shfl_xor(m, 1), l2 = shfl_xor(l, 1);
+    const float mm = fmaxf(m, m2);
+    const float ll = l * fast_exp(m - mm) + l2 * fast_exp(m2 - mm);
+    if (half == 0 && gm < p.nq) {
+        p.part_m[(long)tn * p.nq + gm] = mm;
+        p.part_l[(long)tn * p.nq + gm] = ll;
+    }
+}
+
+// Fold the per-tile partials:  lse_i ; loss += coef * sum_i (lse_i - pos_i)   (one atomic per wave)
+__global__ __launch_bounds__(256) void sim_lse_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                              const float* __restrict__ pos, float* __restrict__ lse,
+                                                              float* __restrict__ loss, int nq, int tiles_n, float coef) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float contrib = 0.f;
+    if (i < nq) {
+        float m = SIM_NEG;
+        for (int t = 0; t < tiles_n; ++t) m = fmaxf(m, part_m[(long)t * nq + i]);
+        float l = 0.f;
+        for (int t = 0; t < tiles_n; ++t) l += part_l[(long)t * nq + i] * fast_exp(part_m[(long)t * nq + i] - m);
+        const float v = (l > 0.f) ? m + logf(l) : logf(1e-20f);     // reference: log(sum + 1e-20)
+        lse[i] = v;
+        contrib = coef * (v - pos[i]);
+    }
+    contrib = wave_sum(contrib);
+    if (lane_id() == 0 && loss != nullptr) atomic_add(loss, contrib);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sim_grad_kernel(SimParams p) {
+    constexpr int VEC = Elem<T>::VEC, LDC = GemmCfg<T>::LDC;
+    XC_LDS_DYNAMIC(lds);
+    const float* Cs = reinterpret_cast<const float*>(lds);
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int m0 = (tile / p.tiles_n) * GEMM_BM, n0 = (tile % p.tiles_n) * GEMM_BN;
+    gemm_mainloop<T, false, false>(reinterpret_cast<const T*>(p.Q), p.d, reinterpret_cast<const T*>(p.K), p.d, p.nq, p.nk,
+                                   m0, n0, 0, p.d, lds);
+    constexpr int CPR = 128 / VEC;
+    T* G = reinterpret_cast<T*>(p.G);
+    float dt = 0.f;
+    for (int id = tid; id < 128 * CPR; id += GEMM_THREADS) {
+        const int row = id / CPR, col = (id % CPR) * VEC;
+        const int gm = m0 + row, gn0 = n0 + col;
+        if (gm < p.nq && gn0 < p.nk) {                      // G rows are padded to a whole chunk: columns >= nk get 0
+            const float lq = p.lse_q[gm];
+            const int dcol = gm + p.diag_off;
+            float g[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int gn = gn0 + k;
+                const float s = Cs[row * LDC + col + k] * p.scale;
+                const bool diag = (gn == dcol);
+                float v = 0.f;
+                if (gn < p.nk) {
+                    if (!(p.dcl && diag)) v = p.a * fast_exp(s - lq) + p.c * fast_exp(s - p.lse_k[gn]);
+                    if (diag) v -= p.e;
+                    dt += v * s;
+                }
+                g[k] = v;
+            }
+            store_vec<T>(G + (long)gm * p.ldg + gn0, g);
+        }
+    }
+    dt = wave_sum(dt);
+    if (lane_id() == 0) atomic_add(p.dtau, dt);
+}
+
+}  // namespace xc

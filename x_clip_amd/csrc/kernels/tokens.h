@@ -1,0 +1,172 @@
+// tokens.h -- gathers / scatters either side of the transformer stacks: text embedding, image patchify
+// (with the patch-dropout keep-set folded in), vision mean-pool, dtype casts.  All HBM-bound.
+#pragma once
+#include "common.h"
+
+namespace xc {
+
+// ---- text embedding (reference TextTransformer.forward, x_clip.py:320-335) ----------------------------------
+// out[b, 0] = cls ; out[b, 1+j] = E[tok[b, j]] + P[j]   (cls == nullptr: no CLS row; P == nullptr: no abs-pos)
+template <typename T>
+__global__ __launch_bounds__(256) void text_embed_fwd_kernel(const long long* __restrict__ tok, const T* __restrict__ E,
+                                                             const T* __restrict__ P, const T* __restrict__ cls,
+                                                             T* __restrict__ out, int batch, int n, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const int npos = n + (cls != nullptr ? 1 : 0);
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= (long)batch * npos) return;
+    const int bi = (int)(row / npos), pos = (int)(row % npos);
+    const int j = pos - (cls != nullptr ? 1 : 0);
+    const int nch = D / VEC;
+    const T* src = (j < 0) ? cls : E + (long)tok[(long)bi * n + j] * D;
+    for (int c = lane; c < nch; c += 64) {
+        float v[VEC];
+        load_vec<T>(src + c * VEC, v);
+        if (j >= 0 && P != nullptr) {
+            float pv[VEC];
+            load_vec<T>(P + (long)j * D + c * VEC, pv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[k] += pv[k];
+        }
+        store_vec<T>(out + row * (long)D + c * VEC, v);
+    }
+}
+
+// Backward: dE[tok] += dout (fp32 atomics, vocabulary rows are hit at random), dP[j] / dcls = column sums over
+// the batch (kept in registers per wave, one atomic per column per wave at the end).
+// grid = (npos, batch splits); block = 4 waves, each wave strides over batch rows of its position.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict__ dout, const long long* __restrict__ tok,
+                                                             float* __restrict__ dE, float* __restrict__ dP,
+                                                             float* __restrict__ dcls, int batch, int n, int D, int has_cls) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const int npos = n + has_cls;
+    const int pos = blockIdx.x;
+    const int j = pos - has_cls;
+    const int nch = D / VEC;
+    float acc[MAXC][VEC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
+    for (int bi = blockIdx.y * 4 + wave_id(); bi < batch; bi += gridDim.y * 4) {
+        const T* src = dout + ((long)bi * npos + pos) * D;
+        float* erow = (j >= 0) ? dE + (long)tok[(long)bi * n + j] * D : nullptr;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float v[VEC];
+                load_vec<T>(src + c * VEC, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    acc[i][k] += v[k];
+                    if (erow != nullptr) atomic_add(erow + c * VEC + k, v[k]);
+                }
+            }
+        }
+    }
+    float* dst = (j >= 0) ? (dP != nullptr ? dP + (long)j * D : nullptr) : dcls;
+    if (dst != nullptr) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) atomic_add(dst + c * VEC + k, acc[i][k]);
+        }
+    }
+}
+
+// ---- patchify: 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (x_clip.py:357) with the patch-dropout keep-set applied ----
+// out[(b, i), e] = img[b, c, ph*p + p1, pw*p + p2],  e = (p1*p + p2)*C + c,  patch = keep ? keep[b, i] : i.
+// One 16-byte output chunk per thread; rows are padded with zeros up to ldo (K multiple of the chunk width).
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ img, const int* __restrict__ keep,
+                                                       T* __restrict__ out, long ldo, int batch, int C, int H, int W,
+                                                       int p, int nkeep) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int gw = W / p;
+    const int rowlen = p * p * C;
+    const int nch = (int)(ldo / VEC);
+    const long total = (long)batch * nkeep * nch;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(id % nch);
+        const long row = id / nch;
+        const int bi = (int)(row / nkeep), i = (int)(row % nkeep);
+        const int patch = keep != nullptr ? keep[row] : i;
+        const int ph = patch / gw, pw = patch % gw;
+        T vals[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int e = ch * VEC + k;
+            if (e < rowlen) {
+                const int c = e % C, p2 = (e / C) % p, p1 = e / (C * p);
+                vals[k] = img[(((long)bi * C + c) * H + ph * p + p1) * W + pw * p + p2];
+            } else {
+                vals[k] = from_f32<T>(0.f);
+            }
+        }
+        st16(out + row * ldo + ch * VEC, *reinterpret_cast<u32x4*>(vals));
+    }
+}
+
+// ---- vision CLS pooling: mean over tokens (x_clip.py:366-370) ---------------------------------------------
+// grid = (batch, ceil(nch / 64)), block = one wave.
+template <typename T>
+__global__ __launch_bounds__(64) void token_mean_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int n, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int c = blockIdx.y * 64 + threadIdx.x;
+    if (c >= D / VEC) return;
+    const T* src = x + (long)blockIdx.x * n * D + c * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int t = 0; t < n; ++t) {
+        float v[VEC];
+        load_vec<T>(src + (long)t * D, v);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+    }
+    const float inv = 1.0f / (float)n;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] *= inv;
+    store_vec<T>(out + (long)blockIdx.x * D + c * VEC, acc);
+}
+
+// dx[b, t] = (accumulate ? dx[b, t] : 0) + dout[b] / n
+template <typename T>
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int batch,
+                                                             int n, int D, int accumulate) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= (long)batch * n) return;
+    const long bi = row / n;
+    const float inv = 1.0f / (float)n;
+    for (int c = lane; c < D / VEC; c += 64) {
+        float v[VEC];
+        load_vec<T>(dout + bi * D + c * VEC, v);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] *= inv;
+        if (accumulate) {
+            float o[VEC];
+            load_vec<T>(dx + row * (long)D + c * VEC, o);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[k] += o[k];
+        }
+        store_vec<T>(dx + row * (long)D + c * VEC, v);
+    }
+}
+
+// ---- fp32 accumulator -> storage type (gain / embedding gradients) ---------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long n,
+                                                            float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = from_f32<T>(src[i] * scale);
+}
+
+}  // namespace xc

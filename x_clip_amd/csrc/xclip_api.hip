@@ -1,0 +1,463 @@
+// xclip_api.hip -- the extern "C" boundary (include/xclip.h): argument checks, dtype / shape dispatch and kernel
+// launches.  No allocation, no synchronisation, no global mutable state besides the thread-local error string.
+#include "xc_device.h"
+
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/xclip.h"
+#include "kernels/attention.h"
+#include "kernels/gemm.h"
+#include "kernels/rows.h"
+#include "kernels/simloss.h"
+#include "kernels/tokens.h"
+
+using namespace xc;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fn, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", fn, what);
+    return 1;
+}
+int check_launch(const char* fn) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: HIP error: %s", fn, hipGetErrorString(e));
+        return 2;
+    }
+    return 0;
+}
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int vec_of(int dtype) { return dtype == XCLIP_BF16 ? 8 : 4; }
+inline int esize(int dtype) { return dtype == XCLIP_BF16 ? 2 : 4; }
+inline bool dtype_ok(int dtype) { return dtype == XCLIP_F32 || dtype == XCLIP_BF16; }
+
+#define XC_REQUIRE(cond, msg) \
+    do {                      \
+        if (!(cond)) return fail(__func__, msg); \
+    } while (0)
+
+// smallest power of two >= ceil(dim / (64 * VEC)), i.e. 16-byte chunks per lane when one wave holds a row
+inline int chunks_per_lane(int64_t dim, int vec) {
+    const int64_t need = (dim / vec + 63) / 64;
+    int c = 1;
+    while (c < need) c <<= 1;
+    return c;
+}
+
+template <typename T, int MAXC>
+void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, float* mean, float* rstd, int rows,
+                   int dim, float eps, int geglu, hipStream_t st) {
+    dim3 grid((rows + 3) / 4), block(256);
+    if (geglu)
+        hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, true>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res,
+                           (T*)y, mean, rstd, rows, dim, eps);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, false>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g,
+                           (const T*)res, (T*)y, mean, rstd, rows, dim, eps);
+}
+template <typename T, int MAXC>
+void launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd, void* dx,
+                   int64_t lddx, float* dg, int rows, int dim, int geglu, hipStream_t st) {
+    int blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid(blocks), block(256);
+    const size_t lds = (size_t)3 * dim * sizeof(float);
+    if (geglu) {
+        XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, true>), lds);
+        hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, true>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
+                           (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+    } else {
+        XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, false>), lds);
+        hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, false>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
+                           (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+    }
+}
+
+// dispatch on (dtype, chunks per lane); F is a macro taking (T, MAXC)
+#define XC_DISPATCH_ROW(dtype, cpl, F)                                   \
+    do {                                                                 \
+        if ((dtype) == XCLIP_BF16) {                                     \
+            switch (cpl) {                                               \
+                case 1: F(bf16_t, 1); break;                             \
+                case 2: F(bf16_t, 2); break;                             \
+                case 4: F(bf16_t, 4); break;                             \
+                case 8: F(bf16_t, 8); break;                             \
+                default: return fail(__func__, "row too wide (bf16 rows up to 4096 elements)"); \
+            }                                                            \
+        } else {                                                         \
+            switch (cpl) {                                               \
+                case 1: F(float, 1); break;                              \
+                case 2: F(float, 2); break;                              \
+                case 4: F(float, 4); break;                              \
+                case 8: F(float, 8); break;                              \
+                case 16: F(float, 16); break;                            \
+                default: return fail(__func__, "row too wide (fp32 rows up to 4096 elements)"); \
+            }                                                            \
+        }                                                                \
+    } while (0)
+
+template <typename T, bool AK, bool BK_>
+void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
+    XC_ALLOW_LDS((gemm_kernel<T, AK, BK_>), GemmCfg<T>::LDS_BYTES);
+    dim3 grid(p.tiles_m * p.tiles_n, splits), block(GEMM_THREADS);
+    hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, block, GemmCfg<T>::LDS_BYTES, st, p);
+}
+
+// split-K policy shared by xclip_gemm and xclip_gemm_workspace_bytes: fill ~512 work-groups, keep >= 4 K steps each
+int gemm_splits(int64_t M, int64_t N, int64_t K, int dtype) {
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int bk = 8 * vec_of(dtype);
+    int64_t s = 512 / tiles;
+    const int64_t maxs = K / (4 * bk);
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : (int)s;
+}
+
+template <typename T, int NW>
+void launch_attn_fwd(AttnParams p, hipStream_t st) {
+    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
+    constexpr int lds = attn_fwd_lds_bytes<T, NW>();
+    XC_ALLOW_LDS((attn_fwd_kernel<T, NW>), lds);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
+}
+template <typename T, int NW>
+void launch_attn_bwd(AttnParams p, hipStream_t st) {
+    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
+    constexpr int lds_q = attn_dq_lds_bytes<T, NW>(), lds_kv = attn_dkv_lds_bytes<T, NW>();
+    XC_ALLOW_LDS((attn_dq_kernel<T, NW>), lds_q);
+    XC_ALLOW_LDS((attn_dkv_kernel<T, NW>), lds_kv);
+    hipLaunchKernelGGL((attn_dq_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_q, st, p);
+    hipLaunchKernelGGL((attn_dkv_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_kv, st, p);
+}
+// waves per work-group: the NW in 1..4 that wastes the fewest padded rows (ties -> larger NW)
+int attn_waves(int64_t n) {
+    int best = 1;
+    int64_t best_pad = -1;
+    for (int nw = 1; nw <= 4; ++nw) {
+        const int64_t rows = ((n + nw * 32 - 1) / (nw * 32)) * nw * 32;
+        if (best_pad < 0 || rows <= best_pad) { best = nw; best_pad = rows; }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xclip_abi_version(void) { return XCLIP_ABI_VERSION; }
+const char* xclip_last_error(void) { return g_err; }
+
+int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, float* mean, float* rstd,
+                        int64_t rows, int64_t dim, float eps, int geglu, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec == 0 && ldx % vec == 0, "dim / ldx must be multiples of the 16-byte chunk");
+    XC_REQUIRE(ldx >= (geglu ? 2 * dim : dim), "ldx too small");
+    XC_REQUIRE(aligned16(x) && aligned16(g) && aligned16(y) && aligned16(res), "pointers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+#define F(T, C) launch_ln_fwd<T, C>(x, ldx, g, res, y, mean, rstd, (int)rows, (int)dim, eps, geglu, (hipStream_t)stream)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    return check_launch(__func__);
+}
+
+int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
+                        void* dx, int64_t lddx, float* dg_accum, int64_t rows, int64_t dim, int geglu, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec == 0 && ldx % vec == 0 && lddx % vec == 0, "dims must be multiples of the 16-byte chunk");
+    XC_REQUIRE(ldx >= (geglu ? 2 * dim : dim) && lddx >= (geglu ? 2 * dim : dim), "leading dimension too small");
+    XC_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(g) && aligned16(dx), "pointers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+#define F(T, C) launch_ln_bwd<T, C>(dy, x, ldx, g, mean, rstd, dx, lddx, dg_accum, (int)rows, (int)dim, geglu, (hipStream_t)stream)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    return check_launch(__func__);
+}
+
+int xclip_l2norm_fwd(const void* x, void* y, float* rnorm, int64_t rows, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(aligned16(x) && aligned16(y), "pointers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define F(T, C) hipLaunchKernelGGL((l2norm_fwd_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)x, (T*)y, rnorm, (int)rows, (int)dim)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    return check_launch(__func__);
+}
+
+int xclip_l2norm_bwd(const void* dy, const void* y, const float* rnorm, void* dx, int64_t rows, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(dx), "pointers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define F(T, C) hipLaunchKernelGGL((l2norm_bwd_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)dy, (const T*)y, rnorm, (T*)dx, (int)rows, (int)dim)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    return check_launch(__func__);
+}
+
+int xclip_text_embed_fwd(const int64_t* tokens, const void* E, const void* P, const void* cls, void* out, int64_t batch,
+                         int64_t n, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(dim > 0 && dim % vec_of(dtype) == 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(aligned16(E) && aligned16(P) && aligned16(cls) && aligned16(out), "pointers must be 16-byte aligned");
+    const int64_t rows = batch * (n + (cls ? 1 : 0));
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((text_embed_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const long long*)tokens,
+                           (const bf16_t*)E, (const bf16_t*)P, (const bf16_t*)cls, (bf16_t*)out, (int)batch, (int)n, (int)dim);
+    else
+        hipLaunchKernelGGL((text_embed_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const long long*)tokens,
+                           (const float*)E, (const float*)P, (const float*)cls, (float*)out, (int)batch, (int)n, (int)dim);
+    return check_launch(__func__);
+}
+
+int xclip_text_embed_bwd(const void* dout, const int64_t* tokens, float* dE_accum, float* dP_accum, float* dcls_accum,
+                         int64_t batch, int64_t n, int64_t dim, int has_cls, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(aligned16(dout), "pointers must be 16-byte aligned");
+    XC_REQUIRE(has_cls == 0 || dcls_accum != nullptr, "dcls_accum required with a CLS row");
+    if (batch == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+    int ysplit = (int)((batch + 31) / 32);
+    if (ysplit > 16) ysplit = 16;
+    dim3 grid((unsigned)(n + (has_cls ? 1 : 0)), ysplit), block(256);
+#define F(T, C) hipLaunchKernelGGL((text_embed_bwd_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)dout, (const long long*)tokens, dE_accum, dP_accum, dcls_accum, (int)batch, (int)n, (int)dim, has_cls ? 1 : 0)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    return check_launch(__func__);
+}
+
+int xclip_patchify(const void* image, const int32_t* keep, void* out, int64_t ldo, int64_t batch, int64_t channels,
+                   int64_t height, int64_t width, int64_t patch, int64_t nkeep, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(patch > 0 && height % patch == 0 && width % patch == 0, "image must be divisible by the patch size");
+    XC_REQUIRE(ldo % vec_of(dtype) == 0 && ldo >= patch * patch * channels, "ldo must cover a patch row, chunk aligned");
+    XC_REQUIRE(aligned16(out), "pointers must be 16-byte aligned");
+    const int64_t total = batch * nkeep * (ldo / vec_of(dtype));
+    if (total == 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((patchify_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)image, (const int*)keep,
+                           (bf16_t*)out, (long)ldo, (int)batch, (int)channels, (int)height, (int)width, (int)patch, (int)nkeep);
+    else
+        hipLaunchKernelGGL((patchify_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)image, (const int*)keep,
+                           (float*)out, (long)ldo, (int)batch, (int)channels, (int)height, (int)width, (int)patch, (int)nkeep);
+    return check_launch(__func__);
+}
+
+int xclip_token_mean_fwd(const void* x, void* out, int64_t batch, int64_t n, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0 && n > 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(aligned16(x) && aligned16(out), "pointers must be 16-byte aligned");
+    if (batch == 0) return 0;
+    dim3 grid((unsigned)batch, (unsigned)((dim / vec + 63) / 64)), block(64);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((token_mean_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, (int)n, (int)dim);
+    else
+        hipLaunchKernelGGL((token_mean_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)out, (int)n, (int)dim);
+    return check_launch(__func__);
+}
+
+int xclip_token_mean_bwd(const void* dout, void* dx, int64_t batch, int64_t n, int64_t dim, int accumulate, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(dim > 0 && dim % vec_of(dtype) == 0 && n > 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(aligned16(dout) && aligned16(dx), "pointers must be 16-byte aligned");
+    if (batch == 0) return 0;
+    dim3 grid((unsigned)((batch * n + 3) / 4)), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((token_mean_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)dout, (bf16_t*)dx, (int)batch, (int)n, (int)dim, accumulate);
+    else
+        hipLaunchKernelGGL((token_mean_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dout, (float*)dx, (int)batch, (int)n, (int)dim, accumulate);
+    return check_launch(__func__);
+}
+
+int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    if (count == 0) return 0;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((cast_from_f32_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)count, scale);
+    else
+        hipLaunchKernelGGL((cast_from_f32_kernel<float>), grid, block, 0, (hipStream_t)stream, src, (float*)dst, (long)count, scale);
+    return check_launch(__func__);
+}
+
+int64_t xclip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype) {
+    const int s = gemm_splits(M, N, K, dtype);
+    return s > 1 ? (int64_t)s * M * N * 4 : 0;
+}
+
+int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+               int64_t M, int64_t N, int64_t K, float alpha, const void* bias, const void* residual, int64_t ldr,
+               const void* addrows, const int32_t* rowidx, int64_t ld_add, void* workspace, int64_t workspace_bytes,
+               int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(M >= 0 && N > 0 && K > 0, "bad shape");
+    XC_REQUIRE(N % vec == 0 && ldc % vec == 0, "N and ldc must be multiples of the 16-byte chunk");
+    XC_REQUIRE(lda % vec == 0 && ldb % vec == 0, "lda / ldb must be multiples of the 16-byte chunk");
+    // operands are read in whole 16-byte chunks: a row must be allocated (and, for a normal operand whose K is not a
+    // chunk multiple, zero padded by the caller) up to the next chunk boundary
+    const int64_t Kp = (K + vec - 1) / vec * vec, Mp = (M + vec - 1) / vec * vec;
+    XC_REQUIRE(a_kmajor ? (lda >= Mp) : (lda >= Kp), "lda must cover A's contiguous dim rounded up to the 16-byte chunk");
+    XC_REQUIRE(b_kmajor ? (ldb >= N) : (ldb >= Kp), "ldb must cover B's contiguous dim rounded up to the 16-byte chunk");
+    XC_REQUIRE(!(a_kmajor && !b_kmajor), "layout (A k-major, B normal) is not used on this path");
+    XC_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && aligned16(bias) && aligned16(residual) && aligned16(addrows) && aligned16(workspace),
+               "pointers must be 16-byte aligned");
+    XC_REQUIRE(residual == nullptr || ldr % vec == 0, "ldr must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(addrows == nullptr || (rowidx != nullptr && ld_add % vec == 0), "addrows needs rowidx and an aligned ld");
+    if (M == 0) return 0;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.alpha = alpha;
+    p.bias = bias; p.residual = residual; p.ldr = ldr; p.addrows = addrows; p.rowidx = rowidx; p.ld_add = ld_add;
+    p.tiles_m = (int)((M + 127) / 128); p.tiles_n = (int)((N + 127) / 128);
+    int splits = gemm_splits(M, N, K, dtype);
+    const bool plain = (bias == nullptr && residual == nullptr && addrows == nullptr);
+    if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
+    const int bk = 8 * vec;
+    p.k_per_split = (int)((((K + splits - 1) / splits) + bk - 1) / bk * bk);
+    p.partial = splits > 1 ? (float*)workspace : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == XCLIP_BF16) {
+        if (!a_kmajor && !b_kmajor) launch_gemm<bf16_t, false, false>(p, splits, st);
+        else if (!a_kmajor && b_kmajor) launch_gemm<bf16_t, false, true>(p, splits, st);
+        else launch_gemm<bf16_t, true, true>(p, splits, st);
+    } else {
+        if (!a_kmajor && !b_kmajor) launch_gemm<float, false, false>(p, splits, st);
+        else if (!a_kmajor && b_kmajor) launch_gemm<float, false, true>(p, splits, st);
+        else launch_gemm<float, true, true>(p, splits, st);
+    }
+    if (splits > 1) {
+        int64_t blocks = (M * (N / 4) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (dtype == XCLIP_BF16)
+            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace,
+                               (bf16_t*)C, (long)ldc, (int)M, (int)N, splits, alpha);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace,
+                               (float*)C, (long)ldc, (int)M, (int)N, splits, alpha);
+    }
+    return check_launch(__func__);
+}
+
+int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n, int64_t heads,
+                        float scale, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
+    XC_REQUIRE(aligned16(qkv) && aligned16(out), "pointers must be 16-byte aligned");
+    if (batch == 0) return 0;
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = qkv; p.mask = mask; p.out = out; p.lse = lse;
+    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = attn_waves(n);
+#define F(T) switch (nw) { case 1: launch_attn_fwd<T, 1>(p, st); break; case 2: launch_attn_fwd<T, 2>(p, st); break; \
+                           case 3: launch_attn_fwd<T, 3>(p, st); break; default: launch_attn_fwd<T, 4>(p, st); break; }
+    if (dtype == XCLIP_BF16) { F(bf16_t) } else { F(float) }
+#undef F
+    return check_launch(__func__);
+}
+
+int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
+                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
+    XC_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "pointers must be 16-byte aligned");
+    if (batch == 0) return 0;
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = qkv; p.mask = mask; p.out = const_cast<void*>(out); p.lse = const_cast<float*>(lse); p.dout = dout;
+    p.delta = delta_ws; p.dqkv = dqkv;
+    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 dgrid((unsigned)((batch * n + 3) / 4)), dblock(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dgrid, dblock, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, (int)batch, (int)n, (int)heads);
+    else
+        hipLaunchKernelGGL((attn_delta_kernel<float>), dgrid, dblock, 0, st, (const float*)out, (const float*)dout, delta_ws, (int)batch, (int)n, (int)heads);
+    const int nw = attn_waves(n);
+#define F(T) switch (nw) { case 1: launch_attn_bwd<T, 1>(p, st); break; case 2: launch_attn_bwd<T, 2>(p, st); break; \
+                           case 3: launch_attn_bwd<T, 3>(p, st); break; default: launch_attn_bwd<T, 4>(p, st); break; }
+    if (dtype == XCLIP_BF16) { F(bf16_t) } else { F(float) }
+#undef F
+    return check_launch(__func__);
+}
+
+int64_t xclip_simloss_workspace_bytes(int64_t nq, int64_t nk) { return 2 * ((nk + 127) / 128) * nq * 4; }
+
+int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, int64_t diag_off, int dcl,
+                      float coef, void* workspace, float* pos, float* lse, float* loss_accum, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(nq > 0 && nk > 0 && d > 0 && d % vec_of(dtype) == 0, "bad shape (d must be a multiple of the 16-byte chunk)");
+    XC_REQUIRE(aligned16(Q) && aligned16(K) && workspace != nullptr, "pointers must be 16-byte aligned / workspace required");
+    SimParams p;
+    memset(&p, 0, sizeof(p));
+    p.Q = Q; p.K = K; p.nq = (int)nq; p.nk = (int)nk; p.d = (int)d; p.scale = scale; p.diag_off = (int)diag_off; p.dcl = dcl;
+    p.tiles_m = (int)((nq + 127) / 128); p.tiles_n = (int)((nk + 127) / 128);
+    p.part_m = (float*)workspace; p.part_l = p.part_m + (int64_t)p.tiles_n * nq; p.pos = pos;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(p.tiles_m * p.tiles_n), block(256);
+    if (dtype == XCLIP_BF16) {
+        XC_ALLOW_LDS((sim_lse_partial_kernel<bf16_t>), GemmCfg<bf16_t>::LDS_BYTES);
+        hipLaunchKernelGGL((sim_lse_partial_kernel<bf16_t>), grid, block, GemmCfg<bf16_t>::LDS_BYTES, st, p);
+    } else {
+        XC_ALLOW_LDS((sim_lse_partial_kernel<float>), GemmCfg<float>::LDS_BYTES);
+        hipLaunchKernelGGL((sim_lse_partial_kernel<float>), grid, block, GemmCfg<float>::LDS_BYTES, st, p);
+    }
+    hipLaunchKernelGGL(sim_lse_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)p.part_m,
+                       (const float*)p.part_l, (const float*)pos, lse, loss_accum, (int)nq, p.tiles_n, coef);
+    return check_launch(__func__);
+}
+
+int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, int64_t diag_off, int dcl,
+                       float a, float c, float e, const float* lse_q, const float* lse_k, void* G, int64_t ldg,
+                       float* dtau_accum, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(nq > 0 && nk > 0 && d > 0 && d % vec == 0, "bad shape (d must be a multiple of the 16-byte chunk)");
+    XC_REQUIRE(ldg % vec == 0 && ldg >= (nk + vec - 1) / vec * vec, "ldg must cover nk rounded up to the chunk");
+    XC_REQUIRE(aligned16(Q) && aligned16(K) && aligned16(G), "pointers must be 16-byte aligned");
+    SimParams p;
+    memset(&p, 0, sizeof(p));
+    p.Q = Q; p.K = K; p.nq = (int)nq; p.nk = (int)nk; p.d = (int)d; p.scale = scale; p.diag_off = (int)diag_off; p.dcl = dcl;
+    p.tiles_m = (int)((nq + 127) / 128); p.tiles_n = (int)((nk + 127) / 128);
+    p.lse_q = lse_q; p.lse_k = lse_k; p.a = a; p.c = c; p.e = e; p.G = G; p.ldg = ldg; p.dtau = dtau_accum;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(p.tiles_m * p.tiles_n), block(256);
+    if (dtype == XCLIP_BF16) {
+        XC_ALLOW_LDS((sim_grad_kernel<bf16_t>), GemmCfg<bf16_t>::LDS_BYTES);
+        hipLaunchKernelGGL((sim_grad_kernel<bf16_t>), grid, block, GemmCfg<bf16_t>::LDS_BYTES, st, p);
+    } else {
+        XC_ALLOW_LDS((sim_grad_kernel<float>), GemmCfg<float>::LDS_BYTES);
+        hipLaunchKernelGGL((sim_grad_kernel<float>), grid, block, GemmCfg<float>::LDS_BYTES, st, p);
+    }
+    return check_launch(__func__);
+}
+
+}  // extern "C"
