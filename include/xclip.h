@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 1
+#define XCLIP_ABI_VERSION 2
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -29,11 +29,15 @@ const char* xclip_last_error(void);
  * y[r,:] = (v - mean) * rstd * g (+ res[r,:]),  v = x[r,:dim]               (geglu = 0, ldx >= dim)
  *                                               v = x[r,:dim] * gelu(x[r,dim:2dim])   (geglu = 1, ldx >= 2 dim)
  * mean/rstd [rows] fp32 are saved for the backward.  eps: 1e-5 for fp32 models, 1e-3 otherwise (x_clip.py:118). */
-int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, float* mean, float* rstd,
-                        int64_t rows, int64_t dim, float eps, int geglu, int dtype, void* stream);
-/* dx [rows, dim] (lddx) -- or [rows, 2 dim] = (d value | d gate) with geglu; dg_accum [dim] fp32 += dy * xhat */
+int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, int64_t ldy, int64_t y_grp,
+                        float* mean, float* rstd, int64_t rows, int64_t dim, float eps, int geglu, int dtype, void* stream);
+/*   y row r lives at y + (r + (y_grp ? r / y_grp + 1 : 0)) * ldy: y_grp = n leaves the CLS slot of a [b, 1+n, dim]
+ *   encoder output free (VisionTransformer.forward x_clip.py:389-390); res [rows, dim] is contiguous.
+ * bwd: dx [rows, dim] (lddx) -- or [rows, 2 dim] = (d value | d gate) with geglu; dg_accum [dim] fp32 += dy * xhat;
+ *   dres [rows, dim] (optional, not with geglu) is added to dx: the skip-path gradient of x + f(LN(x)) (x_clip.py:288-289). */
 int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
-                        void* dx, int64_t lddx, float* dg_accum, int64_t rows, int64_t dim, int geglu, int dtype, void* stream);
+                        const void* dres, void* dx, int64_t lddx, float* dg_accum, int64_t rows, int64_t dim, int geglu, int dtype,
+                        void* stream);
 
 /* ---- l2 normalisation (reference l2norm = F.normalize, x_clip.py:54-55,715) ------------------------------------ */
 int xclip_l2norm_fwd(const void* x, void* y, float* rnorm, int64_t rows, int64_t dim, int dtype, void* stream);
@@ -53,9 +57,22 @@ int xclip_text_embed_bwd(const void* dout, const int64_t* tokens, float* dE_accu
 int xclip_patchify(const void* image, const int32_t* keep, void* out, int64_t ldo, int64_t batch, int64_t channels,
                    int64_t height, int64_t width, int64_t patch, int64_t nkeep, int dtype, void* stream);
 
-/* ---- vision CLS pooling: mean over tokens (x_clip.py:366-370) -------------------------------------------------- */
-int xclip_token_mean_fwd(const void* x, void* out, int64_t batch, int64_t n, int64_t dim, int dtype, void* stream);
-int xclip_token_mean_bwd(const void* dout, void* dx, int64_t batch, int64_t n, int64_t dim, int accumulate, int dtype, void* stream);
+/* ---- vision CLS pooling: mean over tokens (x_clip.py:366-370) --------------------------------------------------
+ * fwd: out[b] = mean_t x[b, t]   with x[b, t] at x + b * x_batch_stride + t * dim (elements).
+ * bwd: dx[b, t] = dout[b] / n + (dsrc ? dsrc[b, t] : 0), dsrc rows at dsrc + b * src_batch_stride + t * dim; dx contiguous. */
+int xclip_token_mean_fwd(const void* x, int64_t x_batch_stride, void* out, int64_t batch, int64_t n, int64_t dim, int dtype,
+                         void* stream);
+int xclip_token_mean_bwd(const void* dout, const void* dsrc, int64_t src_batch_stride, void* dx, int64_t batch, int64_t n,
+                         int64_t dim, int dtype, void* stream);
+
+/* dst[r, :dim] = src[r, :dim], rows at src + r * lds / dst + r * ldd (CLS select / scatter: enc[:, 0], x_clip.py:708-709) */
+int xclip_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t dim, int dtype, void* stream);
+
+/* table_accum[idx[r], :] += src[r, :] (fp32; NULL: skipped) and colsum_accum[:] += sum_r src[r, :] (fp32; NULL: skipped):
+ * the gradients of the position table gathered by the kept-patch index and of the patch-embedding bias
+ * (x_clip.py:358,382-385). */
+int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, float* table_accum, float* colsum_accum,
+                           int64_t rows, int64_t dim, int dtype, void* stream);
 
 /* dst[i] = (dtype) (src[i] * scale) : fp32 gradient accumulators -> parameter dtype */
 int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale, int dtype, void* stream);
@@ -82,18 +99,32 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
                         void* stream);
 
 /* ---- contrastive head (similarity + InfoNCE / DCL, x_clip.py:813-847) ---------------------------------------------
- * S = scale * Q K^T, Q [nq, d], K [nk, d].  Row i's positive is column i + diag_off.
+ * S = scale * exp(*log_scale) * Q K^T, Q [nq, d], K [nk, d]; log_scale (device fp32 scalar, may be NULL) is the
+ * temperature parameter (x_clip.py:574,736) -- it never visits the host.  Row i's positive is column i + diag_off.
  * fwd: lse[i] = log sum_j exp S_ij (positive excluded when dcl); pos[i] = S_{i,i+diag_off};
  *      *loss_accum += coef * sum_i (lse[i] - pos[i]).  workspace: xclip_simloss_workspace_bytes(nq, nk) bytes.
- * grad: G[i,j] = [a exp(S_ij - lse_q[i]) + c exp(S_ij - lse_k[j])] (1 - dcl*[j==i+diag_off]) - e [j==i+diag_off],
- *      G [nq, ldg] in `dtype` (ldg = nk rounded up to the chunk, padding columns written as 0);
- *      *dtau_accum += sum_ij G_ij S_ij.   dQ = scale * G K and dK = scale * G^T Q are ordinary xclip_gemm calls. */
+ * grad: G[i,j] = gmul {[a exp(S_ij - lse_q[i]) + c exp(S_ij - lse_k[j])] (1 - dcl*[j==i+diag_off]) - e [j==i+diag_off]}
+ *      (gmul: device fp32 scalar = upstream d loss, may be NULL), written as G or, with g_times_scale, as
+ *      scale*exp(*log_scale)*G, in `dtype` to G [nq, ldg] (columns nk .. roundup(nk, chunk) written as 0);
+ *      *dtau_accum += sum_ij G_ij S_ij (NULL: skipped).  dQ = scale * G K and dK = scale * G^T Q are xclip_gemm calls. */
 int64_t xclip_simloss_workspace_bytes(int64_t nq, int64_t nk);
-int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, int64_t diag_off, int dcl,
-                      float coef, void* workspace, float* pos, float* lse, float* loss_accum, int dtype, void* stream);
-int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, int64_t diag_off, int dcl,
-                       float a, float c, float e, const float* lse_q, const float* lse_k, void* G, int64_t ldg,
-                       float* dtau_accum, int dtype, void* stream);
+/* The forward in two steps, so the K side can be consumed in chunks as they arrive (the local latents first, every
+ * peer's all-gathered block later, reference x_clip.py:759-764 + distributed.py:14-39): `partial` reduces the columns of
+ * one K chunk into per-128-column-tile (max, sum) pairs stored in slots [tile_slot0, tile_slot0 + ceil(nk/128)) of a
+ * workspace holding 2 * tile_slots * nq floats; diag_off is relative to the chunk (global offset - first column of the
+ * chunk); pos must be zeroed by the caller and is written by the chunk that holds a row's positive.  `combine` folds all
+ * slots into lse and adds coef * sum(lse - pos) to *loss_accum (may be NULL). */
+int xclip_simloss_partial(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
+                          int64_t diag_off, int dcl, void* workspace, int64_t tile_slot0, int64_t tile_slots, float* pos,
+                          int dtype, void* stream);
+int xclip_simloss_combine(const void* workspace, int64_t nq, int64_t tile_slots, const float* pos, float* lse, float* loss_accum,
+                          float coef, void* stream);
+int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
+                      int64_t diag_off, int dcl, float coef, void* workspace, float* pos, float* lse, float* loss_accum, int dtype,
+                      void* stream);
+int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
+                       int64_t diag_off, int dcl, float a, float c, float e, const float* gmul, int g_times_scale,
+                       const float* lse_q, const float* lse_k, void* G, int64_t ldg, float* dtau_accum, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

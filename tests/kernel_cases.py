@@ -130,9 +130,11 @@ def case_token_mean(dev, dtype, batch, n, dim):
     d = rnd((batch, dim), dtype, 15)
     dx = ops.token_mean_bwd(d.to(dev), n)
     close(dx, (ref64(d) / n)[:, None].expand(batch, n, dim), dtype, "mean bwd")
-    base = rnd((batch, n, dim), dtype, 16)
-    acc = ops.token_mean_bwd(d.to(dev), n, into=base.to(dev).clone())
-    close(acc, ref64(base) + (ref64(d) / n)[:, None], dtype, "mean bwd accumulate")
+    # strided forms: the tokens sit behind a CLS slot of a [b, 1+n, D] buffer
+    full = rnd((batch, n + 1, dim), dtype, 16)
+    close(ops.token_mean_fwd(full.to(dev)[:, 1:]), ref64(full)[:, 1:].mean(1), dtype, "mean strided")
+    acc = ops.token_mean_bwd(d.to(dev), n, add=full.to(dev)[:, 1:])
+    close(acc, ref64(full)[:, 1:] + (ref64(d) / n)[:, None], dtype, "mean bwd + source")
 
 
 def case_gemm(dev, dtype, M, N, K, layout, epilogue=False, alpha=1.0):

@@ -1,0 +1,55 @@
+"""CPU end-to-end run of the product `x_clip_amd.CLIP` (host mirror + the C-ABI kernels compiled against the wave64
+emulator) on BASELINE config 0 (cfg1: dim 64, depth 2/2, image 64 patch 32, seq 32, batch 4), checked against the
+reference-generated golden fixtures and against the fp64 oracle."""
+import os
+import sys
+
+import pytest
+import torch
+
+from x_clip_amd import _lib
+
+sys.path.insert(0, os.path.dirname(__file__))
+import clip_cases as C  # noqa: E402
+from emu.build_emu import build  # noqa: E402
+from oracle import clip_oracle as O  # noqa: E402
+
+DEV = torch.device("cpu")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulator_library():
+    _lib._use_library_for_tests(build())
+    yield
+    _lib._use_library_for_tests(None)
+
+
+@pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
+                                  "cfg1_patchdrop"])      # p16_heads2 uses dim_head 32: kernels are built for 64
+def test_clip_matches_reference_fixture(name):
+    C.case_golden(DEV, name)
+
+
+def test_clip_bf16_vs_oracle():
+    C.case_vs_oracle(DEV, torch.bfloat16, O.CFG1, 4)
+
+
+def test_state_dict_keys_and_shapes():
+    from x_clip_amd import CLIP
+    model = CLIP(**O.CFG1.ctor_kwargs())
+    shapes = O.state_dict_shapes(O.CFG1)
+    sd = model.state_dict()
+    assert set(sd) == set(shapes)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+
+
+def test_no_cpu_fallback_without_library():
+    """the product refuses CPU tensors when the real HIP library (not the emulator) is bound"""
+    from x_clip_amd import ops
+    _lib._use_library_for_tests(None)
+    try:
+        with pytest.raises(RuntimeError):
+            ops.l2norm_fwd(torch.randn(4, 64))
+    finally:
+        _lib._use_library_for_tests(build())

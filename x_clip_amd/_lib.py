@@ -25,25 +25,30 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 _SIGNATURES = {
     "xclip_abi_version": (c_int, []),
     "xclip_last_error": (c_char_p, []),
-    "xclip_layernorm_fwd": (c_int, [P, L, P, P, P, P, P, L, L, F, I, I, P]),
-    "xclip_layernorm_bwd": (c_int, [P, P, L, P, P, P, P, L, P, L, L, I, I, P]),
+    "xclip_layernorm_fwd": (c_int, [P, L, P, P, P, L, L, P, P, L, L, F, I, I, P]),
+    "xclip_layernorm_bwd": (c_int, [P, P, L, P, P, P, P, P, L, P, L, L, I, I, P]),
     "xclip_l2norm_fwd": (c_int, [P, P, P, L, L, I, P]),
     "xclip_l2norm_bwd": (c_int, [P, P, P, P, L, L, I, P]),
     "xclip_text_embed_fwd": (c_int, [P, P, P, P, P, L, L, L, I, P]),
     "xclip_text_embed_bwd": (c_int, [P, P, P, P, P, L, L, L, I, I, P]),
     "xclip_patchify": (c_int, [P, P, P, L, L, L, L, L, L, L, I, P]),
-    "xclip_token_mean_fwd": (c_int, [P, P, L, L, L, I, P]),
-    "xclip_token_mean_bwd": (c_int, [P, P, L, L, L, I, I, P]),
+    "xclip_token_mean_fwd": (c_int, [P, L, P, L, L, L, I, P]),
+    "xclip_token_mean_bwd": (c_int, [P, P, L, P, L, L, L, I, P]),
+    "xclip_copy_rows": (c_int, [P, L, P, L, L, L, I, P]),
+    "xclip_rows_scatter_add": (c_int, [P, L, P, P, P, L, L, I, P]),
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),
     "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, F, I, P]),
     "xclip_attention_bwd": (c_int, [P, P, P, P, P, P, P, L, L, L, F, I, P]),
     "xclip_simloss_workspace_bytes": (c_int64, [L, L]),
-    "xclip_simloss_fwd": (c_int, [P, P, L, L, L, F, L, I, F, P, P, P, P, I, P]),
-    "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, L, I, F, F, F, P, P, P, L, P, I, P]),
+    "xclip_simloss_partial": (c_int, [P, P, L, L, L, F, P, L, I, P, L, L, P, I, P]),
+    "xclip_simloss_combine": (c_int, [P, L, L, P, P, P, F, P]),
+    "xclip_simloss_fwd": (c_int, [P, P, L, L, L, F, P, L, I, F, P, P, P, P, I, P]),
+    "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
+ABI_VERSION = 2
 
 
 def _bind(path: str):
@@ -52,8 +57,8 @@ def _bind(path: str):
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.xclip_abi_version() != 1:
-        raise RuntimeError(f"{path}: ABI version {lib.xclip_abi_version()} != 1")
+    if lib.xclip_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.xclip_abi_version()} != {ABI_VERSION} -- rebuild (python -m x_clip_amd.build)")
     return lib
 
 

@@ -1,0 +1,438 @@
+"""Host-side mirror of the reference's public interface for the contrastive-training path: `CLIP`, `TextTransformer`,
+`VisionTransformer` (reference x_clip/x_clip.py:295-390,412-875; exports x_clip/__init__.py:1).
+
+Same constructor keywords and defaults, same `forward` signature / return values / assertion messages, same `state_dict`
+keys and parameter shapes, same parameter construction order (so `torch.manual_seed(s); CLIP(...)`
+draws the same initial weights as the reference) -- but the modules are parameter containers: all arithmetic runs in
+the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is no CPU / ATen fallback; tensors must live
+on an MI355X.
+
+Not on this path yet (constructor raises NotImplementedError): rotary / causal text encoder,
+MLM and visual-SSL side losses, `downsample_image_embeds`, `sim_reg_loss_weight`.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Optional
+
+import torch
+import torch.distributed as distributed
+from torch import nn
+
+from . import functional as XF
+from . import losses as XL
+
+Tensor = torch.Tensor
+
+
+def exists(val):
+    return val is not None
+
+
+def cast_tuple(t):
+    return t if isinstance(t, (tuple, list)) else (t,)
+
+
+# ---- parameter containers with the reference's attribute names ---------------------------------------------------------
+class LayerNorm(nn.Module):
+    """gain-only LayerNorm (x_clip.py:112-121)"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(dim))
+
+
+class PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = LayerNorm(dim)
+        self.fn = fn
+
+
+class GEGLU(nn.Module):
+    pass
+
+
+class FeedForward(nn.Module):
+    """Linear(dim, 2*mult*dim) -> GEGLU -> LayerNorm -> Dropout(0) -> Linear(mult*dim, dim), no biases (x_clip.py:185-199)"""
+
+    def __init__(self, dim, mult=4, dropout=0.):
+        super().__init__()
+        if dropout != 0.:
+            raise NotImplementedError("ff_dropout != 0 is not on the accelerated path (reference default 0)")
+        inner_dim = int(dim * mult)
+        self.net = nn.Sequential(
+            nn.Linear(dim, inner_dim * 2, bias=False),
+            GEGLU(),
+            LayerNorm(inner_dim),
+            nn.Dropout(dropout),
+            nn.Linear(inner_dim, dim, bias=False),
+        )
+
+
+class Attention(nn.Module):
+    """fused-QKV multi-head attention parameters (x_clip.py:201-245)"""
+
+    def __init__(self, dim, dim_head=64, heads=8, causal=False, dropout=0.):
+        super().__init__()
+        if causal:
+            raise NotImplementedError("causal attention is not on the accelerated path yet (SURVEY.md 8(f))")
+        if dropout != 0.:
+            raise NotImplementedError("attn_dropout != 0 is not on the accelerated path (reference default 0)")
+        self.heads = heads
+        self.causal = causal
+        self.scale = dim_head ** -0.5
+        inner_dim = dim_head * heads
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim, bias=False), LayerNorm(dim))
+        self.dropout = nn.Dropout(dropout)
+
+
+class Transformer(nn.Module):
+    """norm_in -> depth x (pre-norm attention + skip, pre-norm feed-forward + skip) -> norm_out (x_clip.py:247-291)"""
+
+    def __init__(self, dim, *, depth, dim_head=64, heads=8, causal=False, attn_dropout=0., ff_dropout=0., ff_mult=4,
+                 checkpoint_during_training=False):
+        super().__init__()
+        self.checkpoint_during_training = checkpoint_during_training
+        self.dim, self.depth, self.heads, self.dim_head = dim, depth, heads, dim_head
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(dim, Attention(dim=dim, dim_head=dim_head, heads=heads, causal=causal, dropout=attn_dropout)),
+                PreNorm(dim, FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout)),
+            ]))
+        self.norm_in = LayerNorm(dim)
+        self.norm_out = LayerNorm(dim)
+
+    def stack_params(self):
+        """flat parameter list in the order x_clip_amd.functional.stack_forward expects"""
+        ps = [self.norm_in.g]
+        for attn, ff in self.layers:
+            ps += [attn.norm.g, attn.fn.to_qkv.weight, attn.fn.to_out[0].weight, attn.fn.to_out[1].g,
+                   ff.norm.g, ff.fn.net[0].weight, ff.fn.net[2].g, ff.fn.net[4].weight]
+        ps.append(self.norm_out.g)
+        return ps
+
+    def spec(self) -> XF.StackSpec:
+        return XF.StackSpec(depth=self.depth, heads=self.heads, dim_head=self.dim_head,
+                            checkpoint=bool(self.training and self.checkpoint_during_training))
+
+    def forward(self, x, rotary_pos_emb=None, mask=None):
+        if exists(rotary_pos_emb):
+            raise NotImplementedError("rotary embeddings are not on the accelerated path yet (SURVEY.md 8(f))")
+        return XF.transformer(x, self.stack_params(), self.spec(), mask)
+
+
+class TextTransformer(nn.Module):
+    """reference TextTransformer (x_clip.py:295-338): forward(x int64 [b, n], mask bool [b, n]) -> [b, n+1, dim]"""
+
+    def __init__(self, dim, *, num_tokens, max_seq_len, dim_head, rotary_pos_emb=None, causal=False, **kwargs):
+        super().__init__()
+        if rotary_pos_emb:
+            raise NotImplementedError("text_rotary_pos_emb is not on the accelerated path yet (SURVEY.md 8(f))")
+        if causal:
+            raise NotImplementedError("text_causal_mask is not on the accelerated path yet (SURVEY.md 8(f); the reference "
+                                      "path itself raises NameError, x_clip.py:683-684)")
+        self.token_emb = nn.Embedding(num_tokens, dim)
+        self.abs_pos_emb = nn.Embedding(max_seq_len, dim)
+        self.rotary_pos_emb = None
+        self.cls_token = nn.Parameter(torch.randn(dim))
+        self.transformer = Transformer(dim, dim_head=dim_head, causal=causal, **kwargs)
+
+    def forward(self, x, mask=None):
+        t = self.transformer
+        return XF.text_encode(x, mask, self.token_emb.weight, self.abs_pos_emb.weight, self.cls_token, t.stack_params(), t.spec())
+
+
+class PatchDropout(nn.Module):
+    """keeps max(1, int(n * (1 - prob))) random patches per sample while training (x_clip.py:134-151).  Here it only
+    draws the kept-index set; the gather is folded into the patchify kernel."""
+
+    def __init__(self, prob):
+        super().__init__()
+        assert 0 <= prob < 1.
+        self.prob = prob
+
+    def draw(self, batch: int, n: int, device, force_keep_all=False) -> Optional[Tensor]:
+        if not self.training or self.prob == 0. or force_keep_all:
+            return None
+        num_patches_keep = max(1, int(n * (1 - self.prob)))
+        return torch.randn(batch, n, device=device).topk(num_patches_keep, dim=-1).indices.to(torch.int32)
+
+
+class VisionTransformer(nn.Module):
+    """reference VisionTransformer (x_clip.py:340-390): forward(image [b, c, H, W]) -> [b, 1 + n_kept, dim]"""
+
+    def __init__(self, dim, *, image_size, patch_size, channels, patch_dropout=0.5, **kwargs):
+        super().__init__()
+        assert image_size % patch_size == 0, 'Image dimensions must be divisible by the patch size.'
+        num_patches = (image_size // patch_size) ** 2
+        patch_dim = channels * patch_size ** 2
+        self.patch_size = patch_size
+        self.num_patches = num_patches
+        # index 0 of the reference Sequential is the einops Rearrange (no parameters): keep `to_tokens.1.*` key names
+        self.to_tokens = nn.Sequential(nn.Identity(), nn.Linear(patch_dim, dim))
+        self.pos_emb = nn.Embedding(num_patches, dim)
+        self.patch_dropout = PatchDropout(patch_dropout)
+        self.transformer = Transformer(dim, **kwargs)
+        self.to_cls_tokens = nn.Sequential(nn.Identity(), nn.Linear(dim, dim, bias=False), nn.Identity())
+        self.keep_indices_override: Optional[Tensor] = None      # parity tests inject the PatchDropout draw here
+
+    def forward(self, x, keep_all_patches=False, keep_indices: Optional[Tensor] = None):
+        if keep_indices is None:
+            keep_indices = self.keep_indices_override
+        if keep_indices is None:
+            keep_indices = self.patch_dropout.draw(x.shape[0], self.num_patches, x.device, keep_all_patches)
+        t = self.transformer
+        return XF.vision_encode(x, keep_indices, self.patch_size, self.to_tokens[1].weight, self.to_tokens[1].bias,
+                                self.pos_emb.weight, self.to_cls_tokens[1].weight, t.stack_params(), t.spec())
+
+
+def model_forward_with_context(*, fn, args, freeze):
+    """x_clip.py:394-408: a frozen encoder runs without a graph and its output is detached"""
+    if not freeze:
+        return fn(*args)
+    with torch.no_grad():
+        enc = fn(*args)
+    return enc.detach()
+
+
+class CLIP(nn.Module):
+    def __init__(
+        self,
+        *,
+        image_encoder=None,
+        text_encoder=None,
+        dim_text=512,
+        dim_image=512,
+        dim_latent=512,
+        num_text_tokens=10000,
+        text_enc_depth=6,
+        text_seq_len=256,
+        text_heads=8,
+        text_dim_head=64,
+        text_has_cls_token=True,
+        text_pad_id=0,
+        text_rotary_pos_emb=False,
+        text_causal_mask=False,
+        text_eos_id=None,
+        text_encode_without_mask=False,
+        visual_enc_depth=6,
+        visual_heads=8,
+        visual_dim_head=64,
+        visual_image_size=256,
+        visual_patch_size=32,
+        visual_patch_dropout=0.5,
+        visual_has_cls_token=True,
+        channels=3,
+        use_all_token_embeds=False,
+        downsample_image_embeds=False,
+        decoupled_contrastive_learning=False,
+        extra_latent_projection=False,
+        use_mlm=False,
+        text_ssl_loss_weight=0.05,
+        use_visual_ssl=False,
+        visual_ssl=None,
+        visual_ssl_type='simsiam',
+        visual_ssl_hidden_layer=-1,
+        simclr_temperature=0.1,
+        image_ssl_loss_weight=0.05,
+        multiview_loss_weight=0.1,
+        checkpoint_during_training=False,
+        sim_reg_loss_weight=0.,
+        **kwargs
+    ):
+        super().__init__()
+        assert use_all_token_embeds or (visual_has_cls_token or text_has_cls_token), 'CLS token must be included on both vision and text transformers if you are not using fine-grained contrastive learning loss'
+
+        self.dim_text = dim_text
+        self.dim_image = dim_image
+        self.dim_latent = dim_latent
+
+        self.image_channels = channels
+        self.image_size = visual_image_size
+
+        self.text_pad_id = text_pad_id
+        self.text_has_cls_token = text_has_cls_token
+        self.text_seq_len = text_seq_len
+
+        self.text_encode_without_mask = text_encode_without_mask
+
+        self.text_causal_mask = text_causal_mask
+        self.text_eos_id = text_eos_id
+
+        assert not (text_causal_mask and not exists(text_eos_id)), 'text EOS token id must be given if using causal mask in text transformer'
+
+        if exists(text_encoder):
+            self.text_transformer = text_encoder
+        else:
+            self.text_transformer = TextTransformer(
+                dim=dim_text,
+                num_tokens=num_text_tokens + (1 if use_mlm else 0),
+                max_seq_len=text_seq_len,
+                depth=text_enc_depth,
+                heads=text_heads,
+                causal=text_causal_mask,
+                dim_head=text_dim_head,
+                rotary_pos_emb=text_rotary_pos_emb,
+                checkpoint_during_training=checkpoint_during_training
+            )
+
+        self.visual_has_cls_token = visual_has_cls_token
+
+        if exists(image_encoder):
+            self.visual_transformer = image_encoder
+        else:
+            self.visual_transformer = VisionTransformer(
+                dim=dim_image,
+                image_size=visual_image_size,
+                patch_size=visual_patch_size,
+                channels=channels,
+                depth=visual_enc_depth,
+                heads=visual_heads,
+                dim_head=visual_dim_head,
+                patch_dropout=visual_patch_dropout,
+                checkpoint_during_training=checkpoint_during_training
+            )
+
+        # side losses of the reference that are outside the accelerated path
+        if use_mlm:
+            raise NotImplementedError("use_mlm: the MLM side loss (x_clip/mlm.py) is outside the accelerated contrastive path")
+        if use_visual_ssl or exists(visual_ssl):
+            raise NotImplementedError("use_visual_ssl / visual_ssl: SimSiam / SimCLR (x_clip/visual_ssl.py) are outside the accelerated contrastive path")
+        self.use_mlm = False
+        self.text_ssl_loss_weight = 0
+        self.use_visual_ssl = False
+        self.image_ssl_loss_weight = 0
+
+        self.to_text_latent = nn.Linear(dim_text, dim_latent, bias=False)
+
+        if downsample_image_embeds:
+            assert use_all_token_embeds, 'must be using all token embeds for contrastive learning in order to downsampling'
+            raise NotImplementedError("downsample_image_embeds is not on the accelerated path yet (SURVEY.md 8(f))")
+        self.to_visual_latent = nn.Linear(dim_image, dim_latent, bias=False)
+
+        self.temperature = nn.Parameter(torch.tensor(1.))
+
+        self.use_all_token_embeds = use_all_token_embeds
+        self.decoupled_contrastive_learning = decoupled_contrastive_learning
+        self.extra_latent_projection = extra_latent_projection
+
+        self.to_text_latent_extra = copy.deepcopy(self.to_text_latent)
+        self.to_visual_latent_extra = copy.deepcopy(self.to_visual_latent)
+
+        self.multiview_loss_weight = multiview_loss_weight
+
+        # latched at construction like the reference (x_clip.py:591): init the process group BEFORE building the model
+        self.requires_all_gather = distributed.is_available() and distributed.is_initialized() and distributed.get_world_size() > 1
+        self.assume_equal_batch = False           # set True to skip the per-step batch-size exchange between ranks
+
+        self.sim_reg_loss_weight = sim_reg_loss_weight
+        self.has_sim_reg_loss = sim_reg_loss_weight > 0.
+        if self.has_sim_reg_loss:
+            raise NotImplementedError("sim_reg_loss_weight > 0 is not on the accelerated path yet (SURVEY.md 8(f); the "
+                                      "reference path raises an einsum rank error without extra_latent_projection)")
+
+    def forward(
+        self,
+        text,
+        image,
+        return_loss=False,
+        return_encodings=False,
+        return_latents=False,
+        freeze_image_encoder=False,
+        freeze_text_encoder=False,
+        text_to_image=True,
+        aug_text=None,
+        aug_image=None
+    ):
+        batch, device = text.shape[0], text.device
+
+        text_mask = text != self.text_pad_id                                               # x_clip.py:614
+
+        num_batch_texts = num_batch_images = 1
+
+        if exists(aug_text):                                                               # x_clip.py:629-639
+            aug_text = cast_tuple(aug_text)
+            assert all(map(lambda t: t.shape == text.shape, aug_text))
+            num_batch_texts = len(aug_text) + 1
+            aug_text = torch.cat(aug_text, dim=0)
+            aug_text_mask = aug_text != self.text_pad_id
+            text_mask = torch.cat((text_mask, aug_text_mask), dim=0)
+            text = torch.cat((text, aug_text), dim=0)
+
+        if exists(aug_image):                                                              # x_clip.py:641-648
+            aug_image = cast_tuple(aug_image)
+            assert all(map(lambda i: i.shape == image.shape, aug_image))
+            num_batch_images = len(aug_image) + 1
+            aug_image = torch.cat(aug_image, dim=0)
+            image = torch.cat((image, aug_image), dim=0)
+
+        is_multiview = (num_batch_texts > 1 or num_batch_images > 1)
+        assert not (return_loss and not self.training), 'loss cannot be used if not training'
+        assert not (not return_loss and is_multiview), 'do not pass in augmented texts or images if not training'
+        assert not (self.multiview_loss_weight == 0 and is_multiview), 'multiview loss weight cannot be 0 if augmented text or images passed in'
+
+        text_args = (text,)
+        if not self.text_encode_without_mask:
+            text_args = (*text_args, text_mask)
+
+        enc_text = model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze_text_encoder)
+        enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
+
+        if return_encodings:                                                               # x_clip.py:697-698
+            return enc_text, enc_image
+
+        if self.use_all_token_embeds:                                                      # x_clip.py:702-706
+            assert enc_text.ndim == 3, 'encoded text must have 3 dimensions (batch, seq, features)'
+            assert enc_image.ndim == 3, 'encoded image must have 3 dimensions (batch, seq [height x width], features)'
+            text_embeds = enc_text[:, 1:] if self.text_has_cls_token else enc_text
+            image_embeds = enc_image[:, 1:] if self.visual_has_cls_token else enc_image
+        else:                                                                              # x_clip.py:708-709
+            text_embeds = XF.select_row(enc_text, 0) if enc_text.ndim == 3 else enc_text
+            image_embeds = XF.select_row(enc_image, 0) if enc_image.ndim == 3 else enc_image
+
+        text_latents = XF.l2norm(XF.linear(text_embeds, self.to_text_latent.weight))       # x_clip.py:713-715
+        image_latents = XF.l2norm(XF.linear(image_embeds, self.to_visual_latent.weight))
+
+        text_latents_extra, image_latents_extra = text_latents, image_latents              # x_clip.py:720-724
+        if self.extra_latent_projection:
+            text_latents_extra = XF.l2norm(XF.linear(text_embeds, self.to_text_latent_extra.weight))
+            image_latents_extra = XF.l2norm(XF.linear(image_embeds, self.to_visual_latent_extra.weight))
+
+        if return_latents:                                                                 # x_clip.py:728-732
+            if self.extra_latent_projection:
+                return text_latents, image_latents, text_latents_extra, image_latents_extra
+            return text_latents, image_latents
+
+        if not return_loss:                                                                # x_clip.py:740-746 (inference only)
+            temp = self.temperature.exp()
+            a, b = (text_latents_extra, image_latents_extra) if self.extra_latent_projection and not text_to_image \
+                else (text_latents, image_latents)
+            if self.use_all_token_embeds:
+                return torch.einsum('b t d, b i d -> b t i', a, b) * temp
+            return torch.einsum('b d, b d -> b', a, b) * temp
+
+        # ---- training loss -----------------------------------------------------------------------------------------------
+        def split_views(t, m):                                                             # '(m b) ... -> m b ...'
+            return t.reshape(m, t.shape[0] // m, *t.shape[1:])
+
+        text_latents = split_views(text_latents, num_batch_texts)
+        image_latents = split_views(image_latents, num_batch_images)
+        if self.extra_latent_projection:
+            text_latents_extra = split_views(text_latents_extra, num_batch_texts)
+            image_latents_extra = split_views(image_latents_extra, num_batch_images)
+
+        multiview_loss_weight = self.multiview_loss_weight if is_multiview else 0          # x_clip.py:851-855
+        cl_loss_weight = 1 - (self.text_ssl_loss_weight + self.image_ssl_loss_weight + multiview_loss_weight)
+
+        if self.use_all_token_embeds:
+            raise NotImplementedError("use_all_token_embeds (FILIP) training loss is not wired into this build yet")
+
+        spec = XL.ContrastiveSpec(dcl=self.decoupled_contrastive_learning, main_weight=cl_loss_weight,
+                                  multiview_weight=multiview_loss_weight, distributed=self.requires_all_gather,
+                                  assume_equal_batch=self.assume_equal_batch)
+        return XL.contrastive_loss(self.temperature, text_latents, image_latents,
+                                   text_latents_extra if self.extra_latent_projection else None,
+                                   image_latents_extra if self.extra_latent_projection else None, spec)

@@ -69,12 +69,15 @@ template <typename T, int MAXC, bool GEGLU>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ g,
                                                      const T* __restrict__ res, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     int rows, int D, float eps) {
+                                                     int rows, int D, float eps, long ldy, int y_grp) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = lane_id();
     const long row = (long)blockIdx.x * 4 + wave_id();
     if (row >= rows) return;                       // whole wave leaves together; no barriers below
     const int nch = D / VEC;
+    // output row: `y_grp` > 0 leaves one row free in front of every group of y_grp rows (the CLS slot of
+    // the vision encoder output, x_clip.py:389-390), so the final LayerNorm writes straight into [b, 1+n, D]
+    const long yrow = y_grp > 0 ? row + row / y_grp + 1 : row;
     float v[MAXC][VEC];
     load_row<T, MAXC, GEGLU>(x + row * ldx, D, lane, v);
     float mean, var;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] += rv[j];
             }
-            store_vec<T>(y + row * (long)D + c * VEC, o);
+            store_vec<T>(y + yrow * ldy + c * VEC, o);
         }
     }
     if (lane == 0) {
@@ -107,12 +110,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
 // xhat = (x - mean) rstd ; dyg = dy g ; dx = rstd (dyg - mean(dyg) - xhat mean(dyg xhat)) ; dg += dy xhat.
 // With GEGLU the LayerNorm input was a = u gelu(t): du = da gelu(t), dt = da u gelu'(t), written to the
 // [rows, 2D] gradient of the FF1 output.  Waves walk the rows grid-stride and keep their dg partials in
-// registers; one LDS fold + one fp32 atomic per column per work-group at the end.
+// registers; one LDS fold + one fp32 atomic per column per work-group at the end.  `dres` (optional, [rows, D]) is
+// added to dx: the pre-norm residual blocks x + f(LN(x)) hand their skip-path gradient straight to this kernel.
 template <typename T, int MAXC, bool GEGLU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long ldx,
                                                      const T* __restrict__ g, const float* __restrict__ mean_in,
-                                                     const float* __restrict__ rstd_in, T* __restrict__ dx, long lddx,
-                                                     float* __restrict__ dg_accum, int rows, int D) {
+                                                     const float* __restrict__ rstd_in, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, long lddx, float* __restrict__ dg_accum, int rows,
+                                                     int D) {
     constexpr int VEC = Elem<T>::VEC;
     XC_LDS_DYNAMIC(lds);
     float* red = reinterpret_cast<float*>(lds);            // [3][D]
@@ -167,6 +172,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     store_vec<T>(dx + row * lddx + c * VEC, du);
                     store_vec<T>(dx + row * lddx + D + c * VEC, dt);
                 } else {
+                    if (dres != nullptr) {                         // gradient arriving over the residual branch
+                        float rv[VEC];
+                        load_vec<T>(dres + row * (long)D + c * VEC, rv);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) da[j] += rv[j];
+                    }
                     store_vec<T>(dx + row * lddx + c * VEC, da);
                 }
             }

@@ -8,9 +8,10 @@
 //             lse_i = log sum_j exp(S_ij)      (j = i + diag_off left out when dcl)
 //             pos_i = S_{i, i + diag_off}
 //             loss += coef * sum_i (lse_i - pos_i)
-//   backward  G_ij = [a exp(S_ij - lse_q[i]) + c exp(S_ij - lse_k[j])] (1 - dcl * delta) - e * delta     (delta = [j == i + diag_off])
-//             G is written once (storage dtype) and consumed by two ordinary GEMMs:
+//   backward  G_ij = gmul {[a exp(S_ij - lse_q[i]) + c exp(S_ij - lse_k[j])] (1 - dcl * delta) - e * delta}     (delta = [j == i + diag_off])
+//             G (optionally pre-multiplied by scale) is written once (storage dtype) and consumed by two ordinary GEMMs:
 //             dQ = scale * G K ("NN"),  dK = scale * G^T Q ("TN");   dtau += sum_ij G_ij S_ij.
+//   scale = host float x exp(device scalar): the temperature and the upstream loss gradient never visit the host.
 //
 // The S tile is produced by the GEMM main loop (128x128 per work-group, MFMA, fp32 in LDS); the forward
 // epilogue reduces each tile row to an online-softmax partial (max, sum) -- two threads per row -- and a second
@@ -24,7 +25,10 @@ namespace xc {
 struct SimParams {
     const void* Q; const void* K;
     int nq, nk, d;
-    float scale;
+    float scale;                           // S = scale * exp(*log_scale) * Q K^T
+    const float* log_scale;                // device scalar (the temperature parameter tau, x_clip.py:574,736) or null
+    const float* gmul;                     // device scalar multiplying G (the upstream d loss) or null
+    int g_times_scale;                     // store scale * G instead of G (folds temp into the dQ / dK GEMMs)
     int diag_off, dcl;
     int tiles_m, tiles_n;
     // forward
@@ -39,6 +43,8 @@ struct SimParams {
 
 constexpr float SIM_NEG = -3.0e38f;
 
+XC_DEV float sim_scale(const SimParams& p) { return p.log_scale != nullptr ? p.scale * expf(*p.log_scale) : p.scale; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void sim_lse_partial_kernel(SimParams p) {
     constexpr int LDC = GemmCfg<T>::LDC;
@@ -51,6 +57,7 @@ __global__ __launch_bounds__(256) void sim_lse_partial_kernel(SimParams p) {
     gemm_mainloop<T, false, false>(reinterpret_cast<const T*>(p.Q), p.d, reinterpret_cast<const T*>(p.K), p.d, p.nq, p.nk,
                                    m0, n0, 0, p.d, lds);
     // two threads per row, 64 columns each, then one shuffle to merge the pair
+    const float scale = sim_scale(p);
     const int row = tid >> 1, half = tid & 1;
     const int gm = m0 + row;
     const int dcol = gm + p.diag_off;
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(256) void sim_lse_partial_kernel(SimParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int gn = n0 + col + k;
-            const float s = v[k] * p.scale;
+            const float s = v[k] * scale;
             if (gn < p.nk) {
                 if (gn == dcol && gm < p.nq) p.pos[gm] = s;
                 if (!(p.dcl && gn == dcol)) {
@@ -116,6 +123,10 @@ __global__ __launch_bounds__(256) void sim_grad_kernel(SimParams p) {
                                    m0, n0, 0, p.d, lds);
     constexpr int CPR = 128 / VEC;
     T* G = reinterpret_cast<T*>(p.G);
+    const float scale = sim_scale(p);
+    const float gm = p.gmul != nullptr ? *p.gmul : 1.0f;
+    const float a = p.a * gm, c = p.c * gm, e = p.e * gm;
+    const float gs = p.g_times_scale ? scale : 1.0f;
     float dt = 0.f;
     for (int id = tid; id < 128 * CPR; id += GEMM_THREADS) {
         const int row = id / CPR, col = (id % CPR) * VEC;
@@ -127,21 +138,24 @@ __global__ __launch_bounds__(256) void sim_grad_kernel(SimParams p) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const int gn = gn0 + k;
-                const float s = Cs[row * LDC + col + k] * p.scale;
+                const float s = Cs[row * LDC + col + k] * scale;
                 const bool diag = (gn == dcol);
                 float v = 0.f;
                 if (gn < p.nk) {
-                    if (!(p.dcl && diag)) v = p.a * fast_exp(s - lq) + p.c * fast_exp(s - p.lse_k[gn]);
-                    if (diag) v -= p.e;
+                    if (!(p.dcl && diag)) {                 // a zero coefficient switches its term off (no exp -> no inf * 0)
+                        if (a != 0.f) v += a * fast_exp(s - lq);
+                        if (c != 0.f) v += c * fast_exp(s - p.lse_k[gn]);
+                    }
+                    if (diag) v -= e;
                     dt += v * s;
                 }
-                g[k] = v;
+                g[k] = v * gs;
             }
             store_vec<T>(G + (long)gm * p.ldg + gn0, g);
         }
     }
     dt = wave_sum(dt);
-    if (lane_id() == 0) atomic_add(p.dtau, dt);
+    if (lane_id() == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
 }
 
 }  // namespace xc

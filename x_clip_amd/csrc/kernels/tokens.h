@@ -114,13 +114,15 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ img
 }
 
 // ---- vision CLS pooling: mean over tokens (x_clip.py:366-370) ---------------------------------------------
+// x[b, t, :] at x + b * xbs + t * D (xbs = batch stride in elements, so the tokens may sit behind a CLS slot).
 // grid = (batch, ceil(nch / 64)), block = one wave.
 template <typename T>
-__global__ __launch_bounds__(64) void token_mean_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int n, int D) {
+__global__ __launch_bounds__(64) void token_mean_fwd_kernel(const T* __restrict__ x, long xbs, T* __restrict__ out, int n,
+                                                            int D) {
     constexpr int VEC = Elem<T>::VEC;
     const int c = blockIdx.y * 64 + threadIdx.x;
     if (c >= D / VEC) return;
-    const T* src = x + (long)blockIdx.x * n * D + c * VEC;
+    const T* src = x + (long)blockIdx.x * xbs + c * VEC;
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
@@ -136,28 +138,85 @@ __global__ __launch_bounds__(64) void token_mean_fwd_kernel(const T* __restrict_
     store_vec<T>(out + (long)blockIdx.x * D + c * VEC, acc);
 }
 
-// dx[b, t] = (accumulate ? dx[b, t] : 0) + dout[b] / n
+// dx[b, t] = dout[b] / n (+ dsrc[b, t], dsrc rows at dsrc + b * sbs + t * D);  dx is contiguous [batch, n, D]
 template <typename T>
-__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int batch,
-                                                             int n, int D, int accumulate) {
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ dsrc, long sbs,
+                                                             T* __restrict__ dx, int batch, int n, int D) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = lane_id();
     const long row = (long)blockIdx.x * 4 + wave_id();
     if (row >= (long)batch * n) return;
-    const long bi = row / n;
+    const long bi = row / n, t = row % n;
     const float inv = 1.0f / (float)n;
     for (int c = lane; c < D / VEC; c += 64) {
         float v[VEC];
         load_vec<T>(dout + bi * D + c * VEC, v);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) v[k] *= inv;
-        if (accumulate) {
+        if (dsrc != nullptr) {
             float o[VEC];
-            load_vec<T>(dx + row * (long)D + c * VEC, o);
+            load_vec<T>(dsrc + bi * sbs + t * D + c * VEC, o);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) v[k] += o[k];
         }
         store_vec<T>(dx + row * (long)D + c * VEC, v);
+    }
+}
+
+// ---- strided row copy: dst[r, :] = src[r, :]  (rows at src + r*lds / dst + r*ldd) ---------------------------
+// Used to drop the CLS-row gradients into a zeroed [b, n, D] gradient buffer and similar re-layouts.
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd,
+                                                        long rows, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int nch = D / VEC;
+    const long total = rows * nch;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        const long r = id / nch;
+        const int c = (int)(id % nch);
+        st16(dst + r * ldd + c * VEC, ld16(src + r * lds_ + c * VEC));
+    }
+}
+
+// ---- row scatter-add / column sum (patch-embed bias and position-table gradients, x_clip.py:358,382-383) ----
+// table[idx[r], :] += src[r, :]  (idx == nullptr: skipped)    colsum[:] += sum_r src[r, :]  (nullptr: skipped)
+// Waves stride over rows; the column sum stays in registers until the end (one atomic per column per wave).
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const T* __restrict__ src, long lds_, const int* __restrict__ idx,
+                                                               float* __restrict__ table, float* __restrict__ colsum, long rows,
+                                                               int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const int nch = D / VEC;
+    float acc[MAXC][VEC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
+    for (long r = (long)blockIdx.x * 4 + wave_id(); r < rows; r += (long)gridDim.x * 4) {
+        float* trow = (table != nullptr && idx != nullptr) ? table + (long)idx[r] * D : nullptr;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float v[VEC];
+                load_vec<T>(src + r * lds_ + c * VEC, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    acc[i][k] += v[k];
+                    if (trow != nullptr) atomic_add(trow + c * VEC + k, v[k]);
+                }
+            }
+        }
+    }
+    if (colsum != nullptr) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) atomic_add(colsum + c * VEC + k, acc[i][k]);
+        }
     }
 }
 

@@ -50,19 +50,19 @@ inline int chunks_per_lane(int64_t dim, int vec) {
 }
 
 template <typename T, int MAXC>
-void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, float* mean, float* rstd, int rows,
-                   int dim, float eps, int geglu, hipStream_t st) {
+void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, int64_t ldy, int y_grp, float* mean,
+                   float* rstd, int rows, int dim, float eps, int geglu, hipStream_t st) {
     dim3 grid((rows + 3) / 4), block(256);
     if (geglu)
         hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, true>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res,
-                           (T*)y, mean, rstd, rows, dim, eps);
+                           (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
     else
         hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, false>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g,
-                           (const T*)res, (T*)y, mean, rstd, rows, dim, eps);
+                           (const T*)res, (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
 }
 template <typename T, int MAXC>
-void launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd, void* dx,
-                   int64_t lddx, float* dg, int rows, int dim, int geglu, hipStream_t st) {
+void launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
+                   const void* dres, void* dx, int64_t lddx, float* dg, int rows, int dim, int geglu, hipStream_t st) {
     int blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     dim3 grid(blocks), block(256);
@@ -70,11 +70,11 @@ void launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, co
     if (geglu) {
         XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, true>), lds);
         hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, true>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
-                           (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+                           (const T*)g, mean, rstd, (const T*)dres, (T*)dx, (long)lddx, dg, rows, dim);
     } else {
         XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, false>), lds);
         hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, false>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
-                           (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+                           (const T*)g, mean, rstd, (const T*)dres, (T*)dx, (long)lddx, dg, rows, dim);
     }
 }
 
@@ -153,31 +153,34 @@ extern "C" {
 int xclip_abi_version(void) { return XCLIP_ABI_VERSION; }
 const char* xclip_last_error(void) { return g_err; }
 
-int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, float* mean, float* rstd,
-                        int64_t rows, int64_t dim, float eps, int geglu, int dtype, void* stream) {
+int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, int64_t ldy, int64_t y_grp,
+                        float* mean, float* rstd, int64_t rows, int64_t dim, float eps, int geglu, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     const int vec = vec_of(dtype);
     XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec == 0 && ldx % vec == 0, "dim / ldx must be multiples of the 16-byte chunk");
     XC_REQUIRE(ldx >= (geglu ? 2 * dim : dim), "ldx too small");
+    XC_REQUIRE(ldy >= dim && ldy % vec == 0 && y_grp >= 0, "ldy must cover a row, chunk aligned; y_grp >= 0");
     XC_REQUIRE(aligned16(x) && aligned16(g) && aligned16(y) && aligned16(res), "pointers must be 16-byte aligned");
     if (rows == 0) return 0;
     const int cpl = chunks_per_lane(dim, vec);
-#define F(T, C) launch_ln_fwd<T, C>(x, ldx, g, res, y, mean, rstd, (int)rows, (int)dim, eps, geglu, (hipStream_t)stream)
+#define F(T, C) launch_ln_fwd<T, C>(x, ldx, g, res, y, ldy, (int)y_grp, mean, rstd, (int)rows, (int)dim, eps, geglu, (hipStream_t)stream)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
     return check_launch(__func__);
 }
 
 int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
-                        void* dx, int64_t lddx, float* dg_accum, int64_t rows, int64_t dim, int geglu, int dtype, void* stream) {
+                        const void* dres, void* dx, int64_t lddx, float* dg_accum, int64_t rows, int64_t dim, int geglu, int dtype,
+                        void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     const int vec = vec_of(dtype);
     XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec == 0 && ldx % vec == 0 && lddx % vec == 0, "dims must be multiples of the 16-byte chunk");
     XC_REQUIRE(ldx >= (geglu ? 2 * dim : dim) && lddx >= (geglu ? 2 * dim : dim), "leading dimension too small");
-    XC_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(g) && aligned16(dx), "pointers must be 16-byte aligned");
+    XC_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(dres), "pointers must be 16-byte aligned");
+    XC_REQUIRE(!(geglu && dres != nullptr), "dres is not defined for the GEGLU variant");
     if (rows == 0) return 0;
     const int cpl = chunks_per_lane(dim, vec);
-#define F(T, C) launch_ln_bwd<T, C>(dy, x, ldx, g, mean, rstd, dx, lddx, dg_accum, (int)rows, (int)dim, geglu, (hipStream_t)stream)
+#define F(T, C) launch_ln_bwd<T, C>(dy, x, ldx, g, mean, rstd, dres, dx, lddx, dg_accum, (int)rows, (int)dim, geglu, (hipStream_t)stream)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
     return check_launch(__func__);
@@ -266,30 +269,69 @@ int xclip_patchify(const void* image, const int32_t* keep, void* out, int64_t ld
     return check_launch(__func__);
 }
 
-int xclip_token_mean_fwd(const void* x, void* out, int64_t batch, int64_t n, int64_t dim, int dtype, void* stream) {
+int xclip_token_mean_fwd(const void* x, int64_t x_batch_stride, void* out, int64_t batch, int64_t n, int64_t dim, int dtype,
+                         void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     const int vec = vec_of(dtype);
     XC_REQUIRE(dim > 0 && dim % vec == 0 && n > 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(x_batch_stride >= n * dim && x_batch_stride % vec == 0, "batch stride must cover n rows, chunk aligned");
     XC_REQUIRE(aligned16(x) && aligned16(out), "pointers must be 16-byte aligned");
     if (batch == 0) return 0;
     dim3 grid((unsigned)batch, (unsigned)((dim / vec + 63) / 64)), block(64);
     if (dtype == XCLIP_BF16)
-        hipLaunchKernelGGL((token_mean_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, (int)n, (int)dim);
+        hipLaunchKernelGGL((token_mean_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (long)x_batch_stride, (bf16_t*)out, (int)n, (int)dim);
     else
-        hipLaunchKernelGGL((token_mean_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)out, (int)n, (int)dim);
+        hipLaunchKernelGGL((token_mean_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (long)x_batch_stride, (float*)out, (int)n, (int)dim);
     return check_launch(__func__);
 }
 
-int xclip_token_mean_bwd(const void* dout, void* dx, int64_t batch, int64_t n, int64_t dim, int accumulate, int dtype, void* stream) {
+int xclip_token_mean_bwd(const void* dout, const void* dsrc, int64_t src_batch_stride, void* dx, int64_t batch, int64_t n,
+                         int64_t dim, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
-    XC_REQUIRE(dim > 0 && dim % vec_of(dtype) == 0 && n > 0, "dim must be a multiple of the 16-byte chunk");
-    XC_REQUIRE(aligned16(dout) && aligned16(dx), "pointers must be 16-byte aligned");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0 && n > 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(dsrc == nullptr || (src_batch_stride >= n * dim && src_batch_stride % vec == 0), "bad source batch stride");
+    XC_REQUIRE(aligned16(dout) && aligned16(dx) && aligned16(dsrc), "pointers must be 16-byte aligned");
     if (batch == 0) return 0;
     dim3 grid((unsigned)((batch * n + 3) / 4)), block(256);
     if (dtype == XCLIP_BF16)
-        hipLaunchKernelGGL((token_mean_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)dout, (bf16_t*)dx, (int)batch, (int)n, (int)dim, accumulate);
+        hipLaunchKernelGGL((token_mean_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)dsrc, (long)src_batch_stride, (bf16_t*)dx, (int)batch, (int)n, (int)dim);
     else
-        hipLaunchKernelGGL((token_mean_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dout, (float*)dx, (int)batch, (int)n, (int)dim, accumulate);
+        hipLaunchKernelGGL((token_mean_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dout, (const float*)dsrc, (long)src_batch_stride, (float*)dx, (int)batch, (int)n, (int)dim);
+    return check_launch(__func__);
+}
+
+int xclip_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0 && lds % vec == 0 && ldd % vec == 0 && lds >= dim && ldd >= dim, "dim / strides must be chunk multiples covering a row");
+    XC_REQUIRE(aligned16(src) && aligned16(dst), "pointers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    int64_t blocks = (rows * (dim / vec) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((copy_rows_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (long)lds, (bf16_t*)dst, (long)ldd, (long)rows, (int)dim);
+    else
+        hipLaunchKernelGGL((copy_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, (long)lds, (float*)dst, (long)ldd, (long)rows, (int)dim);
+    return check_launch(__func__);
+}
+
+int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, float* table_accum, float* colsum_accum, int64_t rows,
+                           int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0 && lds % vec == 0 && lds >= dim, "dim / lds must be chunk multiples covering a row");
+    XC_REQUIRE(aligned16(src), "pointers must be 16-byte aligned");
+    XC_REQUIRE(table_accum == nullptr || idx != nullptr, "table_accum needs idx");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid((unsigned)blocks), block(256);
+#define F(T, C) hipLaunchKernelGGL((rows_scatter_add_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)src, (long)lds, (const int*)idx, table_accum, colsum_accum, (long)rows, (int)dim)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
     return check_launch(__func__);
 }
 
@@ -411,16 +453,18 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
 
 int64_t xclip_simloss_workspace_bytes(int64_t nq, int64_t nk) { return 2 * ((nk + 127) / 128) * nq * 4; }
 
-int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, int64_t diag_off, int dcl,
-                      float coef, void* workspace, float* pos, float* lse, float* loss_accum, int dtype, void* stream) {
+int xclip_simloss_partial(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
+                          int64_t diag_off, int dcl, void* workspace, int64_t tile_slot0, int64_t tile_slots, float* pos, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(nq > 0 && nk > 0 && d > 0 && d % vec_of(dtype) == 0, "bad shape (d must be a multiple of the 16-byte chunk)");
     XC_REQUIRE(aligned16(Q) && aligned16(K) && workspace != nullptr, "pointers must be 16-byte aligned / workspace required");
     SimParams p;
     memset(&p, 0, sizeof(p));
-    p.Q = Q; p.K = K; p.nq = (int)nq; p.nk = (int)nk; p.d = (int)d; p.scale = scale; p.diag_off = (int)diag_off; p.dcl = dcl;
+    p.Q = Q; p.K = K; p.nq = (int)nq; p.nk = (int)nk; p.d = (int)d; p.scale = scale; p.log_scale = log_scale;
+    p.diag_off = (int)diag_off; p.dcl = dcl;
     p.tiles_m = (int)((nq + 127) / 128); p.tiles_n = (int)((nk + 127) / 128);
-    p.part_m = (float*)workspace; p.part_l = p.part_m + (int64_t)p.tiles_n * nq; p.pos = pos;
+    XC_REQUIRE(tile_slot0 >= 0 && tile_slot0 + p.tiles_n <= tile_slots, "column-tile slots out of range");
+    p.part_m = (float*)workspace + tile_slot0 * nq; p.part_l = (float*)workspace + (tile_slots + tile_slot0) * nq; p.pos = pos;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     if (dtype == XCLIP_BF16) {
@@ -430,14 +474,30 @@ int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int6
         XC_ALLOW_LDS((sim_lse_partial_kernel<float>), GemmCfg<float>::LDS_BYTES);
         hipLaunchKernelGGL((sim_lse_partial_kernel<float>), grid, block, GemmCfg<float>::LDS_BYTES, st, p);
     }
-    hipLaunchKernelGGL(sim_lse_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)p.part_m,
-                       (const float*)p.part_l, (const float*)pos, lse, loss_accum, (int)nq, p.tiles_n, coef);
     return check_launch(__func__);
 }
 
-int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, int64_t diag_off, int dcl,
-                       float a, float c, float e, const float* lse_q, const float* lse_k, void* G, int64_t ldg,
-                       float* dtau_accum, int dtype, void* stream) {
+int xclip_simloss_combine(const void* workspace, int64_t nq, int64_t tile_slots, const float* pos, float* lse, float* loss_accum,
+                          float coef, void* stream) {
+    XC_REQUIRE(nq > 0 && tile_slots > 0 && workspace != nullptr && pos != nullptr && lse != nullptr, "bad arguments");
+    const float* part_m = (const float*)workspace;
+    hipLaunchKernelGGL(sim_lse_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part_m,
+                       part_m + tile_slots * nq, pos, lse, loss_accum, (int)nq, (int)tile_slots, coef);
+    return check_launch(__func__);
+}
+
+int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
+                      int64_t diag_off, int dcl, float coef, void* workspace, float* pos, float* lse, float* loss_accum, int dtype,
+                      void* stream) {
+    const int64_t slots = (nk + 127) / 128;
+    const int rc = xclip_simloss_partial(Q, K, nq, nk, d, scale, log_scale, diag_off, dcl, workspace, 0, slots, pos, dtype, stream);
+    if (rc != 0) return rc;
+    return xclip_simloss_combine(workspace, nq, slots, pos, lse, loss_accum, coef, stream);
+}
+
+int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
+                       int64_t diag_off, int dcl, float a, float c, float e, const float* gmul, int g_times_scale,
+                       const float* lse_q, const float* lse_k, void* G, int64_t ldg, float* dtau_accum, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     const int vec = vec_of(dtype);
     XC_REQUIRE(nq > 0 && nk > 0 && d > 0 && d % vec == 0, "bad shape (d must be a multiple of the 16-byte chunk)");
@@ -445,7 +505,8 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
     XC_REQUIRE(aligned16(Q) && aligned16(K) && aligned16(G), "pointers must be 16-byte aligned");
     SimParams p;
     memset(&p, 0, sizeof(p));
-    p.Q = Q; p.K = K; p.nq = (int)nq; p.nk = (int)nk; p.d = (int)d; p.scale = scale; p.diag_off = (int)diag_off; p.dcl = dcl;
+    p.Q = Q; p.K = K; p.nq = (int)nq; p.nk = (int)nk; p.d = (int)d; p.scale = scale; p.log_scale = log_scale;
+    p.gmul = gmul; p.g_times_scale = g_times_scale; p.diag_off = (int)diag_off; p.dcl = dcl;
     p.tiles_m = (int)((nq + 127) / 128); p.tiles_n = (int)((nk + 127) / 128);
     p.lse_q = lse_q; p.lse_k = lse_k; p.a = a; p.c = c; p.e = e; p.G = G; p.ldg = ldg; p.dtau = dtau_accum;
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,383 @@
+"""Autograd boundary of the MI355X path: every differentiable piece of `CLIP.forward` (reference x_clip/x_clip.py:597-875)
+is one `torch.autograd.Function` whose forward AND backward are explicit sequences of C-ABI kernel launches
+(x_clip_amd.ops -> libxclip_hip.so).  torch provides tensors, streams and the autograd graph between these nodes;
+no arithmetic of the hot path is left to ATen and there is no CPU fallback.
+
+Nodes
+  text_encode     TextTransformer.forward   (x_clip.py:317-338)  tokens -> [b, n+1, D]
+  vision_encode   VisionTransformer.forward (x_clip.py:372-390)  image  -> [b, 1+n_keep, D]
+  transformer     Transformer.forward       (x_clip.py:274-291)  the block stack on its own
+  linear / l2norm / select_row              the latent projections, F.normalize, enc[:, 0]  (x_clip.py:708-715)
+
+The block stack keeps the residual stream in the model dtype and saves, per layer, exactly the tensors its backward
+reads (pre-norm outputs, packed QKV, attention output + log-sum-exp, FF1 output, LayerNorm statistics); with
+`checkpoint=True` (reference `checkpoint_during_training`, x_clip.py:69-79,280-286) it keeps only the two residual
+inputs of a layer and re-runs that layer's forward inside the backward.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+Tensor = torch.Tensor
+LAYER_PARAMS = 8          # attn_norm.g, to_qkv.w, to_out.w, to_out_norm.g, ff_norm.g, ff1.w, ff_inner_norm.g, ff2.w
+
+
+@dataclass(frozen=True)
+class StackSpec:
+    depth: int
+    heads: int
+    dim_head: int = 64
+    checkpoint: bool = False
+
+    def __post_init__(self):
+        if self.dim_head != 64:
+            raise NotImplementedError("x_clip_amd attention kernels are built for dim_head = 64 (the reference default)")
+
+
+class _GainGrads:
+    """All LayerNorm gain gradients of one backward share a flat fp32 accumulator (the LN backward kernels add into
+    it with atomics) and are converted to the parameter dtype by one cast launch at the end."""
+
+    def __init__(self, gains: Sequence[Tensor]):
+        self.sizes = [g.numel() for g in gains]
+        self.dtype = gains[0].dtype
+        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=gains[0].device)
+        self.views = list(self.flat.split(self.sizes))
+
+    def finish(self) -> List[Tensor]:
+        if self.dtype == torch.float32:
+            return self.views
+        return list(ops.cast_from_f32(self.flat, self.dtype).split(self.sizes))
+
+
+# ---- one pre-norm residual block pair (x_clip.py:285-289) --------------------------------------------------------------
+def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor]):
+    g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
+    M, D = x.shape
+    inner = heads * 64
+    h, m1, r1 = ops.layernorm_fwd(x, g_attn)                                           # PreNorm           :126
+    qkv = ops.gemm(h, w_qkv, M, 3 * inner, D)                                          # to_qkv            :216
+    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, 64 ** -0.5)     # scale/mask/softmax :217-244
+    p = ops.gemm(o.view(M, inner), w_out, M, D, inner)                                 # to_out.0          :245
+    x1, m2, r2 = ops.layernorm_fwd(p, g_out, res=x)                                    # to_out.1 + skip   :245,288
+    h2, m3, r3 = ops.layernorm_fwd(x1, g_ff)                                           # PreNorm           :126
+    u = ops.gemm(h2, w_ff1, M, w_ff1.shape[0], D)                                      # net.0             :191
+    a, m4, r4 = ops.layernorm_fwd(u, g_inner, geglu=True)                              # GEGLU + net.2     :192-193
+    x2 = ops.gemm(a, w_ff2, M, D, a.shape[1], residual=x1)                             # net.4 + skip      :195,289
+    return x2, (x, h, m1, r1, qkv, o, lse, p, m2, r2, x1, h2, m3, r3, u, a, m4, r4)
+
+
+def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
+                    gain_acc: Sequence[Tensor], need_w: Sequence[bool]):
+    """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2])"""
+    g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
+    dg_attn, dg_out, dg_ff, dg_inner = gain_acc
+    x, h, m1, r1, qkv, o, lse, p, m2, r2, x1, h2, m3, r3, u, a, m4, r4 = saved
+    M, D = x.shape
+    inner = heads * 64
+    F2 = w_ff1.shape[0]
+    Fh = F2 // 2
+    # feed-forward block
+    da = ops.gemm(dx2, w_ff2, M, Fh, D, b_kmajor=True)
+    d_ff2 = ops.gemm(dx2, a, D, Fh, M, a_kmajor=True, b_kmajor=True) if need_w[3] else None
+    du, _ = ops.layernorm_bwd(da, u, g_inner, m4, r4, geglu=True, dg=dg_inner)
+    del da
+    dh2 = ops.gemm(du, w_ff1, M, D, F2, b_kmajor=True)
+    d_ff1 = ops.gemm(du, h2, F2, D, M, a_kmajor=True, b_kmajor=True) if need_w[2] else None
+    del du
+    dx1, _ = ops.layernorm_bwd(dh2, x1, g_ff, m3, r3, dres=dx2, dg=dg_ff)
+    del dh2
+    # attention block
+    dp, _ = ops.layernorm_bwd(dx1, p, g_out, m2, r2, dg=dg_out)
+    do = ops.gemm(dp, w_out, M, inner, D, b_kmajor=True)
+    d_out = ops.gemm(dp, o.view(M, inner), D, inner, M, a_kmajor=True, b_kmajor=True) if need_w[1] else None
+    del dp
+    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, 64 ** -0.5)
+    del do
+    dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
+    d_qkv = ops.gemm(dqkv.view(M, 3 * inner), h, 3 * inner, D, M, a_kmajor=True, b_kmajor=True) if need_w[0] else None
+    del dqkv
+    dx, _ = ops.layernorm_bwd(dh, x, g_attn, m1, r1, dres=dx1, dg=dg_attn)
+    return dx, [d_qkv, d_out, d_ff1, d_ff2]
+
+
+# ---- the whole stack: norm_in -> depth x (attention, feed-forward) -> norm_out ------------------------------------------
+def stack_forward(x0: Tensor, B: int, n: int, spec: StackSpec, params: Sequence[Tensor], mask: Optional[Tensor],
+                  out: Optional[Tensor] = None, out_group: int = 0, keep_tape: bool = True):
+    """x0 [B*n, D] -> norm_out(...) [B*n, D] (or written into `out`, see ops.layernorm_fwd) and the backward tape."""
+    assert len(params) == 2 + LAYER_PARAMS * spec.depth
+    g_in, g_out = params[0], params[-1]
+    x, m_in, r_in = ops.layernorm_fwd(x0, g_in)
+    layers = []
+    for l in range(spec.depth):
+        W = params[1 + LAYER_PARAMS * l: 1 + LAYER_PARAMS * (l + 1)]
+        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask)
+        if keep_tape:
+            layers.append((saved[0],) if spec.checkpoint else saved)
+        x = x_next
+    y, m_out, r_out = ops.layernorm_fwd(x, g_out, out=out, out_group=out_group)
+    tape = (x0, m_in, r_in, layers, x, m_out, r_out) if keep_tape else None
+    return y, tape
+
+
+def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Sequence[Tensor], mask: Optional[Tensor],
+                   need: Sequence[bool]):
+    """dy [B*n, D] contiguous -> (dx0, grads aligned with `params` (None where not needed))"""
+    x0, m_in, r_in, layers, x_last, m_out, r_out = tape
+    gains = [params[0]] + [params[1 + LAYER_PARAMS * l + k] for l in range(spec.depth) for k in (0, 3, 4, 6)] + [params[-1]]
+    gg = _GainGrads(gains)
+    grads: List[Optional[Tensor]] = [None] * len(params)
+    dx, _ = ops.layernorm_bwd(dy, x_last, params[-1], m_out, r_out, dg=gg.views[-1])
+    for l in reversed(range(spec.depth)):
+        base = 1 + LAYER_PARAMS * l
+        W = params[base: base + LAYER_PARAMS]
+        saved = layers[l]
+        if spec.checkpoint:                      # re-run the layer forward from its saved input
+            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask)
+        need_w = [need[base + 1], need[base + 2], need[base + 5], need[base + 7]]
+        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w)
+        layers[l] = None                         # release this layer's activations
+        grads[base + 1], grads[base + 2], grads[base + 5], grads[base + 7] = dws
+    dx0, _ = ops.layernorm_bwd(dx, x0, params[0], m_in, r_in, dg=gg.views[0])
+    gfin = gg.finish()
+    grads[0], grads[-1] = gfin[0], gfin[-1]
+    for l in range(spec.depth):
+        base = 1 + LAYER_PARAMS * l
+        for j, k in enumerate((0, 3, 4, 6)):
+            grads[base + k] = gfin[1 + 4 * l + j]
+    return dx0, [g if nd else None for g, nd in zip(grads, need)]
+
+
+def _contig_grad(d: Optional[Tensor], like_shape, dtype, device) -> Tensor:
+    if d is None:
+        return torch.zeros(like_shape, dtype=dtype, device=device)
+    return d if d.is_contiguous() else d.contiguous()
+
+
+class _TransformerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec: StackSpec, mask: Optional[Tensor], x: Tensor, *params: Tensor):
+        B, n, D = x.shape
+        keep = any(ctx.needs_input_grad)
+        x2 = ops._c(x).view(B * n, D)
+        y, tape = stack_forward(x2, B, n, spec, params, mask, keep_tape=keep)
+        ctx.spec, ctx.mask, ctx.tape, ctx.params, ctx.shape = spec, mask, tape, params, (B, n, D)
+        return y.view(B, n, D)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        B, n, D = ctx.shape
+        need = ctx.needs_input_grad[3:]
+        dy = _contig_grad(dy, (B, n, D), ctx.params[0].dtype, ctx.params[0].device).view(B * n, D)
+        dx, grads = stack_backward(dy, ctx.tape, B, n, ctx.spec, ctx.params, ctx.mask, need)
+        ctx.tape = None
+        return (None, None, dx.view(B, n, D) if ctx.needs_input_grad[2] else None, *grads)
+
+
+def transformer(x: Tensor, params: Sequence[Tensor], spec: StackSpec, mask: Optional[Tensor] = None) -> Tensor:
+    """Transformer.forward (x_clip.py:274-291) on [b, n, D]; mask: bool [b, n] key-padding mask or None."""
+    return _TransformerFn.apply(spec, mask, x, *params)
+
+
+# ---- text encoder ---------------------------------------------------------------------------------------------------------
+class _TextEncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec: StackSpec, tokens: Tensor, mask: Optional[Tensor], E: Tensor, P: Optional[Tensor],
+                cls: Optional[Tensor], *stack: Tensor):
+        B, n = tokens.shape
+        npos = n + (1 if cls is not None else 0)
+        D = E.shape[1]
+        keep = any(ctx.needs_input_grad)
+        if P is not None and P.shape[0] != n:
+            P = P[:n]                                                   # abs_pos_emb(arange(n))      x_clip.py:323
+        x0 = ops.text_embed_fwd(tokens, E, P, cls)                      # token_emb + pos, cls concat  :320-331
+        kmask = None
+        if mask is not None:                                            # F.pad(mask, (1, 0), True)    :334
+            kmask = mask if cls is None else torch.cat([mask.new_ones(B, 1), mask], dim=1)
+            kmask = kmask.contiguous()
+        y, tape = stack_forward(x0.view(B * npos, D), B, npos, spec, stack, kmask, keep_tape=keep)
+        ctx.spec, ctx.kmask, ctx.tape, ctx.stack = spec, kmask, tape, stack
+        ctx.tokens, ctx.meta = tokens, (B, n, npos, D, E.shape[0], P is not None, cls is not None, E.dtype)
+        return y.view(B, npos, D)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        B, n, npos, D, vocab, has_pos, has_cls, dtype = ctx.meta
+        need = ctx.needs_input_grad
+        dy = _contig_grad(dy, (B, npos, D), dtype, ctx.tokens.device).view(B * npos, D)
+        dx0, sgrads = stack_backward(dy, ctx.tape, B, npos, ctx.spec, ctx.stack, ctx.kmask, need[6:])
+        ctx.tape = None
+        dE = dP = dcls = None
+        if need[3] or need[4] or need[5]:
+            aE, aP, acls = ops.text_embed_bwd(dx0.view(B, npos, D), ctx.tokens, vocab, has_pos, has_cls)
+            dE = ops.cast_from_f32(aE, dtype) if need[3] else None
+            dP = ops.cast_from_f32(aP, dtype) if (need[4] and has_pos) else None
+            dcls = ops.cast_from_f32(acls, dtype) if (need[5] and has_cls) else None
+        return (None, None, None, dE, dP, dcls, *sgrads)
+
+
+def text_encode(tokens: Tensor, mask: Optional[Tensor], E: Tensor, P: Optional[Tensor], cls: Optional[Tensor],
+                stack: Sequence[Tensor], spec: StackSpec) -> Tensor:
+    """TextTransformer.forward (x_clip.py:317-338): int64 tokens [b, n] (+ bool key mask [b, n]) -> [b, n+1, D]."""
+    if tokens.dtype != torch.int64:
+        raise TypeError(f"text tokens must be int64, got {tokens.dtype}")
+    if P is not None and tokens.shape[1] > P.shape[0]:
+        raise IndexError(f"text length {tokens.shape[1]} exceeds max_seq_len {P.shape[0]}")
+    if mask is not None and mask.dtype != torch.bool:
+        mask = mask.bool()
+    return _TextEncodeFn.apply(spec, tokens, mask, E, P, cls, *stack)
+
+
+# ---- vision encoder -----------------------------------------------------------------------------------------------------------
+class _VisionEncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec: StackSpec, patch: int, image: Tensor, keep_idx: Optional[Tensor], w_tok: Tensor, b_tok: Tensor,
+                pos: Tensor, w_cls: Tensor, *stack: Tensor):
+        B, C, H, Wd = image.shape
+        D = w_tok.shape[0]
+        npatch = (H // patch) * (Wd // patch)
+        keep = any(ctx.needs_input_grad)
+        if keep_idx is not None:                                        # PatchDropout keep-set        x_clip.py:140-151
+            nk = keep_idx.shape[1]
+            rowidx = keep_idx.reshape(-1)
+        else:
+            nk = npatch
+            rowidx = torch.arange(npatch, dtype=torch.int32, device=image.device).repeat(B)
+        patches = ops.patchify(image, patch, keep_idx)                  # Rearrange (p1 p2 c)          :357
+        Kp = patches.shape[1]
+        if w_tok.shape[1] != Kp:                                        # K padded to the 16-byte chunk (e.g. 588 -> 592)
+            w_pad = w_tok.new_zeros(D, Kp)
+            ops.copy_rows(w_tok, w_pad[:, : w_tok.shape[1]]) if w_tok.shape[1] % ops.vec(w_tok.dtype) == 0 else \
+                w_pad[:, : w_tok.shape[1]].copy_(w_tok)
+        else:
+            w_pad = w_tok
+        # Linear(patch_dim, dim) + bias + pos_emb[patch]                :358,382-383 (dropout after the add == gather of both)
+        tok = ops.gemm(patches, w_pad, B * nk, D, Kp, bias=b_tok, addrows=pos, rowidx=rowidx)
+        enc = torch.empty(B, 1 + nk, D, dtype=tok.dtype, device=tok.device)
+        y, tape = stack_forward(tok, B, nk, spec, stack, None, out=enc.view(B * (1 + nk), D), out_group=nk, keep_tape=keep)
+        pooled = ops.token_mean_fwd(enc[:, 1:])                         # Reduce('b n d -> b d', 'mean') :367
+        ops.gemm(pooled, w_cls, B, D, D, out=enc[:, 0])                 # to_cls_tokens Linear + concat  :368,389-390
+        ctx.spec, ctx.tape, ctx.stack = spec, tape, stack
+        ctx.saved = (patches if keep else None, rowidx, pooled, w_pad, w_cls)
+        ctx.meta = (B, nk, D, npatch, Kp, w_tok.shape[1], w_tok.dtype)
+        return enc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, denc):
+        B, nk, D, npatch, Kp, Kw, dtype = ctx.meta
+        patches, rowidx, pooled, w_pad, w_cls = ctx.saved
+        need = ctx.needs_input_grad
+        denc = _contig_grad(denc, (B, 1 + nk, D), dtype, pooled.device)
+        dcls = denc[:, 0]                                               # [B, D], row stride (1+nk) D
+        dpooled = ops.gemm(dcls, w_cls, B, D, D, b_kmajor=True)
+        dw_cls = ops.gemm(dcls, pooled, D, D, B, a_kmajor=True, b_kmajor=True) if need[7] else None
+        dy = ops.token_mean_bwd(dpooled, nk, add=denc[:, 1:])           # mean-pool backward + direct token gradients
+        dtok, sgrads = stack_backward(dy.view(B * nk, D), ctx.tape, B, nk, ctx.spec, ctx.stack, None, need[8:])
+        ctx.tape = None
+        dw_tok = db = dpos = None
+        if need[4]:
+            dw_tok = ops.gemm(dtok, patches, D, Kp, B * nk, a_kmajor=True, b_kmajor=True)
+            if Kp != Kw:
+                dw_tok = dw_tok[:, :Kw].contiguous()
+        if need[5] or need[6]:
+            acc_b = torch.zeros(D, dtype=torch.float32, device=dtok.device) if need[5] else None
+            acc_p = torch.zeros(npatch, D, dtype=torch.float32, device=dtok.device) if need[6] else None
+            ops.rows_scatter_add(dtok, rowidx, acc_p, acc_b)
+            db = ops.cast_from_f32(acc_b, dtype) if need[5] else None
+            dpos = ops.cast_from_f32(acc_p, dtype) if need[6] else None
+        return (None, None, None, None, dw_tok, db, dpos, dw_cls, *sgrads)
+
+
+def vision_encode(image: Tensor, keep_idx: Optional[Tensor], patch: int, w_tok: Tensor, b_tok: Tensor, pos: Tensor,
+                  w_cls: Tensor, stack: Sequence[Tensor], spec: StackSpec) -> Tensor:
+    """VisionTransformer.forward (x_clip.py:372-390): image [b, c, H, W] -> [b, 1 + n_keep, D].  keep_idx: int32
+    [b, n_keep] kept patch indices (the PatchDropout draw) or None to keep all patches.  The image itself receives no
+    gradient."""
+    if image.dtype != w_tok.dtype:
+        raise TypeError(f"image dtype {image.dtype} must match the model dtype {w_tok.dtype}")
+    if keep_idx is not None and keep_idx.dtype != torch.int32:
+        keep_idx = keep_idx.to(torch.int32)
+    return _VisionEncodeFn.apply(spec, patch, image, None if keep_idx is None else keep_idx.contiguous(), w_tok, b_tok, pos,
+                                 w_cls, *stack)
+
+
+# ---- small differentiable pieces of the head -------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor):
+        lead = x.shape[:-1]
+        K = x.shape[-1]
+        x2 = x if (x.dim() == 2 and x.stride(1) == 1) else ops._c(x).view(-1, K)
+        M, N = x2.shape[0], w.shape[0]
+        y = ops.gemm(x2, w, M, N, K)
+        ctx.save_for_backward(x2, w)
+        ctx.lead = lead
+        return y.view(*lead, N)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = ops._c(dy).view(M, N)
+        dx = ops.gemm(dy2, w, M, K, N, b_kmajor=True).view(*ctx.lead, K) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm(dy2, x2, N, K, M, a_kmajor=True, b_kmajor=True) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def linear(x: Tensor, w: Tensor) -> Tensor:
+    """bias-free nn.Linear (to_text_latent / to_visual_latent, x_clip.py:556,570,713-714)"""
+    return _LinearFn.apply(x, w)
+
+
+class _L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        y, rn = ops.l2norm_fwd(x)
+        ctx.save_for_backward(y, rn)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        y, rn = ctx.saved_tensors
+        return ops.l2norm_bwd(ops._c(dy), y, rn)
+
+
+def l2norm(x: Tensor) -> Tensor:
+    """F.normalize(dim=-1) (x_clip.py:54-55,715)"""
+    return _L2NormFn.apply(x)
+
+
+class _SelectRowFn(torch.autograd.Function):
+    """enc[:, index] as a contiguous [b, D] tensor (x_clip.py:708-709); the backward scatters into a zeroed buffer."""
+
+    @staticmethod
+    def forward(ctx, enc: Tensor, index: int):
+        B, n, D = enc.shape
+        out = torch.empty(B, D, dtype=enc.dtype, device=enc.device)
+        ops.copy_rows(enc[:, index], out)
+        ctx.meta = (B, n, D, index)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        B, n, D, index = ctx.meta
+        denc = torch.zeros(B, n, D, dtype=dout.dtype, device=dout.device)
+        ops.copy_rows(ops._c(dout), denc[:, index])
+        return denc, None
+
+
+def select_row(enc: Tensor, index: int = 0) -> Tensor:
+    return _SelectRowFn.apply(enc, index)

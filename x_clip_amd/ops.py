@@ -69,40 +69,56 @@ def workspace(device, nbytes: int) -> Optional[Tensor]:
 
 
 # ---- LayerNorm family ---------------------------------------------------------------------------------------------
-def layernorm_fwd(x: Tensor, g: Tensor, res: Optional[Tensor] = None, geglu: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
-    """x: [..., D] (or [..., 2D] with geglu) -> y [..., D], mean [rows], rstd [rows]"""
-    _dev_check(x, g, res)
+def layernorm_fwd(x: Tensor, g: Tensor, res: Optional[Tensor] = None, geglu: bool = False, out: Optional[Tensor] = None,
+                  out_group: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
+    """x: [..., D] (or [..., 2D] with geglu) -> y [..., D], mean [rows], rstd [rows].
+    `out` (+ `out_group` = n): write row r of the result to row r + r // n + 1 of the 2-D buffer `out`, i.e. behind
+    the CLS slot of a [b, 1+n, D] encoder output viewed as [b * (1+n), D]."""
+    _dev_check(x, g, res, out)
     x = _c(x)
     width = x.shape[-1]
     dim = width // 2 if geglu else width
     rows = x.numel() // width
-    y = torch.empty(*x.shape[:-1], dim, dtype=x.dtype, device=x.device)
+    if out is None:
+        assert out_group == 0
+        y = torch.empty(*x.shape[:-1], dim, dtype=x.dtype, device=x.device)
+        ldy = dim
+    else:
+        y = out
+        assert y.dim() == 2 and y.stride(1) == 1 and y.shape[1] == dim and y.dtype == x.dtype
+        assert y.shape[0] >= rows + (rows // out_group if out_group else 0)
+        ldy = y.stride(0)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     if res is not None:
         res = _c(res)
-        assert res.shape == y.shape and res.dtype == x.dtype
+        assert res.numel() == rows * dim and res.dtype == x.dtype
     assert g.dtype == x.dtype and g.numel() == dim
     L = _lib.lib()
-    _lib.check(L.xclip_layernorm_fwd(x.data_ptr(), width, _c(g).data_ptr(), _ptr(res), y.data_ptr(), mean.data_ptr(),
-                                     rstd.data_ptr(), rows, dim, ln_eps(x.dtype), int(geglu), dtype_code(x), _stream(x)),
-               "xclip_layernorm_fwd")
+    _lib.check(L.xclip_layernorm_fwd(x.data_ptr(), width, _c(g).data_ptr(), _ptr(res), y.data_ptr(), ldy, out_group,
+                                     mean.data_ptr(), rstd.data_ptr(), rows, dim, ln_eps(x.dtype), int(geglu), dtype_code(x),
+                                     _stream(x)), "xclip_layernorm_fwd")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, geglu: bool = False) -> Tuple[Tensor, Tensor]:
-    """-> dx (shape of x), dg (fp32 [D])"""
-    _dev_check(dy, x, g)
+def layernorm_bwd(dy: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, geglu: bool = False,
+                  dres: Optional[Tensor] = None, dg: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """-> dx (shape of x; + dres when given), dg (fp32 [D]; accumulated into `dg` when passed)"""
+    _dev_check(dy, x, g, dres)
     dy, x = _c(dy), _c(x)
     width = x.shape[-1]
     dim = width // 2 if geglu else width
     rows = x.numel() // width
     dx = torch.empty_like(x)
-    dg = torch.zeros(dim, dtype=torch.float32, device=x.device)
+    if dg is None:
+        dg = torch.zeros(dim, dtype=torch.float32, device=x.device)
+    if dres is not None:
+        dres = _c(dres)
+        assert dres.numel() == rows * dim and dres.dtype == x.dtype
     L = _lib.lib()
     _lib.check(L.xclip_layernorm_bwd(dy.data_ptr(), x.data_ptr(), width, _c(g).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                     dx.data_ptr(), width, dg.data_ptr(), rows, dim, int(geglu), dtype_code(x), _stream(x)),
-               "xclip_layernorm_bwd")
+                                     _ptr(dres), dx.data_ptr(), width, dg.data_ptr(), rows, dim, int(geglu), dtype_code(x),
+                                     _stream(x)), "xclip_layernorm_bwd")
     return dx, dg
 
 
@@ -175,24 +191,51 @@ def patchify(image: Tensor, patch: int, keep: Optional[Tensor]) -> Tensor:
 
 
 def token_mean_fwd(x: Tensor) -> Tensor:
+    """x [b, n, D] (inner two dims contiguous, any batch stride) -> [b, D]"""
     _dev_check(x)
-    x = _c(x)
     b, n, dim = x.shape
+    assert x.stride(2) == 1 and x.stride(1) == dim
     out = torch.empty(b, dim, dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().xclip_token_mean_fwd(x.data_ptr(), out.data_ptr(), b, n, dim, dtype_code(x), _stream(x)),
+    _lib.check(_lib.lib().xclip_token_mean_fwd(x.data_ptr(), x.stride(0), out.data_ptr(), b, n, dim, dtype_code(x), _stream(x)),
                "xclip_token_mean_fwd")
     return out
 
 
-def token_mean_bwd(dout: Tensor, n: int, into: Optional[Tensor] = None) -> Tensor:
-    _dev_check(dout, into)
+def token_mean_bwd(dout: Tensor, n: int, add: Optional[Tensor] = None) -> Tensor:
+    """dx[b, t] = dout[b] / n (+ add[b, t]); add: [b, n, D] with contiguous inner dims and any batch stride"""
+    _dev_check(dout, add)
     dout = _c(dout)
     b, dim = dout.shape
-    dx = into if into is not None else torch.empty(b, n, dim, dtype=dout.dtype, device=dout.device)
-    assert dx.is_contiguous()
-    _lib.check(_lib.lib().xclip_token_mean_bwd(dout.data_ptr(), dx.data_ptr(), b, n, dim, int(into is not None),
-                                               dtype_code(dout), _stream(dout)), "xclip_token_mean_bwd")
+    dx = torch.empty(b, n, dim, dtype=dout.dtype, device=dout.device)
+    if add is not None:
+        assert tuple(add.shape) == (b, n, dim) and add.stride(2) == 1 and add.stride(1) == dim and add.dtype == dout.dtype
+    _lib.check(_lib.lib().xclip_token_mean_bwd(dout.data_ptr(), _ptr(add), 0 if add is None else add.stride(0), dx.data_ptr(), b, n,
+                                               dim, dtype_code(dout), _stream(dout)), "xclip_token_mean_bwd")
     return dx
+
+
+def copy_rows(src: Tensor, dst: Tensor) -> Tensor:
+    """dst[r] = src[r] for 2-D views with unit inner stride and arbitrary row strides"""
+    _dev_check(src, dst)
+    assert src.dim() == 2 and dst.dim() == 2 and src.shape == dst.shape and src.stride(1) == 1 and dst.stride(1) == 1
+    assert src.dtype == dst.dtype
+    rows, dim = src.shape
+    _lib.check(_lib.lib().xclip_copy_rows(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), rows, dim, dtype_code(src),
+                                          _stream(src)), "xclip_copy_rows")
+    return dst
+
+
+def rows_scatter_add(src: Tensor, idx: Optional[Tensor], table: Optional[Tensor], colsum: Optional[Tensor]):
+    """table[idx[r]] += src[r] (fp32 table) and colsum += src.sum(0) (fp32); either accumulator may be None"""
+    _dev_check(src, idx, table, colsum)
+    assert src.dim() == 2 and src.stride(1) == 1
+    rows, dim = src.shape
+    if idx is not None:
+        assert idx.dtype == torch.int32 and idx.numel() == rows and idx.is_contiguous()
+    for t in (table, colsum):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    _lib.check(_lib.lib().xclip_rows_scatter_add(src.data_ptr(), src.stride(0), _ptr(idx), _ptr(table), _ptr(colsum), rows, dim,
+                                                 dtype_code(src), _stream(src)), "xclip_rows_scatter_add")
 
 
 def cast_from_f32(src: Tensor, dtype, scale: float = 1.0) -> Tensor:
@@ -265,33 +308,68 @@ def attention_bwd(qkv: Tensor, mask: Optional[Tensor], out: Tensor, dout: Tensor
 
 
 # ---- contrastive head ---------------------------------------------------------------------------------------------------
-def simloss_fwd(q: Tensor, k: Tensor, scale: float, diag_off: int, dcl: bool, coef: float, loss_accum: Optional[Tensor]):
-    """-> lse [nq] fp32, pos [nq] fp32;  loss_accum (fp32 scalar tensor) += coef * sum(lse - pos)"""
-    _dev_check(q, k, loss_accum)
-    q, k = _c(q), _c(k)
+def _scale_args(scale, log_scale: Optional[Tensor]):
+    if log_scale is not None:
+        assert log_scale.dtype == torch.float32 and log_scale.numel() == 1
+    return float(scale), _ptr(log_scale)
+
+
+def simloss_fwd(q: Tensor, k: Tensor, scale: float, diag_off: int, dcl: bool, coef: float, loss_accum: Optional[Tensor],
+                log_scale: Optional[Tensor] = None):
+    """S = scale * exp(log_scale) * q k^T -> lse [nq] fp32, pos [nq] fp32;  loss_accum (fp32 scalar) += coef * sum(lse - pos)"""
+    return simloss_chunked_fwd(q, [(k, 0)], scale, diag_off, dcl, coef, loss_accum, log_scale)
+
+
+def simloss_chunked_fwd(q: Tensor, k_chunks, scale: float, diag_off: int, dcl: bool, coef: float, loss_accum: Optional[Tensor],
+                        log_scale: Optional[Tensor] = None, before_chunk=None):
+    """Same result as simloss_fwd(q, K) with K given as a list of (chunk [nk_c, d], first global column) in the order they
+    should be consumed; `before_chunk(c)` (optional) runs before chunk c is launched, e.g. to wait for its all-gather."""
+    _dev_check(q, *[kc for kc, _ in k_chunks], loss_accum, log_scale)
+    q = _c(q)
     nq, d = q.shape
-    nk = k.shape[0]
     L = _lib.lib()
-    ws = workspace(q.device, L.xclip_simloss_workspace_bytes(nq, nk))
+    sc, lsp = _scale_args(scale, log_scale)
+    slots = sum((kc.shape[0] + 127) // 128 for kc, _ in k_chunks)
+    ws = workspace(q.device, 2 * slots * nq * 4)
     pos = torch.zeros(nq, dtype=torch.float32, device=q.device)
     lse = torch.empty(nq, dtype=torch.float32, device=q.device)
-    _lib.check(L.xclip_simloss_fwd(q.data_ptr(), k.data_ptr(), nq, nk, d, scale, diag_off, int(dcl), coef, ws.data_ptr(),
-                                   pos.data_ptr(), lse.data_ptr(), _ptr(loss_accum), dtype_code(q), _stream(q)),
-               "xclip_simloss_fwd")
+    slot0 = 0
+    for c, (kc, col0) in enumerate(k_chunks):
+        if before_chunk is not None:
+            before_chunk(c)
+        kc = _c(kc)
+        nk = kc.shape[0]
+        assert kc.shape[1] == d and kc.dtype == q.dtype
+        _lib.check(L.xclip_simloss_partial(q.data_ptr(), kc.data_ptr(), nq, nk, d, sc, lsp, diag_off - col0, int(dcl), ws.data_ptr(),
+                                           slot0, slots, pos.data_ptr(), dtype_code(q), _stream(q)), "xclip_simloss_partial")
+        slot0 += (nk + 127) // 128
+    _lib.check(L.xclip_simloss_combine(ws.data_ptr(), nq, slots, pos.data_ptr(), lse.data_ptr(), _ptr(loss_accum), coef, _stream(q)),
+               "xclip_simloss_combine")
     return lse, pos
 
 
 def simloss_grad(q: Tensor, k: Tensor, scale: float, diag_off: int, dcl: bool, a: float, c: float, e: float, lse_q: Tensor,
-                 lse_k: Tensor, dtau_accum: Tensor) -> Tensor:
-    """-> G [nq, nk rounded up to the chunk] in q.dtype (padding columns are zero); dtau_accum += sum(G * S)"""
-    _dev_check(q, k, lse_q, lse_k, dtau_accum)
+                 lse_k: Tensor, dtau_accum: Optional[Tensor], log_scale: Optional[Tensor] = None, gmul: Optional[Tensor] = None,
+                 times_scale: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """-> G [nq, nk rounded up to the chunk] in q.dtype (padding columns are zero); dtau_accum += sum(G * S).
+    `out`: a [nq, >= roundup(nk)] view (unit inner stride) to write into, e.g. a column block of a wider G."""
+    _dev_check(q, k, lse_q, lse_k, dtau_accum, log_scale, gmul, out)
     q, k = _c(q), _c(k)
     nq, d = q.shape
     nk = k.shape[0]
     v = vec(q.dtype)
     ldg = (nk + v - 1) // v * v
-    G = torch.empty(nq, ldg, dtype=q.dtype, device=q.device)
-    _lib.check(_lib.lib().xclip_simloss_grad(q.data_ptr(), k.data_ptr(), nq, nk, d, scale, diag_off, int(dcl), a, c, e,
-                                             lse_q.data_ptr(), lse_k.data_ptr(), G.data_ptr(), ldg, dtau_accum.data_ptr(),
-                                             dtype_code(q), _stream(q)), "xclip_simloss_grad")
+    if out is None:
+        G = torch.empty(nq, ldg, dtype=q.dtype, device=q.device)
+    else:
+        G = out
+        assert G.dim() == 2 and G.stride(1) == 1 and G.shape[0] == nq and G.shape[1] >= ldg and G.dtype == q.dtype
+    assert lse_q.dtype == torch.float32 and lse_k.dtype == torch.float32 and lse_q.numel() == nq and lse_k.numel() == nk
+    assert lse_q.is_contiguous() and lse_k.is_contiguous()
+    if gmul is not None:
+        assert gmul.dtype == torch.float32 and gmul.numel() == 1
+    sc, lsp = _scale_args(scale, log_scale)
+    _lib.check(_lib.lib().xclip_simloss_grad(q.data_ptr(), k.data_ptr(), nq, nk, d, sc, lsp, diag_off, int(dcl), a, c, e, _ptr(gmul),
+                                             int(times_scale), lse_q.data_ptr(), lse_k.data_ptr(), G.data_ptr(), G.stride(0),
+                                             _ptr(dtau_accum), dtype_code(q), _stream(q)), "xclip_simloss_grad")
     return G
