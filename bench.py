@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py -- image-text pairs/s (forward + backward) of the CLIP contrastive-training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one `loss = clip(text, image, return_loss=True); loss.backward()` on one synthetic batch (randint tokens,
+randn images, random-init weights of the reference's default architecture), plus the data-parallel gradient all-reduce
+when N > 1.  Workload = BASELINE.json configs[1]: default CLIP (dim 512, depth 6/6, image 256 patch 32, text seq 256,
+patch dropout 0.5), bf16, local batch 1024, InfoNCE; weak scaling (1024 pairs per GPU, global batch 1024 N, the global
+similarity matrix sharded over the ranks after an RCCL all-gather of the latents).
+
+Prints ONE JSON line on rank 0 (metric/value/unit/..., plus `roofline` for the dominant kernel family -- the MFMA GEMM --
+measured live with HIP events on the launch stream during the timed steps, and `cpu_baseline` = the CPU oracle timed on a
+bounded sample on this host's cores, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_BF16 = 2.5e15            # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def model_flops_per_pair(model, n_text_tokens, n_img_tokens, n_patches_embedded):
+    """algorithmic forward FLOPs per (text, image) pair of the work this implementation executes;
+    fwd + bwd = 3x.  Patch embedding is counted on the patches actually embedded (kept patches only)."""
+    def tower(t, n):
+        D, I = t.dim, t.heads * t.dim_head
+        per_tok = 2 * D * 3 * I + 2 * I * D + 2 * D * 8 * D + 2 * 4 * D * D
+        return t.depth * (n * per_tok + 4 * n * n * I)
+    tt, vt = model.text_transformer.transformer, model.visual_transformer.transformer
+    patch_dim = model.visual_transformer.to_tokens[1].weight.shape[1]
+    f = tower(tt, n_text_tokens) + tower(vt, n_img_tokens)
+    f += 2 * n_patches_embedded * patch_dim * vt.dim + 2 * vt.dim * vt.dim
+    f += 2 * tt.dim * model.dim_latent + 2 * vt.dim * model.dim_latent
+    return f
+
+
+def cpu_baseline(budget_s=20.0):
+    """the CPU oracle (oracle/clip_oracle.py = torch-CPU restatement of the reference, pinned to reference golden vectors)
+    timed on a bounded sample of the same workload: default architecture, fp32, batch 8, forward + backward."""
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig()
+    sd = {k: v.requires_grad_(True) for k, v in O.make_state_dict(cfg, 0, torch.float32).items()}
+    b = 8
+    text, image, _, _ = O.make_inputs(cfg, b, 1)
+    image = image.float()
+    g = torch.Generator().manual_seed(2)
+    keep = torch.randn(b, cfg.num_patches, generator=g).topk(cfg.num_patches // 2, dim=-1).indices
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        loss = O.clip_forward(sd, cfg, text, image, keep_idx=keep)
+        loss.backward()
+    step()
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        step()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 20:
+            break
+    return {"value": round(b * iters / el, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/clip_oracle.py clip_forward+backward, default CLIP fp32, batch {b}, patch dropout 0.5, "
+                      f"{iters} steps in {el:.1f} s on {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the per-launch GEMM event probe")
+    ap.add_argument("--dcl", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)          # BEFORE the model: CLIP latches requires_all_gather
+
+    from x_clip_amd import CLIP, ops
+    from x_clip_amd.distributed import GradSync
+
+    torch.manual_seed(0)
+    model = CLIP(decoupled_contrastive_learning=args.dcl).to(torch.bfloat16).to(dev)
+    model.train()
+    model.assume_equal_batch = True
+    sync = GradSync(model) if world > 1 else None
+
+    b = args.batch
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    text = torch.randint(0, 10000, (b, model.text_seq_len), generator=g).to(dev)
+    image = torch.randn(b, 3, model.image_size, model.image_size, generator=g).to(torch.bfloat16).to(dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss = model(text, image, return_loss=True)
+        loss.backward()
+        if sync is not None:
+            sync.finish()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    probe = None if args.no_probe else ops.GemmProbe()
+    fence()
+    t0 = time.perf_counter()
+    if probe is not None:
+        probe.__enter__()
+    for _ in range(args.steps):
+        loss = step()
+    if probe is not None:
+        probe.__exit__(None, None, None)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.detach())
+
+    vt = model.visual_transformer
+    n_keep = max(1, int(vt.num_patches * (1 - vt.patch_dropout.prob)))
+    fwd_flops = model_flops_per_pair(model, model.text_seq_len + 1, n_keep, n_keep)
+    pairs = b * world * args.steps
+    value = pairs / elapsed
+    out = {
+        "metric": "image-text pairs/sec (fwd+bwd) at global batch; MFMA% + HBM GB/s",
+        "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic (randint tokens, randn images, random-init weights)",
+        "config": {"workload": "BASELINE configs[1]: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, "
+                               "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ", fwd+bwd",
+                   "local_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
+                   "gflop_per_pair_fwd_bwd": round(3 * fwd_flops / 1e9, 3)},
+        "model_mfma_frac": round(value * 3 * fwd_flops / (world * MFMA_PEAK_BF16), 4),
+        "loss": round(loss_val, 5),
+    }
+    if probe is not None:
+        launches, flops, secs = probe.summary()
+        ach = flops / secs / 1e12 if secs > 0 else 0.0
+        out["roofline"] = {"kernel": "xclip_gemm (gemm_kernel<bf16> NT/NN/TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
+                           "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                           "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": None,
+                           "launches_per_step": launches // max(args.steps, 1),
+                           "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
+                           "share_of_step": round(secs / elapsed, 4)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

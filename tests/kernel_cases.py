@@ -263,3 +263,87 @@ def case_simloss_closed_form(dev, dtype, B, d, dcl):
     sc = float(np.abs(want["dT"]).max())
     close(dT, torch.tensor(want["dT"]), dtype, "dT", scale=sc, mult=4.0)
     close(dI, torch.tensor(want["dI"]), dtype, "dI", scale=sc, mult=4.0)
+
+
+def case_layernorm_residual_paths(dev, dtype, rows, dim, grp):
+    """LN forward writing behind a CLS slot of every `grp` rows + LN backward with the skip-path gradient added"""
+    x = rnd((rows, dim), dtype, 30)
+    g = (1 + 0.1 * rnd((dim,), torch.float32, 31)).to(dtype)
+    dy = rnd((rows, dim), dtype, 32)
+    dres = rnd((rows, dim), dtype, 33)
+    nb = rows // grp
+    out = torch.full((nb * (grp + 1), dim), 7.0, dtype=dtype).to(dev)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), g.to(dev), out=out, out_group=grp)
+    x64 = ref64(x).requires_grad_(True)
+    g64 = ref64(g)
+    mu = x64.mean(-1, keepdim=True)
+    var = ((x64 - mu) ** 2).mean(-1, keepdim=True)
+    yr = (x64 - mu) * torch.rsqrt(var + ops.ln_eps(dtype)) * g64
+    got = out.cpu().view(nb, grp + 1, dim)
+    close(got[:, 1:].reshape(rows, dim), yr, dtype, "ln grouped y")
+    assert float((got[:, 0].float() - 7.0).abs().max()) == 0.0, "CLS slots must stay untouched"
+    yr.backward(ref64(dy))
+    dx, _ = ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, dres=dres.to(dev))
+    close(dx, x64.grad + ref64(dres), dtype, "ln dx + dres", mult=2.0)
+
+
+def case_row_moves(dev, dtype):
+    """copy_rows on strided views, rows_scatter_add (table + column sum)"""
+    src = rnd((6, 5, 64), dtype, 34).to(dev)
+    dst = torch.zeros(6, 64, dtype=dtype, device=dev)
+    ops.copy_rows(src[:, 2], dst)
+    assert torch.equal(dst.cpu(), src[:, 2].cpu())
+    back = torch.zeros(6, 5, 64, dtype=dtype, device=dev)
+    ops.copy_rows(dst, back[:, 3])
+    assert torch.equal(back[:, 3].cpu(), dst.cpu()) and float(back[:, :3].abs().sum()) == 0.0
+    rows, D, T = 300, 72 if dtype == torch.bfloat16 else 68, 7
+    s = rnd((rows, D), dtype, 35)
+    idx = (torch.arange(rows) * 5 % T).to(torch.int32)
+    table = torch.zeros(T, D, dtype=torch.float32, device=dev)
+    col = torch.zeros(D, dtype=torch.float32, device=dev)
+    ops.rows_scatter_add(s.to(dev), idx.to(dev), table, col)
+    want = torch.zeros(T, D, dtype=torch.float64).index_add_(0, idx.long(), ref64(s))
+    close(table, want, torch.float32, "scatter table", mult=8.0)
+    close(col, ref64(s).sum(0), torch.float32, "column sum", mult=8.0)
+
+
+def case_simloss_chunked(dev, dtype, dcl):
+    """K consumed in rank-sized chunks (local chunk first), temperature as a device scalar, gmul + scale folded into G"""
+    nq, d, sizes, rank = 24, 64, [24, 16, 24], 2
+    B = sum(sizes)
+    off = sum(sizes[:rank])
+    T = O.l2_normalize(rnd((nq, d), torch.float32, 36)).to(dtype)
+    I = O.l2_normalize(rnd((B, d), torch.float32, 37)).to(dtype)
+    tau = torch.tensor([0.9], dtype=torch.float32)
+    temp = math.exp(0.9)
+    offs = [sum(sizes[:r]) for r in range(len(sizes))]
+    order = [rank] + [r for r in range(len(sizes)) if r != rank]
+    chunks = [(I[offs[r]: offs[r] + sizes[r]].contiguous().to(dev), offs[r]) for r in order]
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    seen = []
+    lse, pos = ops.simloss_chunked_fwd(T.to(dev), chunks, 1.0, off, dcl, 0.25, loss, log_scale=tau.to(dev),
+                                       before_chunk=lambda c: seen.append(c))
+    assert seen == [0, 1, 2]
+    lse1, pos1 = ops.simloss_fwd(T.to(dev), I.to(dev), temp, off, dcl, 0.25, None)
+    close(lse, lse1.cpu(), dtype, "chunked lse", scale=float(lse1.abs().max()))
+    close(pos, pos1.cpu(), dtype, "chunked pos", scale=float(pos1.abs().max()) + 1e-6)
+    S = temp * ref64(T) @ ref64(I).t()
+    diag = torch.zeros(nq, B, dtype=torch.bool)
+    diag[torch.arange(nq), torch.arange(nq) + off] = True
+    E = S.exp().masked_fill(diag, 0.0) if dcl else S.exp()
+    close(loss, (0.25 * (E.sum(1).log() - S[diag]).sum()).reshape(1), dtype, "chunked loss", mult=2.0)
+    # G written chunk-wise into a wide buffer, pre-multiplied by temp and by a device-side upstream gradient
+    a, c = 0.02, 0.0
+    gm = torch.tensor([1.7], dtype=torch.float32)
+    v = ops.vec(dtype)
+    G = torch.zeros(nq, B, dtype=dtype, device=dev)
+    dtau = torch.zeros(1, dtype=torch.float32, device=dev)
+    lk = torch.zeros(B, dtype=torch.float32, device=dev)
+    for (K, col0) in chunks:
+        ops.simloss_grad(T.to(dev), K, 1.0, off - col0, dcl, a, c, a + c, lse, lk[col0: col0 + K.shape[0]].contiguous(), dtau,
+                         log_scale=tau.to(dev), gmul=gm.to(dev), times_scale=True, out=G[:, col0: col0 + K.shape[0]])
+    lq = lse.cpu().double()
+    offm = (~diag).double() if dcl else torch.ones_like(S)
+    Gr = 1.7 * (a * (S - lq[:, None]).exp() * offm - (a + c) * diag.double())
+    close(G, temp * Gr, dtype, "chunked G", mult=2.0)
+    close(dtau, (Gr * S).sum().reshape(1), dtype, "chunked dtau", scale=float((Gr * S).abs().sum()), mult=2.0)

@@ -1,0 +1,138 @@
+"""MI355X end-to-end parity of the product `x_clip_amd.CLIP` through libxclip_hip.so: reference golden fixtures, the fp64
+oracle at small and medium shapes (fp32 and bf16), and size-independent properties at the full BASELINE configs[1]
+shape (local batch 1024, bf16)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+import clip_cases as C  # noqa: E402
+from oracle import clip_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+MID = O.ClipConfig(dim_text=512, dim_image=512, dim_latent=512, num_text_tokens=2000, text_enc_depth=2, text_seq_len=70,
+                   text_heads=8, visual_enc_depth=2, visual_image_size=128, visual_patch_size=32, visual_heads=8)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_library():
+    from x_clip_amd import _lib
+    _lib._use_library_for_tests(None)
+    _lib.lib()                       # raises if libxclip_hip.so is missing: there is no fallback
+    yield
+
+
+@pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
+                                  "cfg1_patchdrop"])
+def test_clip_matches_reference_fixture(name):
+    C.case_golden(DEV, name)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_cfg1_vs_oracle(dtype):
+    C.case_vs_oracle(DEV, dtype, O.CFG1, 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_mid_vs_oracle(dtype):
+    C.case_vs_oracle(DEV, dtype, MID, 24)
+
+
+def test_mid_patch_dropout_multiview_dcl_fp32():
+    import dataclasses
+    cfg = dataclasses.replace(MID, decoupled_contrastive_learning=True, extra_latent_projection=True)
+    C.case_vs_oracle(DEV, torch.float32, cfg, 16, n_aug_text=1, n_aug_image=1, patch_keep=8)
+
+
+def test_checkpointing_is_bit_identical():
+    from x_clip_amd import CLIP
+    torch.manual_seed(3)
+    a = CLIP(**MID.ctor_kwargs(), visual_patch_dropout=0.0).to(DEV).train()
+    b = CLIP(**MID.ctor_kwargs(), visual_patch_dropout=0.0, checkpoint_during_training=True).to(DEV).train()
+    b.load_state_dict(a.state_dict())
+    text, image, _, _ = O.make_inputs(MID, 8, 5)
+    for m in (a, b):
+        m(text.to(DEV), image.float().to(DEV), return_loss=True).backward()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None
+        elif "token_emb" in k or k.endswith(".g") or "pos_emb" in k or "cls_token" in k or k.endswith("bias"):
+            torch.testing.assert_close(pa.grad, pb.grad, rtol=1e-4, atol=1e-6)      # fp32 atomics: order varies
+        else:
+            assert torch.equal(pa.grad, pb.grad), k
+
+
+def test_freeze_and_early_returns():
+    from x_clip_amd import CLIP
+    m = CLIP(**MID.ctor_kwargs(), visual_patch_dropout=0.0).to(DEV).train()
+    text, image, _, _ = O.make_inputs(MID, 8, 6)
+    text, image = text.to(DEV), image.float().to(DEV)
+    m(text, image, return_loss=True, freeze_text_encoder=True).backward()
+    assert all(p.grad is None for p in m.text_transformer.parameters())
+    assert all(p.grad is not None for p in m.visual_transformer.parameters())
+    assert m.to_text_latent.weight.grad is not None
+    et, ei = m(text, image, return_encodings=True)
+    assert et.shape == (8, MID.text_seq_len + 1, 512) and ei.shape == (8, 1 + MID.num_patches, 512)
+    tl, il = m(text, image, return_latents=True)
+    m.eval()
+    sim = m(text, image)
+    want = (tl.double() * il.double()).sum(-1) * math.e
+    torch.testing.assert_close(sim.double(), want, rtol=1e-4, atol=1e-5)
+    with pytest.raises(AssertionError, match="loss cannot be used if not training"):
+        m(text, image, return_loss=True)
+
+
+def test_pluggable_encoders_head_only():
+    """the reference's encoder hooks: any nn.Module; nn.Identity + float 'text' exercises only projections + head"""
+    from x_clip_amd import CLIP
+    import numpy as np
+    B, d = 96, 128
+    m = CLIP(dim_text=d, dim_image=d, dim_latent=d, text_encoder=torch.nn.Identity(), image_encoder=torch.nn.Identity(),
+             text_encode_without_mask=True, decoupled_contrastive_learning=True).to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    xt = torch.randn(B, d, generator=g).to(DEV).requires_grad_(True)
+    xi = torch.randn(B, d, generator=g).to(DEV).requires_grad_(True)
+    loss = m(xt, xi, return_loss=True)
+    loss.backward()
+    Wt, Wi = m.to_text_latent.weight.detach().double().cpu(), m.to_visual_latent.weight.detach().double().cpu()
+    T = O.l2_normalize(xt.detach().double().cpu() @ Wt.t())
+    I = O.l2_normalize(xi.detach().double().cpu() @ Wi.t())
+    want = O.simloss_closed_form(T.numpy(), I.numpy(), 1.0, True)
+    assert abs(float(loss.detach()) - want["loss"]) < 1e-5
+    assert abs(float(m.temperature.grad) - want["dtau"]) < 1e-5
+    assert xt.grad is not None and torch.isfinite(xt.grad).all()
+
+
+def test_full_size_properties_bf16():
+    """BASELINE configs[1] (default CLIP, local batch 1024, bf16): encoders are row-independent (latents of a 1024 batch
+    equal the latents of its two halves), the fused loss equals an fp64 evaluation from the latents, gradients are
+    finite and the step is repeatable."""
+    from x_clip_amd import CLIP
+    torch.manual_seed(0)
+    m = CLIP(visual_patch_dropout=0.0).to(torch.bfloat16).to(DEV).train()
+    b = 1024
+    g = torch.Generator().manual_seed(1234)
+    text = torch.randint(0, 10000, (b, 256), generator=g).to(DEV)
+    image = torch.randn(b, 3, 256, 256, generator=g).to(torch.bfloat16).to(DEV)
+    with torch.no_grad():
+        tl, il = m(text, image, return_latents=True)
+        tl2 = torch.cat([m(text[i: i + 512], image[i: i + 512], return_latents=True)[0] for i in (0, 512)])
+    assert torch.equal(tl, tl2), "text latents must not depend on which other rows share the batch"
+    loss = m(text, image, return_loss=True)
+    loss.backward()
+    S = math.e * tl.double() @ il.double().t()
+    want = 0.5 * ((S.exp().sum(1).log() - S.diag()).mean() + (S.exp().sum(0).log() - S.diag()).mean())
+    assert abs(float(loss.detach()) - float(want)) < 2e-3 * float(want), (float(loss.detach()), float(want))
+    for k, p in m.named_parameters():
+        if "_extra" in k:
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    g1 = m.to_text_latent.weight.grad.clone()
+    m.zero_grad()
+    m(text, image, return_loss=True).backward()
+    assert torch.equal(g1, m.to_text_latent.weight.grad)

@@ -88,3 +88,19 @@ def test_simloss(dtype, dcl):
 @pytest.mark.parametrize("dcl", [False, True])
 def test_simloss_closed_form(dtype, dcl):
     K.case_simloss_closed_form(DEV, dtype, 12, 64, dcl)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_layernorm_residual_paths(dtype):
+    K.case_layernorm_residual_paths(DEV, dtype, 12, 64, 4)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_row_moves(dtype):
+    K.case_row_moves(DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dcl", [False, True])
+def test_simloss_chunked(dtype, dcl):
+    K.case_simloss_chunked(DEV, dtype, dcl)

@@ -91,3 +91,19 @@ def test_simloss(dtype, dcl):
 def test_simloss_closed_form(dtype, dcl):
     K.case_simloss_closed_form(DEV, dtype, 12, 64, dcl)
     K.case_simloss_closed_form(DEV, dtype, 520, 512, dcl)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_layernorm_residual_paths(dtype):
+    K.case_layernorm_residual_paths(DEV, dtype, 640, 512, 32)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_row_moves(dtype):
+    K.case_row_moves(DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("dcl", [False, True])
+def test_simloss_chunked(dtype, dcl):
+    K.case_simloss_chunked(DEV, dtype, dcl)

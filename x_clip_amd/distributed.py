@@ -133,3 +133,69 @@ class AllGather(torch.autograd.Function):
 
 
 all_gather = AllGather.apply
+
+
+# ---- data-parallel gradient averaging (the reference leaves this to the user's DDP wrapper; bench.py needs it) -----------
+class GradSync:
+    """Bucketed gradient all-reduce overlapped with the backward: parameters are grouped into buckets (one per top-level
+    sub-module: vision tower, text tower, head); when the last gradient of a bucket has been produced the bucket is
+    flattened and all-reduced asynchronously on the process group's stream (RCCL over xGMI on MI355X) while autograd
+    keeps running the remaining backward.  `finish()` waits, scales by 1/world and points each `.grad` at its slice of
+    the reduced flat buffer.  Equivalent to DistributedDataParallel's mean-reduction for this model."""
+
+    def __init__(self, module: torch.nn.Module, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.buckets = []
+        rest = [p for p in module.parameters(recurse=False) if p.requires_grad]
+        for _, child in module.named_children():
+            ps = [p for p in child.parameters() if p.requires_grad]
+            if sum(p.numel() for p in ps) >= (1 << 20):
+                self.buckets.append(ps)                      # a tower: its own bucket, reduced while the other tower runs
+            else:
+                rest += ps
+        if rest:
+            self.buckets.append(rest)
+        self._pending = []
+        self._count = [0] * len(self.buckets)
+        self._works = []
+        self._handles = []
+        for bi, ps in enumerate(self.buckets):
+            for p in ps:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def _make_hook(self, bi):
+        def hook(param):
+            self._count[bi] += 1
+            if self._count[bi] == len(self.buckets[bi]):
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        ps = [p for p in self.buckets[bi] if p.grad is not None]
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append((work, flat, ps))
+
+    def finish(self):
+        """call after loss.backward(): buckets whose hook count never completed (unused parameters) are flushed too"""
+        for bi in range(len(self.buckets)):
+            if 0 < self._count[bi] < len(self.buckets[bi]):
+                self._launch(bi)
+            self._count[bi] = 0
+        for work, flat, ps in self._works:
+            work.wait()
+            flat.mul_(1.0 / self.world)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad = flat[off: off + n].view_as(p)
+                off += n
+        self._works = []
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -128,10 +128,7 @@ class _ContrastiveFn(torch.autograd.Function):
         dtau = torch.zeros(1, dtype=torch.float32, device=dev)
         grads = {name: [None] * len(views) for name, views in mats.items()}
         offsets = [sum(sizes[:r]) for r in range(len(sizes))]
-        aligned = all(s % v == 0 for s in sizes)
-        if spec.distributed and not aligned:
-            raise NotImplementedError(f"x_clip_amd: per-rank batch sizes must be multiples of {v} for the sharded loss "
-                                      f"backward (got {sizes})")
+        aligned = all(s % v == 0 for s in sizes)    # else: chunk columns would start off a 16-byte boundary inside G
 
         def lse_chunk(idx, r):
             return lse_all[r, idx, : sizes[r]] if spec.distributed else lse_local[idx]
@@ -143,6 +140,11 @@ class _ContrastiveFn(torch.autograd.Function):
             G = torch.empty(b, ldg, dtype=dt, device=dev)
             chunks = gathered[kn].chunks(kv) if spec.distributed else [(mats[kn][kv], 0)]
             order = [rank] + [r for r in range(len(sizes)) if r != rank]
+            if spec.distributed and not aligned:
+                # ragged per-rank batches (distributed.py:23-37): compact the peers' blocks once and treat them as one chunk
+                by_rank = {r: ch for ch, r in zip(chunks, order)}
+                chunks = [(torch.cat([by_rank[r][0] for r in range(len(sizes))], dim=0), 0)]
+                order = [None]
             zero_q = None
             for (K, col0), r in zip(chunks, order):
                 if lse_q_idx >= 0:
@@ -150,7 +152,12 @@ class _ContrastiveFn(torch.autograd.Function):
                 else:
                     zero_q = zero_q if zero_q is not None else torch.zeros(b, dtype=torch.float32, device=dev)
                     lq = zero_q
-                lk = lse_chunk(lse_k_idx, r) if lse_k_idx >= 0 else torch.zeros(K.shape[0], dtype=torch.float32, device=dev)
+                if lse_k_idx < 0:
+                    lk = torch.zeros(K.shape[0], dtype=torch.float32, device=dev)
+                elif r is None:
+                    lk = torch.cat([lse_chunk(lse_k_idx, q) for q in range(len(sizes))])
+                else:
+                    lk = lse_chunk(lse_k_idx, r)
                 ops.simloss_grad(Q, K, 1.0, off - col0, spec.dcl, a, c, a + c, lq, ops._c(lk), dtau if want_dtau else None,
                                  log_scale=tau32, gmul=gmul, times_scale=True, out=G[:, col0: col0 + (K.shape[0] + v - 1) // v * v])
                 grads[qn][qv] = _acc_gemm(grads[qn][qv], G[:, col0: col0 + K.shape[0]], K, b, d, K.shape[0], a_kmajor=False)

@@ -248,6 +248,28 @@ def cast_from_f32(src: Tensor, dtype, scale: float = 1.0) -> Tensor:
 
 
 # ---- GEMM -----------------------------------------------------------------------------------------------------------
+class GemmProbe:
+    """Optional live measurement of the GEMM launches (bench.py's `roofline` leg): while active, every xclip_gemm call
+    is bracketed by HIP events on the stream it is launched on; `summary()` returns (launches, flops, seconds)."""
+    active: Optional["GemmProbe"] = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        GemmProbe.active = self
+        return self
+
+    def __exit__(self, *exc):
+        GemmProbe.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        flops = sum(r[0] for r in self.records)
+        secs = sum(r[1].elapsed_time(r[2]) for r in self.records) * 1e-3
+        return len(self.records), flops, secs
+
+
 def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False, alpha: float = 1.0,
          bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, addrows: Optional[Tensor] = None,
          rowidx: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
@@ -270,11 +292,18 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
     plain = bias is None and residual is None and addrows is None
     wbytes = L.xclip_gemm_workspace_bytes(M, N, K, code) if plain else 0
     ws = workspace(a.device, wbytes)
+    probe = GemmProbe.active if a.is_cuda else None
+    if probe is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(a.device))
     _lib.check(L.xclip_gemm(int(a_kmajor), int(b_kmajor), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
                             out.stride(0), M, N, K, alpha, _ptr(bias), _ptr(residual),
                             0 if residual is None else residual.stride(0), _ptr(addrows), _ptr(rowidx),
                             0 if addrows is None else addrows.stride(0), _ptr(ws), 0 if ws is None else ws.numel(), code,
                             _stream(a)), "xclip_gemm")
+    if probe is not None:
+        ev1.record(torch.cuda.current_stream(a.device))
+        probe.records.append((2.0 * M * N * K, ev0, ev1))
     return out
 
 
