@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 2
+#define XCLIP_ABI_VERSION 3
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -34,10 +34,12 @@ int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* r
 /*   y row r lives at y + (r + (y_grp ? r / y_grp + 1 : 0)) * ldy: y_grp = n leaves the CLS slot of a [b, 1+n, dim]
  *   encoder output free (VisionTransformer.forward x_clip.py:389-390); res [rows, dim] is contiguous.
  * bwd: dx [rows, dim] (lddx) -- or [rows, 2 dim] = (d value | d gate) with geglu; dg_accum [dim] fp32 += dy * xhat;
- *   dres [rows, dim] (optional, not with geglu) is added to dx: the skip-path gradient of x + f(LN(x)) (x_clip.py:288-289). */
+ *   dres [rows, dim] (optional, not with geglu) is added to dx: the skip-path gradient of x + f(LN(x)) (x_clip.py:288-289);
+ *   workspace: xclip_layernorm_bwd_workspace_bytes(rows, dim) bytes of scratch (per-work-group gain-gradient partials). */
+int64_t xclip_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
 int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
-                        const void* dres, void* dx, int64_t lddx, float* dg_accum, int64_t rows, int64_t dim, int geglu, int dtype,
-                        void* stream);
+                        const void* dres, void* dx, int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes,
+                        int64_t rows, int64_t dim, int geglu, int dtype, void* stream);
 
 /* ---- l2 normalisation (reference l2norm = F.normalize, x_clip.py:54-55,715) ------------------------------------ */
 int xclip_l2norm_fwd(const void* x, void* y, float* rnorm, int64_t rows, int64_t dim, int dtype, void* stream);

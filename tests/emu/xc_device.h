@@ -312,6 +312,25 @@ inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
     return d;
 }
 
+// LDS DMA: lane-linear 16-byte pieces (performed immediately; the real one completes at wait_vmem() + barrier)
+inline void glds16(const void* gsrc, void* lds_wave_base) {
+    memcpy((unsigned char*)lds_wave_base + 16 * lane_id(), gsrc, 16);
+}
+inline void wait_vmem() {}
+// transpose read: lane c of a 16-lane group, slot j <- element (c & 3) at the address supplied by lane 4j + (c >> 2)
+inline s16x4 lds_read_tr16(const void* p) {
+    auto tab = xcemu::wave_exchange(&p, sizeof(p));
+    const int l = lane_id(), g = l >> 4, c = l & 15;
+    s16x4 out;
+    for (int j = 0; j < 4; ++j) {
+        const void* src;
+        memcpy(&src, tab[16 * g + 4 * j + (c >> 2)], sizeof(src));
+        out[j] = ((const short*)src)[c & 3];
+    }
+    return out;
+}
+inline int uniform(int v) { return v; }
+
 inline void atomic_add(float* p, float v) { *p += v; }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }

@@ -104,3 +104,14 @@ def test_row_moves(dtype):
 @pytest.mark.parametrize("dcl", [False, True])
 def test_simloss_chunked(dtype, dcl):
     K.case_simloss_chunked(DEV, dtype, dcl)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm2_layouts(layout):
+    """256x256 DMA-staged bf16 kernel (gemm2.h): ragged M and N tiles, two K steps"""
+    K.case_gemm(DEV, torch.bfloat16, 264, 136, 128, layout)
+
+
+def test_gemm2_epilogue_and_splitk():
+    K.case_gemm(DEV, torch.bfloat16, 136, 264, 64, "nt", epilogue=True, alpha=0.5)
+    K.case_gemm(DEV, torch.bfloat16, 128, 136, 1024, "tn")           # split-K slabs + reduce

@@ -107,3 +107,16 @@ def test_row_moves(dtype):
 @pytest.mark.parametrize("dcl", [False, True])
 def test_simloss_chunked(dtype, dcl):
     K.case_simloss_chunked(DEV, dtype, dcl)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K_", [(264, 136, 128), (1032, 1536, 512), (2048, 512, 2048), (520, 776, 192)])
+def test_gemm2_layouts(layout, M, N, K_):
+    K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout)
+
+
+def test_gemm2_epilogue_and_splitk():
+    K.case_gemm(DEV, torch.bfloat16, 1032, 520, 3072, "nt", epilogue=True, alpha=0.5)
+    K.case_gemm(DEV, torch.bfloat16, 1536, 512, 64 * 700, "tn")      # wgrad shape: long token contraction, split-K
+    K.case_gemm(DEV, torch.bfloat16, 512, 2048, 64 * 333, "tn")
+    K.case_gemm(DEV, torch.bfloat16, 4096, 512, 64 * 129, "nn")

@@ -77,6 +77,24 @@ XC_DEV f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- LDS DMA and transpose read (gfx950) -----------------------------------------------------------------
+// glds16: every lane copies 16 bytes from its own global address to LDS at lds_wave_base + 16 * lane
+// (global_load_lds_dwordx4: the destination is wave-uniform base + lane * 16, the source is per lane; no VGPR
+// round trip, completion is tracked by vmcnt).  Measured layout: tools/probes/tr_read_probe.txt.
+XC_DEV void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// wait until every outstanding vector-memory operation of this wave (LDS DMA included) has completed
+XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// lds_read_tr16 (ds_read_b64_tr_b16): within each 16-lane group, lane c (slot j) receives the 16-bit element
+// at addr[lane 4j + (c >> 2) of the group] + (c & 3): a 4 x 16 block whose rows are addressed by the lanes is
+// returned transposed -- 4 consecutive ROWS of one column per lane (tools/probes/tr_read_probe.txt).
+XC_DEV s16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+XC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 XC_DEV void atomic_add(float* p, float v) { atomicAdd(p, v); }
 
 XC_DEV float fast_exp(float x) { return __expf(x); }

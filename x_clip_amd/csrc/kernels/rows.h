@@ -110,13 +110,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
 // xhat = (x - mean) rstd ; dyg = dy g ; dx = rstd (dyg - mean(dyg) - xhat mean(dyg xhat)) ; dg += dy xhat.
 // With GEGLU the LayerNorm input was a = u gelu(t): du = da gelu(t), dt = da u gelu'(t), written to the
 // [rows, 2D] gradient of the FF1 output.  Waves walk the rows grid-stride and keep their dg partials in
-// registers; one LDS fold + one fp32 atomic per column per work-group at the end.  `dres` (optional, [rows, D]) is
+// registers; one LDS fold + one row of per-work-group partial sums at the end.  `dres` (optional, [rows, D]) is
 // added to dx: the pre-norm residual blocks x + f(LN(x)) hand their skip-path gradient straight to this kernel.
 template <typename T, int MAXC, bool GEGLU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long ldx,
                                                      const T* __restrict__ g, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const T* __restrict__ dres,
-                                                     T* __restrict__ dx, long lddx, float* __restrict__ dg_accum, int rows,
+                                                     T* __restrict__ dx, long lddx, float* __restrict__ dg_partial, int rows,
                                                      int D) {
     constexpr int VEC = Elem<T>::VEC;
     XC_LDS_DYNAMIC(lds);
@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             }
         }
     }
-    // fold the 4 waves' dg partials, then one atomic per column
+    // fold the 4 waves' dg partials; every work-group stores ITS column sums as row blockIdx.x of dg_partial
+    // [gridDim.x, D] (no atomics: thousands of work-groups adding into the same D floats serialise in L2 and cost a
+    // fixed ~0.4 ms per call); colsum_fold_kernel adds the rows into the caller's accumulator.
     if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     sync();
     if (wave == 0) {
+        float* out = dg_partial + (long)blockIdx.x * D;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
@@ -202,10 +205,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const int col = c * VEC + j;
-                    atomic_add(dg_accum + col, dgacc[i][j] + red[col] + red[D + col] + red[2 * D + col]);
+                    out[col] = dgacc[i][j] + red[col] + red[D + col] + red[2 * D + col];
                 }
         }
     }
+}
+
+// accum[c] += sum_r partial[r, c]  for partial [nrows, D] fp32.  grid = (ceil(D / 64), slices); each wave sums a strip
+// of rows for 64 columns (coalesced 256-byte row segments), the 4 waves fold through LDS, one atomic per column per
+// work-group (slices-way contention only).
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, float* __restrict__ accum, int nrows,
+                                                          int D) {
+    XC_LDS_DYNAMIC(lds);                                 // 4 x 64 floats
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(lds);
+    const int lane = lane_id(), wave = wave_id();
+    const int col = blockIdx.x * 64 + lane;
+    const int strips = gridDim.y * 4;
+    const int per = (nrows + strips - 1) / strips;
+    const int r0 = (blockIdx.y * 4 + wave) * per;
+    const int r1 = r0 + per < nrows ? r0 + per : nrows;
+    float s = 0.f;
+    if (col < D)
+        for (int r = r0; r < r1; ++r) s += partial[(long)r * D + col];
+    red[wave][lane] = s;
+    sync();
+    if (wave == 0 && col < D) atomic_add(accum + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
 // ---- l2 normalisation -------------------------------------------------------------------------------------

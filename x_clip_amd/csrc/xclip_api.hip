@@ -9,6 +9,7 @@
 #include "../../include/xclip.h"
 #include "kernels/attention.h"
 #include "kernels/gemm.h"
+#include "kernels/gemm2.h"
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
 #include "kernels/tokens.h"
@@ -60,11 +61,16 @@ void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, v
         hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, false>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g,
                            (const T*)res, (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
 }
+constexpr int LN_BWD_MAX_BLOCKS = 2048;
+inline int ln_bwd_blocks(int64_t rows) {
+    const int64_t b = (rows + 3) / 4;
+    return (int)(b > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : b);
+}
+
 template <typename T, int MAXC>
 void launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
                    const void* dres, void* dx, int64_t lddx, float* dg, int rows, int dim, int geglu, hipStream_t st) {
-    int blocks = (rows + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = ln_bwd_blocks(rows);
     dim3 grid(blocks), block(256);
     const size_t lds = (size_t)3 * dim * sizeof(float);
     if (geglu) {
@@ -106,6 +112,27 @@ void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
     XC_ALLOW_LDS((gemm_kernel<T, AK, BK_>), GemmCfg<T>::LDS_BYTES);
     dim3 grid(p.tiles_m * p.tiles_n, splits), block(GEMM_THREADS);
     hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, block, GemmCfg<T>::LDS_BYTES, st, p);
+}
+
+template <bool AK, bool BK_>
+void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
+    XC_ALLOW_LDS((gemm2_kernel<AK, BK_>), G2_LDS_BYTES);
+    dim3 grid(p.tiles_m * p.tiles_n, splits), block(G2_THREADS);
+    hipLaunchKernelGGL((gemm2_kernel<AK, BK_>), grid, block, G2_LDS_BYTES, st, p);
+}
+
+// the 256x256 DMA-staged kernel (gemm2.h) takes every bf16 problem whose contraction is a multiple of its K step and
+// whose output is at least a tile wide; everything else (fp32, ragged K, tiny outputs) goes to the 128x128 kernel
+inline bool use_gemm2(int64_t M, int64_t N, int64_t K, int dtype) {
+    return dtype == XCLIP_BF16 && K % G2_BK == 0 && M >= 128 && N >= 128 && M % 8 == 0;
+}
+int gemm2_splits(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ((M + G2_BM - 1) / G2_BM) * ((N + G2_BN - 1) / G2_BN);
+    int64_t s = 256 / tiles;
+    const int64_t maxs = K / (4 * G2_BK);
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : (int)s;
 }
 
 // split-K policy shared by xclip_gemm and xclip_gemm_workspace_bytes: fill ~512 work-groups, keep >= 4 K steps each
@@ -169,20 +196,30 @@ int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* r
     return check_launch(__func__);
 }
 
+int64_t xclip_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim) { return (int64_t)ln_bwd_blocks(rows) * dim * 4; }
+
 int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
-                        const void* dres, void* dx, int64_t lddx, float* dg_accum, int64_t rows, int64_t dim, int geglu, int dtype,
-                        void* stream) {
+                        const void* dres, void* dx, int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes,
+                        int64_t rows, int64_t dim, int geglu, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     const int vec = vec_of(dtype);
     XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec == 0 && ldx % vec == 0 && lddx % vec == 0, "dims must be multiples of the 16-byte chunk");
     XC_REQUIRE(ldx >= (geglu ? 2 * dim : dim) && lddx >= (geglu ? 2 * dim : dim), "leading dimension too small");
     XC_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(dres), "pointers must be 16-byte aligned");
     XC_REQUIRE(!(geglu && dres != nullptr), "dres is not defined for the GEGLU variant");
+    XC_REQUIRE(workspace != nullptr && workspace_bytes >= xclip_layernorm_bwd_workspace_bytes(rows, dim) && aligned16(workspace),
+               "workspace of xclip_layernorm_bwd_workspace_bytes(rows, dim) bytes required");
     if (rows == 0) return 0;
     const int cpl = chunks_per_lane(dim, vec);
-#define F(T, C) launch_ln_bwd<T, C>(dy, x, ldx, g, mean, rstd, dres, dx, lddx, dg_accum, (int)rows, (int)dim, geglu, (hipStream_t)stream)
+    float* partial = (float*)workspace;
+#define F(T, C) launch_ln_bwd<T, C>(dy, x, ldx, g, mean, rstd, dres, dx, lddx, partial, (int)rows, (int)dim, geglu, (hipStream_t)stream)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
+    const int nblk = ln_bwd_blocks(rows);
+    int slices = nblk / 64;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices), dim3(256), 1024, (hipStream_t)stream,
+                       (const float*)partial, dg_accum, nblk, (int)dim);
     return check_launch(__func__);
 }
 
@@ -349,7 +386,7 @@ int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale,
 }
 
 int64_t xclip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype) {
-    const int s = gemm_splits(M, N, K, dtype);
+    const int s = use_gemm2(M, N, K, dtype) ? gemm2_splits(M, N, K) : gemm_splits(M, N, K, dtype);
     return s > 1 ? (int64_t)s * M * N * 4 : 0;
 }
 
@@ -373,18 +410,40 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
     XC_REQUIRE(residual == nullptr || ldr % vec == 0, "ldr must be a multiple of the 16-byte chunk");
     XC_REQUIRE(addrows == nullptr || (rowidx != nullptr && ld_add % vec == 0), "addrows needs rowidx and an aligned ld");
     if (M == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool plain = (bias == nullptr && residual == nullptr && addrows == nullptr);
+    if (use_gemm2(M, N, K, dtype)) {
+        Gemm2Params q;
+        q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = (bf16_t*)C; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
+        q.M = (int)M; q.N = (int)N; q.K = (int)K; q.alpha = alpha;
+        q.bias = (const bf16_t*)bias; q.residual = (const bf16_t*)residual; q.ldr = ldr;
+        q.addrows = (const bf16_t*)addrows; q.rowidx = rowidx; q.ld_add = ld_add;
+        q.tiles_m = (int)((M + G2_BM - 1) / G2_BM); q.tiles_n = (int)((N + G2_BN - 1) / G2_BN);
+        int splits = gemm2_splits(M, N, K);
+        if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
+        q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);
+        q.partial = splits > 1 ? (float*)workspace : nullptr;
+        if (!a_kmajor && !b_kmajor) launch_gemm2<false, false>(q, splits, st);
+        else if (!a_kmajor && b_kmajor) launch_gemm2<false, true>(q, splits, st);
+        else launch_gemm2<true, true>(q, splits, st);
+        if (splits > 1) {
+            int64_t blocks = (M * (N / 4) + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace,
+                               (bf16_t*)C, (long)ldc, (int)M, (int)N, splits, alpha);
+        }
+        return check_launch(__func__);
+    }
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.alpha = alpha;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.addrows = addrows; p.rowidx = rowidx; p.ld_add = ld_add;
     p.tiles_m = (int)((M + 127) / 128); p.tiles_n = (int)((N + 127) / 128);
     int splits = gemm_splits(M, N, K, dtype);
-    const bool plain = (bias == nullptr && residual == nullptr && addrows == nullptr);
     if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
     const int bk = 8 * vec;
     p.k_per_split = (int)((((K + splits - 1) / splits) + bk - 1) / bk * bk);
     p.partial = splits > 1 ? (float*)workspace : nullptr;
-    hipStream_t st = (hipStream_t)stream;
     if (dtype == XCLIP_BF16) {
         if (!a_kmajor && !b_kmajor) launch_gemm<bf16_t, false, false>(p, splits, st);
         else if (!a_kmajor && b_kmajor) launch_gemm<bf16_t, false, true>(p, splits, st);

@@ -116,9 +116,10 @@ def layernorm_bwd(dy: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, 
         dres = _c(dres)
         assert dres.numel() == rows * dim and dres.dtype == x.dtype
     L = _lib.lib()
+    ws = workspace(x.device, L.xclip_layernorm_bwd_workspace_bytes(rows, dim))
     _lib.check(L.xclip_layernorm_bwd(dy.data_ptr(), x.data_ptr(), width, _c(g).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                     _ptr(dres), dx.data_ptr(), width, dg.data_ptr(), rows, dim, int(geglu), dtype_code(x),
-                                     _stream(x)), "xclip_layernorm_bwd")
+                                     _ptr(dres), dx.data_ptr(), width, dg.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
+                                     rows, dim, int(geglu), dtype_code(x), _stream(x)), "xclip_layernorm_bwd")
     return dx, dg
 
 
