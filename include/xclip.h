@@ -76,6 +76,14 @@ int xclip_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_
 int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, float* table_accum, float* colsum_accum,
                            int64_t rows, int64_t dim, int dtype, void* stream);
 
+/* table_accum[sorted_ids[e], :] += src[row(perm[e]), :], e in [0, count): `sorted_ids` ascending (int64), perm[e] = the flat
+ * index entry e had before sorting, row(p) = (p / n_in) * n_out + p % n_in + row_off.  Equal ids are summed in registers and
+ * flushed once per run: the token-embedding gradient (nn.Embedding backward of x_clip.py:320) with n_in = n, n_out = n + cls,
+ * row_off = cls; the position-table gradient of the kept patches (x_clip.py:382-385) with n_in = n_out = 1, row_off = 0.
+ * xclip_text_embed_bwd may be called with dE_accum = NULL when the embedding gradient is produced this way. */
+int xclip_scatter_add_sorted(const void* src, int64_t lds, const int64_t* sorted_ids, const int64_t* perm, float* table_accum,
+                             int64_t count, int64_t dim, int64_t n_in, int64_t n_out, int64_t row_off, int dtype, void* stream);
+
 /* dst[i] = (dtype) (src[i] * scale) : fp32 gradient accumulators -> parameter dtype */
 int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale, int dtype, void* stream);
 

@@ -330,10 +330,12 @@ inline s16x4 lds_read_tr16(const void* p) {
     return out;
 }
 inline int uniform(int v) { return v; }
+inline void wave_sync() { int z = 0; (void)xcemu::wave_exchange(&z, sizeof(z)); }      // lanes are fibres: rendezvous
 
 inline void atomic_add(float* p, float v) { *p += v; }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
+inline float fast_rcp(float x) { return 1.0f / x; }
 
 }  // namespace xc
 

@@ -347,3 +347,35 @@ def case_simloss_chunked(dev, dtype, dcl):
     Gr = 1.7 * (a * (S - lq[:, None]).exp() * offm - (a + c) * diag.double())
     close(G, temp * Gr, dtype, "chunked G", mult=2.0)
     close(dtau, (Gr * S).sum().reshape(1), dtype, "chunked dtau", scale=float((Gr * S).abs().sum()), mult=2.0)
+
+
+def case_scatter_sorted(dev, dtype):
+    """sorted segmented scatter-add == index_add, incl. the text row map (rows behind a CLS slot) and runs crossing chunks"""
+    b, n, D, vocab = 9, 37, 64, 23
+    g = torch.Generator().manual_seed(41)
+    tok = torch.randint(0, vocab, (b, n), generator=g)
+    tok[:, :5] = 7                                          # a long run spanning several wave chunks
+    dout = rnd((b, n + 1, D), dtype, 42)
+    st = torch.sort(tok.reshape(-1))
+    table = torch.zeros(vocab, D, dtype=torch.float32, device=dev)
+    ops.scatter_add_sorted(dout.to(dev).view(b * (n + 1), D), st.values.to(dev), st.indices.to(dev), table, n_in=n, n_out=n + 1, row_off=1)
+    want = torch.zeros(vocab, D, dtype=torch.float64).index_add_(0, tok.reshape(-1), ref64(dout)[:, 1:].reshape(-1, D))
+    close(table, want, torch.float32, "sorted scatter", mult=8.0)
+    dE, dP, dcls = ops.text_embed_bwd(dout.to(dev), tok.to(dev), vocab, True, True, sorted_tokens=(st.values.to(dev), st.indices.to(dev)))
+    close(dE, want, torch.float32, "dE sorted", mult=8.0)
+    close(dP, ref64(dout)[:, 1:].sum(0), torch.float32, "dP", mult=8.0)
+    close(dcls, ref64(dout)[:, 0].sum(0), torch.float32, "dcls", mult=8.0)
+
+
+def case_gelu_accuracy(dev, dtype):
+    """the shared-exponential erf GELU stays within fp32 round-off class of the exact one, forward and backward"""
+    rows, dim = 64, 64
+    x = torch.linspace(-9, 9, rows * 2 * dim).reshape(rows, 2 * dim).to(dtype)
+    x[:, :dim] = 1.0                                        # value = 1 -> the LN input is gelu(gate) itself
+    g = torch.ones(dim, dtype=dtype)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), g.to(dev), None, True)
+    x64 = ref64(x)
+    v = O.geglu(x64)
+    mu = v.mean(-1, keepdim=True)
+    yr = (v - mu) * torch.rsqrt(((v - mu) ** 2).mean(-1, keepdim=True) + ops.ln_eps(dtype))
+    close(y, yr, dtype, "gelu via geglu-ln")

@@ -115,3 +115,9 @@ def test_gemm2_layouts(layout):
 def test_gemm2_epilogue_and_splitk():
     K.case_gemm(DEV, torch.bfloat16, 136, 264, 64, "nt", epilogue=True, alpha=0.5)
     K.case_gemm(DEV, torch.bfloat16, 128, 136, 1024, "tn")           # split-K slabs + reduce
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_scatter_sorted_and_gelu(dtype):
+    K.case_scatter_sorted(DEV, dtype)
+    K.case_gelu_accuracy(DEV, dtype)

@@ -120,3 +120,9 @@ def test_gemm2_epilogue_and_splitk():
     K.case_gemm(DEV, torch.bfloat16, 1536, 512, 64 * 700, "tn")      # wgrad shape: long token contraction, split-K
     K.case_gemm(DEV, torch.bfloat16, 512, 2048, 64 * 333, "tn")
     K.case_gemm(DEV, torch.bfloat16, 4096, 512, 64 * 129, "nn")
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_scatter_sorted_and_gelu(dtype):
+    K.case_scatter_sorted(DEV, dtype)
+    K.case_gelu_accuracy(DEV, dtype)

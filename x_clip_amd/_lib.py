@@ -37,6 +37,7 @@ _SIGNATURES = {
     "xclip_token_mean_bwd": (c_int, [P, P, L, P, L, L, L, I, P]),
     "xclip_copy_rows": (c_int, [P, L, P, L, L, L, I, P]),
     "xclip_rows_scatter_add": (c_int, [P, L, P, P, P, L, L, I, P]),
+    "xclip_scatter_add_sorted": (c_int, [P, L, P, P, P, L, L, L, L, L, I, P]),
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),

@@ -94,10 +94,14 @@ XC_DEV s16x4 lds_read_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 XC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// orders this wave's LDS traffic around a wave-private hand-off (lanes exchange data through LDS without a work-group
+// barrier): the hardware executes a wave's LDS instructions in order; this only stops the compiler from reordering.
+XC_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
 XC_DEV void atomic_add(float* p, float v) { atomicAdd(p, v); }
 
 XC_DEV float fast_exp(float x) { return __expf(x); }
 XC_DEV float fast_rsqrt(float x) { return rsqrtf(x); }
+XC_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 }  // namespace xc

@@ -166,8 +166,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     load_vec<T>(x + row * ldx + D + c * VEC, t);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
-                        du[j] = da[j] * gelu_erf(t[j]);
-                        dt[j] = da[j] * u[j] * gelu_erf_grad(t[j]);
+                        float cdf, pdf;
+                        gelu_parts(t[j], cdf, pdf);
+                        du[j] = da[j] * (t[j] * cdf);                          // d/du [u gelu(t)]
+                        dt[j] = da[j] * u[j] * (cdf + t[j] * pdf);             // d/dt [u gelu(t)]
                     }
                     store_vec<T>(dx + row * lddx + c * VEC, du);
                     store_vec<T>(dx + row * lddx + D + c * VEC, dt);

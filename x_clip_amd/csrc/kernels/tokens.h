@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict
         for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
     for (int bi = blockIdx.y * 4 + wave_id(); bi < batch; bi += gridDim.y * 4) {
         const T* src = dout + ((long)bi * npos + pos) * D;
-        float* erow = (j >= 0) ? dE + (long)tok[(long)bi * n + j] * D : nullptr;
+        float* erow = (j >= 0 && dE != nullptr) ? dE + (long)tok[(long)bi * n + j] * D : nullptr;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
@@ -216,6 +216,62 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const T* __restri
             if (c < nch)
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) atomic_add(colsum + c * VEC + k, acc[i][k]);
+        }
+    }
+}
+
+// ---- sorted segmented scatter-add (token-embedding / position-table gradients) --------------------------------
+// table[ids[e], :] += src[row(perm[e]), :] for e in [0, count), where `ids` is SORTED ascending and perm[e] is the
+// original position of entry e; row(p) = (p / n_in) * n_out + p % n_in + row_off maps a flat token index to its row of
+// src (text: p = b * n + j -> row b * (n+1) + j + 1 behind the CLS slot; plain row scatter: n_in = n_out = 1).
+// One wave per `chunk` consecutive sorted entries: equal ids are summed in registers and flushed with one fp32
+// atomic per column when the id changes -- a vocabulary row hit k times costs ~1 flush instead of k, which is what made
+// the unsorted scatter (one atomic per element) the slowest non-GEMM kernel of the step.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void scatter_add_sorted_kernel(const T* __restrict__ src, long lds_, const long long* __restrict__ ids,
+                                                                 const long long* __restrict__ perm, float* __restrict__ table,
+                                                                 long count, int D, int n_in, int n_out, int row_off, int chunk) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const int nch = D / VEC;
+    const long e0 = ((long)blockIdx.x * 4 + wave_id()) * chunk;
+    if (e0 >= count) return;
+    const long e1 = e0 + chunk < count ? e0 + chunk : count;
+    float acc[MAXC][VEC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
+    long long cur = ids[e0];
+    for (long e = e0; e <= e1; ++e) {
+        const long long id = e < e1 ? ids[e] : -1;
+        if (id != cur) {                                   // wave-uniform: flush the finished run
+            float* trow = table + (long)cur * D;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        atomic_add(trow + c * VEC + k, acc[i][k]);
+                        acc[i][k] = 0.f;
+                    }
+            }
+            cur = id;
+        }
+        if (e < e1) {
+            const long p = (long)perm[e];
+            const long row = (p / n_in) * n_out + p % n_in + row_off;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
+                    float v[VEC];
+                    load_vec<T>(src + row * lds_ + c * VEC, v);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[i][k] += v[k];
+                }
+            }
         }
     }
 }

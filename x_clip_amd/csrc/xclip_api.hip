@@ -8,6 +8,8 @@
 
 #include "../../include/xclip.h"
 #include "kernels/attention.h"
+#include "kernels/attention2.h"
+#include "kernels/attention3.h"
 #include "kernels/gemm.h"
 #include "kernels/gemm2.h"
 #include "kernels/rows.h"
@@ -161,6 +163,19 @@ void launch_attn_bwd(AttnParams p, hipStream_t st) {
     XC_ALLOW_LDS((attn_dkv_kernel<T, NW>), lds_kv);
     hipLaunchKernelGGL((attn_dq_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_q, st, p);
     hipLaunchKernelGGL((attn_dkv_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_kv, st, p);
+}
+template <int NW>
+void launch_attn2_fwd(AttnParams p, hipStream_t st) {
+    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
+    constexpr int lds = attn2_lds_bytes<NW>();
+    hipLaunchKernelGGL((attn2_fwd_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
+}
+template <int NW>
+void launch_attn2_bwd(AttnParams p, hipStream_t st) {
+    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
+    constexpr int lds = attn2_lds_bytes<NW>();
+    hipLaunchKernelGGL((attn2_dq_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((attn2_dkv_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
 }
 // waves per work-group: the NW in 1..4 that wastes the fewest padded rows (ties -> larger NW)
 int attn_waves(int64_t n) {
@@ -372,6 +387,25 @@ int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, flo
     return check_launch(__func__);
 }
 
+int xclip_scatter_add_sorted(const void* src, int64_t lds, const int64_t* sorted_ids, const int64_t* perm, float* table_accum,
+                             int64_t count, int64_t dim, int64_t n_in, int64_t n_out, int64_t row_off, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0 && lds % vec == 0 && lds >= dim, "dim / lds must be chunk multiples covering a row");
+    XC_REQUIRE(aligned16(src) && sorted_ids != nullptr && perm != nullptr && table_accum != nullptr, "bad pointers");
+    XC_REQUIRE(n_in > 0 && n_out > 0, "bad row map");
+    if (count == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+    int64_t chunk = (count + 16383) / 16384;               // ~16k waves; at least 16 entries per wave
+    if (chunk < 16) chunk = 16;
+    const int64_t waves = (count + chunk - 1) / chunk;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define F(T, C) hipLaunchKernelGGL((scatter_add_sorted_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)src, (long)lds, (const long long*)sorted_ids, (const long long*)perm, table_accum, (long)count, (int)dim, (int)n_in, (int)n_out, (int)row_off, (int)chunk)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    return check_launch(__func__);
+}
+
 int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     if (count == 0) return 0;
@@ -477,10 +511,19 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     p.qkv = qkv; p.mask = mask; p.out = out; p.lse = lse;
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // head-resident kernel: one work-group per (batch, head)
+        XC_ALLOW_LDS(attn3_fwd_kernel, 160 * 1024);
+        const int nwq = (int)((n + 31) / 32);
+        hipLaunchKernelGGL(attn3_fwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
+        return check_launch(__func__);
+    }
     const int nw = attn_waves(n);
 #define F(T) switch (nw) { case 1: launch_attn_fwd<T, 1>(p, st); break; case 2: launch_attn_fwd<T, 2>(p, st); break; \
                            case 3: launch_attn_fwd<T, 3>(p, st); break; default: launch_attn_fwd<T, 4>(p, st); break; }
-    if (dtype == XCLIP_BF16) { F(bf16_t) } else { F(float) }
+    if (dtype == XCLIP_BF16) {
+        switch (nw) { case 1: launch_attn2_fwd<1>(p, st); break; case 2: launch_attn2_fwd<2>(p, st); break;
+                      case 3: launch_attn2_fwd<3>(p, st); break; default: launch_attn2_fwd<4>(p, st); break; }
+    } else { F(float) }
 #undef F
     return check_launch(__func__);
 }
@@ -497,6 +540,12 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     p.delta = delta_ws; p.dqkv = dqkv;
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
+        XC_ALLOW_LDS(attn3_bwd_kernel, 160 * 1024);
+        const int nwq = (int)((n + 31) / 32);
+        hipLaunchKernelGGL(attn3_bwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
+        return check_launch(__func__);
+    }
     dim3 dgrid((unsigned)((batch * n + 3) / 4)), dblock(256);
     if (dtype == XCLIP_BF16)
         hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dgrid, dblock, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, (int)batch, (int)n, (int)heads);
@@ -505,7 +554,10 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     const int nw = attn_waves(n);
 #define F(T) switch (nw) { case 1: launch_attn_bwd<T, 1>(p, st); break; case 2: launch_attn_bwd<T, 2>(p, st); break; \
                            case 3: launch_attn_bwd<T, 3>(p, st); break; default: launch_attn_bwd<T, 4>(p, st); break; }
-    if (dtype == XCLIP_BF16) { F(bf16_t) } else { F(float) }
+    if (dtype == XCLIP_BF16) {
+        switch (nw) { case 1: launch_attn2_bwd<1>(p, st); break; case 2: launch_attn2_bwd<2>(p, st); break;
+                      case 3: launch_attn2_bwd<3>(p, st); break; default: launch_attn2_bwd<4>(p, st); break; }
+    } else { F(float) }
 #undef F
     return check_launch(__func__);
 }

@@ -217,7 +217,9 @@ class _TextEncodeFn(torch.autograd.Function):
         ctx.tape = None
         dE = dP = dcls = None
         if need[3] or need[4] or need[5]:
-            aE, aP, acls = ops.text_embed_bwd(dx0.view(B, npos, D), ctx.tokens, vocab, has_pos, has_cls)
+            st = torch.sort(ctx.tokens.reshape(-1))                      # index plumbing: ids ascending + their positions
+            aE, aP, acls = ops.text_embed_bwd(dx0.view(B, npos, D), ctx.tokens, vocab, has_pos, has_cls,
+                                              sorted_tokens=(st.values, st.indices) if need[3] else None)
             dE = ops.cast_from_f32(aE, dtype) if need[3] else None
             dP = ops.cast_from_f32(aP, dtype) if (need[4] and has_pos) else None
             dcls = ops.cast_from_f32(acls, dtype) if (need[5] and has_cls) else None
@@ -291,7 +293,11 @@ class _VisionEncodeFn(torch.autograd.Function):
         if need[5] or need[6]:
             acc_b = torch.zeros(D, dtype=torch.float32, device=dtok.device) if need[5] else None
             acc_p = torch.zeros(npatch, D, dtype=torch.float32, device=dtok.device) if need[6] else None
-            ops.rows_scatter_add(dtok, rowidx, acc_p, acc_b)
+            if need[5]:
+                ops.rows_scatter_add(dtok, None, None, acc_b)           # bias gradient = column sum
+            if need[6]:
+                st = torch.sort(rowidx.to(torch.int64))                 # index plumbing
+                ops.scatter_add_sorted(dtok, st.values, st.indices, acc_p)
             db = ops.cast_from_f32(acc_b, dtype) if need[5] else None
             dpos = ops.cast_from_f32(acc_p, dtype) if need[6] else None
         return (None, None, None, None, dw_tok, db, dpos, dw_cls, *sgrads)

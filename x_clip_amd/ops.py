@@ -159,8 +159,10 @@ def text_embed_fwd(tokens: Tensor, E: Tensor, P: Optional[Tensor], cls: Optional
     return out
 
 
-def text_embed_bwd(dout: Tensor, tokens: Tensor, vocab: int, has_pos: bool, has_cls: bool):
-    """-> fp32 accumulators dE [vocab, D], dP [n, D] | None, dcls [D] | None"""
+def text_embed_bwd(dout: Tensor, tokens: Tensor, vocab: int, has_pos: bool, has_cls: bool, sorted_tokens=None):
+    """-> fp32 accumulators dE [vocab, D], dP [n, D] | None, dcls [D] | None.
+    sorted_tokens = (ids ascending [b*n] int64, perm [b*n] int64) (a torch.sort of tokens.flatten()): the embedding
+    gradient is then a segmented sum over equal ids instead of one atomic per element."""
     _dev_check(dout, tokens)
     dout, tokens = _c(dout), _c(tokens)
     b, n = tokens.shape
@@ -168,9 +170,27 @@ def text_embed_bwd(dout: Tensor, tokens: Tensor, vocab: int, has_pos: bool, has_
     dE = torch.zeros(vocab, dim, dtype=torch.float32, device=dout.device)
     dP = torch.zeros(n, dim, dtype=torch.float32, device=dout.device) if has_pos else None
     dcls = torch.zeros(dim, dtype=torch.float32, device=dout.device) if has_cls else None
-    _lib.check(_lib.lib().xclip_text_embed_bwd(dout.data_ptr(), tokens.data_ptr(), dE.data_ptr(), _ptr(dP), _ptr(dcls), b, n,
-                                               dim, int(has_cls), dtype_code(dout), _stream(dout)), "xclip_text_embed_bwd")
+    L = _lib.lib()
+    if has_pos or has_cls or sorted_tokens is None:
+        _lib.check(L.xclip_text_embed_bwd(dout.data_ptr(), tokens.data_ptr(), 0 if sorted_tokens is not None else dE.data_ptr(),
+                                          _ptr(dP), _ptr(dcls), b, n, dim, int(has_cls), dtype_code(dout), _stream(dout)),
+                   "xclip_text_embed_bwd")
+    if sorted_tokens is not None:
+        ids, perm = sorted_tokens
+        npos = n + int(has_cls)
+        scatter_add_sorted(dout.view(b * npos, dim), ids, perm, dE, n_in=n, n_out=npos, row_off=int(has_cls))
     return dE, dP, dcls
+
+
+def scatter_add_sorted(src: Tensor, sorted_ids: Tensor, perm: Tensor, table: Tensor, n_in: int = 1, n_out: int = 1, row_off: int = 0):
+    """table[sorted_ids[e]] += src[(perm[e] // n_in) * n_out + perm[e] % n_in + row_off]; sorted_ids ascending"""
+    _dev_check(src, sorted_ids, perm, table)
+    assert src.dim() == 2 and src.stride(1) == 1 and table.dtype == torch.float32 and table.is_contiguous()
+    assert sorted_ids.dtype == torch.int64 and perm.dtype == torch.int64 and sorted_ids.is_contiguous() and perm.is_contiguous()
+    assert sorted_ids.numel() == perm.numel() and table.shape[1] == src.shape[1]
+    _lib.check(_lib.lib().xclip_scatter_add_sorted(src.data_ptr(), src.stride(0), sorted_ids.data_ptr(), perm.data_ptr(),
+                                                   table.data_ptr(), sorted_ids.numel(), src.shape[1], n_in, n_out, row_off,
+                                                   dtype_code(src), _stream(src)), "xclip_scatter_add_sorted")
 
 
 def patchify(image: Tensor, patch: int, keep: Optional[Tensor]) -> Tensor:
