@@ -222,6 +222,8 @@ inline hipError_t hipFuncSetAttributeMaxDynLds(const void*, int) { return 0; }
     xcemu::launch([=]() { kernel(__VA_ARGS__); }, grid, block)
 inline void __syncthreads() { xcemu::block_barrier(); }
 
+inline int xc_num_cus() { return 3; }          // small on purpose: persistent kernels wrap around in the tests
+
 namespace xc {
 
 typedef uint16_t bf16_t;
@@ -316,6 +318,7 @@ inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
 inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * lane_id(), gsrc, 16);
 }
+inline void glds4(const void* gsrc, void* lds_wave_base) { memcpy((unsigned char*)lds_wave_base + 4 * lane_id(), gsrc, 4); }
 inline void wait_vmem() {}
 // transpose read: lane c of a 16-lane group, slot j <- element (c & 3) at the address supplied by lane 4j + (c >> 2)
 inline s16x4 lds_read_tr16(const void* p) {
@@ -331,6 +334,19 @@ inline s16x4 lds_read_tr16(const void* p) {
 }
 inline int uniform(int v) { return v; }
 inline void wave_sync() { int z = 0; (void)xcemu::wave_exchange(&z, sizeof(z)); }      // lanes are fibres: rendezvous
+
+#define XC_WAIT_VMEM_LE(N) ((void)0)
+inline void barrier_nodrain() { xcemu::block_barrier(); }
+inline void mfma_prio(int) {}
+inline void sched_fence() {}
+inline void permlane32_swap(uint32_t& a, uint32_t& b) {
+    struct P { uint32_t a, b; } mine{a, b};
+    auto tab = xcemu::wave_exchange(&mine, sizeof(P));
+    const int l = lane_id();
+    P other;
+    memcpy(&other, tab[l ^ 32], sizeof(P));
+    if (l >= 32) a = other.b; else b = other.a;      // upper half of a <-> lower half of b
+}
 
 inline void atomic_add(float* p, float v) { *p += v; }
 inline float fast_exp(float x) { return expf(x); }

@@ -112,8 +112,15 @@ def test_gemm2_layouts(layout):
     K.case_gemm(DEV, torch.bfloat16, 264, 136, 128, layout)
 
 
+@pytest.mark.parametrize("layout", ["nt", "tn"])
+def test_gemm3_persistent_wraparound(layout):
+    """6 tiles on the emulator's 3 'CUs': every work-group walks two tiles (cross-tile DMA prefetch, stage parity carry-over)"""
+    K.case_gemm(DEV, torch.bfloat16, 520, 264, 192, layout)
+
+
 def test_gemm2_epilogue_and_splitk():
     K.case_gemm(DEV, torch.bfloat16, 136, 264, 64, "nt", epilogue=True, alpha=0.5)
+    K.case_gemm(DEV, torch.bfloat16, 776, 264, 64, "nt", epilogue=True, alpha=0.5)      # persistent + epilogue terms
     K.case_gemm(DEV, torch.bfloat16, 128, 136, 1024, "tn")           # split-K slabs + reduce
 
 

@@ -1,0 +1,69 @@
+// Micro-benchmark (MI355X): per-CU throughput of filling LDS from an L2-resident buffer with
+//   mode 0: global_load_lds_dwordx4, lane-linear sources (8 rows x 128 B per wave-instruction, row stride `ld`)
+//   mode 1: same, 16-byte chunks permuted within each 128-byte row (the gemm2/gemm3 source swizzle)
+//   mode 2: global_load_dwordx4 -> registers -> ds_write_b128 (register staging)
+//   mode 3: global_load_lds, fully contiguous 1 KiB per wave-instruction
+// 512 threads per work-group, one work-group per CU, each K step = 64 KiB (two 32 KiB operand tiles), barrier per step.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k(const unsigned short* __restrict__ A, long ld, int rows_total, int steps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row_base = (blockIdx.x * 256) % (rows_total - 256);
+    u32x4 keep = {0, 0, 0, 0};
+    for (int s = 0; s < steps; ++s) {
+        unsigned char* buf = lds + (s & 1) * 65536;
+        const int k0 = (s * 64) % 448;                     // within a 512-wide row
+        for (int op = 0; op < 2; ++op) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int id = wave * 4 + q;
+                const int row = id * 8 + (lane >> 3);
+                int chunk = lane & 7;
+                if (MODE == 1) chunk ^= (row >> 1) & 7;
+                const unsigned short* src = A + (long)(row_base + op * 256 + row) * ld + k0 + chunk * 8;
+                if (MODE == 3) src = A + (long)(row_base + op * 256) * ld + (long)id * 512 + lane * 8;
+                if (MODE == 2) {
+                    u32x4 v = *reinterpret_cast<const u32x4*>(src);
+                    *reinterpret_cast<u32x4*>(buf + op * 32768 + id * 1024 + lane * 16) = v;
+                } else {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(buf + op * 32768 + id * 1024), 16, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        keep ^= *reinterpret_cast<const u32x4*>(lds + ((s & 1) * 65536) + tid * 16);
+    }
+    if (keep[0] == 0x12345678u) sink[0] = 1.f;
+}
+
+int main() {
+    const int rows = 8192; const long ld = 512;            // 8 MiB buffer: L2 / MALL resident
+    unsigned short* A; float* sink;
+    hipMalloc(&A, rows * ld * 2); hipMalloc(&sink, 4);
+    hipMemset(A, 1, rows * ld * 2);
+    const int steps = 2000, grid = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 4; ++mode) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            switch (mode) {
+                case 0: hipLaunchKernelGGL(k<0>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
+                case 1: hipLaunchKernelGGL(k<1>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
+                case 2: hipLaunchKernelGGL(k<2>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
+                default: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep == 1) printf("mode %d: %.3f ms, %.2f us per 64 KiB step, %.1f GB/s per CU, %.2f TB/s chip\n", mode, ms, ms * 1e3 / steps,
+                                 65536.0 * steps / (ms * 1e-3) / 1e9, 65536.0 * steps * grid / (ms * 1e-3) / 1e12);
+        }
+    }
+    return 0;
+}

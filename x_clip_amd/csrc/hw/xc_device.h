@@ -24,6 +24,17 @@
         }                                                                                                    \
     } while (0)
 
+// compute units of the current device (persistent kernels launch one work-group per CU)
+inline int xc_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 namespace xc {
 
 typedef uint16_t bf16_t;                                            // raw bfloat16 bits
@@ -85,6 +96,12 @@ XC_DEV void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// glds4: 4 bytes per lane (global_load_lds_dword) -- used as an L2 PREFETCH: one lane per 128-byte line, landing in a
+// scratch LDS area nobody reads; costs no VGPR and is tracked by vmcnt like any other DMA piece
+XC_DEV void glds4(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
 // wait until every outstanding vector-memory operation of this wave (LDS DMA included) has completed
 XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // lds_read_tr16 (ds_read_b64_tr_b16): within each 16-lane group, lane c (slot j) receives the 16-bit element
@@ -97,6 +114,24 @@ XC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // orders this wave's LDS traffic around a wave-private hand-off (lanes exchange data through LDS without a work-group
 // barrier): the hardware executes a wave's LDS instructions in order; this only stops the compiler from reordering.
 XC_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+// counted wait: returns when at most N of this wave's vector-memory operations (LDS DMA included) are still outstanding
+#define XC_WAIT_VMEM_LE(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// bare s_barrier (no implicit vmcnt(0) drain, unlike __syncthreads() with LDS DMA in flight -- cdna_hip_programming.md
+// section 5 "Pipelining across barriers"); pending LDS reads of this wave are drained first
+XC_DEV void barrier_nodrain() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+// pins the instruction order at this point (the compiler may not move anything across it)
+XC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+XC_DEV void mfma_prio(int on) { if (on) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+// lanes 32-63 of `a` swap with lanes 0-31 of `b` (v_permlane32_swap): widens row-per-lane epilogue stores to 16 bytes
+XC_DEV void permlane32_swap(uint32_t& a, uint32_t& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
 
 XC_DEV void atomic_add(float* p, float v) { atomicAdd(p, v); }
 

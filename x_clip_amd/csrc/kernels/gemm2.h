@@ -59,6 +59,28 @@ XC_DEV void g2_stage(const bf16_t* X, long ld, int outer0, int nouter, int k0, u
     }
 }
 
+// one 1 KiB piece (q = 0..3) of an operand tile: lets the caller spread the DMA issue between MFMAs
+template <bool KMAJOR>
+XC_DEV void g2_stage_piece(const bf16_t* X, long ld, int outer0, int nouter, int k0, unsigned char* tile, int wave, int lane, int q) {
+    const int id = wave * 4 + q;
+    const bf16_t* src;
+    if (!KMAJOR) {
+        const int row = id * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int g = outer0 + row;
+        g = g < nouter ? g : nouter - 1;
+        src = X + (long)g * ld + k0 + chunk * 8;
+    } else {
+        const int panel = id >> 3;
+        const int row = (id & 7) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        int g = outer0 + panel * 64 + chunk * 8;
+        g = g < nouter ? g : nouter - 8;
+        src = X + (long)(k0 + row) * ld + g;
+    }
+    glds16(src, tile + id * 1024);
+}
+
 // ---- fragment reads ----------------------------------------------------------------------------------------------
 // normal image: rows [r0, r0 + 32) of the tile, k-block kk (16 k): lane (i = lane & 31, h = lane >> 5) -> 8 k
 XC_DEV u32x4 g2_frag_normal(const unsigned char* tile, int r0, int kk, int lane) {

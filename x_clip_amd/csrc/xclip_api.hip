@@ -4,6 +4,7 @@
 
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/xclip.h"
@@ -12,6 +13,7 @@
 #include "kernels/attention3.h"
 #include "kernels/gemm.h"
 #include "kernels/gemm2.h"
+#include "kernels/gemm3.h"
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
 #include "kernels/tokens.h"
@@ -116,11 +118,32 @@ void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, block, GemmCfg<T>::LDS_BYTES, st, p);
 }
 
+// XCLIP_GEMM=2 selects the two-phase kernel (gemm2.h) for A/B measurements; default is the ring-pipelined gemm3.h
+inline bool gemm_two_phase() {
+    static const bool v = [] { const char* e = getenv("XCLIP_GEMM"); return e != nullptr && e[0] == '2'; }();
+    return v;
+}
 template <bool AK, bool BK_>
 void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
-    XC_ALLOW_LDS((gemm2_kernel<AK, BK_>), G2_LDS_BYTES);
     dim3 grid(p.tiles_m * p.tiles_n, splits), block(G2_THREADS);
-    hipLaunchKernelGGL((gemm2_kernel<AK, BK_>), grid, block, G2_LDS_BYTES, st, p);
+    if (gemm_two_phase()) {
+        XC_ALLOW_LDS((gemm2_kernel<AK, BK_>), G2_LDS_BYTES);
+        hipLaunchKernelGGL((gemm2_kernel<AK, BK_>), grid, block, G2_LDS_BYTES, st, p);
+    } else {
+        // persistent: one work-group per CU walks the tiles (split-K problems are sized to ~one tile per work-group already)
+        int gx = p.tiles_m * p.tiles_n;
+        const int cus = xc_num_cus();
+        if (gx * splits > cus && splits == 1) gx = gx < cus ? gx : cus;
+        dim3 pgrid(gx, splits);
+        static const int abl = [] { const char* e = getenv("XCLIP_GEMM_ABL"); return e ? atoi(e) : 0; }();
+        if (abl != 0 && !AK && !BK_) {                      // measurement-only variants of the NT kernel
+#define XC_ABL(N) case N: XC_ALLOW_LDS((gemm3_kernel<false, false, N>), G3_LDS_BYTES); hipLaunchKernelGGL((gemm3_kernel<false, false, N>), pgrid, block, G3_LDS_BYTES, st, p); return;
+            switch (abl) { XC_ABL(1) XC_ABL(2) XC_ABL(3) XC_ABL(4) default: break; }
+#undef XC_ABL
+        }
+        XC_ALLOW_LDS((gemm3_kernel<AK, BK_>), G3_LDS_BYTES);
+        hipLaunchKernelGGL((gemm3_kernel<AK, BK_>), pgrid, block, G3_LDS_BYTES, st, p);
+    }
 }
 
 // the 256x256 DMA-staged kernel (gemm2.h) takes every bf16 problem whose contraction is a multiple of its K step and
