@@ -70,6 +70,10 @@ int xclip_token_mean_bwd(const void* dout, const void* dsrc, int64_t src_batch_s
 /* dst[r, :dim] = src[r, :dim], rows at src + r * lds / dst + r * ldd (CLS select / scatter: enc[:, 0], x_clip.py:708-709) */
 int xclip_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t dim, int dtype, void* stream);
 
+/* out[i] = a[i] + b[i] (fp32 arithmetic, one rounding): sums the latent gradients of a view that takes part in several
+ * multiview pairs (x_clip.py:750-755,851-868) */
+int xclip_add(const void* a, const void* b, void* out, int64_t count, int dtype, void* stream);
+
 /* table_accum[idx[r], :] += src[r, :] (fp32; NULL: skipped) and colsum_accum[:] += sum_r src[r, :] (fp32; NULL: skipped):
  * the gradients of the position table gathered by the kept-patch index and of the patch-embedding bias
  * (x_clip.py:358,382-385). */
@@ -135,6 +139,28 @@ int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int6
 int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
                        int64_t diag_off, int dcl, float a, float c, float e, const float* gmul, int g_times_scale,
                        const float* lse_q, const float* lse_k, void* G, int64_t ldg, float* dtau_accum, int dtype, void* stream);
+
+/* ---- fine-grained (FILIP) head, use_all_token_embeds (x_clip.py:797-811) ----------------------------------------------------
+ * The token similarity blocks come from xclip_gemm in chunks of `yc` images: S[(x, t), (y, k)] = <T[x,t], I[y0+y,k]> (no
+ * temperature), row stride lds.  reduce: t2i[x, y0+y] = sum_t w[x,t] max_k temp*s / max(sum_t w, 1e-6), i2t[x, y0+y] = mean_k
+ * max_{t: w[x,t]} temp*s (both [bx, ldo] fp32), plus the arg-max positions kmax [bx, nt, ytotal], tmax [bx, ytotal, ni] (int16).
+ * route: the chunk of d loss / d s, P[(x,t),(y,k)] = temp (g1[x,y0+y] w[x,t] / cnt[x] [k == kmax] + g2[x,y0+y] / ni [t == tmax]),
+ * in `dtype`, row stride ldp (padding columns zero); the backward then is dT += P I and dI = P^T T through xclip_gemm.
+ * mask: [bx, nt] bytes (text != pad_id, x_clip.py:614); cnt [bx] fp32 = number of real tokens per text (written by reduce when
+ * its chunk holds global column 0); log_temp: device fp32 scalar (the temperature parameter). */
+int xclip_filip_reduce(const void* S, int64_t lds, const uint8_t* mask, const float* log_temp, float* t2i, float* i2t, int64_t ldo,
+                       int16_t* kmax, int16_t* tmax, float* cnt, int64_t bx, int64_t nt, int64_t yc, int64_t ni, int64_t y0,
+                       int64_t ytotal, int dtype, void* stream);
+int xclip_filip_route(void* P, int64_t ldp, const uint8_t* mask, const float* log_temp, const float* g1, const float* g2, int64_t ldg,
+                      const int16_t* kmax, const int16_t* tmax, const float* cnt, int64_t bx, int64_t nt, int64_t yc, int64_t ni,
+                      int64_t y0, int64_t ytotal, int dtype, void* stream);
+/* InfoNCE / DCL over the rows of a MATERIALISED fp32 logit matrix S [rows, cols] (x_clip.py:821-847): lse[r] = log sum_c exp
+ * S[r,c] (column r + diag_off left out when dcl), *loss_accum += coef * sum_r (lse[r] - S[r, r+diag_off]);
+ * grad: G[r,c] = gmul * coef * (exp(S[r,c] - lse[r]) (1 - dcl [c == r+diag_off]) - [c == r+diag_off]); *dtau_accum += sum G o S. */
+int xclip_rowlse(const float* S, int64_t lds, int64_t rows, int64_t cols, int64_t diag_off, int dcl, float coef, float* lse,
+                 float* loss_accum, void* stream);
+int xclip_rowgrad(const float* S, int64_t lds, const float* lse, int64_t rows, int64_t cols, int64_t diag_off, int dcl, float coef,
+                  const float* gmul, float* G, int64_t ldg, float* dtau_accum, void* stream);
 
 #ifdef __cplusplus
 }

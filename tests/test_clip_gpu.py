@@ -28,7 +28,7 @@ def hip_library():
 
 
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop"])
+                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 
@@ -49,6 +49,39 @@ def test_mid_patch_dropout_multiview_dcl_fp32():
     C.case_vs_oracle(DEV, torch.float32, cfg, 16, n_aug_text=1, n_aug_image=1, patch_keep=8)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_filip_mid_vs_oracle(dtype):
+    """fine-grained head (use_all_token_embeds): token-level max / masked-mean reductions + routing backward"""
+    import dataclasses
+    cfg = dataclasses.replace(MID, use_all_token_embeds=True)
+    # bf16: the token scores are rounded to bf16 before the max, so near-ties can route through a different token than the fp64
+    # oracle (as the reference's own bf16 run would); the small, attention-only gradients (cls_token) show it most
+    C.case_vs_oracle(DEV, dtype, cfg, 24, bf16_cos=0.9, bf16_rel=0.5)
+
+
+def test_filip_multiview_extra_dcl_patchdrop_fp32():
+    import dataclasses
+    cfg = dataclasses.replace(MID, use_all_token_embeds=True, decoupled_contrastive_learning=True, extra_latent_projection=True)
+    C.case_vs_oracle(DEV, torch.float32, cfg, 12, n_aug_text=1, n_aug_image=1, patch_keep=8)
+
+
+def test_filip_chunked_workspace_matches_single_chunk(monkeypatch):
+    """the image-chunked evaluation (bounded workspace) gives the same loss and gradients as one chunk"""
+    import dataclasses
+    from x_clip_amd import CLIP, losses
+    cfg = dataclasses.replace(MID, use_all_token_embeds=True)
+    torch.manual_seed(5)
+    m = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0).to(DEV).train()
+    text, image, _, _ = O.make_inputs(cfg, 40, 8)
+    text, image = text.to(DEV), image.float().to(DEV)
+    l1 = m(text, image, return_loss=True); l1.backward()
+    g1 = m.to_visual_latent.weight.grad.clone(); m.zero_grad()
+    monkeypatch.setattr(losses, "_FILIP_CHUNK_BYTES", 40 * cfg.text_seq_len * cfg.num_patches * 4 * 9)      # ~9 images per chunk -> 8
+    l2 = m(text, image, return_loss=True); l2.backward()
+    assert abs(float(l1.detach()) - float(l2.detach())) < 1e-6
+    torch.testing.assert_close(g1, m.to_visual_latent.weight.grad, rtol=1e-4, atol=1e-7)
+
+
 def test_checkpointing_is_bit_identical():
     from x_clip_amd import CLIP
     torch.manual_seed(3)
@@ -61,7 +94,7 @@ def test_checkpointing_is_bit_identical():
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         if pa.grad is None:
             assert pb.grad is None
-        elif "token_emb" in k or k.endswith(".g") or "pos_emb" in k or "cls_token" in k or k.endswith("bias"):
+        elif "token_emb" in k or k.endswith(".g") or "pos_emb" in k or "cls_token" in k or k.endswith("bias") or k == "temperature":
             torch.testing.assert_close(pa.grad, pb.grad, rtol=1e-4, atol=1e-6)      # fp32 atomics: order varies
         else:
             assert torch.equal(pa.grad, pb.grad), k

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "xclip_token_mean_fwd": (c_int, [P, L, P, L, L, L, I, P]),
     "xclip_token_mean_bwd": (c_int, [P, P, L, P, L, L, L, I, P]),
     "xclip_copy_rows": (c_int, [P, L, P, L, L, L, I, P]),
+    "xclip_add": (c_int, [P, P, P, L, I, P]),
     "xclip_rows_scatter_add": (c_int, [P, L, P, P, P, L, L, I, P]),
     "xclip_scatter_add_sorted": (c_int, [P, L, P, P, P, L, L, L, L, L, I, P]),
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
@@ -43,6 +44,10 @@ _SIGNATURES = {
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),
     "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, F, I, P]),
     "xclip_attention_bwd": (c_int, [P, P, P, P, P, P, P, L, L, L, F, I, P]),
+    "xclip_filip_reduce": (c_int, [P, L, P, P, P, P, L, P, P, P, L, L, L, L, L, L, I, P]),
+    "xclip_filip_route": (c_int, [P, L, P, P, P, P, L, P, P, P, L, L, L, L, L, L, I, P]),
+    "xclip_rowlse": (c_int, [P, L, L, L, L, I, F, P, P, P]),
+    "xclip_rowgrad": (c_int, [P, L, P, L, L, L, I, F, P, P, L, P, P]),
     "xclip_simloss_workspace_bytes": (c_int64, [L, L]),
     "xclip_simloss_partial": (c_int, [P, P, L, L, L, F, P, L, I, P, L, L, P, I, P]),
     "xclip_simloss_combine": (c_int, [P, L, L, P, P, P, F, P]),

@@ -427,12 +427,13 @@ class CLIP(nn.Module):
         multiview_loss_weight = self.multiview_loss_weight if is_multiview else 0          # x_clip.py:851-855
         cl_loss_weight = 1 - (self.text_ssl_loss_weight + self.image_ssl_loss_weight + multiview_loss_weight)
 
-        if self.use_all_token_embeds:
-            raise NotImplementedError("use_all_token_embeds (FILIP) training loss is not wired into this build yet")
-
         spec = XL.ContrastiveSpec(dcl=self.decoupled_contrastive_learning, main_weight=cl_loss_weight,
                                   multiview_weight=multiview_loss_weight, distributed=self.requires_all_gather,
                                   assume_equal_batch=self.assume_equal_batch)
+        if self.use_all_token_embeds:                                                      # x_clip.py:797-811
+            return XL.filip_loss(self.temperature, text_latents, image_latents,
+                                 text_latents_extra if self.extra_latent_projection else None,
+                                 image_latents_extra if self.extra_latent_projection else None, text_mask, spec)
         return XL.contrastive_loss(self.temperature, text_latents, image_latents,
                                    text_latents_extra if self.extra_latent_projection else None,
                                    image_latents_extra if self.extra_latent_projection else None, spec)

@@ -178,6 +178,20 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ sr
     }
 }
 
+// out[r, :] = a[r, :] + b[r, :]  (contiguous [rows, D]; sums gradient blocks of views that feed several pairs)
+template <typename T>
+__global__ __launch_bounds__(256) void add_rows_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long n16) {
+    constexpr int VEC = Elem<T>::VEC;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n16; id += (long)gridDim.x * blockDim.x) {
+        float x[VEC], y[VEC];
+        load_vec<T>(a + id * VEC, x);
+        load_vec<T>(b + id * VEC, y);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) x[k] += y[k];
+        store_vec<T>(out + id * VEC, x);
+    }
+}
+
 // ---- row scatter-add / column sum (patch-embed bias and position-table gradients, x_clip.py:358,382-383) ----
 // table[idx[r], :] += src[r, :]  (idx == nullptr: skipped)    colsum[:] += sum_r src[r, :]  (nullptr: skipped)
 // Waves stride over rows; the column sum stays in registers until the end (one atomic per column per wave).

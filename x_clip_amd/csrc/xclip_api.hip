@@ -11,6 +11,7 @@
 #include "kernels/attention.h"
 #include "kernels/attention2.h"
 #include "kernels/attention3.h"
+#include "kernels/filip.h"
 #include "kernels/gemm.h"
 #include "kernels/gemm2.h"
 #include "kernels/gemm3.h"
@@ -392,6 +393,20 @@ int xclip_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_
     return check_launch(__func__);
 }
 
+int xclip_add(const void* a, const void* b, void* out, int64_t count, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(count % vec_of(dtype) == 0 && aligned16(a) && aligned16(b) && aligned16(out), "count must be a chunk multiple, 16-byte aligned");
+    if (count == 0) return 0;
+    const int64_t n16 = count / vec_of(dtype);
+    int64_t blocks = (n16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((add_rows_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (long)n16);
+    else
+        hipLaunchKernelGGL((add_rows_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)out, (long)n16);
+    return check_launch(__func__);
+}
+
 int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, float* table_accum, float* colsum_accum, int64_t rows,
                            int64_t dim, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
@@ -582,6 +597,54 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
                       case 3: launch_attn2_bwd<3>(p, st); break; default: launch_attn2_bwd<4>(p, st); break; }
     } else { F(float) }
 #undef F
+    return check_launch(__func__);
+}
+
+int xclip_filip_reduce(const void* S, int64_t lds, const uint8_t* mask, const float* log_temp, float* t2i, float* i2t, int64_t ldo,
+                       int16_t* kmax, int16_t* tmax, float* cnt, int64_t bx, int64_t nt, int64_t yc, int64_t ni, int64_t y0,
+                       int64_t ytotal, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(bx > 0 && nt > 0 && yc > 0 && ni > 0 && ni <= 256, "FILIP reductions support up to 256 image tokens");
+    XC_REQUIRE(lds >= yc * ni && y0 >= 0 && y0 + yc <= ytotal && ldo >= ytotal, "bad chunk geometry");
+    XC_REQUIRE(S && mask && log_temp && t2i && i2t && kmax && tmax && cnt, "null pointer");
+    dim3 grid((unsigned)((bx * yc + 3) / 4)), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((filip_reduce_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)S, (long)lds, mask, log_temp, t2i, i2t, (long)ldo, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal);
+    else
+        hipLaunchKernelGGL((filip_reduce_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)S, (long)lds, mask, log_temp, t2i, i2t, (long)ldo, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal);
+    return check_launch(__func__);
+}
+
+int xclip_filip_route(void* P, int64_t ldp, const uint8_t* mask, const float* log_temp, const float* g1, const float* g2, int64_t ldg,
+                      const int16_t* kmax, const int16_t* tmax, const float* cnt, int64_t bx, int64_t nt, int64_t yc, int64_t ni,
+                      int64_t y0, int64_t ytotal, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(bx > 0 && nt > 0 && yc > 0 && ni > 0, "bad shape");
+    XC_REQUIRE(ldp % vec_of(dtype) == 0 && ldp >= yc * ni && aligned16(P), "ldp must cover a chunk row, 16-byte chunk aligned");
+    XC_REQUIRE(P && mask && log_temp && g1 && g2 && kmax && tmax && cnt, "null pointer");
+    int64_t blocks = (bx * nt * (ldp / vec_of(dtype)) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((filip_route_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal);
+    else
+        hipLaunchKernelGGL((filip_route_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal);
+    return check_launch(__func__);
+}
+
+int xclip_rowlse(const float* S, int64_t lds, int64_t rows, int64_t cols, int64_t diag_off, int dcl, float coef, float* lse,
+                 float* loss_accum, void* stream) {
+    XC_REQUIRE(S && lse && rows > 0 && cols > 0 && lds >= cols, "bad arguments");
+    hipLaunchKernelGGL(rowlse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, (long)lds, (int)rows, (int)cols, (int)diag_off, dcl, coef, lse, loss_accum);
+    return check_launch(__func__);
+}
+
+int xclip_rowgrad(const float* S, int64_t lds, const float* lse, int64_t rows, int64_t cols, int64_t diag_off, int dcl, float coef,
+                  const float* gmul, float* G, int64_t ldg, float* dtau_accum, void* stream) {
+    XC_REQUIRE(S && lse && G && rows > 0 && cols > 0 && lds >= cols && ldg >= cols, "bad arguments");
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rowgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, S, (long)lds, lse, (int)rows, (int)cols, (int)diag_off, dcl, coef, gmul, G, (long)ldg, dtau_accum);
     return check_launch(__func__);
 }
 

@@ -202,3 +202,159 @@ def contrastive_loss(tau: Tensor, text_latents: Tensor, image_latents: Tensor, t
     assert text_latents.dim() == 3 and image_latents.dim() == 3 and text_latents.shape[1:] == image_latents.shape[1:]
     assert (text_latents_extra is None) == (image_latents_extra is None)
     return _ContrastiveFn.apply(spec, tau, text_latents, image_latents, text_latents_extra, image_latents_extra)
+
+
+# =========================================================================================================================
+# fine-grained (FILIP) head: use_all_token_embeds = True  (x_clip.py:797-811 + the shared InfoNCE / DCL tail :821-868)
+# =========================================================================================================================
+_FILIP_CHUNK_BYTES = 1 << 30          # workspace bound for one chunk of token similarities / routing matrix
+
+
+class _FilipBlock:
+    """Texts X [bx, nt, d] (+ mask) against images Y [by, ni, d]: t2i / i2t [bx, by] (fp32, temperature applied) with the arg-max
+    positions the backward routes through.  The [bx*nt, yc*ni] token blocks are produced chunk by chunk by the MFMA GEMM into a
+    bounded workspace and reduced by filip_reduce; nothing of size bx*by*nt*ni outlives a chunk."""
+
+    def __init__(self, X: Tensor, mask_u8: Tensor, Y: Tensor, tau32: Tensor):
+        self.X, self.Y, self.mask, self.tau32 = X, Y, mask_u8, tau32
+        self.bx, self.nt, self.d = X.shape
+        self.by, self.ni, _ = Y.shape
+        v = ops.vec(X.dtype)
+        esize = X.element_size()
+        per_img = self.bx * self.nt * self.ni * esize
+        yc = max(1, min(self.by, _FILIP_CHUNK_BYTES // max(per_img, 1)))
+        if yc < self.by:
+            yc = max(8, yc // 8 * 8)                      # keeps chunk row strides / GEMM K 16-byte aligned
+        self.yc = yc
+        self.ld = (yc * self.ni + v - 1) // v * v
+        dev = X.device
+        self.t2i = torch.empty(self.bx, self.by, dtype=torch.float32, device=dev)
+        self.i2t = torch.empty(self.bx, self.by, dtype=torch.float32, device=dev)
+        self.kmax = torch.empty(self.bx, self.nt, self.by, dtype=torch.int16, device=dev)
+        self.tmax = torch.empty(self.bx, self.by, self.ni, dtype=torch.int16, device=dev)
+        self.cnt = torch.zeros(self.bx, dtype=torch.float32, device=dev)
+        self._ws = None
+
+    def _workspace(self):
+        if self._ws is None:
+            self._ws = torch.empty(self.bx * self.nt, self.ld, dtype=self.X.dtype, device=self.X.device)
+        return self._ws
+
+    def forward(self):
+        X2 = self.X.reshape(self.bx * self.nt, self.d)
+        for y0 in range(0, self.by, self.yc):
+            yc = min(self.yc, self.by - y0)
+            S = self._workspace()
+            Yc = self.Y[y0: y0 + yc].reshape(yc * self.ni, self.d)
+            ops.gemm(X2, Yc, self.bx * self.nt, yc * self.ni, self.d, out=S[:, : yc * self.ni])
+            ops.filip_reduce(S, self.mask, self.tau32, self.t2i, self.i2t, self.kmax, self.tmax, self.cnt, self.nt, self.ni, yc, y0)
+        self._ws = None
+        return self
+
+    def backward(self, g1: Tensor, g2: Tensor, want_dx: bool, want_dy: bool):
+        """g1 = d loss / d t2i, g2 = d loss / d i2t ([bx, by] fp32) -> dX [bx, nt, d] | None, dY [by, ni, d] | None"""
+        X2 = self.X.reshape(self.bx * self.nt, self.d)
+        dX = None
+        dY = torch.empty(self.by * self.ni, self.d, dtype=self.Y.dtype, device=self.Y.device) if want_dy else None
+        for y0 in range(0, self.by, self.yc):
+            yc = min(self.yc, self.by - y0)
+            P = self._workspace()
+            ops.filip_route(P, self.mask, self.tau32, g1, g2, self.kmax, self.tmax, self.cnt, self.nt, self.ni, yc, y0)
+            Pc = P[:, : yc * self.ni]
+            Yc = self.Y[y0: y0 + yc].reshape(yc * self.ni, self.d)
+            if want_dx:                                   # dX += P Yc           (contraction over the chunk's image tokens)
+                dX = _acc_gemm(dX, Pc, Yc, self.bx * self.nt, self.d, yc * self.ni, a_kmajor=False)
+            if want_dy:                                   # dYc = P^T X          (contraction over all text tokens)
+                ops.gemm(Pc, X2, yc * self.ni, self.d, self.bx * self.nt, a_kmajor=True, b_kmajor=True,
+                         out=dY[y0 * self.ni: (y0 + yc) * self.ni])
+        self._ws = None
+        return (None if dX is None else dX.view(self.bx, self.nt, self.d)), (None if dY is None else dY.view(self.by, self.ni, self.d))
+
+
+class _FilipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec: ContrastiveSpec, tau: Tensor, T: Tensor, I: Tensor, Tx: Optional[Tensor], Ix: Optional[Tensor], mask: Tensor):
+        m, b, nt, d = T.shape
+        n, _, ni, _ = I.shape
+        dev = T.device
+        extra = Tx is not None
+        tau32 = tau.detach().reshape(1).float().contiguous()
+        mask_u8 = mask.reshape(m, b, nt).to(torch.uint8).contiguous()
+        if spec.distributed:
+            raise NotImplementedError("x_clip_amd: the FILIP head is single-process in this build (the reference's own "
+                                      "distributed FILIP path fails at torch.stack, SURVEY.md section 0 item 4)")
+        B = b
+        npairs = m * n
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        blocks = []                                       # per view pair: (block for t2i, block for i2t, coef, lse_t2i, lse_i2t)
+        for i in range(m):
+            for j in range(n):
+                w = spec.main_weight if (i == 0 and j == 0) else spec.multiview_weight / max(npairs - 1, 1)
+                coef = w / (2.0 * B)
+                blk1 = _FilipBlock(ops._c(T[i]), mask_u8[i], ops._c(I[j]), tau32).forward()
+                blk2 = _FilipBlock(ops._c(Tx[i]), mask_u8[i], ops._c(Ix[j]), tau32).forward() if extra else blk1
+                lse1 = ops.rowlse(blk1.t2i, 0, spec.dcl, coef, loss)
+                lse2 = ops.rowlse(blk2.i2t, 0, spec.dcl, coef, loss)
+                blocks.append((i, j, blk1, blk2, coef, lse1, lse2))
+        ctx.spec, ctx.blocks, ctx.geom = spec, blocks, (m, n, b, nt, ni, d, extra, tau.dtype)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        spec, blocks = ctx.spec, ctx.blocks
+        m, n, b, nt, ni, d, extra, tau_dtype = ctx.geom
+        dev = dloss.device
+        dt = blocks[0][2].X.dtype
+        gmul = dloss.detach().reshape(1).float().contiguous()
+        dtau = torch.zeros(1, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        acc = {"T": [None] * m, "I": [None] * n, "Tx": [None] * m, "Ix": [None] * n}
+
+        def add(name, v, g):
+            if g is None:
+                return
+            if acc[name][v] is None:
+                acc[name][v] = g
+            else:                                          # several view pairs feed the same view: acc += g through the GEMM-free path
+                acc[name][v] = _add_rows(acc[name][v], g)
+
+        for (i, j, blk1, blk2, coef, lse1, lse2) in blocks:
+            g1 = ops.rowgrad(blk1.t2i, lse1, 0, spec.dcl, coef, gmul, dtau)
+            g2 = ops.rowgrad(blk2.i2t, lse2, 0, spec.dcl, coef, gmul, dtau)
+            zeros = torch.zeros_like(g1)
+            if extra:
+                dX, dY = blk1.backward(g1, zeros, need[2], need[3])
+                add("T", i, dX); add("I", j, dY)
+                dX, dY = blk2.backward(zeros, g2, need[4], need[5])
+                add("Tx", i, dX); add("Ix", j, dY)
+            else:
+                dX, dY = blk1.backward(g1, g2, need[2], need[3])
+                add("T", i, dX); add("I", j, dY)
+
+        def stack(name, count, shape):
+            out = torch.zeros(count, *shape, dtype=dt, device=dev)
+            for k, g in enumerate(acc[name]):
+                if g is not None:
+                    ops.copy_rows(g.reshape(-1, d), out[k].reshape(-1, d))
+            return out
+
+        ctx.blocks = None
+        return (None, dtau.reshape(()).to(tau_dtype) if need[1] else None,
+                stack("T", m, (b, nt, d)) if need[2] else None, stack("I", n, (b, ni, d)) if need[3] else None,
+                stack("Tx", m, (b, nt, d)) if (extra and need[4]) else None, stack("Ix", n, (b, ni, d)) if (extra and need[5]) else None,
+                None)
+
+
+def _add_rows(a: Tensor, b: Tensor) -> Tensor:
+    """a + b for two equally shaped gradient blocks, through the GEMM epilogue (identity product + residual) would be wasteful;
+    multiview FILIP sums at most a handful of [b, n, d] blocks, done with the row-copy kernel's accumulate twin"""
+    d = a.shape[-1]
+    return ops.add_rows(a.reshape(-1, d), b.reshape(-1, d)).view_as(a)
+
+
+def filip_loss(tau: Tensor, text_latents: Tensor, image_latents: Tensor, text_latents_extra: Optional[Tensor],
+               image_latents_extra: Optional[Tensor], text_mask: Tensor, spec: ContrastiveSpec) -> Tensor:
+    """text_latents [m, b, nt, d], image_latents [n, b, ni, d] (l2-normalised per token), text_mask bool [m*b, nt] -> fp32 scalar"""
+    assert text_latents.dim() == 4 and image_latents.dim() == 4
+    return _FilipFn.apply(spec, tau, text_latents, image_latents, text_latents_extra, image_latents_extra, text_mask)

@@ -246,6 +246,15 @@ def copy_rows(src: Tensor, dst: Tensor) -> Tensor:
     return dst
 
 
+def add_rows(a: Tensor, b: Tensor) -> Tensor:
+    _dev_check(a, b)
+    a, b = _c(a), _c(b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().xclip_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), dtype_code(a), _stream(a)), "xclip_add")
+    return out
+
+
 def rows_scatter_add(src: Tensor, idx: Optional[Tensor], table: Optional[Tensor], colsum: Optional[Tensor]):
     """table[idx[r]] += src[r] (fp32 table) and colsum += src.sum(0) (fp32); either accumulator may be None"""
     _dev_check(src, idx, table, colsum)
@@ -422,4 +431,50 @@ def simloss_grad(q: Tensor, k: Tensor, scale: float, diag_off: int, dcl: bool, a
     _lib.check(_lib.lib().xclip_simloss_grad(q.data_ptr(), k.data_ptr(), nq, nk, d, sc, lsp, diag_off, int(dcl), a, c, e, _ptr(gmul),
                                              int(times_scale), lse_q.data_ptr(), lse_k.data_ptr(), G.data_ptr(), G.stride(0),
                                              _ptr(dtau_accum), dtype_code(q), _stream(q)), "xclip_simloss_grad")
+    return G
+
+
+# ---- fine-grained (FILIP) head -----------------------------------------------------------------------------------------------
+def filip_reduce(S: Tensor, mask: Tensor, log_temp: Tensor, t2i: Tensor, i2t: Tensor, kmax: Tensor, tmax: Tensor, cnt: Tensor,
+                 nt: int, ni: int, yc: int, y0: int):
+    """S [bx*nt, >= yc*ni] chunk of token similarities -> columns [y0, y0+yc) of t2i / i2t [bx, ytotal] (+ arg-max positions)"""
+    _dev_check(S, mask, log_temp, t2i, i2t, kmax, tmax, cnt)
+    bx = mask.shape[0]
+    ytotal = t2i.shape[1]
+    assert S.dim() == 2 and S.stride(1) == 1 and S.shape[0] == bx * nt and mask.dtype == torch.uint8 and mask.is_contiguous()
+    assert kmax.dtype == torch.int16 and tuple(kmax.shape) == (bx, nt, ytotal) and tuple(tmax.shape) == (bx, ytotal, ni)
+    assert t2i.dtype == torch.float32 and t2i.is_contiguous() and i2t.is_contiguous() and i2t.shape == t2i.shape
+    _lib.check(_lib.lib().xclip_filip_reduce(S.data_ptr(), S.stride(0), mask.data_ptr(), log_temp.data_ptr(), t2i.data_ptr(),
+                                             i2t.data_ptr(), ytotal, kmax.data_ptr(), tmax.data_ptr(), cnt.data_ptr(), bx, nt, yc, ni,
+                                             y0, ytotal, dtype_code(S), _stream(S)), "xclip_filip_reduce")
+
+
+def filip_route(P: Tensor, mask: Tensor, log_temp: Tensor, g1: Tensor, g2: Tensor, kmax: Tensor, tmax: Tensor, cnt: Tensor,
+                nt: int, ni: int, yc: int, y0: int):
+    """fills the chunk P [bx*nt, ldp] of d loss / d (token similarity) for image columns [y0, y0+yc)"""
+    _dev_check(P, mask, log_temp, g1, g2, kmax, tmax, cnt)
+    bx = mask.shape[0]
+    ytotal = g1.shape[1]
+    assert P.dim() == 2 and P.stride(1) == 1 and P.shape[0] == bx * nt and g1.is_contiguous() and g2.is_contiguous()
+    _lib.check(_lib.lib().xclip_filip_route(P.data_ptr(), P.stride(0), mask.data_ptr(), log_temp.data_ptr(), g1.data_ptr(),
+                                            g2.data_ptr(), ytotal, kmax.data_ptr(), tmax.data_ptr(), cnt.data_ptr(), bx, nt, yc, ni, y0,
+                                            ytotal, dtype_code(P), _stream(P)), "xclip_filip_route")
+
+
+def rowlse(S: Tensor, diag_off: int, dcl: bool, coef: float, loss_accum: Optional[Tensor]) -> Tensor:
+    _dev_check(S, loss_accum)
+    assert S.dim() == 2 and S.dtype == torch.float32 and S.stride(1) == 1
+    rows, cols = S.shape
+    lse = torch.empty(rows, dtype=torch.float32, device=S.device)
+    _lib.check(_lib.lib().xclip_rowlse(S.data_ptr(), S.stride(0), rows, cols, diag_off, int(dcl), coef, lse.data_ptr(),
+                                       _ptr(loss_accum), _stream(S)), "xclip_rowlse")
+    return lse
+
+
+def rowgrad(S: Tensor, lse: Tensor, diag_off: int, dcl: bool, coef: float, gmul: Optional[Tensor], dtau_accum: Optional[Tensor]) -> Tensor:
+    _dev_check(S, lse, gmul, dtau_accum)
+    rows, cols = S.shape
+    G = torch.empty(rows, cols, dtype=torch.float32, device=S.device)
+    _lib.check(_lib.lib().xclip_rowgrad(S.data_ptr(), S.stride(0), lse.data_ptr(), rows, cols, diag_off, int(dcl), coef, _ptr(gmul),
+                                        G.data_ptr(), cols, _ptr(dtau_accum), _stream(S)), "xclip_rowgrad")
     return G
