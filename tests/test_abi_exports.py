@@ -1,0 +1,35 @@
+"""The C-ABI library loads and exports every symbol include/xclip.h declares (no compute, no GPU needed)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "xclip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(xclip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from x_clip_amd import _lib
+    from x_clip_amd.build import build
+    path = build()
+    lib = ctypes.CDLL(path)
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/xclip.h but not exported by {path}"
+    assert set(_lib.EXPORTS) == set(syms), set(_lib.EXPORTS) ^ set(syms)
+    lib.xclip_abi_version.restype = ctypes.c_int
+    assert lib.xclip_abi_version() == _lib.ABI_VERSION
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "x_clip_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
