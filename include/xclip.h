@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 3
+#define XCLIP_ABI_VERSION 4
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -76,9 +76,10 @@ int xclip_add(const void* a, const void* b, void* out, int64_t count, int dtype,
 
 /* table_accum[idx[r], :] += src[r, :] (fp32; NULL: skipped) and colsum_accum[:] += sum_r src[r, :] (fp32; NULL: skipped):
  * the gradients of the position table gathered by the kept-patch index and of the patch-embedding bias
- * (x_clip.py:358,382-385). */
+ * (x_clip.py:358,382-385).  workspace (optional, xclip_rows_scatter_add_workspace_bytes): per-wave partial rows for the column sum. */
+int64_t xclip_rows_scatter_add_workspace_bytes(int64_t rows, int64_t dim);
 int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, float* table_accum, float* colsum_accum,
-                           int64_t rows, int64_t dim, int dtype, void* stream);
+                           int64_t rows, int64_t dim, void* workspace, int64_t workspace_bytes, int dtype, void* stream);
 
 /* table_accum[sorted_ids[e], :] += src[row(perm[e]), :], e in [0, count): `sorted_ids` ascending (int64), perm[e] = the flat
  * index entry e had before sorting, row(p) = (p / n_in) * n_out + p % n_in + row_off.  Equal ids are summed in registers and
@@ -124,7 +125,7 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
 int64_t xclip_simloss_workspace_bytes(int64_t nq, int64_t nk);
 /* The forward in two steps, so the K side can be consumed in chunks as they arrive (the local latents first, every
  * peer's all-gathered block later, reference x_clip.py:759-764 + distributed.py:14-39): `partial` reduces the columns of
- * one K chunk into per-128-column-tile (max, sum) pairs stored in slots [tile_slot0, tile_slot0 + ceil(nk/128)) of a
+ * one K chunk into per-64-column (max, sum) pairs stored in slots [tile_slot0, tile_slot0 + ceil(nk/64)) of a
  * workspace holding 2 * tile_slots * nq floats; diag_off is relative to the chunk (global offset - first column of the
  * chunk); pos must be zeroed by the caller and is written by the chunk that holds a row's positive.  `combine` folds all
  * slots into lse and adds coef * sum(lse - pos) to *loss_accum (may be NULL). */

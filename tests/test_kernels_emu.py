@@ -128,3 +128,9 @@ def test_gemm2_epilogue_and_splitk():
 def test_scatter_sorted_and_gelu(dtype):
     K.case_scatter_sorted(DEV, dtype)
     K.case_gelu_accuracy(DEV, dtype)
+
+
+@pytest.mark.parametrize("dcl", [False, True])
+def test_simloss_on_gemm3_loop(dcl):
+    """bf16 problems at least a tile wide run on the persistent gemm3 loop (simloss3.h): ragged rows and columns, 2 x 2 tiles"""
+    K.case_simloss(DEV, torch.bfloat16, 264, 392, 64, dcl, diag_off=100)

@@ -126,3 +126,10 @@ def test_gemm2_epilogue_and_splitk():
 def test_scatter_sorted_and_gelu(dtype):
     K.case_scatter_sorted(DEV, dtype)
     K.case_gelu_accuracy(DEV, dtype)
+
+
+@pytest.mark.parametrize("dcl", [False, True])
+def test_simloss_on_gemm3_loop(dcl):
+    K.case_simloss(DEV, torch.bfloat16, 264, 392, 64, dcl, diag_off=100)
+    K.case_simloss(DEV, torch.bfloat16, 1024, 4096, 512, dcl, diag_off=2048)
+    K.case_simloss_closed_form(DEV, torch.bfloat16, 1032, 512, dcl)

@@ -43,11 +43,12 @@ __global__ __launch_bounds__(512) void k(const unsigned short* __restrict__ A, l
     if (keep[0] == 0x12345678u) sink[0] = 1.f;
 }
 
-int main() {
-    const int rows = 8192; const long ld = 512;            // 8 MiB buffer: L2 / MALL resident
+int main(int argc, char** argv) {
+    const int rows = 8192; const long ld = argc > 1 ? atol(argv[1]) : 512;   // default: 8 MiB buffer, L2 / MALL resident
     unsigned short* A; float* sink;
-    hipMalloc(&A, rows * ld * 2); hipMalloc(&sink, 4);
+    hipMalloc(&A, rows * ld * 2 + 65536); hipMalloc(&sink, 4);
     hipMemset(A, 1, rows * ld * 2);
+    printf("ld = %ld elements (%ld B row stride)\n", ld, ld * 2);
     const int steps = 2000, grid = 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 4; ++mode) {

@@ -37,7 +37,8 @@ _SIGNATURES = {
     "xclip_token_mean_bwd": (c_int, [P, P, L, P, L, L, L, I, P]),
     "xclip_copy_rows": (c_int, [P, L, P, L, L, L, I, P]),
     "xclip_add": (c_int, [P, P, P, L, I, P]),
-    "xclip_rows_scatter_add": (c_int, [P, L, P, P, P, L, L, I, P]),
+    "xclip_rows_scatter_add_workspace_bytes": (c_int64, [L, L]),
+    "xclip_rows_scatter_add": (c_int, [P, L, P, P, P, L, L, P, L, I, P]),
     "xclip_scatter_add_sorted": (c_int, [P, L, P, P, P, L, L, L, L, L, I, P]),
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
@@ -55,7 +56,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def _bind(path: str):

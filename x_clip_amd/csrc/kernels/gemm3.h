@@ -25,8 +25,6 @@ XC_DEV void g3_add4(float (&v)[4], const bf16_t* p) {
     v[0] += u2f(t[0] << 16); v[1] += u2f(t[0] & 0xffff0000u); v[2] += u2f(t[1] << 16); v[3] += u2f(t[1] & 0xffff0000u);
 }
 
-// ABL (measurement only, XCLIP_GEMM_ABL): 0 = the product kernel; 1 = MFMAs removed; 2 = DMA only for the first tile;
-// 3 = epilogue stores removed; 4 = LDS fragment reads removed
 // L2 prefetch stream (one 4-byte LDS-DMA touch per future 128-byte line, G3_PD K steps ahead).  MEASURED SLOWER on MI355X
 // (qkv fwd 644 -> 603 TF/s, wgrad 900 -> 742): vmcnt retires in order, so every K step then waits on a one-step-old HBM
 // access.  Kept behind this switch as a documented negative result.
@@ -52,9 +50,11 @@ XC_DEV void g3_prefetch(const bf16_t* X, long ld, int outer0, int nouter, int k0
     glds4(src, sink);
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
-__global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
-    XC_LDS_DYNAMIC(lds);
+// The persistent tile loop shared by the GEMM and by the contrastive-head kernels (simloss3.h): `epi(acc, m0, n0, full)` is
+// called once per finished 256 x 256 tile with the TRANSPOSED accumulators (see below) and must report how many global
+// stores per lane it issued when `full` (interior tile) so the next tile's first wait can leave exactly those in flight.
+template <bool A_KMAJOR, bool B_KMAJOR, int ABL, class Epilogue>
+XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = uniform(tid >> 6);
@@ -188,67 +188,85 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
         }
     }
 
-    // ---- epilogue: registers -> global, one output row per lane -----------------------------------------------------------
-    const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);           // interior tile: no per-element range checks
+    stores_pending = epi(acc, m0, n0);
+    }   // tile loop
+}
+
+// ---- the GEMM epilogue: registers -> global, one output row per lane ------------------------------------------------------------
+template <int ABL>
+struct G3GemmEpilogue {
+    const Gemm2Params& p;
+    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
+        const int lane = threadIdx.x & 63, h = lane >> 5;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);       // interior tile: no per-element range checks
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
-        const bool row_ok = full || gm < p.M;
-        const int gmc = row_ok ? gm : p.M - 1;
-        const long add_row = p.addrows != nullptr ? (long)p.rowidx[gmc] * p.ld_add : 0;
+        for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
+            const bool row_ok = full || gm < p.M;
+            const int gmc = row_ok ? gm : p.M - 1;
+            const long add_row = p.addrows != nullptr ? (long)p.rowidx[gmc] * p.ld_add : 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nb = n0 + wn * 64 + j * 32;
-            if (p.partial != nullptr) {
-                float* slab = p.partial + ((long)blockIdx.y * p.M + gmc) * p.N;
+            for (int j = 0; j < 2; ++j) {
+                const int nb = n0 + wn * 64 + j * 32;
+                if (p.partial != nullptr) {
+                    float* slab = p.partial + ((long)blockIdx.y * p.M + gmc) * p.N;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int gn = nb + 4 * h + 8 * q;
-                    if (row_ok && (full || gn < p.N)) {
-                        u32x4 v = {f2u(acc[i][j][4 * q]), f2u(acc[i][j][4 * q + 1]), f2u(acc[i][j][4 * q + 2]), f2u(acc[i][j][4 * q + 3])};
-                        st16(slab + gn, v);
+                    for (int q = 0; q < 4; ++q) {
+                        const int gn = nb + 4 * h + 8 * q;
+                        if (row_ok && (full || gn < p.N)) {
+                            u32x4 v = {f2u(acc[i][j][4 * q]), f2u(acc[i][j][4 * q + 1]), f2u(acc[i][j][4 * q + 2]), f2u(acc[i][j][4 * q + 3])};
+                            st16(slab + gn, v);
+                        }
+                    }
+                    continue;
+                }
+                float v[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[q][e] = acc[i][j][4 * q + e] * p.alpha;
+                if (p.bias != nullptr || p.addrows != nullptr || p.residual != nullptr) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int gn = nb + 4 * h + 8 * q;                         // 4 consecutive columns; clamped reads, masked stores
+                        gn = (full || gn < p.N) ? gn : p.N - 4;
+                        if (p.bias != nullptr) g3_add4(v[q], p.bias + gn);
+                        if (p.addrows != nullptr) g3_add4(v[q], p.addrows + add_row + gn);
+                        if (p.residual != nullptr) g3_add4(v[q], p.residual + (long)gmc * p.ldr + gn);
                     }
                 }
-                continue;
-            }
-            float v[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[q][e] = acc[i][j][4 * q + e] * p.alpha;
-            if (p.bias != nullptr || p.addrows != nullptr || p.residual != nullptr) {
+                uint32_t pk[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    int gn = nb + 4 * h + 8 * q;                         // 4 consecutive columns; clamped reads, masked stores
-                    gn = (full || gn < p.N) ? gn : p.N - 4;
-                    if (p.bias != nullptr) g3_add4(v[q], p.bias + gn);
-                    if (p.addrows != nullptr) g3_add4(v[q], p.addrows + add_row + gn);
-                    if (p.residual != nullptr) g3_add4(v[q], p.residual + (long)gmc * p.ldr + gn);
+                    pk[q][0] = (uint32_t)f2bf(v[q][0]) | ((uint32_t)f2bf(v[q][1]) << 16);
+                    pk[q][1] = (uint32_t)f2bf(v[q][2]) | ((uint32_t)f2bf(v[q][3]) << 16);
                 }
-            }
-            uint32_t pk[4][2];
+                // quads (0,1) and (2,3): lower lanes end up with columns [0,8) / [16,24), upper lanes with [8,16) / [24,32)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                pk[q][0] = (uint32_t)f2bf(v[q][0]) | ((uint32_t)f2bf(v[q][1]) << 16);
-                pk[q][1] = (uint32_t)f2bf(v[q][2]) | ((uint32_t)f2bf(v[q][3]) << 16);
-            }
-            // quads (0,1) and (2,3): lower lanes end up with columns [0,8) / [16,24), upper lanes with [8,16) / [24,32)
-#pragma unroll
-            for (int qq = 0; qq < 4; qq += 2) {
-                permlane32_swap(pk[qq][0], pk[qq + 1][0]);
-                permlane32_swap(pk[qq][1], pk[qq + 1][1]);
-                const int gn = nb + qq * 8 + 8 * h;
-                if (row_ok && (full || gn < p.N)) {
-                    u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 1][0], pk[qq + 1][1]};
-                    if (ABL == 3) { asm volatile("" :: "v"(o)); }
-                    else st16(p.C + (long)gm * p.ldc + gn, o);
+                for (int qq = 0; qq < 4; qq += 2) {
+                    permlane32_swap(pk[qq][0], pk[qq + 1][0]);
+                    permlane32_swap(pk[qq][1], pk[qq + 1][1]);
+                    const int gn = nb + qq * 8 + 8 * h;
+                    if (row_ok && (full || gn < p.N)) {
+                        u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 1][0], pk[qq + 1][1]};
+                        if (ABL == 3) { asm volatile("" :: "v"(o)); }
+                        else st16(p.C + (long)gm * p.ldc + gn, o);
+                    }
                 }
             }
         }
+        // interior tiles issue exactly 16 (bf16) / 32 (fp32 split-K slab) stores per lane; ragged ones are drained fully
+        return full ? (p.partial != nullptr ? 32 : 16) : 0;
     }
-    // interior tiles issue exactly 16 (bf16) / 32 (fp32 split-K slab) stores per lane; ragged ones are drained fully
-    stores_pending = full ? (p.partial != nullptr ? 32 : 16) : 0;
-    }   // tile loop
+};
+
+// ABL (measurement only, XCLIP_GEMM_ABL): 0 = the product kernel; 1 = MFMAs removed; 2 = DMA only for the first tile;
+// 3 = epilogue stores removed; 4 = LDS fragment reads removed
+template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
+    XC_LDS_DYNAMIC(lds);
+    g3_run<A_KMAJOR, B_KMAJOR, ABL>(p, lds, G3GemmEpilogue<ABL>{p});
 }
 
 }  // namespace xc

@@ -14,8 +14,8 @@
 //   scale = host float x exp(device scalar): the temperature and the upstream loss gradient never visit the host.
 //
 // The S tile is produced by the GEMM main loop (128x128 per work-group, MFMA, fp32 in LDS); the forward
-// epilogue reduces each tile row to an online-softmax partial (max, sum) -- two threads per row -- and a second
-// tiny kernel folds the per-tile partials.  Algorithmic HBM traffic of the forward: (nq + nk) * d * e read,
+// epilogue reduces each tile row to online-softmax partials (max, sum) per 64-column slot -- two threads per row -- and a
+// second tiny kernel folds the per-slot partials.  Algorithmic HBM traffic of the forward: (nq + nk) * d * e read,
 // 2 * nq * tiles_n * 4 written; the backward adds nq * nk * e for G (written once, read twice).
 #pragma once
 #include "gemm.h"
@@ -83,32 +83,54 @@ __global__ __launch_bounds__(256) void sim_lse_partial_kernel(SimParams p) {
             }
         }
     }
-    const float m2 = shfl_xor(m, 1), l2 = shfl_xor(l, 1);
-    const float mm = fmaxf(m, m2);
-    const float ll = l * fast_exp(m - mm) + l2 * fast_exp(m2 - mm);
-    if (half == 0 && gm < p.nq) {
-        p.part_m[(long)tn * p.nq + gm] = mm;
-        p.part_l[(long)tn * p.nq + gm] = ll;
+    // one (max, sum) partial per row and 64-column SLOT (two slots per 128-column tile: one per thread of the row pair)
+    if (gm < p.nq && n0 + half * 64 < p.nk) {
+        const long slot = (long)tn * 2 + half;
+        p.part_m[slot * p.nq + gm] = m;
+        p.part_l[slot * p.nq + gm] = l;
     }
 }
 
-// Fold the per-tile partials:  lse_i ; loss += coef * sum_i (lse_i - pos_i)   (one atomic per wave)
-__global__ __launch_bounds__(256) void sim_lse_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
-                                                              const float* __restrict__ pos, float* __restrict__ lse,
-                                                              float* __restrict__ loss, int nq, int tiles_n, float coef) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    float contrib = 0.f;
+// Fold the per-slot partials:  lse_i ; loss += coef * sum_i (lse_i - pos_i).
+// Work-group = 64 rows x 16 waves: lane = row (every load is a coalesced 256-byte row segment of part_m / part_l [slots][nq]),
+// wave w folds slots w, w + 16, ... online, the 16 per-wave (max, sum) pairs of a row meet in LDS.  (One thread per row
+// walking all slots -- the first version -- took longer than the MFMA kernel it follows at nk = 32768.)
+__global__ __launch_bounds__(1024) void sim_lse_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                               const float* __restrict__ pos, float* __restrict__ lse,
+                                                               float* __restrict__ loss, int nq, int slots, float coef) {
+    XC_LDS_DYNAMIC(lds);
+    float* red_m = reinterpret_cast<float*>(lds);           // [16][64]
+    float* red_l = red_m + 16 * 64;
+    const int lane = lane_id(), wave = wave_id();
+    const int i = blockIdx.x * 64 + lane;
+    float m = SIM_NEG, l = 0.f;
     if (i < nq) {
-        float m = SIM_NEG;
-        for (int t = 0; t < tiles_n; ++t) m = fmaxf(m, part_m[(long)t * nq + i]);
-        float l = 0.f;
-        for (int t = 0; t < tiles_n; ++t) l += part_l[(long)t * nq + i] * fast_exp(part_m[(long)t * nq + i] - m);
-        const float v = (l > 0.f) ? m + logf(l) : logf(1e-20f);     // reference: log(sum + 1e-20)
-        lse[i] = v;
-        contrib = coef * (v - pos[i]);
+        for (int t = wave; t < slots; t += 16) {
+            const float pm = part_m[(long)t * nq + i], pl = part_l[(long)t * nq + i];
+            const float mm = fmaxf(m, pm);
+            l = l * fast_exp(m - mm) + pl * fast_exp(pm - mm);
+            m = mm;
+        }
     }
-    contrib = wave_sum(contrib);
-    if (lane_id() == 0 && loss != nullptr) atomic_add(loss, contrib);
+    red_m[wave * 64 + lane] = m;
+    red_l[wave * 64 + lane] = l;
+    sync();
+    if (wave == 0) {
+        float contrib = 0.f;
+        if (i < nq) {
+            float mm = SIM_NEG;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) mm = fmaxf(mm, red_m[w * 64 + lane]);
+            float ll = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) ll += red_l[w * 64 + lane] * fast_exp(red_m[w * 64 + lane] - mm);
+            const float v = (ll > 0.f) ? mm + logf(ll) : logf(1e-20f);     // reference: log(sum + 1e-20)
+            lse[i] = v;
+            contrib = coef * (v - pos[i]);
+        }
+        contrib = wave_sum(contrib);
+        if (lane == 0 && loss != nullptr) atomic_add(loss, contrib);
+    }
 }
 
 template <typename T>

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const T* __restrict__ a, 
 template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const T* __restrict__ src, long lds_, const int* __restrict__ idx,
                                                                float* __restrict__ table, float* __restrict__ colsum, long rows,
-                                                               int D) {
+                                                               int D, float* __restrict__ colsum_partial) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = lane_id();
     const int nch = D / VEC;
@@ -223,7 +223,16 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const T* __restri
             }
         }
     }
-    if (colsum != nullptr) {
+    if (colsum_partial != nullptr) {                          // one partial row per WAVE; colsum_fold_kernel adds them up
+        float* out = colsum_partial + ((long)blockIdx.x * 4 + wave_id()) * D;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) out[c * VEC + k] = acc[i][k];
+        }
+    } else if (colsum != nullptr) {
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;

@@ -17,6 +17,7 @@
 #include "kernels/gemm3.h"
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
+#include "kernels/simloss3.h"
 #include "kernels/tokens.h"
 
 using namespace xc;
@@ -407,8 +408,14 @@ int xclip_add(const void* a, const void* b, void* out, int64_t count, int dtype,
     return check_launch(__func__);
 }
 
+int64_t xclip_rows_scatter_add_workspace_bytes(int64_t rows, int64_t dim) {
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    return blocks * 4 * dim * 4;
+}
+
 int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, float* table_accum, float* colsum_accum, int64_t rows,
-                           int64_t dim, int dtype, void* stream) {
+                           int64_t dim, void* workspace, int64_t workspace_bytes, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     const int vec = vec_of(dtype);
     XC_REQUIRE(dim > 0 && dim % vec == 0 && lds % vec == 0 && lds >= dim, "dim / lds must be chunk multiples covering a row");
@@ -417,11 +424,18 @@ int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, flo
     if (rows == 0) return 0;
     const int cpl = chunks_per_lane(dim, vec);
     int64_t blocks = (rows + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;
+    // column sums go through per-wave partial rows + a fold (thousands of waves adding into the same `dim` floats serialise)
+    float* partial = (colsum_accum != nullptr && workspace != nullptr && workspace_bytes >= blocks * 4 * dim * 4) ? (float*)workspace : nullptr;
     dim3 grid((unsigned)blocks), block(256);
-#define F(T, C) hipLaunchKernelGGL((rows_scatter_add_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)src, (long)lds, (const int*)idx, table_accum, colsum_accum, (long)rows, (int)dim)
+#define F(T, C) hipLaunchKernelGGL((rows_scatter_add_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)src, (long)lds, (const int*)idx, table_accum, colsum_accum, (long)rows, (int)dim, partial)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
+    if (partial != nullptr) {
+        // every wave writes its row (waves without rows write zeros), so all blocks * 4 rows are defined
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), 4), dim3(256), 1024, (hipStream_t)stream,
+                           (const float*)partial, colsum_accum, (int)(blocks * 4), (int)dim);
+    }
     return check_launch(__func__);
 }
 
@@ -648,7 +662,17 @@ int xclip_rowgrad(const float* S, int64_t lds, const float* lse, int64_t rows, i
     return check_launch(__func__);
 }
 
-int64_t xclip_simloss_workspace_bytes(int64_t nq, int64_t nk) { return 2 * ((nk + 127) / 128) * nq * 4; }
+int64_t xclip_simloss_workspace_bytes(int64_t nq, int64_t nk) { return 2 * ((nk + 63) / 64) * nq * 4; }
+
+// the gemm3-based head kernels take bf16 problems at least a tile wide whose feature dim is a whole number of K steps
+inline bool use_sim3(int64_t nq, int64_t nk, int64_t d, int dtype) {
+    return dtype == XCLIP_BF16 && d % G2_BK == 0 && nq >= 128 && nk >= 128;
+}
+inline dim3 sim3_grid(int64_t nq, int64_t nk) {
+    int64_t tiles = ((nq + G2_BM - 1) / G2_BM) * ((nk + G2_BN - 1) / G2_BN);
+    const int cus = xc_num_cus();
+    return dim3((unsigned)(tiles < cus ? tiles : cus));
+}
 
 int xclip_simloss_partial(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
                           int64_t diag_off, int dcl, void* workspace, int64_t tile_slot0, int64_t tile_slots, float* pos, int dtype, void* stream) {
@@ -660,9 +684,14 @@ int xclip_simloss_partial(const void* Q, const void* K, int64_t nq, int64_t nk, 
     p.Q = Q; p.K = K; p.nq = (int)nq; p.nk = (int)nk; p.d = (int)d; p.scale = scale; p.log_scale = log_scale;
     p.diag_off = (int)diag_off; p.dcl = dcl;
     p.tiles_m = (int)((nq + 127) / 128); p.tiles_n = (int)((nk + 127) / 128);
-    XC_REQUIRE(tile_slot0 >= 0 && tile_slot0 + p.tiles_n <= tile_slots, "column-tile slots out of range");
+    XC_REQUIRE(tile_slot0 >= 0 && tile_slot0 + (nk + 63) / 64 <= tile_slots, "column slots out of range");
     p.part_m = (float*)workspace + tile_slot0 * nq; p.part_l = (float*)workspace + (tile_slots + tile_slot0) * nq; p.pos = pos;
     hipStream_t st = (hipStream_t)stream;
+    if (use_sim3(nq, nk, d, dtype)) {
+        XC_ALLOW_LDS(sim3_lse_kernel, G2_LDS_BYTES);
+        hipLaunchKernelGGL(sim3_lse_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
+        return check_launch(__func__);
+    }
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     if (dtype == XCLIP_BF16) {
         XC_ALLOW_LDS((sim_lse_partial_kernel<bf16_t>), GemmCfg<bf16_t>::LDS_BYTES);
@@ -678,7 +707,7 @@ int xclip_simloss_combine(const void* workspace, int64_t nq, int64_t tile_slots,
                           float coef, void* stream) {
     XC_REQUIRE(nq > 0 && tile_slots > 0 && workspace != nullptr && pos != nullptr && lse != nullptr, "bad arguments");
     const float* part_m = (const float*)workspace;
-    hipLaunchKernelGGL(sim_lse_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part_m,
+    hipLaunchKernelGGL(sim_lse_combine_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(1024), 2 * 16 * 64 * 4, (hipStream_t)stream, part_m,
                        part_m + tile_slots * nq, pos, lse, loss_accum, (int)nq, (int)tile_slots, coef);
     return check_launch(__func__);
 }
@@ -686,7 +715,7 @@ int xclip_simloss_combine(const void* workspace, int64_t nq, int64_t tile_slots,
 int xclip_simloss_fwd(const void* Q, const void* K, int64_t nq, int64_t nk, int64_t d, float scale, const float* log_scale,
                       int64_t diag_off, int dcl, float coef, void* workspace, float* pos, float* lse, float* loss_accum, int dtype,
                       void* stream) {
-    const int64_t slots = (nk + 127) / 128;
+    const int64_t slots = (nk + 63) / 64;
     const int rc = xclip_simloss_partial(Q, K, nq, nk, d, scale, log_scale, diag_off, dcl, workspace, 0, slots, pos, dtype, stream);
     if (rc != 0) return rc;
     return xclip_simloss_combine(workspace, nq, slots, pos, lse, loss_accum, coef, stream);
@@ -707,6 +736,11 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
     p.tiles_m = (int)((nq + 127) / 128); p.tiles_n = (int)((nk + 127) / 128);
     p.lse_q = lse_q; p.lse_k = lse_k; p.a = a; p.c = c; p.e = e; p.G = G; p.ldg = ldg; p.dtau = dtau_accum;
     hipStream_t st = (hipStream_t)stream;
+    if (use_sim3(nq, nk, d, dtype)) {
+        XC_ALLOW_LDS(sim3_grad_kernel, G2_LDS_BYTES);
+        hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
+        return check_launch(__func__);
+    }
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     if (dtype == XCLIP_BF16) {
         XC_ALLOW_LDS((sim_grad_kernel<bf16_t>), GemmCfg<bf16_t>::LDS_BYTES);

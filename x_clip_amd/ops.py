@@ -264,8 +264,10 @@ def rows_scatter_add(src: Tensor, idx: Optional[Tensor], table: Optional[Tensor]
         assert idx.dtype == torch.int32 and idx.numel() == rows and idx.is_contiguous()
     for t in (table, colsum):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
-    _lib.check(_lib.lib().xclip_rows_scatter_add(src.data_ptr(), src.stride(0), _ptr(idx), _ptr(table), _ptr(colsum), rows, dim,
-                                                 dtype_code(src), _stream(src)), "xclip_rows_scatter_add")
+    L = _lib.lib()
+    ws = workspace(src.device, L.xclip_rows_scatter_add_workspace_bytes(rows, dim)) if colsum is not None else None
+    _lib.check(L.xclip_rows_scatter_add(src.data_ptr(), src.stride(0), _ptr(idx), _ptr(table), _ptr(colsum), rows, dim, _ptr(ws),
+                                        0 if ws is None else ws.numel(), dtype_code(src), _stream(src)), "xclip_rows_scatter_add")
 
 
 def cast_from_f32(src: Tensor, dtype, scale: float = 1.0) -> Tensor:
@@ -388,7 +390,7 @@ def simloss_chunked_fwd(q: Tensor, k_chunks, scale: float, diag_off: int, dcl: b
     nq, d = q.shape
     L = _lib.lib()
     sc, lsp = _scale_args(scale, log_scale)
-    slots = sum((kc.shape[0] + 127) // 128 for kc, _ in k_chunks)
+    slots = sum((kc.shape[0] + 63) // 64 for kc, _ in k_chunks)
     ws = workspace(q.device, 2 * slots * nq * 4)
     pos = torch.zeros(nq, dtype=torch.float32, device=q.device)
     lse = torch.empty(nq, dtype=torch.float32, device=q.device)
@@ -401,7 +403,7 @@ def simloss_chunked_fwd(q: Tensor, k_chunks, scale: float, diag_off: int, dcl: b
         assert kc.shape[1] == d and kc.dtype == q.dtype
         _lib.check(L.xclip_simloss_partial(q.data_ptr(), kc.data_ptr(), nq, nk, d, sc, lsp, diag_off - col0, int(dcl), ws.data_ptr(),
                                            slot0, slots, pos.data_ptr(), dtype_code(q), _stream(q)), "xclip_simloss_partial")
-        slot0 += (nk + 127) // 128
+        slot0 += (nk + 63) // 64
     _lib.check(L.xclip_simloss_combine(ws.data_ptr(), nq, slots, pos.data_ptr(), lse.data_ptr(), _ptr(loss_accum), coef, _stream(q)),
                "xclip_simloss_combine")
     return lse, pos
