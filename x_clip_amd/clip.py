@@ -328,11 +328,23 @@ class CLIP(nn.Module):
         self.requires_all_gather = distributed.is_available() and distributed.is_initialized() and distributed.get_world_size() > 1
         self.assume_equal_batch = False           # set True to skip the per-step batch-size exchange between ranks
 
+        self.overlap_towers = True                 # issue the vision tower on a side stream next to the text tower (GPU only)
+        self._streams = {}
+
         self.sim_reg_loss_weight = sim_reg_loss_weight
         self.has_sim_reg_loss = sim_reg_loss_weight > 0.
         if self.has_sim_reg_loss:
             raise NotImplementedError("sim_reg_loss_weight > 0 is not on the accelerated path yet (SURVEY.md 8(f); the "
                                       "reference path raises an einsum rank error without extra_latent_projection)")
+
+    def _side_stream(self, device):
+        if device.type != "cuda":
+            return None
+        st = self._streams.get(device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            self._streams[device] = st
+        return st
 
     def forward(
         self,
@@ -378,8 +390,20 @@ class CLIP(nn.Module):
         if not self.text_encode_without_mask:
             text_args = (*text_args, text_mask)
 
-        enc_text = model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze_text_encoder)
-        enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
+        # The two towers are independent until the head.  On a GPU the vision tower is issued on a side HIP stream (autograd
+        # replays its backward there too), so its small kernels fill the gaps the text tower's leaves; the head waits for both.
+        side = self._side_stream(image.device) if self.overlap_towers else None
+        if side is not None:
+            main = torch.cuda.current_stream(image.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
+            enc_text = model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze_text_encoder)
+            main.wait_stream(side)
+            enc_image.record_stream(main)
+        else:
+            enc_text = model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze_text_encoder)
+            enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
 
         if return_encodings:                                                               # x_clip.py:697-698
             return enc_text, enc_image

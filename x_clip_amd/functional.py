@@ -25,6 +25,45 @@ from torch.autograd.function import once_differentiable
 from . import ops
 
 Tensor = torch.Tensor
+
+# Weight-gradient GEMMs are off the critical path of the backward (only the optimiser consumes them), so they are issued on a
+# side HIP stream -- one per (device, issuing stream) -- where they run beside the HBM-bound LayerNorm / attention backward
+# kernels of the main chain; stack_backward joins the two streams before it returns.
+OVERLAP_WGRAD = True
+_wgrad_streams = {}
+
+
+class _SideGemm:
+    def __init__(self, device):
+        self.main = self.side = None
+        if OVERLAP_WGRAD and device.type == "cuda":
+            self.main = torch.cuda.current_stream(device)
+            key = (device, self.main.cuda_stream)
+            self.side = _wgrad_streams.get(key)
+            if self.side is None:
+                self.side = _wgrad_streams[key] = torch.cuda.Stream(device=device)
+        self.outs = []
+
+    def wgrad(self, dy: Tensor, x: Tensor, N1: int, N2: int, M: int) -> Tensor:
+        """dW [N1, N2] = dy^T x (contraction over the M token rows), issued on the side stream"""
+        if self.side is None:
+            return ops.gemm(dy, x, N1, N2, M, a_kmajor=True, b_kmajor=True)
+        self.side.wait_stream(self.main)                     # dy was just produced on the main stream
+        with torch.cuda.stream(self.side):
+            out = ops.gemm(dy, x, N1, N2, M, a_kmajor=True, b_kmajor=True)
+        dy.record_stream(self.side)                          # keep the operands' memory until the side stream is done
+        x.record_stream(self.side)
+        self.outs.append(out)
+        return out
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+            for o in self.outs:
+                o.record_stream(self.main)
+        self.outs = []
+
+
 LAYER_PARAMS = 8          # attn_norm.g, to_qkv.w, to_out.w, to_out_norm.g, ff_norm.g, ff1.w, ff_inner_norm.g, ff2.w
 
 
@@ -74,7 +113,7 @@ def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, m
 
 
 def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
-                    gain_acc: Sequence[Tensor], need_w: Sequence[bool]):
+                    gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm"):
     """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2])"""
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     dg_attn, dg_out, dg_ff, dg_inner = gain_acc
@@ -85,23 +124,23 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     Fh = F2 // 2
     # feed-forward block
     da = ops.gemm(dx2, w_ff2, M, Fh, D, b_kmajor=True)
-    d_ff2 = ops.gemm(dx2, a, D, Fh, M, a_kmajor=True, b_kmajor=True) if need_w[3] else None
+    d_ff2 = sg.wgrad(dx2, a, D, Fh, M) if need_w[3] else None
     du, _ = ops.layernorm_bwd(da, u, g_inner, m4, r4, geglu=True, dg=dg_inner)
     del da
     dh2 = ops.gemm(du, w_ff1, M, D, F2, b_kmajor=True)
-    d_ff1 = ops.gemm(du, h2, F2, D, M, a_kmajor=True, b_kmajor=True) if need_w[2] else None
+    d_ff1 = sg.wgrad(du, h2, F2, D, M) if need_w[2] else None
     del du
     dx1, _ = ops.layernorm_bwd(dh2, x1, g_ff, m3, r3, dres=dx2, dg=dg_ff)
     del dh2
     # attention block
     dp, _ = ops.layernorm_bwd(dx1, p, g_out, m2, r2, dg=dg_out)
     do = ops.gemm(dp, w_out, M, inner, D, b_kmajor=True)
-    d_out = ops.gemm(dp, o.view(M, inner), D, inner, M, a_kmajor=True, b_kmajor=True) if need_w[1] else None
+    d_out = sg.wgrad(dp, o.view(M, inner), D, inner, M) if need_w[1] else None
     del dp
     dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, 64 ** -0.5)
     del do
     dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
-    d_qkv = ops.gemm(dqkv.view(M, 3 * inner), h, 3 * inner, D, M, a_kmajor=True, b_kmajor=True) if need_w[0] else None
+    d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M) if need_w[0] else None
     del dqkv
     dx, _ = ops.layernorm_bwd(dh, x, g_attn, m1, r1, dres=dx1, dg=dg_attn)
     return dx, [d_qkv, d_out, d_ff1, d_ff2]
@@ -133,6 +172,7 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
     gains = [params[0]] + [params[1 + LAYER_PARAMS * l + k] for l in range(spec.depth) for k in (0, 3, 4, 6)] + [params[-1]]
     gg = _GainGrads(gains)
     grads: List[Optional[Tensor]] = [None] * len(params)
+    sg = _SideGemm(dy.device)
     dx, _ = ops.layernorm_bwd(dy, x_last, params[-1], m_out, r_out, dg=gg.views[-1])
     for l in reversed(range(spec.depth)):
         base = 1 + LAYER_PARAMS * l
@@ -141,10 +181,11 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
         if spec.checkpoint:                      # re-run the layer forward from its saved input
             _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask)
         need_w = [need[base + 1], need[base + 2], need[base + 5], need[base + 7]]
-        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w)
+        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg)
         layers[l] = None                         # release this layer's activations
         grads[base + 1], grads[base + 2], grads[base + 5], grads[base + 7] = dws
     dx0, _ = ops.layernorm_bwd(dx, x0, params[0], m_in, r_in, dg=gg.views[0])
+    sg.join()
     gfin = gg.finish()
     grads[0], grads[-1] = gfin[0], gfin[-1]
     for l in range(spec.depth):

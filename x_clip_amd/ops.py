@@ -58,13 +58,15 @@ _workspaces = {}
 
 
 def workspace(device, nbytes: int) -> Optional[Tensor]:
-    """grow-only scratch per device; kernels using it are ordered on the caller's stream"""
+    """grow-only scratch per (device, stream): kernels using it are ordered on that stream, and two streams (the vision tower
+    runs beside the text tower) never share a scratch buffer"""
     if nbytes <= 0:
         return None
-    ws = _workspaces.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else (device, 0)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 
