@@ -92,11 +92,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    # XCLIP_BENCH_ONE_DEVICE=1 + XCLIP_BENCH_BACKEND=gloo: functional check of the multi-rank path on a single-GPU box
+    if os.environ.get("XCLIP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)          # BEFORE the model: CLIP latches requires_all_gather
+        backend = os.environ.get("XCLIP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # BEFORE the model: CLIP latches requires_all_gather
+        else:
+            dist.init_process_group(backend)
 
     from x_clip_amd import CLIP, ops
     from x_clip_amd.distributed import GradSync

@@ -129,3 +129,51 @@ def test_two_ranks_even_batches_gradsync_vs_oracle(tmp_path):
             rel = float((g - want).norm() / want.norm().clamp_min(1e-30))
             assert rel < 3e-4, (k, rel)
         assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
+
+
+def _worker_filip(rank, world, port, cfg_kwargs, batch, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emu.build_emu import build
+    from x_clip_amd import CLIP, _lib
+    from oracle import clip_oracle as O
+    _lib._use_library_for_tests(build())
+    cfg = O.ClipConfig(**cfg_kwargs)
+    sd = O.make_state_dict(cfg, 15, torch.float32)
+    text, image, _, _ = O.make_inputs(cfg, batch * world, 16)
+    sl = slice(rank * batch, (rank + 1) * batch)
+    model = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)
+    model.load_state_dict(sd)
+    model.train()
+    loss = model(text[sl], image[sl].float(), return_loss=True)
+    loss.backward()
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dcl", [False, True])
+def test_two_ranks_filip_vs_oracle(tmp_path, dcl):
+    """fine-grained (FILIP) head across 2 ranks -- a configuration the reference cannot run (torch.stack of text and image
+    latents): every rank's loss = single-process global-batch oracle loss, rank-summed gradients = oracle gradients"""
+    from oracle import clip_oracle as O
+    import dataclasses
+    cfg = dataclasses.replace(O.CFG1, use_all_token_embeds=True, decoupled_contrastive_learning=dcl)
+    batch, world = 4, 2
+    port = 33500 + (os.getpid() % 2000) + (1 if dcl else 0)
+    mp.spawn(_worker_filip, args=(world, port, dataclasses.asdict(cfg), batch, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    sd = {k: v.double().requires_grad_(True) for k, v in O.make_state_dict(cfg, 15, torch.float32).items()}
+    text, image, _, _ = O.make_inputs(cfg, batch * world, 16)
+    ref = O.clip_forward(sd, cfg, text, image.float().double())
+    ref.backward()
+    for o in outs:
+        assert abs(o["loss"] - float(ref.detach())) < 1e-5, (o["loss"], float(ref.detach()))
+    for k, v in sd.items():
+        if v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        g0, g1 = outs[0]["grads"][k], outs[1]["grads"][k]
+        tot = (g0 + g1).double() / (world if k == "temperature" else 1)
+        rel = float((tot - v.grad).norm() / v.grad.norm().clamp_min(1e-30))
+        assert rel < 3e-4, (k, rel)

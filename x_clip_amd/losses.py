@@ -271,7 +271,24 @@ class _FilipBlock:
         return (None if dX is None else dX.view(self.bx, self.nt, self.d)), (None if dY is None else dY.view(self.by, self.ni, self.d))
 
 
+def _gather_rows(t: Tensor, sizes, group) -> Tensor:
+    """[rows_r, ...] on every rank -> [sum rows, ...] in rank order (one flat all-gather; ragged batches padded on the wire)"""
+    t2 = t.reshape(t.shape[0], -1)
+    gv = xdist.GatheredViews([t2], sizes, group)
+    gv.wait()
+    if all(sz == sizes[0] for sz in sizes):
+        out = gv.bufs[0].view(sum(sizes), t2.shape[1])
+    else:
+        out = torch.cat([gv.bufs[0][r, : sizes[r]] for r in range(len(sizes))], dim=0)
+    return out.view(sum(sizes), *t.shape[1:])
+
+
 class _FilipFn(torch.autograd.Function):
+    """Rank-sharded when torch.distributed is initialised: rank r evaluates the row block (its texts x all images) -- every loss
+    term is indexed by a text row in this mode -- and, in the backward, the column block (all texts x its images) again to route
+    the gradient of ITS image tokens; ranks exchange token latents, masks and the per-row log-sum-exp vectors only.  (The
+    reference cannot run this configuration: torch.stack of text and image latents)"""
+
     @staticmethod
     def forward(ctx, spec: ContrastiveSpec, tau: Tensor, T: Tensor, I: Tensor, Tx: Optional[Tensor], Ix: Optional[Tensor], mask: Tensor):
         m, b, nt, d = T.shape
@@ -281,56 +298,91 @@ class _FilipFn(torch.autograd.Function):
         tau32 = tau.detach().reshape(1).float().contiguous()
         mask_u8 = mask.reshape(m, b, nt).to(torch.uint8).contiguous()
         if spec.distributed:
-            raise NotImplementedError("x_clip_amd: the FILIP head is single-process in this build (the reference's own "
-                                      "distributed FILIP path fails at torch.stack, SURVEY.md section 0 item 4)")
-        B = b
+            sizes = [b] * xdist.dist.get_world_size(spec.group) if spec.assume_equal_batch else xdist.exchange_sizes(b, dev, spec.group)
+            rank = xdist.dist.get_rank(spec.group)
+            off, B = sum(sizes[:rank]), sum(sizes)
+        else:
+            sizes, rank, off, B = [b], 0, 0, b
+
+        def everyone(t):                                 # [b, ...] -> [B, ...]
+            return _gather_rows(ops._c(t), sizes, spec.group) if spec.distributed else ops._c(t)
+
+        Ts = [ops._c(T[i]) for i in range(m)]
+        Is_all = [everyone(I[j]) for j in range(n)]
+        Txs = [ops._c(Tx[i]) for i in range(m)] if extra else None
+        Ixs_all = [everyone(Ix[j]) for j in range(n)] if extra else None
         npairs = m * n
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        blocks = []                                       # per view pair: (block for t2i, block for i2t, coef, lse_t2i, lse_i2t)
+        blocks = []
         for i in range(m):
             for j in range(n):
                 w = spec.main_weight if (i == 0 and j == 0) else spec.multiview_weight / max(npairs - 1, 1)
                 coef = w / (2.0 * B)
-                blk1 = _FilipBlock(ops._c(T[i]), mask_u8[i], ops._c(I[j]), tau32).forward()
-                blk2 = _FilipBlock(ops._c(Tx[i]), mask_u8[i], ops._c(Ix[j]), tau32).forward() if extra else blk1
-                lse1 = ops.rowlse(blk1.t2i, 0, spec.dcl, coef, loss)
-                lse2 = ops.rowlse(blk2.i2t, 0, spec.dcl, coef, loss)
+                blk1 = _FilipBlock(Ts[i], mask_u8[i], Is_all[j], tau32).forward()
+                blk2 = _FilipBlock(Txs[i], mask_u8[i], Ixs_all[j], tau32).forward() if extra else blk1
+                lse1 = ops.rowlse(blk1.t2i, off, spec.dcl, coef, loss)
+                lse2 = ops.rowlse(blk2.i2t, off, spec.dcl, coef, loss)
                 blocks.append((i, j, blk1, blk2, coef, lse1, lse2))
-        ctx.spec, ctx.blocks, ctx.geom = spec, blocks, (m, n, b, nt, ni, d, extra, tau.dtype)
+        if spec.distributed:
+            xdist.all_reduce_scalars(loss, spec.group)
+        ctx.spec, ctx.blocks = spec, blocks
+        ctx.local = (Ts, Txs, [ops._c(I[j]) for j in range(n)], [ops._c(Ix[j]) for j in range(n)] if extra else None, mask_u8)
+        ctx.geom = (m, n, b, nt, ni, d, extra, tau.dtype, sizes, off, B, tau32)
         return loss.reshape(())
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dloss):
         spec, blocks = ctx.spec, ctx.blocks
-        m, n, b, nt, ni, d, extra, tau_dtype = ctx.geom
+        m, n, b, nt, ni, d, extra, tau_dtype, sizes, off, B, tau32 = ctx.geom
+        Ts, Txs, Is_loc, Ixs_loc, mask_u8 = ctx.local
         dev = dloss.device
-        dt = blocks[0][2].X.dtype
+        dt = Ts[0].dtype
         gmul = dloss.detach().reshape(1).float().contiguous()
         dtau = torch.zeros(1, dtype=torch.float32, device=dev)
         need = ctx.needs_input_grad
         acc = {"T": [None] * m, "I": [None] * n, "Tx": [None] * m, "Ix": [None] * n}
 
         def add(name, v, g):
-            if g is None:
-                return
-            if acc[name][v] is None:
-                acc[name][v] = g
-            else:                                          # several view pairs feed the same view: acc += g through the GEMM-free path
-                acc[name][v] = _add_rows(acc[name][v], g)
+            if g is not None:
+                acc[name][v] = g if acc[name][v] is None else _add_rows(acc[name][v], g)
+
+        # column blocks (distributed only): all texts x this rank's images, built once per text view / image view pair
+        if spec.distributed:
+            T_all = [_gather_rows(t, sizes, spec.group) for t in Ts]
+            Tx_all = [_gather_rows(t, sizes, spec.group) for t in Txs] if extra else None
+            mask_all = [_gather_rows(mask_u8[i], sizes, spec.group).contiguous() for i in range(m)]
 
         for (i, j, blk1, blk2, coef, lse1, lse2) in blocks:
-            g1 = ops.rowgrad(blk1.t2i, lse1, 0, spec.dcl, coef, gmul, dtau)
-            g2 = ops.rowgrad(blk2.i2t, lse2, 0, spec.dcl, coef, gmul, dtau)
+            g1 = ops.rowgrad(blk1.t2i, lse1, off, spec.dcl, coef, gmul, dtau)
+            g2 = ops.rowgrad(blk2.i2t, lse2, off, spec.dcl, coef, gmul, dtau)
             zeros = torch.zeros_like(g1)
+            local_images = not spec.distributed
             if extra:
-                dX, dY = blk1.backward(g1, zeros, need[2], need[3])
+                dX, dY = blk1.backward(g1, zeros, need[2], need[3] and local_images)
                 add("T", i, dX); add("I", j, dY)
-                dX, dY = blk2.backward(zeros, g2, need[4], need[5])
+                dX, dY = blk2.backward(zeros, g2, need[4], need[5] and local_images)
                 add("Tx", i, dX); add("Ix", j, dY)
             else:
-                dX, dY = blk1.backward(g1, g2, need[2], need[3])
+                dX, dY = blk1.backward(g1, g2, need[2], need[3] and local_images)
                 add("T", i, dX); add("I", j, dY)
+            if spec.distributed and (need[3] or (extra and need[5])):
+                # d loss / d (this rank's image tokens) needs the gradient factors of EVERY text row against the local
+                # images: recompute that column block and weight it with the owners' log-sum-exp vectors
+                lse1_all = _gather_rows(lse1, sizes, spec.group).contiguous()
+                lse2_all = _gather_rows(lse2, sizes, spec.group).contiguous()
+                cb1 = _FilipBlock(T_all[i], mask_all[i], Is_loc[j], tau32).forward()
+                cb2 = _FilipBlock(Tx_all[i], mask_all[i], Ixs_loc[j], tau32).forward() if extra else cb1
+                h1 = ops.rowgrad(cb1.t2i, lse1_all, -off, spec.dcl, coef, gmul, None)
+                h2 = ops.rowgrad(cb2.i2t, lse2_all, -off, spec.dcl, coef, gmul, None)
+                hz = torch.zeros_like(h1)
+                if extra:
+                    _, dY = cb1.backward(h1, hz, False, need[3]); add("I", j, dY)
+                    _, dY = cb2.backward(hz, h2, False, need[5]); add("Ix", j, dY)
+                else:
+                    _, dY = cb1.backward(h1, h2, False, need[3]); add("I", j, dY)
+        if spec.distributed:
+            xdist.all_reduce_scalars(dtau, spec.group)
 
         def stack(name, count, shape):
             out = torch.zeros(count, *shape, dtype=dt, device=dev)
@@ -339,7 +391,7 @@ class _FilipFn(torch.autograd.Function):
                     ops.copy_rows(g.reshape(-1, d), out[k].reshape(-1, d))
             return out
 
-        ctx.blocks = None
+        ctx.blocks = ctx.local = None
         return (None, dtau.reshape(()).to(tau_dtype) if need[1] else None,
                 stack("T", m, (b, nt, d)) if need[2] else None, stack("I", n, (b, ni, d)) if need[3] else None,
                 stack("Tx", m, (b, nt, d)) if (extra and need[4]) else None, stack("Ix", n, (b, ni, d)) if (extra and need[5]) else None,
