@@ -173,9 +173,17 @@ def main():
     if probe is not None:
         launches, flops, secs = probe.summary()
         ach = flops / secs / 1e12 if secs > 0 else 0.0
+        traffic = None                                        # HBM-side bytes per launch from the committed PMC passes of this command
+        try:
+            with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as f:
+                traffic = round(json.load(f)["bytes_per_launch"])
+        except Exception:
+            pass
         out["roofline"] = {"kernel": "xclip_gemm (gemm_kernel<bf16> NT/NN/TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                           "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": None,
+                           "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": traffic,
+                           "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command (profiles/r01_step7_hbm_traffic_pmc.txt)",
+                           "algorithmic_bytes_per_launch": round(probe.algorithmic_bytes / max(launches, 1)),
                            "launches_per_step": launches // max(args.steps, 1),
                            "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
                            "share_of_step": round(secs / elapsed, 4)}

@@ -82,6 +82,34 @@ def test_filip_chunked_workspace_matches_single_chunk(monkeypatch):
     torch.testing.assert_close(g1, m.to_visual_latent.weight.grad, rtol=1e-4, atol=1e-7)
 
 
+def test_vit_l_like_shapes_vs_oracle():
+    """BASELINE configs[4]-like widths (text dim 768 / 12 heads, vision dim 1024 / 16 heads, patch 14 -> 588-wide patch rows padded
+    to the 16-byte chunk, latent 768, one augmented text + image, patch dropout) at a small depth / batch"""
+    cfg = O.ClipConfig(dim_text=768, dim_image=1024, dim_latent=768, num_text_tokens=3000, text_enc_depth=1, text_seq_len=77,
+                       text_heads=12, visual_enc_depth=2, visual_image_size=56, visual_patch_size=14, visual_heads=16)
+    C.case_vs_oracle(DEV, torch.float32, cfg, 8, n_aug_text=1, n_aug_image=1, patch_keep=8)
+    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 8, n_aug_text=1, n_aug_image=1, patch_keep=8)
+
+
+def test_filip_config4_like_bf16_runs_at_scale():
+    """BASELINE configs[3]-like FILIP step (image 224 patch 16 -> 98 kept patches, seq 77) at local batch 256: finite loss near
+    ln(B), finite gradients, chunked workspace path exercised"""
+    from x_clip_amd import CLIP
+    torch.manual_seed(0)
+    m = CLIP(use_all_token_embeds=True, visual_image_size=224, visual_patch_size=16, text_seq_len=77, text_enc_depth=2,
+             visual_enc_depth=2).to(torch.bfloat16).to(DEV).train()
+    b = 256
+    g = torch.Generator().manual_seed(7)
+    text = torch.randint(0, 10000, (b, 77), generator=g).to(DEV)
+    image = torch.randn(b, 3, 224, 224, generator=g).to(torch.bfloat16).to(DEV)
+    loss = m(text, image, return_loss=True)
+    loss.backward()
+    assert torch.isfinite(loss) and abs(float(loss.detach()) - math.log(b)) < 1.0
+    for k, p in m.named_parameters():
+        if "_extra" not in k:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
 def test_checkpointing_is_bit_identical():
     from x_clip_amd import CLIP
     torch.manual_seed(3)

@@ -301,6 +301,7 @@ class GemmProbe:
         torch.cuda.synchronize()
         flops = sum(r[0] for r in self.records)
         secs = sum(r[1].elapsed_time(r[2]) for r in self.records) * 1e-3
+        self.algorithmic_bytes = sum(r[3] for r in self.records)
         return len(self.records), flops, secs
 
 
@@ -337,7 +338,8 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
                             _stream(a)), "xclip_gemm")
     if probe is not None:
         ev1.record(torch.cuda.current_stream(a.device))
-        probe.records.append((2.0 * M * N * K, ev0, ev1))
+        esz = a.element_size()
+        probe.records.append((2.0 * M * N * K, ev0, ev1, (M * K + N * K + M * N) * esz + (M * N * esz if residual is not None else 0)))
     return out
 
 
