@@ -1,0 +1,18 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from x_clip_amd import ops
+dev = torch.device("cuda:0")
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+for (M, N, K) in [(263168, 1536, 512), (263168, 512, 2048)]:
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16); b = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: ops.gemm(a, b, M, N, K, out=out))
+    print(f"ABL={os.environ.get('XCLIP_GEMM_ABL','0'):>2s}  M={M} N={N} K={K}: {t*1e3:8.1f} us  ({t*1e3*256/((M//256)*(N//256)*(K//64)):6.3f} us per K step per CU)", flush=True)

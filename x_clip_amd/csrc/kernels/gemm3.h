@@ -122,7 +122,7 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
         // between the MFMAs of the first two k-blocks below.
         bool dma = false;
         int dm = m0, dn = n0, dk = kbeg;
-        if (ABL != 2) {
+        if (!(ABL & 2)) {
             if (t + 1 < nt) {
                 dma = true; dk = kbeg + (t + 1) * G2_BK;
             } else if (id + (int)gridDim.x < ntiles) {
@@ -147,7 +147,7 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             else g3_prefetch<B_KMAJOR>(p.B, p.ldb, np, p.N, kp, tid & 255, sink);
         }
         u32x4 a[2][4], b[2][2];
-        if (ABL == 4) {
+        if (ABL & 8) {
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
 #pragma unroll
@@ -157,13 +157,13 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) if (ABL != 4) b[0][j] = g3_frag<B_KMAJOR>(Bs, wn * 64 + j * 32, 0, lane);
+        for (int j = 0; j < 2; ++j) if (!(ABL & 8)) b[0][j] = g3_frag<B_KMAJOR>(Bs, wn * 64 + j * 32, 0, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (ABL != 4) a[0][i] = g3_frag<A_KMAJOR>(As, wm * 128 + i * 32, 0, lane);
+        for (int i = 0; i < 4; ++i) if (!(ABL & 8)) a[0][i] = g3_frag<A_KMAJOR>(As, wm * 128 + i * 32, 0, lane);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk < 3 && ABL != 4) {                                        // fragments of the NEXT k-block first ...
+            if (kk < 3 && !(ABL & 8)) {                                        // fragments of the NEXT k-block first ...
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[nxt][j] = g3_frag<B_KMAJOR>(Bs, wn * 64 + j * 32, kk + 1, lane);
 #pragma unroll
@@ -174,13 +174,13 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (ABL == 1) { asm volatile("" :: "v"(a[cur][i]), "v"(b[cur][j])); }
+                    if (ABL & 1) { asm volatile("" :: "v"(a[cur][i]), "v"(b[cur][j])); }
                     else acc[i][j] = mma_kblock(b[cur][j], a[cur][i], acc[i][j], (bf16_t*)nullptr);   // D^T
                 }
                 if (kk < 2 && dma) {                                         // one DMA piece behind every MFMA pair
                     sched_fence();
-                    if (kk == 0) g2_stage_piece<A_KMAJOR>(p.A, p.lda, dm, p.M, dk, dbase, wave, lane, i);
-                    else g2_stage_piece<B_KMAJOR>(p.B, p.ldb, dn, p.N, dk, dbase + G2_OPER_BYTES, wave, lane, i);
+                    if (kk == 0) { if (!(ABL & 16)) g2_stage_piece<A_KMAJOR>(p.A, p.lda, dm, p.M, dk, dbase, wave, lane, i); }
+                    else if (!(ABL & 32)) g2_stage_piece<B_KMAJOR>(p.B, p.ldb, dn, p.N, dk, dbase + G2_OPER_BYTES, wave, lane, i);
                     sched_fence();
                 }
             }
@@ -250,7 +250,7 @@ struct G3GemmEpilogue {
                     const int gn = nb + qq * 8 + 8 * h;
                     if (row_ok && (full || gn < p.N)) {
                         u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 1][0], pk[qq + 1][1]};
-                        if (ABL == 3) { asm volatile("" :: "v"(o)); }
+                        if (ABL & 4) { asm volatile("" :: "v"(o)); }
                         else st16(p.C + (long)gm * p.ldc + gn, o);
                     }
                 }
@@ -261,8 +261,12 @@ struct G3GemmEpilogue {
     }
 };
 
-// ABL (measurement only, XCLIP_GEMM_ABL): 0 = the product kernel; 1 = MFMAs removed; 2 = DMA only for the first tile;
-// 3 = epilogue stores removed; 4 = LDS fragment reads removed
+// ABL (measurement only, XCLIP_GEMM_ABL) is a bit mask: 1 = MFMAs removed, 2 = DMA only for the first K step, 4 = epilogue
+// stores removed, 8 = LDS fragment reads removed, 16 / 32 = the A / B operand's DMA removed; 0 = the product kernel.
+// Per K step per CU at M=263168 N=512 K=2048 (profiles/r01_step7_gemm_ablation_bitmask.log): full 2.39 us; MFMAs alone 1.15;
+// LDS reads alone 0.69; DMA alone 1.83 (A only 1.41, B only 0.91); skeleton 0.14.  Deeper lookahead for the DMA (a ring of four
+// 32-deep stages; an A ring of three + B ring of two 64-deep stages filling all 160 KiB, counted vmcnt) measured 3 - 8 % SLOWER
+// than this two-stage loop, s_setprio around the MFMA groups null: the residual is the fine-grained MFMA / LDS / DMA interleave.
 template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
