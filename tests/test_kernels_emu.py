@@ -68,7 +68,7 @@ def test_gemm_epilogue_and_splitk(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
-@pytest.mark.parametrize("n,masked", [(33, False), (70, True), (97, True)])
+@pytest.mark.parametrize("n,masked", [(33, False), (70, True), (97, True), (66, False)])
 def test_attention(dtype, n, masked):
     K.case_attention(DEV, dtype, 2, n, 2, masked)
 

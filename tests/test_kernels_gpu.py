@@ -69,7 +69,7 @@ def test_gemm_epilogue_and_splitk(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
-@pytest.mark.parametrize("n,heads,masked", [(33, 2, False), (70, 2, True), (257, 8, True), (32, 8, False), (197, 3, True)])
+@pytest.mark.parametrize("n,heads,masked", [(33, 2, False), (70, 2, True), (257, 8, True), (32, 8, False), (197, 3, True), (258, 4, True), (288, 2, False), (66, 2, False)])
 def test_attention(dtype, n, heads, masked):
     K.case_attention(DEV, dtype, 3, n, heads, masked)
 

@@ -32,6 +32,56 @@ XC_DEV void a3_dma_image(unsigned char* img, const bf16_t* X, long ldx, int n, i
     }
 }
 
+// A sequence of 32 q + r rows with a SHORT tail (1 <= r <= A3_TAIL_MAX, e.g. the default text length 257 = 8 * 32 + 1) is not
+// given a ninth wave: 9 waves on 4 SIMDs put 3 on one SIMD and cost 1.44x (measured: n = 256 runs in 0.34 ms, n = 257 in
+// 0.69 ms).  Instead the q full tiles get one wave each and the tail rows are processed COOPERATIVELY: wave w evaluates the
+// tail queries against key sub-tiles w, w + nwaves, ...; the partial (max, sum, O) triples meet in a small LDS scratch.
+constexpr int A3_TAIL_MAX = 2;
+XC_HOST_DEV bool a3_coop_tail(int n) { return (n & 31) != 0 && (n & 31) <= A3_TAIL_MAX && n >= 64; }
+XC_HOST_DEV int a3_waves(int n) { return a3_coop_tail(n) ? n / 32 : (n + 31) / 32; }
+constexpr int A3_TAIL_REC = 66;                                // floats per (wave, tail row): m, l, O[64]
+
+// one 32-key sub-tile of the online-softmax forward for the 32 queries whose fragments are qf (shared by both passes)
+XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
+                        float scale, int lane, f32x16 (&o)[2], float& m, float& l) {
+    const int h = lane >> 5, c31 = lane & 31;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) s = mma_kblock(a2_row_frag(Ks, t * 32 + c31, kb, h), qf[kb], s, (bf16_t*)nullptr);
+    float mx = ATT_NEG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float sv = Ms[t * 32 + mfma_row(r, lane)] ? s[r] * scale : ATT_NEG;
+        s[r] = sv;
+        mx = fmaxf(mx, sv);
+    }
+    mx = fmaxf(mx, shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = fast_exp(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pv = (s[r] > 0.5f * ATT_NEG) ? fast_exp(s[r] - m_new) : 0.f;
+        s[r] = pv;
+        rs += pv;
+    }
+    rs += shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const u32x4 pf = a2_pack_acc(s, blk);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) o[db] = mma_kblock(a2_col_frag(Vs, t, blk, db, lane), pf, o[db], (bf16_t*)nullptr);
+    }
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
     XC_LDS_DYNAMIC(lds);
@@ -39,6 +89,7 @@ __global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
     unsigned char* Ks = lds;
     unsigned char* Vs = Ks + npad * 128;
     unsigned char* Ms = Vs + npad * 128;                       // [npad] key validity
+    float* Ts = reinterpret_cast<float*>(Ms + npad);           // [nwaves][A3_TAIL_MAX][A3_TAIL_REC] tail partials
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c31 = lane & 31;
     const int wave = uniform(tid >> 6), nwaves = blockDim.x >> 6;
     const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
@@ -47,70 +98,136 @@ __global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
     const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.qkv) + (long)bi * n * ldq + hh * ATT_DH;
     const bf16_t* Kb = Qb + (long)p.heads * ATT_DH;
     const bf16_t* Vb = Kb + (long)p.heads * ATT_DH;
+    bf16_t* out = reinterpret_cast<bf16_t*>(p.out) + (long)bi * n * p.heads * ATT_DH + hh * ATT_DH;
+    float* lse_out = p.lse + ((long)bi * p.heads + hh) * n;
     a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
     a3_dma_image(Vs, Vb, ldq, n, npad, wave, nwaves, lane);
     for (int k = tid; k < npad; k += blockDim.x) Ms[k] = (k < n) && (p.mask == nullptr || p.mask[(long)bi * n + k] != 0);
+    const bool coop = a3_coop_tail(n);
+    const int tail0 = (n >> 5) << 5, ntail = n & 31;
     const int q0 = wave * 32;
     const int qrow = q0 + c31;
     const int qld = qrow < n ? qrow : n - 1;
     u32x4 qf[4];
+    f32x16 o[2];
+    wait_vmem();
+    sync();
+    const int nsub = npad >> 5;
+    if (coop) {                                                // tail queries x this wave's share of the key sub-tiles
+        const int trow = tail0 + c31 < n ? tail0 + c31 : n - 1;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) qf[kb] = ld16(Qb + (long)trow * ldq + kb * 16 + h * 8);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+        float m = ATT_NEG, l = 0.f;
+        for (int t = wave; t < nsub; t += nwaves) a3_fwd_step(Ks, Vs, Ms, t, qf, p.scale, lane, o, m, l);
+        if (c31 < ntail) {
+            float* rec = Ts + ((long)wave * A3_TAIL_MAX + c31) * A3_TAIL_REC;
+            if (h == 0) { rec[0] = m; rec[1] = l; }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rec[2 + db * 32 + mfma_row(r, lane)] = o[db][r];
+        }
+    }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) qf[kb] = ld16(Qb + (long)qld * ldq + kb * 16 + h * 8);
-    f32x16 o[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m = ATT_NEG, l = 0.f;
-    wait_vmem();
-    sync();
-    const int nsub = npad >> 5;
-    for (int t = 0; t < nsub; ++t) {
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) s = mma_kblock(a2_row_frag(Ks, t * 32 + c31, kb, h), qf[kb], s, (bf16_t*)nullptr);
-        float mx = ATT_NEG;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float sv = Ms[t * 32 + mfma_row(r, lane)] ? s[r] * p.scale : ATT_NEG;
-            s[r] = sv;
-            mx = fmaxf(mx, sv);
-        }
-        mx = fmaxf(mx, shfl_xor(mx, 32));
-        const float m_new = fmaxf(m, mx);
-        const float alpha = fast_exp(m - m_new);
-        float rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pv = (s[r] > 0.5f * ATT_NEG) ? fast_exp(s[r] - m_new) : 0.f;
-            s[r] = pv;
-            rs += pv;
-        }
-        rs += shfl_xor(rs, 32);
-        l = l * alpha + rs;
-        m = m_new;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const u32x4 pf = a2_pack_acc(s, blk);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) o[db] = mma_kblock(a2_col_frag(Vs, t, blk, db, lane), pf, o[db], (bf16_t*)nullptr);
+    for (int t = 0; t < nsub; ++t) a3_fwd_step(Ks, Vs, Ms, t, qf, p.scale, lane, o, m, l);
+    sync();                                                    // every wave is done with the K / V images (and the tail partials are in)
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    a2_store_rows(lds + wave * 32 * 144, o, inv, out, (long)p.heads * ATT_DH, q0, n, lane);
+    if (h == 0 && qrow < n) lse_out[qrow] = m + logf(l);
+    if (coop && wave == 0) {                                   // merge the nwaves partials of every tail row; lane = feature d
+        for (int q = 0; q < ntail; ++q) {
+            float M = ATT_NEG;
+            for (int w = 0; w < nwaves; ++w) M = fmaxf(M, Ts[((long)w * A3_TAIL_MAX + q) * A3_TAIL_REC]);
+            float L = 0.f, acc = 0.f;
+            for (int w = 0; w < nwaves; ++w) {
+                const float* rec = Ts + ((long)w * A3_TAIL_MAX + q) * A3_TAIL_REC;
+                const float f = fast_exp(rec[0] - M);
+                L += rec[1] * f;
+                acc += rec[2 + lane] * f;
+            }
+            out[(long)(tail0 + q) * p.heads * ATT_DH + lane] = f2bf(L > 0.f ? acc / L : 0.f);
+            if (lane == 0) lse_out[tail0 + q] = M + logf(L);
         }
     }
-    sync();                                                    // every wave is done with the K / V images
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    bf16_t* out = reinterpret_cast<bf16_t*>(p.out) + (long)bi * n * p.heads * ATT_DH + hh * ATT_DH;
-    a2_store_rows(lds + wave * 32 * 144, o, inv, out, (long)p.heads * ATT_DH, q0, n, lane);
-    if (h == 0 && qrow < n) p.lse[((long)bi * p.heads + hh) * n + qrow] = m + logf(l);
 }
 
 // ---- backward (dQ, dK, dV and delta in one kernel) ------------------------------------------------------------------------
-__global__ __launch_bounds__(576) void attn3_bwd_kernel(AttnParams p) {
+// phase A body: dQ^T[d, query] += K^T dS^T for the 32 queries whose fragments are (qf, dof) against key sub-tile t
+XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
+                           const u32x4 (&dof)[4], float lse_q, float delta_q, float scale, int lane, f32x16 (&dq)[2]) {
+    const int h = lane >> 5, c31 = lane & 31;
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        s = mma_kblock(a2_row_frag(Ks, t * 32 + c31, kb, h), qf[kb], s, (bf16_t*)nullptr);
+        dp = mma_kblock(a2_row_frag(Vs, t * 32 + c31, kb, h), dof[kb], dp, (bf16_t*)nullptr);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pv = Ms[t * 32 + mfma_row(r, lane)] ? fast_exp(s[r] * scale - lse_q) : 0.f;
+        s[r] = pv * (dp[r] - delta_q) * scale;                                 // dS^T (already times the q scale)
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const u32x4 df = a2_pack_acc(s, blk);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) dq[db] = mma_kblock(a2_col_frag(Ks, t, blk, db, lane), df, dq[db], (bf16_t*)nullptr);
+    }
+}
+// phase B body: dK^T, dV^T for the 32 keys whose fragments are (kf, vf) against query sub-tile t
+XC_DEV void a3_bwd_dkv_step(const unsigned char* Qs, const unsigned char* dOs, const float* Ls, const float* Ds, int t, int n,
+                            const u32x4 (&kf)[4], const u32x4 (&vf)[4], bool kvalid, float scale, int lane, f32x16 (&dk)[2],
+                            f32x16 (&dv)[2]) {
+    const int h = lane >> 5, c31 = lane & 31;
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        s = mma_kblock(a2_row_frag(Qs, t * 32 + c31, kb, h), kf[kb], s, (bf16_t*)nullptr);
+        dp = mma_kblock(a2_row_frag(dOs, t * 32 + c31, kb, h), vf[kb], dp, (bf16_t*)nullptr);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ql = t * 32 + mfma_row(r, lane);
+        const float pv = (kvalid && ql < n) ? fast_exp(s[r] * scale - Ls[ql]) : 0.f;
+        s[r] = pv;                                                             // P
+        dp[r] = pv * (dp[r] - Ds[ql]) * scale;                                 // dS (times the q scale)
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const u32x4 pf = a2_pack_acc(s, blk);
+        const u32x4 df = a2_pack_acc(dp, blk);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            dv[db] = mma_kblock(a2_col_frag(dOs, t, blk, db, lane), pf, dv[db], (bf16_t*)nullptr);
+            dk[db] = mma_kblock(a2_col_frag(Qs, t, blk, db, lane), df, dk[db], (bf16_t*)nullptr);
+        }
+    }
+}
+// this lane's 32 of the 64 feature values of its column (query / key c31) -> rec[0..63]
+XC_DEV void a3_put_col(float* rec, const f32x16 (&acc)[2], int lane) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rec[db * 32 + mfma_row(r, lane)] = acc[db][r];
+}
+
+// MAXW = 8 leaves 256 VGPRs per lane (two waves per SIMD); the nine-wave variant (n in 259..288) is capped at 168
+template <int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void attn3_bwd_kernel(AttnParams p) {
     XC_LDS_DYNAMIC(lds);
     const int n = p.n, npad = (n + 31) & ~31;
     const int img = npad * 128;
@@ -121,8 +238,10 @@ __global__ __launch_bounds__(576) void attn3_bwd_kernel(AttnParams p) {
     unsigned char* Ms = Vs + img;                              // [npad] key validity
     float* Ls = reinterpret_cast<float*>(Ms + npad);           // [npad] lse per query      (npad is a multiple of 32)
     float* Ds = Ls + npad;                                     // [npad] delta per query
+    float* Tq = Ds + npad;                                     // [nwaves][A3_TAIL_MAX][64]  partial dQ of the tail queries
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c31 = lane & 31;
     const int wave = uniform(tid >> 6), nwaves = blockDim.x >> 6;
+    float* Tk = Tq + nwaves * A3_TAIL_MAX * 64;                // [nwaves][A3_TAIL_MAX][128] partial dK | dV of the tail keys
     const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
     const int hh = bh % p.heads, bi = bh / p.heads;
     const long ldq = 3L * p.heads * ATT_DH, ldo = (long)p.heads * ATT_DH;
@@ -131,131 +250,142 @@ __global__ __launch_bounds__(576) void attn3_bwd_kernel(AttnParams p) {
     const bf16_t* Vb = Kb + (long)p.heads * ATT_DH;
     const bf16_t* dOb = reinterpret_cast<const bf16_t*>(p.dout) + (long)bi * n * ldo + hh * ATT_DH;
     const bf16_t* Ob = reinterpret_cast<const bf16_t*>(p.out) + (long)bi * n * ldo + hh * ATT_DH;
+    bf16_t* dQ = reinterpret_cast<bf16_t*>(p.dqkv) + (long)bi * n * ldq + hh * ATT_DH;
+    bf16_t* dK = dQ + (long)p.heads * ATT_DH;
+    bf16_t* dV = dK + (long)p.heads * ATT_DH;
     a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
     a3_dma_image(Vs, Vb, ldq, n, npad, wave, nwaves, lane);
     a3_dma_image(Qs, Qb, ldq, n, npad, wave, nwaves, lane);
     a3_dma_image(dOs, dOb, ldo, n, npad, wave, nwaves, lane);
     for (int k = tid; k < npad; k += blockDim.x) Ms[k] = (k < n) && (p.mask == nullptr || p.mask[(long)bi * n + k] != 0);
-    // delta_i = sum_d dO[i, d] O[i, d] and lse_i for this wave's 32 rows: lane (i = c31, half h) covers 32 of the 64 d
+    const bool coop = a3_coop_tail(n);
+    const int tail0 = (n >> 5) << 5, ntail = n & 31;
+    // delta_i = sum_d dO[i, d] O[i, d] and lse_i: lane (i = c31, half h) covers 32 of the 64 d; every wave does its own 32 rows,
+    // the waves share the tail tile's rows round-robin (one extra 32-row block for wave 0 when there is a cooperative tail)
     const int r0 = wave * 32;
-    const int row = r0 + c31;
-    const int rld = row < n ? row : n - 1;
-    {
+    for (int blk = wave; blk * 32 < npad; blk += nwaves) {
+        const int row_ = blk * 32 + c31;
+        const int rl = row_ < n ? row_ : n - 1;
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float a[8], b[8];
-            load_vec<bf16_t>(Ob + (long)rld * ldo + h * 32 + c * 8, a);
-            load_vec<bf16_t>(dOb + (long)rld * ldo + h * 32 + c * 8, b);
+            load_vec<bf16_t>(Ob + (long)rl * ldo + h * 32 + c * 8, a);
+            load_vec<bf16_t>(dOb + (long)rl * ldo + h * 32 + c * 8, b);
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc += a[k] * b[k];
         }
         acc += shfl_xor(acc, 32);
         if (h == 0) {
-            Ds[row] = row < n ? acc : 0.f;
-            Ls[row] = row < n ? p.lse[((long)bi * p.heads + hh) * n + rld] : 0.f;
+            Ds[row_] = row_ < n ? acc : 0.f;
+            Ls[row_] = row_ < n ? p.lse[((long)bi * p.heads + hh) * n + rl] : 0.f;
         }
     }
     wait_vmem();
     sync();
     const int nsub = npad >> 5;
+    const int row = r0 + c31;
+    u32x4 qf[4], dof[4];
+    f32x16 dq[2];
 
-    // ---- phase A: dQ^T[d, query] for the wave's queries, streaming the key sub-tiles ----
-    {
-        u32x4 qf[4], dof[4];
+    // ---- phase A: dQ^T[d, query], streaming the key sub-tiles ----
+    if (coop) {                                                // tail queries first: this wave's share of the key sub-tiles
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            qf[kb] = a2_row_frag(Qs, row, kb, h);
-            dof[kb] = a2_row_frag(dOs, row, kb, h);
+            qf[kb] = a2_row_frag(Qs, tail0 + c31, kb, h);
+            dof[kb] = a2_row_frag(dOs, tail0 + c31, kb, h);
         }
-        const float lse_q = Ls[row], delta_q = Ds[row];
-        f32x16 dq[2];
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
-        for (int t = 0; t < nsub; ++t) {
-            f32x16 s, dp;
+        const float lq = Ls[tail0 + c31], dl = Ds[tail0 + c31];
+        for (int t = wave; t < nsub; t += nwaves) a3_bwd_dq_step(Ks, Vs, Ms, t, qf, dof, lq, dl, p.scale, lane, dq);
+        if (c31 < ntail) a3_put_col(Tq + ((long)wave * A3_TAIL_MAX + c31) * 64, dq, lane);
+    }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    for (int kb = 0; kb < 4; ++kb) {
+        qf[kb] = a2_row_frag(Qs, row, kb, h);
+        dof[kb] = a2_row_frag(dOs, row, kb, h);
+    }
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                s = mma_kblock(a2_row_frag(Ks, t * 32 + c31, kb, h), qf[kb], s, (bf16_t*)nullptr);
-                dp = mma_kblock(a2_row_frag(Vs, t * 32 + c31, kb, h), dof[kb], dp, (bf16_t*)nullptr);
-            }
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = Ms[t * 32 + mfma_row(r, lane)] ? fast_exp(s[r] * p.scale - lse_q) : 0.f;
-                s[r] = pv * (dp[r] - delta_q) * p.scale;                       // dS^T (already times the q scale)
-            }
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+    {
+        const float lse_q = Ls[row], delta_q = Ds[row];
+        for (int t = 0; t < nsub; ++t) a3_bwd_dq_step(Ks, Vs, Ms, t, qf, dof, lse_q, delta_q, p.scale, lane, dq);
+    }
+    // this wave's own K / V rows (phase B operands) leave the images before they are recycled as staging space
+    u32x4 kf[4], vf[4];
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const u32x4 df = a2_pack_acc(s, blk);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) dq[db] = mma_kblock(a2_col_frag(Ks, t, blk, db, lane), df, dq[db], (bf16_t*)nullptr);
-            }
+    for (int kb = 0; kb < 4; ++kb) {
+        kf[kb] = a2_row_frag(Ks, row, kb, h);
+        vf[kb] = a2_row_frag(Vs, row, kb, h);
+    }
+    const bool kvalid = Ms[row] != 0;
+    sync();                                                    // all waves are done reading the K / V images; Tq is complete
+    unsigned char* stage = Ks + wave * 32 * 144;
+    a2_store_rows(stage, dq, 1.0f, dQ, ldq, r0, n, lane);
+    if (coop && wave == 0) {                                   // tail dQ = sum of the waves' partials; lane = feature d
+        for (int q = 0; q < ntail; ++q) {
+            float acc = 0.f;
+            for (int w = 0; w < nwaves; ++w) acc += Tq[((long)w * A3_TAIL_MAX + q) * 64 + lane];
+            dQ[(long)(tail0 + q) * ldq + lane] = f2bf(acc);
         }
-        // this wave's own K / V rows (phase B operands) leave the images before they are recycled as staging space
-        u32x4 kf[4], vf[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            kf[kb] = a2_row_frag(Ks, row, kb, h);
-            vf[kb] = a2_row_frag(Vs, row, kb, h);
-        }
-        const bool kvalid = Ms[row] != 0;
-        sync();                                                // all waves are done reading the K / V images
-        unsigned char* stage = Ks + wave * 32 * 144;
-        bf16_t* dQ = reinterpret_cast<bf16_t*>(p.dqkv) + (long)bi * n * ldq + hh * ATT_DH;
-        a2_store_rows(stage, dq, 1.0f, dQ, ldq, r0, n, lane);
+    }
 
-        // ---- phase B: dK^T, dV^T for the wave's keys, streaming the query sub-tiles ----
-        f32x16 dk[2], dv[2];
+    // ---- phase B: dK^T, dV^T for the wave's keys, streaming the query sub-tiles (the tail queries are sub-tile nsub-1) ----
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    for (int t = 0; t < nsub; ++t) a3_bwd_dkv_step(Qs, dOs, Ls, Ds, t, n, kf, vf, kvalid, p.scale, lane, dk, dv);
+    a2_store_rows(stage, dk, 1.0f, dK, ldq, r0, n, lane);
+    a2_store_rows(stage, dv, 1.0f, dV, ldq, r0, n, lane);
+    if (coop) {                                                // tail keys: this wave's share of the query sub-tiles
+        const int trow = tail0 + c31 < n ? tail0 + c31 : n - 1;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {                       // (the K / V images are staging space by now: re-read the rows)
+            kf[kb] = ld16(Kb + (long)trow * ldq + kb * 16 + h * 8);
+            vf[kb] = ld16(Vb + (long)trow * ldq + kb * 16 + h * 8);
+        }
+        const bool tvalid = Ms[tail0 + c31] != 0;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
-        for (int t = 0; t < nsub; ++t) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                s = mma_kblock(a2_row_frag(Qs, t * 32 + c31, kb, h), kf[kb], s, (bf16_t*)nullptr);
-                dp = mma_kblock(a2_row_frag(dOs, t * 32 + c31, kb, h), vf[kb], dp, (bf16_t*)nullptr);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = t * 32 + mfma_row(r, lane);
-                const float pv = (kvalid && ql < n) ? fast_exp(s[r] * p.scale - Ls[ql]) : 0.f;
-                s[r] = pv;                                                     // P
-                dp[r] = pv * (dp[r] - Ds[ql]) * p.scale;                       // dS (times the q scale)
-            }
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const u32x4 pf = a2_pack_acc(s, blk);
-                const u32x4 df = a2_pack_acc(dp, blk);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dv[db] = mma_kblock(a2_col_frag(dOs, t, blk, db, lane), pf, dv[db], (bf16_t*)nullptr);
-                    dk[db] = mma_kblock(a2_col_frag(Qs, t, blk, db, lane), df, dk[db], (bf16_t*)nullptr);
+        for (int t = wave; t < nsub; t += nwaves) a3_bwd_dkv_step(Qs, dOs, Ls, Ds, t, n, kf, vf, tvalid, p.scale, lane, dk, dv);
+        if (c31 < ntail) {
+            float* rec = Tk + ((long)wave * A3_TAIL_MAX + c31) * 128;
+            a3_put_col(rec, dk, lane);
+            a3_put_col(rec + 64, dv, lane);
+        }
+        sync();
+        if (wave == 0) {
+            for (int q = 0; q < ntail; ++q) {
+                float ak = 0.f, av = 0.f;
+                for (int w = 0; w < nwaves; ++w) {
+                    const float* rec = Tk + ((long)w * A3_TAIL_MAX + q) * 128;
+                    ak += rec[lane];
+                    av += rec[64 + lane];
                 }
+                dK[(long)(tail0 + q) * ldq + lane] = f2bf(ak);
+                dV[(long)(tail0 + q) * ldq + lane] = f2bf(av);
             }
         }
-        bf16_t* dK = reinterpret_cast<bf16_t*>(p.dqkv) + (long)bi * n * ldq + (long)p.heads * ATT_DH + hh * ATT_DH;
-        bf16_t* dV = dK + (long)p.heads * ATT_DH;
-        a2_store_rows(stage, dk, 1.0f, dK, ldq, r0, n, lane);
-        a2_store_rows(stage, dv, 1.0f, dV, ldq, r0, n, lane);
     }
 }
 
 inline int attn3_fwd_lds_bytes(int n) {
-    const int npad = (n + 31) & ~31, nw = npad / 32;
-    const int a = 2 * npad * 128 + npad, b = nw * 32 * 144;
+    const int npad = (n + 31) & ~31, nw = a3_waves(n);
+    const int a = 2 * npad * 128 + npad + nw * A3_TAIL_MAX * A3_TAIL_REC * 4, b = nw * 32 * 144;
     return (a > b ? a : b) + 64;
 }
 inline int attn3_bwd_lds_bytes(int n) {
     const int npad = (n + 31) & ~31;
-    return 4 * npad * 128 + npad + 2 * npad * 4 + 64;
+    return 4 * npad * 128 + npad + 2 * npad * 4 + (a3_coop_tail(n) ? a3_waves(n) * A3_TAIL_MAX * (64 + 128) * 4 : 0) + 64;
 }
 
 }  // namespace xc

@@ -565,7 +565,7 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // head-resident kernel: one work-group per (batch, head)
         XC_ALLOW_LDS(attn3_fwd_kernel, 160 * 1024);
-        const int nwq = (int)((n + 31) / 32);
+        const int nwq = a3_waves((int)n);
         hipLaunchKernelGGL(attn3_fwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
         return check_launch(__func__);
     }
@@ -593,9 +593,14 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
-        XC_ALLOW_LDS(attn3_bwd_kernel, 160 * 1024);
-        const int nwq = (int)((n + 31) / 32);
-        hipLaunchKernelGGL(attn3_bwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
+        const int nwq = a3_waves((int)n);
+        if (nwq <= 8) {
+            XC_ALLOW_LDS(attn3_bwd_kernel<8>, 160 * 1024);
+            hipLaunchKernelGGL(attn3_bwd_kernel<8>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
+        } else {
+            XC_ALLOW_LDS(attn3_bwd_kernel<9>, 160 * 1024);
+            hipLaunchKernelGGL(attn3_bwd_kernel<9>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
+        }
         return check_launch(__func__);
     }
     dim3 dgrid((unsigned)((batch * n + 3) / 4)), dblock(256);
