@@ -213,6 +213,115 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
+// GEGLU variant, a = u gelu(t) feeding the LayerNorm.  The generic kernel above evaluates the GELU twice per element (once
+// for a, once for its derivative) and at 2048-wide rows that makes it VALU-bound (~75 ops per element against 20 bytes of
+// traffic).  Here one pass produces gelu(t), u gelu'(t) and the normalised a and keeps them in registers (4 x MAXC x VEC
+// floats per lane) until the row's two reductions are known; gamma sits in LDS.  One exp + one rcp per element.
+// SPLIT waves share a row (each MAXC chunks per lane of its D / SPLIT columns) so that wide rows stay under 168 VGPRs
+// (three waves per SIMD); their two partial sums meet in LDS, double-buffered so one barrier per row suffices.
+template <typename T, int MAXC, int SPLIT>
+__global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long ldx,
+                                                           const T* __restrict__ g, const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in, T* __restrict__ dx, long lddx,
+                                                           float* __restrict__ dg_partial, int rows, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int RPB = 4 / SPLIT;                         // rows per work-group pass
+    XC_LDS_DYNAMIC(lds);
+    float* red = reinterpret_cast<float*>(lds);            // [4][D / SPLIT] dg partials of the four waves
+    float* sred = red + 4 * (D / SPLIT);                   // [2][4][2] row sums (s1, s2) per wave, two buffers
+    T* gs = reinterpret_cast<T*>(sred + 16);               // [D] gamma
+    const int lane = lane_id(), wave = wave_id();
+    const int part = wave % SPLIT, slot = wave / SPLIT;
+    const int nch = D / VEC / SPLIT, c0 = part * nch;      // this wave's chunks: c0 + [0, nch)
+    for (int c = threadIdx.x; c < D / VEC; c += blockDim.x) st16(gs + c * VEC, ld16(g + c * VEC));
+    float dgacc[MAXC][VEC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dgacc[i][j] = 0.f;
+    sync();
+    int it = 0;
+    for (long base = (long)blockIdx.x * RPB; base < rows; base += (long)gridDim.x * RPB, ++it) {
+        const long row = base + slot;
+        const bool live = row < rows;
+        const long rr = live ? row : rows - 1;
+        const float rstd = rstd_in[rr], shift = -mean_in[rr] * rstd;
+        float ge[MAXC][VEC], udge[MAXC][VEC], ah[MAXC][VEC], dyg[MAXC][VEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float u[VEC], t[VEC], gv[VEC];
+                load_vec<T>(x + rr * ldx + (c0 + c) * VEC, u);
+                load_vec<T>(x + rr * ldx + D + (c0 + c) * VEC, t);
+                load_vec<T>(dy + rr * (long)D + (c0 + c) * VEC, dyg[i]);
+                load_vec<T>(gs + (c0 + c) * VEC, gv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float cdf, pdf;
+                    gelu_parts(t[j], cdf, pdf);
+                    ge[i][j] = t[j] * cdf;                                     // gelu(t)
+                    udge[i][j] = u[j] * (cdf + t[j] * pdf);                    // u gelu'(t)
+                    ah[i][j] = u[j] * ge[i][j] * rstd + shift;                 // normalised a
+                    if (live) dgacc[i][j] += dyg[i][j] * ah[i][j];
+                    dyg[i][j] *= gv[j];
+                    s1 += dyg[i][j];
+                    s2 += dyg[i][j] * ah[i][j];
+                }
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (SPLIT > 1) {
+            float* buf = sred + (it & 1) * 8;
+            if (lane == 0) { buf[wave * 2] = s1; buf[wave * 2 + 1] = s2; }
+            sync();
+            s1 = 0.f; s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < SPLIT; ++q) { s1 += buf[(slot * SPLIT + q) * 2]; s2 += buf[(slot * SPLIT + q) * 2 + 1]; }
+        }
+        const float k1 = s1 / (float)D * rstd;
+        const float k2 = s2 / (float)D * rstd;
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
+                    float du[VEC], dt[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float da = dyg[i][j] * rstd - k1 - ah[i][j] * k2;
+                        du[j] = da * ge[i][j];
+                        dt[j] = da * udge[i][j];
+                    }
+                    store_vec<T>(dx + row * lddx + (c0 + c) * VEC, du);
+                    store_vec<T>(dx + row * lddx + D + (c0 + c) * VEC, dt);
+                }
+            }
+        }
+    }
+    // every wave parks its dg partials; the first SPLIT waves fold the RPB row slots of their column part
+    const int Dw = D / SPLIT;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) red[wave * Dw + c * VEC + j] = dgacc[i][j];
+    }
+    sync();
+    if (wave < SPLIT) {
+        float* out = dg_partial + (long)blockIdx.x * D + wave * Dw;
+        for (int col = lane; col < Dw; col += 64) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < RPB; ++q) acc += red[(q * SPLIT + wave) * Dw + col];
+            out[col] = acc;
+        }
+    }
+}
+
 // accum[c] += sum_r partial[r, c]  for partial [nrows, D] fp32.  grid = (ceil(D / 64), slices); each wave sums a strip
 // of rows for 64 columns (coalesced 256-byte row segments), the 4 waves fold through LDS, one atomic per column per
 // work-group (slices-way contention only).

@@ -80,9 +80,19 @@ void launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, co
     dim3 grid(blocks), block(256);
     const size_t lds = (size_t)3 * dim * sizeof(float);
     if (geglu) {
-        XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, true>), lds);
-        hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, true>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
-                           (const T*)g, mean, rstd, (const T*)dres, (T*)dx, (long)lddx, dg, rows, dim);
+        // rows wider than 3 chunks per lane are shared by two waves (register budget: three waves per SIMD)
+        constexpr int SPLIT = (MAXC >= 4 && MAXC % 2 == 0) ? 2 : 1;
+        constexpr int C = MAXC / SPLIT;
+        const size_t lds2 = ((size_t)4 * dim + 16) * sizeof(float) + (size_t)dim * sizeof(T);
+        if (SPLIT == 2 && (dim / Elem<T>::VEC) % 2 == 0) {
+            XC_ALLOW_LDS((ln_geglu_bwd_kernel<T, C, SPLIT>), lds2);
+            hipLaunchKernelGGL((ln_geglu_bwd_kernel<T, C, SPLIT>), grid, block, lds2, st, (const T*)dy, (const T*)x, (long)ldx,
+                               (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+        } else {
+            XC_ALLOW_LDS((ln_geglu_bwd_kernel<T, MAXC, 1>), lds2);
+            hipLaunchKernelGGL((ln_geglu_bwd_kernel<T, MAXC, 1>), grid, block, lds2, st, (const T*)dy, (const T*)x, (long)ldx,
+                               (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+        }
     } else {
         XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, false>), lds);
         hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, false>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
