@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-probe", action="store_true", help="skip the per-launch GEMM event probe")
+    ap.add_argument("--no-probe", action="store_true", help="skip the per-launch GEMM event probe pass after the timed region")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side streams for the vision tower / weight gradients "
                     "(use this for rocprofv3 kernel-trace runs whose per-kernel averages should be of kernels running alone)")
     ap.add_argument("--dcl", action="store_true")
@@ -147,12 +147,8 @@ def main():
     probe = None if args.no_probe else ops.GemmProbe()
     fence()
     t0 = time.perf_counter()
-    if probe is not None:
-        probe.__enter__()
     for _ in range(args.steps):
         loss = step()
-    if probe is not None:
-        probe.__exit__(None, None, None)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -179,13 +175,13 @@ def main():
         "loss": round(loss_val, 5),
     }
     if probe is not None:
-        # the timed region runs weight-gradient GEMMs and the vision tower on side streams, so an event pair there brackets a
-        # kernel that shares the chip with others; the kernel's own duration is measured in a second pass of the same K steps on a
-        # single stream (this is also what `rocprofv3 --kernel-trace` of `bench.py --no-overlap` reports)
-        ov_launches, ov_flops, ov_secs = probe.summary()
+        # Per-launch GEMM durations: HIP events around every xclip_gemm launch, on the stream it is launched on, over K more
+        # steps of the same workload right after the timed region.  That pass runs on a single stream: in the timed region
+        # weight-gradient GEMMs and the vision tower run on side streams, so an event pair there brackets a kernel that shares
+        # the chip with others (and ~300 event records per step cost ~2 ms of the step).  `rocprofv3 --kernel-trace` of
+        # `bench.py --no-overlap` reports the same per-kernel averages (profiles/).
         set_overlap(False)
         step()
-        probe = ops.GemmProbe()
         fence()
         with probe:
             for _ in range(args.steps):
@@ -202,16 +198,12 @@ def main():
         out["roofline"] = {"kernel": "xclip_gemm (gemm_kernel<bf16> NT/NN/TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": traffic,
-                           "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command (profiles/r01_step7_hbm_traffic_pmc.txt)",
+                           "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command (profiles/r01_step9_hbm_traffic_pmc.txt)",
                            "algorithmic_bytes_per_launch": round(probe.algorithmic_bytes / max(launches, 1)),
                            "launches_per_step": launches // max(args.steps, 1),
                            "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
                            "measured": "HIP events around every xclip_gemm launch on its own stream, K steps on a single stream "
-                                       "(kernels alone on the chip) right after the timed region",
-                           "in_timed_region": {"avg_launch_us": round(ov_secs / max(ov_launches, 1) * 1e6, 2),
-                                               "achieved": round(ov_flops / ov_secs / 1e12 if ov_secs > 0 else 0.0, 2),
-                                               "note": "same probe inside the timed region, where GEMMs co-run with kernels of the "
-                                                       "other tower / the weight-gradient stream"}}
+                                       "(kernels alone on the chip) right after the timed region"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

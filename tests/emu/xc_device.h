@@ -335,6 +335,11 @@ inline s16x4 lds_read_tr16(const void* p) {
 inline int uniform(int v) { return v; }
 inline void wave_sync() { int z = 0; (void)xcemu::wave_exchange(&z, sizeof(z)); }      // lanes are fibres: rendezvous
 
+template <int OFF>
+inline u32x4 lds_read16_async(const void* p) { return *reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(p) + OFF); }
+inline u32x2 lds_read_tr16_async(const void* p) { return __builtin_bit_cast(u32x2, lds_read_tr16(p)); }
+template <int N>
+inline void lds_wait(u32x4 (&)[4], u32x4 (&)[2]) {}
 #define XC_WAIT_VMEM_LE(N) ((void)0)
 inline void barrier_nodrain() { xcemu::block_barrier(); }
 inline void mfma_prio(int) {}

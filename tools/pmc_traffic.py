@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""HBM-side traffic per kernel family from two rocprofv3 PMC passes of the same command (CSV output):
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d F -o p -- <cmd>
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d W -o p -- <cmd>
+    python tools/pmc_traffic.py F/p_counter_collection.csv W/p_counter_collection.csv [gemm_traffic.json]
+FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts the 128-byte requests of wide coalesced reads as 64 B -> x2
+(MI355X_MICROARCH.md, HBM section).  Infinity-Cache hits are part of FETCH_SIZE (fabric traffic: an upper bound on HBM reads)."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("void ", "").replace("xc::", "").replace("unsigned short", "bf16")[:60]
+
+
+def load(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                k = short(r["Kernel_Name"])
+                tot[k] += float(r["Counter_Value"])
+                cnt[k] += 1
+    return tot, cnt
+
+
+def main():
+    fetch, nf = load(sys.argv[1], "FETCH_SIZE")
+    write, _ = load(sys.argv[2], "WRITE_SIZE")
+    rows = []
+    for k in fetch:
+        n = nf[k]
+        rd = 2 * fetch[k] * 1024 / n / 1e6
+        wr = write.get(k, 0.0) * 1024 / n / 1e6
+        rows.append((k, n, fetch[k] / n, rd, wr, rd + wr))
+    rows.sort(key=lambda r: -r[5] * r[1])
+    print(f"{'kernel':60s} {'launches':>8s} {'FETCH KiB/launch':>18s} {'reads x2 (MB)':>14s} {'writes (MB)':>12s} {'total (MB)':>11s}")
+    for r in rows[:24]:
+        print(f"{r[0]:60s} {r[1]:8d} {r[2]:18.0f} {r[3]:14.1f} {r[4]:12.1f} {r[5]:11.1f}")
+    g = [r for r in rows if r[0].startswith("gemm3_kernel")]
+    n = sum(r[1] for r in g)
+    per = sum(r[5] * r[1] for r in g) / max(n, 1)
+    print(f"# gemm3 family: {n} launches, {per:.1f} MB per launch (reads x2 + writes)")
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as f:
+            json.dump({"kernel_family": "gemm3_kernel", "bytes_per_launch": per * 1e6, "launches": n,
+                       "source": "tools/pmc_traffic.py over rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (FETCH_SIZE x2 gfx950 correction)"}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from x_clip_amd import ops
 dev = torch.device("cuda:0")
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=20, warm=20):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

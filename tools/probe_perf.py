@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 bf = torch.bfloat16
 
 
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=20, warm=10):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

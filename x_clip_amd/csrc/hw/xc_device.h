@@ -110,6 +110,30 @@ XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 XC_DEV s16x4 lds_read_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
+// ---- LDS reads outside the compiler's wait-count model -----------------------------------------------------------
+// hipcc's waitcnt pass drains lgkmcnt to 0 before the first use of ANY pending ds_read result in the GEMM loops (measured:
+// every fragment batch was followed by s_waitcnt lgkmcnt(0) ahead of the MFMAs it was supposed to overlap).  These
+// variants issue the read as volatile asm -- invisible to that pass -- and lds_wait<N>() is the hand-placed s_waitcnt; the
+// registers passed to it are "modified" by it as far as the compiler knows, so no consumer can be moved above the wait.
+// Rule for users: nothing but MFMAs on OTHER registers between a read and its wait (straight-line code, no loop back-edge).
+XC_DEV uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int OFF>
+XC_DEV u32x4 lds_read16_async(const void* p) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr(p)), "n"(OFF));
+    return v;
+}
+XC_DEV u32x2 lds_read_tr16_async(const void* p) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr(p)));
+    return v;
+}
+template <int N>
+XC_DEV void lds_wait(u32x4 (&a)[4], u32x4 (&b)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+}
 XC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // orders this wave's LDS traffic around a wave-private hand-off (lanes exchange data through LDS without a work-group
 // barrier): the hardware executes a wave's LDS instructions in order; this only stops the compiler from reordering.

@@ -3,10 +3,11 @@
 // operands).  Two things change, both driven by measurements of gemm2.h on MI355X (about 8 us fixed + 2.1 us per K step
 // per tile against 0.85 us of MFMA work per K step):
 //   * the fragment reads are software pipelined by hand: the six ds_reads of k-block kk+1 are issued BEFORE the eight
-//     MFMAs of k-block kk and the order is pinned (sched_barrier), so the compiler's counted lgkmcnt leaves them in flight
-//     under the MFMAs.  (Left alone, hipcc emits read -> lgkmcnt(0) -> 2-4 MFMAs -> read ... and exposes the LDS latency
-//     eight times per K step; a ring of four 32-deep stages with counted vmcnt was measured SLOWER than the two-stage
-//     loop -- the barriers, not the DMA latency, were the cost.)
+//     MFMAs of k-block kk, as volatile asm the compiler's wait-count pass does not see, and waited for (lds_wait) AFTER
+//     those MFMAs.  (With builtin / plain loads hipcc put s_waitcnt lgkmcnt(0) between every read batch and the MFMAs it
+//     was meant to overlap, whatever the source order and sched_barriers said: LDS reads and MFMAs simply added up,
+//     0.69 + 1.15 us per K step.  A ring of four 32-deep stages with counted vmcnt was measured SLOWER than the two-stage
+//     loop.)
 //   * the epilogue goes straight from the accumulators to global memory: the MFMAs are issued with swapped operands
 //     (D^T = B-fragment x A-fragment), so a lane owns ONE output row and 4 consecutive columns per register quad;
 //     v_permlane32_swap pairs the quads into 16-byte stores (cdna_hip_programming.md T21).  No LDS staging and no
@@ -16,9 +17,35 @@
 
 namespace xc {
 
-template <bool KMAJOR>
+// Fragment I (0..3) of a wave's strip starting at tile row / column o0, k-block kk, issued as an untracked LDS read
+// (xc_device.h: lds_read16_async); same addressing as g2_frag_normal / g2_frag_kmajor.
+template <bool KMAJOR, int I>
 XC_DEV u32x4 g3_frag(const unsigned char* tile, int o0, int kk, int lane) {
-    return KMAJOR ? g2_frag_kmajor(tile, o0, kk, lane) : g2_frag_normal(tile, o0, kk, lane);
+    if (!KMAJOR) {
+        const int row = o0 + (lane & 31);                                     // + 32 I rows = + 4096 I bytes, same swizzle
+        const int chunk = (kk * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
+        return lds_read16_async<I * 4096>(tile + row * 128 + chunk * 16);
+    } else {
+        const int g = lane >> 4, tt = lane & 15;
+        const int col = o0 + I * 32 + 16 * (g & 1) + (tt & 3) * 4;
+        const int krow = kk * 16 + 8 * (g >> 1) + (tt >> 2);
+        const int panel = col >> 6, colp = col & 63;
+        const int chunk = (colp >> 3) ^ (((krow >> 1) & 1) << 2);
+        const unsigned char* p = tile + panel * 8192 + krow * 128 + chunk * 16 + (colp & 7) * 2;
+        const u32x2 lo = lds_read_tr16_async(p);                              // k = 8 * (lane >> 5) + 0..3
+        const u32x2 hi = lds_read_tr16_async(p + 4 * 128);                    // k = 8 * (lane >> 5) + 4..7
+        u32x4 f = {lo[0], lo[1], hi[0], hi[1]};
+        return f;
+    }
+}
+template <bool A_KMAJOR, bool B_KMAJOR>
+XC_DEV void g3_read_frags(const unsigned char* As, const unsigned char* Bs, int am, int bn, int kk, int lane, u32x4 (&a)[4], u32x4 (&b)[2]) {
+    b[0] = g3_frag<B_KMAJOR, 0>(Bs, bn, kk, lane);
+    b[1] = g3_frag<B_KMAJOR, 1>(Bs, bn, kk, lane);
+    a[0] = g3_frag<A_KMAJOR, 0>(As, am, kk, lane);
+    a[1] = g3_frag<A_KMAJOR, 1>(As, am, kk, lane);
+    a[2] = g3_frag<A_KMAJOR, 2>(As, am, kk, lane);
+    a[3] = g3_frag<A_KMAJOR, 3>(As, am, kk, lane);
 }
 XC_DEV void g3_add4(float (&v)[4], const bf16_t* p) {
     const u32x2 t = *reinterpret_cast<const u32x2*>(p);
@@ -53,6 +80,24 @@ XC_DEV void g3_prefetch(const bf16_t* X, long ld, int outer0, int nouter, int k0
 // The persistent tile loop shared by the GEMM and by the contrastive-head kernels (simloss3.h): `epi(acc, m0, n0, full)` is
 // called once per finished 256 x 256 tile with the TRANSPOSED accumulators (see below) and must report how many global
 // stores per lane it issued when `full` (interior tile) so the next tile's first wait can leave exactly those in flight.
+// (The return value is no longer needed by the loop below -- its one wait per K step drains everything -- and is ignored.)
+//
+// Schedule of one K step (4 k-blocks C0..C3 of 8 MFMAs per wave; fragments of k-block kk+1 are read under the MFMAs of kk):
+//
+//     [read kk1] C0 + B pieces of DMA(s+1)   [read kk2] C1   [read kk3] C2   wait DMA(s+1); BARRIER   [read kk0 of s+1] C3 + A
+//                                                                                                      pieces of DMA(s+2)
+//
+// The barrier that publishes the next stage sits BEFORE the last k-block, not after it: when a wave leaves the barrier it
+// still has eight MFMAs whose operands are already in registers, and those cover the LDS latency of the first fragment reads
+// from the new stage.  (With the barrier at the K-step boundary every wave came out of it with nothing to compute until twelve
+// ds_reads returned -- all eight waves at once, 96 KiB through the 128 B/clk LDS port, ~0.4 us of idle matrix cores per K
+// step.)  Stage s&1 is free for DMA(s+2) from that same barrier on (every wave has finished its kk3 reads), which also gives
+// the A operand -- the one that streams from HBM -- a full K step of lookahead with only two 64 KiB stages.
+// DMA issue schedule: the piece (0-3 = A, 4-7 = B) that follows MFMA pair i of k-block kk, -1 = none: A0-3 in C3 (the k-block
+// right after the barrier that frees the stage), B0-3 in the next step's C0.  Measured alternatives, all slower: 3 + 3 + 2 over
+// C3 / C0 / C1 (+1.5 %), 2 per k-block (+3 %), all eight in one k-block with the two wave halves alternating (+12 %).
+XC_DEV constexpr int g3_dma_piece(int kk, int i) { return kk == 3 ? i : (kk == 0 ? 4 + i : -1); }
+
 template <bool A_KMAJOR, bool B_KMAJOR, int ABL, class Epilogue>
 XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int tid = threadIdx.x;
@@ -63,33 +108,65 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
     const int nt = (kend - kbeg) / G2_BK;
-    const int h = lane >> 5;
+    const int stride = gridDim.x;
 
     // Persistent: this work-group walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (tile ids are XCD-remapped so that
     // concurrently running work-groups of one XCD share A row-panels in that XCD's L2).  The K steps of consecutive tiles
-    // form ONE stream through the two LDS stages: the DMA of the next tile's first K step is issued before this tile's
-    // epilogue, and the epilogue's stores drain under the next tile's MFMAs (counted vmcnt, bare barriers).
+    // form ONE stream through the two LDS stages; the DMA iterator (tile did, K step dt) runs up to two steps ahead of the
+    // MFMAs, across tile boundaries, and the epilogue's stores drain under the next tile's first k-blocks.
     auto tile_origin = [&](int id, int& m0, int& n0) {
         const int tile = xcd_remap(id, ntiles);
         m0 = (tile / p.tiles_n) * G2_BM;
         n0 = (tile % p.tiles_n) * G2_BN;
     };
-    auto stage = [&](int buf, int m0, int n0, int k0) {
-        unsigned char* base = lds + buf * G2_STAGE_BYTES;
-        g2_stage<A_KMAJOR>(p.A, p.lda, m0, p.M, k0, base, wave, lane);
-        g2_stage<B_KMAJOR>(p.B, p.ldb, n0, p.N, k0, base + G2_OPER_BYTES, wave, lane);
+    int did = blockIdx.x, dt = 0, dm = 0, dn = 0;
+    bool dvalid = did < ntiles && nt > 0;
+    if (!dvalid) return;                                      // (uniform over the work-group)
+    tile_origin(did, dm, dn);
+    auto dma_next = [&]() {
+        if (++dt == nt) {
+            dt = 0;
+            did += stride;
+            dvalid = did < ntiles;
+            if (dvalid) tile_origin(did, dm, dn);
+        }
+        if (ABL & 2) dvalid = false;
     };
-    int step = 0;                                             // running K-step counter: LDS stage = step & 1
-    int m0, n0;
-    if ((int)blockIdx.x < ntiles && nt > 0) {
-        tile_origin(blockIdx.x, m0, n0);
-        stage(0, m0, n0, kbeg);
+    g2_stage<A_KMAJOR>(p.A, p.lda, dm, p.M, kbeg, lds, wave, lane);
+    g2_stage<B_KMAJOR>(p.B, p.ldb, dn, p.N, kbeg, lds + G2_OPER_BYTES, wave, lane);
+    dma_next();
+    XC_WAIT_VMEM_LE(0);
+    barrier_nodrain();                                        // step 0 has landed for every wave
+    if (dvalid) {                                             // the pieces of DMA(1) that the loop would have issued in "C3 of step -1"
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = g3_dma_piece(3, i);
+            if (piece < 0) continue;
+            if (piece < 4) { if (!(ABL & 16)) g2_stage_piece<A_KMAJOR>(p.A, p.lda, dm, p.M, kbeg + dt * G2_BK, lds + G2_STAGE_BYTES, wave, lane, piece); }
+            else if (!(ABL & 32)) g2_stage_piece<B_KMAJOR>(p.B, p.ldb, dn, p.N, kbeg + dt * G2_BK, lds + G2_STAGE_BYTES + G2_OPER_BYTES, wave, lane, piece - 4);
+        }
     }
-    int stores_pending = 0;                                  // epilogue stores per lane of the previous tile still in flight
-    for (int id = blockIdx.x; id < ntiles; id += gridDim.x) {
+
+    u32x4 a[2][4], b[2][2];
+    if (ABL & 8) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[x][i] = zero16();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[x][j] = zero16();
+        }
+    } else {
+        g3_read_frags<A_KMAJOR, B_KMAJOR>(lds, lds + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[0], b[0]);
+        lds_wait<0>(a[0], b[0]);
+    }
+
+    int step = 0;                                             // running K-step counter: LDS stage = step & 1
+    for (int id = blockIdx.x; id < ntiles; id += stride) {
+    int m0, n0;
     tile_origin(id, m0, n0);
     // acc[i][j] holds the TRANSPOSED 32 x 32 block: register r of lane l is
-    // C[m = m0 + wm*128 + i*32 + (l & 31)][n = n0 + wn*64 + j*32 + (r & 3) + 8 (r >> 2) + 4 (l >> 5)]
+    // C[m = i-block row (l & 31)][n = j-block column (r & 3) + 8 (r >> 2) + 4 (l >> 5)]
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -99,77 +176,29 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int t = 0; t < nt; ++t, ++step) {
-        // this K step's DMA (issued one step ago) has landed for every wave; the previous tile's epilogue stores
-        // (16 or 32 per lane, younger than that DMA) may stay in flight
-        // (in issue order: 8 DMA pieces, 1 prefetch touch, then possibly the epilogue stores; vmcnt retires in order)
-        if (G3_L2_PREFETCH) {
-            if (stores_pending == 16) XC_WAIT_VMEM_LE(17);
-            else if (stores_pending == 32) XC_WAIT_VMEM_LE(33);
-            else if (step > 0) XC_WAIT_VMEM_LE(1);
-            else XC_WAIT_VMEM_LE(0);
-        } else {
-            if (stores_pending == 16) XC_WAIT_VMEM_LE(16);
-            else if (stores_pending == 32) XC_WAIT_VMEM_LE(32);
-            else XC_WAIT_VMEM_LE(0);
-        }
-        stores_pending = 0;
-        barrier_nodrain();
-        const unsigned char* As = lds + (step & 1) * G2_STAGE_BYTES;
-        const unsigned char* Bs = As + G2_OPER_BYTES;
-        // next K step of this tile -- or the first K step of the NEXT tile -- goes into the other stage (its last readers
-        // passed the barrier above).  Its 8 DMA pieces per wave are NOT issued here in a burst (measured: 47 % of the wave
-        // cycles were issue stalls with all 8 waves queueing 8 pieces each right after the barrier) but one at a time
-        // between the MFMAs of the first two k-blocks below.
-        bool dma = false;
-        int dm = m0, dn = n0, dk = kbeg;
-        if (!(ABL & 2)) {
-            if (t + 1 < nt) {
-                dma = true; dk = kbeg + (t + 1) * G2_BK;
-            } else if (id + (int)gridDim.x < ntiles) {
-                dma = true; tile_origin(id + gridDim.x, dm, dn);
-            }
-        }
-        unsigned char* dbase = lds + ((step + 1) & 1) * G2_STAGE_BYTES;
-        // L2 prefetch of the tiles G3_PD steps ahead (possibly in the next tile): waves 0-3 touch A's 256 lines, waves 4-7
-        // B's when B streams from HBM too (wgrad), else A's once more; exactly ONE instruction per wave per K step
-        if (G3_L2_PREFETCH) {
-            int tp = t + G3_PD, mp = m0, np = n0;
-            bool ok = true;
-            if (tp >= nt) {
-                tp -= nt;
-                const int idn = id + (int)gridDim.x;
-                ok = idn < ntiles && tp < nt;
-                if (ok) tile_origin(idn, mp, np);
-            }
-            const int kp = kbeg + (ok ? tp : t) * G2_BK;       // nothing ahead: re-touch the current step (count stays uniform)
-            unsigned char* sink = lds + G2_LDS_BYTES + wave * 256;
-            if (wave < 4 || !(A_KMAJOR && B_KMAJOR)) g3_prefetch<A_KMAJOR>(p.A, p.lda, mp, p.M, kp, tid & 255, sink);
-            else g3_prefetch<B_KMAJOR>(p.B, p.ldb, np, p.N, kp, tid & 255, sink);
-        }
-        u32x4 a[2][4], b[2][2];
-        if (ABL & 8) {
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[x][i] = zero16();
-#pragma unroll
-                for (int j = 0; j < 2; ++j) b[x][j] = zero16();
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) if (!(ABL & 8)) b[0][j] = g3_frag<B_KMAJOR>(Bs, wn * 64 + j * 32, 0, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (!(ABL & 8)) a[0][i] = g3_frag<A_KMAJOR>(As, wm * 128 + i * 32, 0, lane);
+        unsigned char* cur_stage = lds + (step & 1) * G2_STAGE_BYTES;
+        unsigned char* nxt_stage = lds + ((step + 1) & 1) * G2_STAGE_BYTES;
+        const unsigned char* As = cur_stage;
+        const unsigned char* Bs = cur_stage + G2_OPER_BYTES;
+        const bool more = (t + 1 < nt) || (id + stride < ntiles);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk < 3 && !(ABL & 8)) {                                        // fragments of the NEXT k-block first ...
-#pragma unroll
-                for (int j = 0; j < 2; ++j) b[nxt][j] = g3_frag<B_KMAJOR>(Bs, wn * 64 + j * 32, kk + 1, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[nxt][i] = g3_frag<A_KMAJOR>(As, wm * 128 + i * 32, kk + 1, lane);
+            if (kk < 3) {
+                if (!(ABL & 8))                                              // fragments of the NEXT k-block first ...
+                    g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
+            } else {
+                XC_WAIT_VMEM_LE(0);                                          // this wave's share of DMA(step + 1) (and any epilogue stores)
+                barrier_nodrain();                                           // ... everybody's; and nobody reads stage step & 1 any more
+                if (more && !(ABL & 8))
+                    g3_read_frags<A_KMAJOR, B_KMAJOR>(nxt_stage, nxt_stage + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[nxt], b[nxt]);
             }
             sched_fence();                                                   // ... then this k-block's MFMAs, order pinned
+            // this wave's 8 DMA pieces of the stage freed by the barrier above (A0-3, B0-3) trickle out behind MFMA pairs of
+            // C3 and of the next step's first k-blocks: g3_dma_piece(kk, i) says which one goes after pair i of k-block kk
+            unsigned char* dst = (kk == 3) ? cur_stage : nxt_stage;
+            const int dk = kbeg + dt * G2_BK;
+            const int dma_m = (ABL & 64) ? (dm & 256) : dm;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -177,18 +206,25 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     if (ABL & 1) { asm volatile("" :: "v"(a[cur][i]), "v"(b[cur][j])); }
                     else acc[i][j] = mma_kblock(b[cur][j], a[cur][i], acc[i][j], (bf16_t*)nullptr);   // D^T
                 }
-                if (kk < 2 && dma) {                                         // one DMA piece behind every MFMA pair
+                const int piece = g3_dma_piece(kk, i);
+                if (piece >= 0 && dvalid) {
                     sched_fence();
-                    if (kk == 0) { if (!(ABL & 16)) g2_stage_piece<A_KMAJOR>(p.A, p.lda, dm, p.M, dk, dbase, wave, lane, i); }
-                    else if (!(ABL & 32)) g2_stage_piece<B_KMAJOR>(p.B, p.ldb, dn, p.N, dk, dbase + G2_OPER_BYTES, wave, lane, i);
+                    if (piece < 4) {
+                        if (!(ABL & 16)) g2_stage_piece<A_KMAJOR>(p.A, p.lda, dma_m, p.M, dk, dst, wave, lane, piece);
+                    } else {
+                        if (!(ABL & 32)) g2_stage_piece<B_KMAJOR>(p.B, p.ldb, dn, p.N, dk, dst + G2_OPER_BYTES, wave, lane, piece - 4);
+                    }
                     sched_fence();
                 }
             }
+            if (kk == 0 && dvalid) dma_next();                  // this wave's share of the stage is on its way
+            sched_fence();
+            if (!(ABL & 8)) lds_wait<0>(a[nxt], b[nxt]);                     // landed long ago: the 8 MFMAs above covered the latency
             sched_fence();
         }
     }
 
-    stores_pending = epi(acc, m0, n0);
+    (void)epi(acc, m0, n0);
     }   // tile loop
 }
 
@@ -262,11 +298,14 @@ struct G3GemmEpilogue {
 };
 
 // ABL (measurement only, XCLIP_GEMM_ABL) is a bit mask: 1 = MFMAs removed, 2 = DMA only for the first K step, 4 = epilogue
-// stores removed, 8 = LDS fragment reads removed, 16 / 32 = the A / B operand's DMA removed; 0 = the product kernel.
-// Per K step per CU at M=263168 N=512 K=2048 (profiles/r01_step7_gemm_ablation_bitmask.log): full 2.39 us; MFMAs alone 1.15;
-// LDS reads alone 0.69; DMA alone 1.83 (A only 1.41, B only 0.91); skeleton 0.14.  Deeper lookahead for the DMA (a ring of four
-// 32-deep stages; an A ring of three + B ring of two 64-deep stages filling all 160 KiB, counted vmcnt) measured 3 - 8 % SLOWER
-// than this two-stage loop, s_setprio around the MFMA groups null: the residual is the fine-grained MFMA / LDS / DMA interleave.
+// stores removed, 8 = LDS fragment reads removed, 16 / 32 = the A / B operand's DMA removed, 64 = A's DMA source wrapped to 512
+// rows (L2-resident); 0 = the product kernel.  Per K step per CU at M=263168 N=512 K=2048, warm clocks
+// (profiles/r01_step9_gemm_ablation.log):  full 2.11 us;  MFMAs alone 1.14;  MFMA + LDS reads 1.57;  MFMA + DMA 1.79;  DMA alone
+// 1.65 (1.15 with A from L2: the L2 -> LDS path gives ~60 GB/s per CU whatever the source pattern -- 128-byte row pieces and
+// contiguous 32 KiB blocks time the same, padded row strides too);  skeleton 0.21;  the epilogue's stores cost 0.1 us per K
+// step at K=2048 and 0.56 at K=512.  Before the fragment reads went to untracked asm the full loop was 2.39 and MFMA + reads
+// 1.78.  Negative results kept for the record: a ring of four 32-deep stages, an A-ring of three + B-ring of two 64-deep stages
+// (all 160 KiB), s_setprio around the MFMA groups, L2 prefetch touches, staggered work-group starts, other DMA issue schedules.
 template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);

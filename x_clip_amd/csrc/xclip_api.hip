@@ -150,7 +150,7 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
         static const int abl = [] { const char* e = getenv("XCLIP_GEMM_ABL"); return e ? atoi(e) : 0; }();
         if (abl != 0 && !AK && !BK_) {                      // measurement-only variants of the NT kernel
 #define XC_ABL(N) case N: XC_ALLOW_LDS((gemm3_kernel<false, false, N>), G3_LDS_BYTES); hipLaunchKernelGGL((gemm3_kernel<false, false, N>), pgrid, block, G3_LDS_BYTES, st, p); return;
-            switch (abl) { XC_ABL(1) XC_ABL(2) XC_ABL(4) XC_ABL(8) XC_ABL(3) XC_ABL(9) XC_ABL(10) XC_ABL(11) XC_ABL(14) XC_ABL(15) XC_ABL(25) XC_ABL(41) default: break; }
+            switch (abl) { XC_ABL(1) XC_ABL(2) XC_ABL(4) XC_ABL(8) XC_ABL(3) XC_ABL(9) XC_ABL(10) XC_ABL(11) XC_ABL(14) XC_ABL(15) XC_ABL(25) XC_ABL(41) XC_ABL(64) XC_ABL(73) XC_ABL(105) default: break; }
 #undef XC_ABL
         }
         XC_ALLOW_LDS((gemm3_kernel<AK, BK_>), G3_LDS_BYTES);
