@@ -305,7 +305,11 @@ struct G3GemmEpilogue {
 // contiguous 32 KiB blocks time the same, padded row strides too);  skeleton 0.21;  the epilogue's stores cost 0.1 us per K
 // step at K=2048 and 0.56 at K=512.  Before the fragment reads went to untracked asm the full loop was 2.39 and MFMA + reads
 // 1.78.  Negative results kept for the record: a ring of four 32-deep stages, an A-ring of three + B-ring of two 64-deep stages
-// (all 160 KiB), s_setprio around the MFMA groups, L2 prefetch touches, staggered work-group starts, other DMA issue schedules.
+// (all 160 KiB), s_setprio around the MFMA groups, L2 prefetch touches, staggered work-group starts, other DMA issue schedules,
+// accumulators pinned to AGPRs (the compiler then splits 128 / 128 and spills), an epilogue transposed through wave-private LDS
+// so that every store is a full 128-byte line (K=512: 508 vs 510 us -- the 86 us the stores cost there are not a coalescing
+// problem), the tile's last B pieces issued before the epilogue so its stores may stay in flight one more K step (no change),
+// one fragment read in front of each MFMA instead of six up front (+1 %).
 template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
