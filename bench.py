@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-launch GEMM event probe pass after the timed region")
+    ap.add_argument("--overlap", default="both", choices=["both", "towers", "wgrad"], help="which side streams to use (diagnostics)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side streams for the vision tower / weight gradients "
                     "(use this for rocprofv3 kernel-trace runs whose per-kernel averages should be of kernels running alone)")
     ap.add_argument("--dcl", action="store_true")
@@ -129,12 +130,14 @@ def main():
             sync.finish()
         return loss
 
-    def set_overlap(on):
-        functional.OVERLAP_WGRAD = on
-        model.overlap_towers = on
+    def set_overlap(on, which="both"):
+        functional.OVERLAP_WGRAD = on and which in ("both", "wgrad")
+        model.overlap_towers = on and which in ("both", "towers")
 
     if args.no_overlap:
         set_overlap(False)
+    elif args.overlap != "both":
+        set_overlap(True, args.overlap)
     for _ in range(args.warmup):
         step()
 
@@ -146,10 +149,12 @@ def main():
 
     probe = None if args.no_probe else ops.GemmProbe()
     fence()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
+    ms1 = torch.cuda.memory_stats(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -173,6 +178,9 @@ def main():
                    "gflop_per_pair_fwd_bwd": round(3 * fwd_flops / 1e9, 3)},
         "model_mfma_frac": round(value * 3 * fwd_flops / (world * MFMA_PEAK_BF16), 4),
         "loss": round(loss_val, 5),
+        # hipMalloc calls inside the timed region (0 once the caching allocator is warm) and the peak footprint
+        "allocator": {"device_mallocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+                      "peak_reserved_gb": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 2)},
     }
     if probe is not None:
         # Per-launch GEMM durations: HIP events around every xclip_gemm launch, on the stream it is launched on, over K more

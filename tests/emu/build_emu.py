@@ -8,10 +8,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "x_clip_amd", "csrc")
 OUT = os.path.join(HERE, "libxclip_emu.so")
+UNITS = ["xclip_api.hip", "xclip_attn.hip"]                  # the product's translation units (x_clip_amd/build.py)
 
 
 def sources():
-    out = [os.path.join(CSRC, "xclip_api.hip"), os.path.join(HERE, "xc_device.h"), os.path.join(ROOT, "include", "xclip.h")]
+    out = [os.path.join(CSRC, u) for u in UNITS] + [os.path.join(CSRC, "api_common.h"), os.path.join(HERE, "xc_device.h"),
+                                                    os.path.join(ROOT, "include", "xclip.h")]
     kdir = os.path.join(CSRC, "kernels")
     out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir))]
     return out
@@ -24,7 +26,7 @@ def build(force=False):
     if not os.path.exists(cxx):
         cxx = "clang++"
     cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi",
-           "-I", HERE, "-I", CSRC, os.path.join(CSRC, "xclip_api.hip"), "-o", OUT]
+           "-I", HERE, "-I", CSRC, *[os.path.join(CSRC, u) for u in UNITS], "-o", OUT]
     subprocess.run(cmd, check=True)
     return OUT
 

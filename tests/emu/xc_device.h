@@ -355,6 +355,7 @@ inline void permlane32_swap(uint32_t& a, uint32_t& b) {
 
 inline void atomic_add(float* p, float v) { *p += v; }
 inline float fast_exp(float x) { return expf(x); }
+inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 

@@ -13,9 +13,17 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxclip_hip.so")
 
 
+UNITS = [  # (source, extra flags)
+    ("xclip_api.hip", []),
+    # MFMA results stay in ordinary VGPRs in this unit: the attention kernels consume every accumulator with VALU right away and
+    # the default heuristic parked them in AGPRs (32 v_accvgpr_read per 12 MFMAs in the backward's inner loop)
+    ("xclip_attn.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
+]
+
+
 def _sources():
-    out = [os.path.join(CSRC, "xclip_api.hip"), os.path.join(CSRC, "hw", "xc_device.h"),
-           os.path.join(os.path.dirname(HERE), "include", "xclip.h")]
+    out = [os.path.join(CSRC, u) for u, _ in UNITS] + [os.path.join(CSRC, "api_common.h"), os.path.join(CSRC, "hw", "xc_device.h"),
+                                                        os.path.join(os.path.dirname(HERE), "include", "xclip.h")]
     kdir = os.path.join(CSRC, "kernels")
     out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir))]
     return out
@@ -25,12 +33,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in _sources()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mcode-object-version=5",
-           "-ffp-contract=fast", "-Wno-unused-value",
-           "-I", os.path.join(CSRC, "hw"), "-I", CSRC, os.path.join(CSRC, "xclip_api.hip"), "-o", LIB]
+    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-ffp-contract=fast",
+              "-Wno-unused-value", "-I", os.path.join(CSRC, "hw"), "-I", CSRC]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.run(cmd, check=True)
+        common.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for unit, extra in UNITS:                                   # the units compile side by side
+        obj = os.path.join(objdir, unit.replace(".hip", ".o"))
+        objs.append(obj)
+        procs.append(subprocess.Popen([hipcc, *common, *extra, "-c", os.path.join(CSRC, unit), "-o", obj]))
+    if any(p.wait() != 0 for p in procs):
+        raise RuntimeError("hipcc failed")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], check=True)
     return LIB
 
 

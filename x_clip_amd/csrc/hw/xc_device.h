@@ -160,6 +160,7 @@ XC_DEV void permlane32_swap(uint32_t& a, uint32_t& b) {
 XC_DEV void atomic_add(float* p, float v) { atomicAdd(p, v); }
 
 XC_DEV float fast_exp(float x) { return __expf(x); }
+XC_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }        // bare v_exp_f32
 XC_DEV float fast_rsqrt(float x) { return rsqrtf(x); }
 XC_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

@@ -163,8 +163,9 @@ __global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
 
 // ---- backward (dQ, dK, dV and delta in one kernel) ------------------------------------------------------------------------
 // phase A body: dQ^T[d, query] += K^T dS^T for the 32 queries whose fragments are (qf, dof) against key sub-tile t
+// (lse2_q = lse_q log2(e) and scale2 = scale log2(e): the probability is one fma + a bare v_exp_f32)
 XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
-                           const u32x4 (&dof)[4], float lse_q, float delta_q, float scale, int lane, f32x16 (&dq)[2]) {
+                           const u32x4 (&dof)[4], float lse2_q, float delta_q, float scale, float scale2, int lane, f32x16 (&dq)[2]) {
     const int h = lane >> 5, c31 = lane & 31;
     f32x16 s, dp;
 #pragma unroll
@@ -176,7 +177,7 @@ XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Vs, con
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float pv = Ms[t * 32 + mfma_row(r, lane)] ? fast_exp(s[r] * scale - lse_q) : 0.f;
+        const float pv = Ms[t * 32 + mfma_row(r, lane)] ? fast_exp2(s[r] * scale2 - lse2_q) : 0.f;
         s[r] = pv * (dp[r] - delta_q) * scale;                                 // dS^T (already times the q scale)
     }
 #pragma unroll
@@ -187,24 +188,36 @@ XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Vs, con
     }
 }
 // phase B body: dK^T, dV^T for the 32 keys whose fragments are (kf, vf) against query sub-tile t
-XC_DEV void a3_bwd_dkv_step(const unsigned char* Qs, const unsigned char* dOs, const float* Ls, const float* Ds, int t, int n,
-                            const u32x4 (&kf)[4], const u32x4 (&vf)[4], bool kvalid, float scale, int lane, f32x16 (&dk)[2],
-                            f32x16 (&dv)[2]) {
+XC_DEV void a3_bwd_dkv_step(const unsigned char* Qs, const unsigned char* dOs, const float* Ls2, const float* Ds, int t, int n,
+                            const u32x4 (&kf)[4], const u32x4 (&vf)[4], bool kvalid, float scale, float scale2, int lane,
+                            f32x16 (&dk)[2], f32x16 (&dv)[2]) {
     const int h = lane >> 5, c31 = lane & 31;
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    // lse log2(e) and delta of the 16 queries this lane's accumulator registers belong to: rows 8 q + 4 h + (0..3) of the
+    // sub-tile, i.e. four 16-byte LDS reads each -- issued up front, unconditionally (rows >= n hold 0 and are masked by a
+    // select below; a conditional load here compiled to sixteen exec-masked branches with an LDS round trip each)
+    float l2[16], dl[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32x4 a = ld16(Ls2 + t * 32 + 8 * q + 4 * h), b = ld16(Ds + t * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { l2[4 * q + e] = u2f(a[e]); dl[4 * q + e] = u2f(b[e]); }
+    }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         s = mma_kblock(a2_row_frag(Qs, t * 32 + c31, kb, h), kf[kb], s, (bf16_t*)nullptr);
         dp = mma_kblock(a2_row_frag(dOs, t * 32 + c31, kb, h), vf[kb], dp, (bf16_t*)nullptr);
     }
+    const bool full = t * 32 + 32 <= n;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ql = t * 32 + mfma_row(r, lane);
-        const float pv = (kvalid && ql < n) ? fast_exp(s[r] * scale - Ls[ql]) : 0.f;
+        float pv = fast_exp2(s[r] * scale2 - l2[r]);
+        pv = (kvalid && (full || ql < n)) ? pv : 0.f;
         s[r] = pv;                                                             // P
-        dp[r] = pv * (dp[r] - Ds[ql]) * scale;                                 // dS (times the q scale)
+        dp[r] = pv * (dp[r] - dl[r]) * scale;                                  // dS (times the q scale)
     }
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -225,23 +238,55 @@ XC_DEV void a3_put_col(float* rec, const f32x16 (&acc)[2], int lane) {
         for (int r = 0; r < 16; ++r) rec[db * 32 + mfma_row(r, lane)] = acc[db][r];
 }
 
-// MAXW = 8 leaves 256 VGPRs per lane (two waves per SIMD); the nine-wave variant (n in 259..288) is capped at 168
-template <int MAXW>
-__global__ __launch_bounds__(MAXW * 64) void attn3_bwd_kernel(AttnParams p) {
+// acc[db] (rows = d = 32 db + mfma_row, column = this lane's row c31) -> dst rows [row0, row0 + 32), straight from the
+// registers: a lane owns a row, v_permlane32_swap pairs the 4-column quads into 16-byte stores (as the GEMM epilogue)
+XC_DEV void a3_store_rows_direct(const f32x16 (&acc)[2], bf16_t* dst, long ldd, int row0, int nrows, int lane) {
+    const int c31 = lane & 31, h = lane >> 5;
+    const int row = row0 + c31;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pk[q][0] = (uint32_t)f2bf(acc[db][4 * q]) | ((uint32_t)f2bf(acc[db][4 * q + 1]) << 16);
+            pk[q][1] = (uint32_t)f2bf(acc[db][4 * q + 2]) | ((uint32_t)f2bf(acc[db][4 * q + 3]) << 16);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; qq += 2) {
+            permlane32_swap(pk[qq][0], pk[qq + 1][0]);
+            permlane32_swap(pk[qq][1], pk[qq + 1][1]);
+            if (row < nrows) {
+                u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 1][0], pk[qq + 1][1]};
+                st16(dst + (long)row * ldd + db * 32 + qq * 8 + 8 * h, o);
+            }
+        }
+    }
+}
+// this lane's 16-byte pieces of row `r` of X (the operand layout a2_row_frag returns), straight from global memory
+XC_DEV void a3_row_frags(const bf16_t* X, long ldx, int r, int lane, u32x4 (&f)[4]) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) f[kb] = ld16(X + (long)r * ldx + kb * 16 + h * 8);
+}
+
+// Two operand images at a time: phase A needs the K and V images (its own Q / dO rows come straight from global memory,
+// L2 hits: the image DMA of the other work-group / phase asks for the same lines), phase B the Q and dO images (own K / V
+// rows from global), so the second pair is DMA'd over the first between the phases and a head needs ~80 KB of LDS instead
+// of 160: TWO work-groups of four waves per CU (each wave takes every fourth 32-row block), one computing while the other
+// waits for HBM.  (The one-work-group-per-CU version measured load + store skeleton 405 us, phase A 225, phase B 395, total
+// 1060 = their sum at n = 256.)  p.chunks is a measurement switch here (XCLIP_ATTN_ABL: 1 = skip phase A, 2 = skip phase B).
+__global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
     XC_LDS_DYNAMIC(lds);
     const int n = p.n, npad = (n + 31) & ~31;
     const int img = npad * 128;
-    unsigned char* Qs = lds;
-    unsigned char* dOs = Qs + img;
-    unsigned char* Ks = dOs + img;
-    unsigned char* Vs = Ks + img;
-    unsigned char* Ms = Vs + img;                              // [npad] key validity
-    float* Ls = reinterpret_cast<float*>(Ms + npad);           // [npad] lse per query      (npad is a multiple of 32)
+    unsigned char* R0 = lds;                                   // K, then Q
+    unsigned char* R1 = R0 + img;                              // V, then dO
+    unsigned char* Ms = R1 + img;                              // [npad] key validity
+    float* Ls = reinterpret_cast<float*>(Ms + npad);           // [npad] lse log2(e) per query (npad is a multiple of 32)
     float* Ds = Ls + npad;                                     // [npad] delta per query
-    float* Tq = Ds + npad;                                     // [nwaves][A3_TAIL_MAX][64]  partial dQ of the tail queries
+    float* Tp = Ds + npad;                                     // [nwaves][A3_TAIL_MAX][128] tail partials: dQ (phase A), dK | dV (phase B)
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c31 = lane & 31;
     const int wave = uniform(tid >> 6), nwaves = blockDim.x >> 6;
-    float* Tk = Tq + nwaves * A3_TAIL_MAX * 64;                // [nwaves][A3_TAIL_MAX][128] partial dK | dV of the tail keys
     const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
     const int hh = bh % p.heads, bi = bh / p.heads;
     const long ldq = 3L * p.heads * ATT_DH, ldo = (long)p.heads * ATT_DH;
@@ -253,17 +298,16 @@ __global__ __launch_bounds__(MAXW * 64) void attn3_bwd_kernel(AttnParams p) {
     bf16_t* dQ = reinterpret_cast<bf16_t*>(p.dqkv) + (long)bi * n * ldq + hh * ATT_DH;
     bf16_t* dK = dQ + (long)p.heads * ATT_DH;
     bf16_t* dV = dK + (long)p.heads * ATT_DH;
-    a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
-    a3_dma_image(Vs, Vb, ldq, n, npad, wave, nwaves, lane);
-    a3_dma_image(Qs, Qb, ldq, n, npad, wave, nwaves, lane);
-    a3_dma_image(dOs, dOb, ldo, n, npad, wave, nwaves, lane);
+    a3_dma_image(R0, Kb, ldq, n, npad, wave, nwaves, lane);
+    a3_dma_image(R1, Vb, ldq, n, npad, wave, nwaves, lane);
     for (int k = tid; k < npad; k += blockDim.x) Ms[k] = (k < n) && (p.mask == nullptr || p.mask[(long)bi * n + k] != 0);
     const bool coop = a3_coop_tail(n);
     const int tail0 = (n >> 5) << 5, ntail = n & 31;
-    // delta_i = sum_d dO[i, d] O[i, d] and lse_i: lane (i = c31, half h) covers 32 of the 64 d; every wave does its own 32 rows,
-    // the waves share the tail tile's rows round-robin (one extra 32-row block for wave 0 when there is a cooperative tail)
-    const int r0 = wave * 32;
-    for (int blk = wave; blk * 32 < npad; blk += nwaves) {
+    const int nblk = a3_waves(n);                              // 32-row blocks owned by single waves (without a cooperative tail)
+    const int nsub = npad >> 5;
+    const float scale2 = p.scale * 1.4426950408889634f;
+    // delta_i = sum_d dO[i, d] O[i, d] and lse_i log2(e): lane (i = c31, half h) covers 32 of the 64 d
+    for (int blk = wave; blk < nsub; blk += nwaves) {
         const int row_ = blk * 32 + c31;
         const int rl = row_ < n ? row_ : n - 1;
         float acc = 0.f;
@@ -278,96 +322,95 @@ __global__ __launch_bounds__(MAXW * 64) void attn3_bwd_kernel(AttnParams p) {
         acc += shfl_xor(acc, 32);
         if (h == 0) {
             Ds[row_] = row_ < n ? acc : 0.f;
-            Ls[row_] = row_ < n ? p.lse[((long)bi * p.heads + hh) * n + rl] : 0.f;
+            Ls[row_] = row_ < n ? p.lse[((long)bi * p.heads + hh) * n + rl] * 1.4426950408889634f : 0.f;
         }
     }
     wait_vmem();
     sync();
-    const int nsub = npad >> 5;
-    const int row = r0 + c31;
-    u32x4 qf[4], dof[4];
-    f32x16 dq[2];
 
-    // ---- phase A: dQ^T[d, query], streaming the key sub-tiles ----
-    if (coop) {                                                // tail queries first: this wave's share of the key sub-tiles
+    // ---- phase A: dQ^T[d, query] for the wave's query blocks, streaming the key sub-tiles of the K / V images ----
+    u32x4 f0[4], f1[4];                                        // the block's own rows: (Q, dO) in phase A, (K, V) in phase B
+    f32x16 g0[2], g1[2];                                       // dQ in phase A; dK, dV in phase B
+    if (!(p.chunks & 1)) {
+        if (coop) {                                            // tail queries first: this wave's share of the key sub-tiles
+            const int trow = tail0 + c31 < n ? tail0 + c31 : n - 1;
+            a3_row_frags(Qb, ldq, trow, lane, f0);
+            a3_row_frags(dOb, ldo, trow, lane, f1);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            qf[kb] = a2_row_frag(Qs, tail0 + c31, kb, h);
-            dof[kb] = a2_row_frag(dOs, tail0 + c31, kb, h);
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g0[db][r] = 0.f;
+            const float lq = Ls[tail0 + c31], dl = Ds[tail0 + c31];
+            for (int t = wave; t < nsub; t += nwaves) a3_bwd_dq_step(R0, R1, Ms, t, f0, f1, lq, dl, p.scale, scale2, lane, g0);
+            if (c31 < ntail) a3_put_col(Tp + ((long)wave * A3_TAIL_MAX + c31) * 128, g0, lane);
         }
+        for (int rb = wave; rb < nblk; rb += nwaves) {
+            const int row = rb * 32 + c31;
+            const int rl = row < n ? row : n - 1;
+            a3_row_frags(Qb, ldq, rl, lane, f0);
+            a3_row_frags(dOb, ldo, rl, lane, f1);
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
-        const float lq = Ls[tail0 + c31], dl = Ds[tail0 + c31];
-        for (int t = wave; t < nsub; t += nwaves) a3_bwd_dq_step(Ks, Vs, Ms, t, qf, dof, lq, dl, p.scale, lane, dq);
-        if (c31 < ntail) a3_put_col(Tq + ((long)wave * A3_TAIL_MAX + c31) * 64, dq, lane);
+                for (int r = 0; r < 16; ++r) g0[db][r] = 0.f;
+            const float lse_q = Ls[row], delta_q = Ds[row];
+            for (int t = 0; t < nsub; ++t) a3_bwd_dq_step(R0, R1, Ms, t, f0, f1, lse_q, delta_q, p.scale, scale2, lane, g0);
+            a3_store_rows_direct(g0, dQ, ldq, rb * 32, n, lane);
+        }
     }
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        qf[kb] = a2_row_frag(Qs, row, kb, h);
-        dof[kb] = a2_row_frag(dOs, row, kb, h);
-    }
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
-    {
-        const float lse_q = Ls[row], delta_q = Ds[row];
-        for (int t = 0; t < nsub; ++t) a3_bwd_dq_step(Ks, Vs, Ms, t, qf, dof, lse_q, delta_q, p.scale, lane, dq);
-    }
-    // this wave's own K / V rows (phase B operands) leave the images before they are recycled as staging space
-    u32x4 kf[4], vf[4];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        kf[kb] = a2_row_frag(Ks, row, kb, h);
-        vf[kb] = a2_row_frag(Vs, row, kb, h);
-    }
-    const bool kvalid = Ms[row] != 0;
-    sync();                                                    // all waves are done reading the K / V images; Tq is complete
-    unsigned char* stage = Ks + wave * 32 * 144;
-    a2_store_rows(stage, dq, 1.0f, dQ, ldq, r0, n, lane);
-    if (coop && wave == 0) {                                   // tail dQ = sum of the waves' partials; lane = feature d
+    sync();                                                    // every wave is done with the K / V images; the tail partials are complete
+    a3_dma_image(R0, Qb, ldq, n, npad, wave, nwaves, lane);
+    a3_dma_image(R1, dOb, ldo, n, npad, wave, nwaves, lane);
+    if (coop && wave == 0 && !(p.chunks & 1)) {                // tail dQ = sum of the waves' partials; lane = feature d
         for (int q = 0; q < ntail; ++q) {
             float acc = 0.f;
-            for (int w = 0; w < nwaves; ++w) acc += Tq[((long)w * A3_TAIL_MAX + q) * 64 + lane];
+            for (int w = 0; w < nwaves; ++w) acc += Tp[((long)w * A3_TAIL_MAX + q) * 128 + lane];
             dQ[(long)(tail0 + q) * ldq + lane] = f2bf(acc);
         }
     }
+    wait_vmem();
+    sync();                                                    // Q / dO images in place; Tp may be reused
 
-    // ---- phase B: dK^T, dV^T for the wave's keys, streaming the query sub-tiles (the tail queries are sub-tile nsub-1) ----
-    f32x16 dk[2], dv[2];
+    // ---- phase B: dK^T, dV^T for the wave's key blocks, streaming the query sub-tiles of the Q / dO images ----
+    if (!(p.chunks & 2)) {
+        for (int rb = wave; rb < nblk; rb += nwaves) {
+            const int row = rb * 32 + c31;
+            const int rl = row < n ? row : n - 1;
+            a3_row_frags(Kb, ldq, rl, lane, f0);
+            a3_row_frags(Vb, ldq, rl, lane, f1);
+            const bool kvalid = Ms[row] != 0;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
-    for (int t = 0; t < nsub; ++t) a3_bwd_dkv_step(Qs, dOs, Ls, Ds, t, n, kf, vf, kvalid, p.scale, lane, dk, dv);
-    a2_store_rows(stage, dk, 1.0f, dK, ldq, r0, n, lane);
-    a2_store_rows(stage, dv, 1.0f, dV, ldq, r0, n, lane);
-    if (coop) {                                                // tail keys: this wave's share of the query sub-tiles
-        const int trow = tail0 + c31 < n ? tail0 + c31 : n - 1;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {                       // (the K / V images are staging space by now: re-read the rows)
-            kf[kb] = ld16(Kb + (long)trow * ldq + kb * 16 + h * 8);
-            vf[kb] = ld16(Vb + (long)trow * ldq + kb * 16 + h * 8);
+                for (int r = 0; r < 16; ++r) { g0[db][r] = 0.f; g1[db][r] = 0.f; }
+            for (int t = 0; t < nsub; ++t) a3_bwd_dkv_step(R0, R1, Ls, Ds, t, n, f0, f1, kvalid, p.scale, scale2, lane, g0, g1);
+            a3_store_rows_direct(g0, dK, ldq, rb * 32, n, lane);
+            a3_store_rows_direct(g1, dV, ldq, rb * 32, n, lane);
         }
-        const bool tvalid = Ms[tail0 + c31] != 0;
+        if (coop) {                                            // tail keys: this wave's share of the query sub-tiles
+            const int trow = tail0 + c31 < n ? tail0 + c31 : n - 1;
+            a3_row_frags(Kb, ldq, trow, lane, f0);
+            a3_row_frags(Vb, ldq, trow, lane, f1);
+            const bool tvalid = Ms[tail0 + c31] != 0;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
-        for (int t = wave; t < nsub; t += nwaves) a3_bwd_dkv_step(Qs, dOs, Ls, Ds, t, n, kf, vf, tvalid, p.scale, lane, dk, dv);
-        if (c31 < ntail) {
-            float* rec = Tk + ((long)wave * A3_TAIL_MAX + c31) * 128;
-            a3_put_col(rec, dk, lane);
-            a3_put_col(rec + 64, dv, lane);
+                for (int r = 0; r < 16; ++r) { g0[db][r] = 0.f; g1[db][r] = 0.f; }
+            for (int t = wave; t < nsub; t += nwaves) a3_bwd_dkv_step(R0, R1, Ls, Ds, t, n, f0, f1, tvalid, p.scale, scale2, lane, g0, g1);
+            if (c31 < ntail) {
+                float* rec = Tp + ((long)wave * A3_TAIL_MAX + c31) * 128;
+                a3_put_col(rec, g0, lane);
+                a3_put_col(rec + 64, g1, lane);
+            }
         }
+    }
+    if (coop) {
         sync();
-        if (wave == 0) {
+        if (wave == 0 && !(p.chunks & 2)) {
             for (int q = 0; q < ntail; ++q) {
                 float ak = 0.f, av = 0.f;
                 for (int w = 0; w < nwaves; ++w) {
-                    const float* rec = Tk + ((long)w * A3_TAIL_MAX + q) * 128;
+                    const float* rec = Tp + ((long)w * A3_TAIL_MAX + q) * 128;
                     ak += rec[lane];
                     av += rec[64 + lane];
                 }
@@ -378,6 +421,9 @@ __global__ __launch_bounds__(MAXW * 64) void attn3_bwd_kernel(AttnParams p) {
     }
 }
 
+constexpr int A3_BWD_WAVES = 4;
+XC_HOST_DEV int a3_bwd_waves(int n) { const int b = a3_waves(n); return b < A3_BWD_WAVES ? b : A3_BWD_WAVES; }
+
 inline int attn3_fwd_lds_bytes(int n) {
     const int npad = (n + 31) & ~31, nw = a3_waves(n);
     const int a = 2 * npad * 128 + npad + nw * A3_TAIL_MAX * A3_TAIL_REC * 4, b = nw * 32 * 144;
@@ -385,7 +431,7 @@ inline int attn3_fwd_lds_bytes(int n) {
 }
 inline int attn3_bwd_lds_bytes(int n) {
     const int npad = (n + 31) & ~31;
-    return 4 * npad * 128 + npad + 2 * npad * 4 + (a3_coop_tail(n) ? a3_waves(n) * A3_TAIL_MAX * (64 + 128) * 4 : 0) + 64;
+    return 2 * npad * 128 + npad + 2 * npad * 4 + (a3_coop_tail(n) ? a3_bwd_waves(n) * A3_TAIL_MAX * 128 * 4 : 0) + 64;
 }
 
 }  // namespace xc

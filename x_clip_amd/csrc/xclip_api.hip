@@ -2,15 +2,7 @@
 // launches.  No allocation, no synchronisation, no global mutable state besides the thread-local error string.
 #include "xc_device.h"
 
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include "../../include/xclip.h"
-#include "kernels/attention.h"
-#include "kernels/attention2.h"
-#include "kernels/attention3.h"
+#include "api_common.h"
 #include "kernels/filip.h"
 #include "kernels/gemm.h"
 #include "kernels/gemm2.h"
@@ -21,8 +13,9 @@
 #include "kernels/tokens.h"
 
 using namespace xc;
+using namespace xcapi;
 
-namespace {
+namespace xcapi {
 
 thread_local char g_err[512] = "";
 
@@ -38,15 +31,10 @@ int check_launch(const char* fn) {
     }
     return 0;
 }
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-inline int vec_of(int dtype) { return dtype == XCLIP_BF16 ? 8 : 4; }
-inline int esize(int dtype) { return dtype == XCLIP_BF16 ? 2 : 4; }
-inline bool dtype_ok(int dtype) { return dtype == XCLIP_F32 || dtype == XCLIP_BF16; }
 
-#define XC_REQUIRE(cond, msg) \
-    do {                      \
-        if (!(cond)) return fail(__func__, msg); \
-    } while (0)
+}  // namespace xcapi
+
+namespace {
 
 // smallest power of two >= ceil(dim / (64 * VEC)), i.e. 16-byte chunks per lane when one wave holds a row
 inline int chunks_per_lane(int64_t dim, int vec) {
@@ -88,10 +76,15 @@ void launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, co
             XC_ALLOW_LDS((ln_geglu_bwd_kernel<T, C, SPLIT>), lds2);
             hipLaunchKernelGGL((ln_geglu_bwd_kernel<T, C, SPLIT>), grid, block, lds2, st, (const T*)dy, (const T*)x, (long)ldx,
                                (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
-        } else {
-            XC_ALLOW_LDS((ln_geglu_bwd_kernel<T, MAXC, 1>), lds2);
-            hipLaunchKernelGGL((ln_geglu_bwd_kernel<T, MAXC, 1>), grid, block, lds2, st, (const T*)dy, (const T*)x, (long)ldx,
+        } else if (MAXC <= 4) {
+            constexpr int C1 = MAXC <= 4 ? MAXC : 1;
+            XC_ALLOW_LDS((ln_geglu_bwd_kernel<T, C1, 1>), lds2);
+            hipLaunchKernelGGL((ln_geglu_bwd_kernel<T, C1, 1>), grid, block, lds2, st, (const T*)dy, (const T*)x, (long)ldx,
                                (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+        } else {                                               // very wide rows with an odd chunk count: the generic two-pass kernel
+            XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, true>), lds);
+            hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, true>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
+                               (const T*)g, mean, rstd, (const T*)dres, (T*)dx, (long)lddx, dg, rows, dim);
         }
     } else {
         XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, false>), lds);
@@ -181,46 +174,6 @@ int gemm_splits(int64_t M, int64_t N, int64_t K, int dtype) {
     if (s > maxs) s = maxs;
     if (s > 64) s = 64;
     return s < 2 ? 1 : (int)s;
-}
-
-template <typename T, int NW>
-void launch_attn_fwd(AttnParams p, hipStream_t st) {
-    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
-    constexpr int lds = attn_fwd_lds_bytes<T, NW>();
-    XC_ALLOW_LDS((attn_fwd_kernel<T, NW>), lds);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
-}
-template <typename T, int NW>
-void launch_attn_bwd(AttnParams p, hipStream_t st) {
-    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
-    constexpr int lds_q = attn_dq_lds_bytes<T, NW>(), lds_kv = attn_dkv_lds_bytes<T, NW>();
-    XC_ALLOW_LDS((attn_dq_kernel<T, NW>), lds_q);
-    XC_ALLOW_LDS((attn_dkv_kernel<T, NW>), lds_kv);
-    hipLaunchKernelGGL((attn_dq_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_q, st, p);
-    hipLaunchKernelGGL((attn_dkv_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_kv, st, p);
-}
-template <int NW>
-void launch_attn2_fwd(AttnParams p, hipStream_t st) {
-    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
-    constexpr int lds = attn2_lds_bytes<NW>();
-    hipLaunchKernelGGL((attn2_fwd_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
-}
-template <int NW>
-void launch_attn2_bwd(AttnParams p, hipStream_t st) {
-    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
-    constexpr int lds = attn2_lds_bytes<NW>();
-    hipLaunchKernelGGL((attn2_dq_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
-    hipLaunchKernelGGL((attn2_dkv_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
-}
-// waves per work-group: the NW in 1..4 that wastes the fewest padded rows (ties -> larger NW)
-int attn_waves(int64_t n) {
-    int best = 1;
-    int64_t best_pad = -1;
-    for (int nw = 1; nw <= 4; ++nw) {
-        const int64_t rows = ((n + nw * 32 - 1) / (nw * 32)) * nw * 32;
-        if (best_pad < 0 || rows <= best_pad) { best = nw; best_pad = rows; }
-    }
-    return best;
 }
 
 }  // namespace
@@ -559,73 +512,6 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
             hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace,
                                (float*)C, (long)ldc, (int)M, (int)N, splits, alpha);
     }
-    return check_launch(__func__);
-}
-
-int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n, int64_t heads,
-                        float scale, int dtype, void* stream) {
-    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
-    XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
-    XC_REQUIRE(aligned16(qkv) && aligned16(out), "pointers must be 16-byte aligned");
-    if (batch == 0) return 0;
-    AttnParams p;
-    memset(&p, 0, sizeof(p));
-    p.qkv = qkv; p.mask = mask; p.out = out; p.lse = lse;
-    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // head-resident kernel: one work-group per (batch, head)
-        XC_ALLOW_LDS(attn3_fwd_kernel, 160 * 1024);
-        const int nwq = a3_waves((int)n);
-        hipLaunchKernelGGL(attn3_fwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
-        return check_launch(__func__);
-    }
-    const int nw = attn_waves(n);
-#define F(T) switch (nw) { case 1: launch_attn_fwd<T, 1>(p, st); break; case 2: launch_attn_fwd<T, 2>(p, st); break; \
-                           case 3: launch_attn_fwd<T, 3>(p, st); break; default: launch_attn_fwd<T, 4>(p, st); break; }
-    if (dtype == XCLIP_BF16) {
-        switch (nw) { case 1: launch_attn2_fwd<1>(p, st); break; case 2: launch_attn2_fwd<2>(p, st); break;
-                      case 3: launch_attn2_fwd<3>(p, st); break; default: launch_attn2_fwd<4>(p, st); break; }
-    } else { F(float) }
-#undef F
-    return check_launch(__func__);
-}
-
-int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
-                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int dtype, void* stream) {
-    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
-    XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
-    XC_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "pointers must be 16-byte aligned");
-    if (batch == 0) return 0;
-    AttnParams p;
-    memset(&p, 0, sizeof(p));
-    p.qkv = qkv; p.mask = mask; p.out = const_cast<void*>(out); p.lse = const_cast<float*>(lse); p.dout = dout;
-    p.delta = delta_ws; p.dqkv = dqkv;
-    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
-        const int nwq = a3_waves((int)n);
-        if (nwq <= 8) {
-            XC_ALLOW_LDS(attn3_bwd_kernel<8>, 160 * 1024);
-            hipLaunchKernelGGL(attn3_bwd_kernel<8>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
-        } else {
-            XC_ALLOW_LDS(attn3_bwd_kernel<9>, 160 * 1024);
-            hipLaunchKernelGGL(attn3_bwd_kernel<9>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
-        }
-        return check_launch(__func__);
-    }
-    dim3 dgrid((unsigned)((batch * n + 3) / 4)), dblock(256);
-    if (dtype == XCLIP_BF16)
-        hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dgrid, dblock, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, (int)batch, (int)n, (int)heads);
-    else
-        hipLaunchKernelGGL((attn_delta_kernel<float>), dgrid, dblock, 0, st, (const float*)out, (const float*)dout, delta_ws, (int)batch, (int)n, (int)heads);
-    const int nw = attn_waves(n);
-#define F(T) switch (nw) { case 1: launch_attn_bwd<T, 1>(p, st); break; case 2: launch_attn_bwd<T, 2>(p, st); break; \
-                           case 3: launch_attn_bwd<T, 3>(p, st); break; default: launch_attn_bwd<T, 4>(p, st); break; }
-    if (dtype == XCLIP_BF16) {
-        switch (nw) { case 1: launch_attn2_bwd<1>(p, st); break; case 2: launch_attn2_bwd<2>(p, st); break;
-                      case 3: launch_attn2_bwd<3>(p, st); break; default: launch_attn2_bwd<4>(p, st); break; }
-    } else { F(float) }
-#undef F
     return check_launch(__func__);
 }
 

@@ -1,0 +1,125 @@
+// xclip_attn.hip -- the attention entry points of include/xclip.h.  A translation unit of its own because it is compiled with
+// -mllvm -amdgpu-mfma-vgpr-form: the attention kernels consume every MFMA result with VALU right away, and the default
+// heuristic parked those accumulators in AGPRs (32 v_accvgpr_read per 12 MFMAs in the backward's inner loop); the same flag
+// makes the contrastive-head kernels of the other unit spill.
+#include "xc_device.h"
+
+#include "api_common.h"
+#include "kernels/attention.h"
+#include "kernels/attention2.h"
+#include "kernels/attention3.h"
+
+using namespace xc;
+using namespace xcapi;
+
+namespace {
+
+template <typename T, int NW>
+void launch_attn_fwd(AttnParams p, hipStream_t st) {
+    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
+    constexpr int lds = attn_fwd_lds_bytes<T, NW>();
+    XC_ALLOW_LDS((attn_fwd_kernel<T, NW>), lds);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
+}
+template <typename T, int NW>
+void launch_attn_bwd(AttnParams p, hipStream_t st) {
+    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
+    constexpr int lds_q = attn_dq_lds_bytes<T, NW>(), lds_kv = attn_dkv_lds_bytes<T, NW>();
+    XC_ALLOW_LDS((attn_dq_kernel<T, NW>), lds_q);
+    XC_ALLOW_LDS((attn_dkv_kernel<T, NW>), lds_kv);
+    hipLaunchKernelGGL((attn_dq_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_q, st, p);
+    hipLaunchKernelGGL((attn_dkv_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_kv, st, p);
+}
+template <int NW>
+void launch_attn2_fwd(AttnParams p, hipStream_t st) {
+    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
+    constexpr int lds = attn2_lds_bytes<NW>();
+    hipLaunchKernelGGL((attn2_fwd_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
+}
+template <int NW>
+void launch_attn2_bwd(AttnParams p, hipStream_t st) {
+    p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
+    constexpr int lds = attn2_lds_bytes<NW>();
+    hipLaunchKernelGGL((attn2_dq_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((attn2_dkv_kernel<NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
+}
+// waves per work-group: the NW in 1..4 that wastes the fewest padded rows (ties -> larger NW)
+int attn_waves(int64_t n) {
+    int best = 1;
+    int64_t best_pad = -1;
+    for (int nw = 1; nw <= 4; ++nw) {
+        const int64_t rows = ((n + nw * 32 - 1) / (nw * 32)) * nw * 32;
+        if (best_pad < 0 || rows <= best_pad) { best = nw; best_pad = rows; }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n, int64_t heads,
+                        float scale, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
+    XC_REQUIRE(aligned16(qkv) && aligned16(out), "pointers must be 16-byte aligned");
+    if (batch == 0) return 0;
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = qkv; p.mask = mask; p.out = out; p.lse = lse;
+    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // head-resident kernel: one work-group per (batch, head)
+        XC_ALLOW_LDS(attn3_fwd_kernel, 160 * 1024);
+        const int nwq = a3_waves((int)n);
+        hipLaunchKernelGGL(attn3_fwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
+        return check_launch(__func__);
+    }
+    const int nw = attn_waves(n);
+#define F(T) switch (nw) { case 1: launch_attn_fwd<T, 1>(p, st); break; case 2: launch_attn_fwd<T, 2>(p, st); break; \
+                           case 3: launch_attn_fwd<T, 3>(p, st); break; default: launch_attn_fwd<T, 4>(p, st); break; }
+    if (dtype == XCLIP_BF16) {
+        switch (nw) { case 1: launch_attn2_fwd<1>(p, st); break; case 2: launch_attn2_fwd<2>(p, st); break;
+                      case 3: launch_attn2_fwd<3>(p, st); break; default: launch_attn2_fwd<4>(p, st); break; }
+    } else { F(float) }
+#undef F
+    return check_launch(__func__);
+}
+
+int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
+                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
+    XC_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "pointers must be 16-byte aligned");
+    if (batch == 0) return 0;
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = qkv; p.mask = mask; p.out = const_cast<void*>(out); p.lse = const_cast<float*>(lse); p.dout = dout;
+    p.delta = delta_ws; p.dqkv = dqkv;
+    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
+        const int nwq = a3_bwd_waves((int)n);
+        static const int abl = [] { const char* e = getenv("XCLIP_ATTN_ABL"); return e ? atoi(e) : 0; }();   // measurement only
+        p.chunks = abl;
+        XC_ALLOW_LDS(attn3_bwd_kernel, 160 * 1024);
+        hipLaunchKernelGGL(attn3_bwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
+        return check_launch(__func__);
+    }
+    dim3 dgrid((unsigned)((batch * n + 3) / 4)), dblock(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dgrid, dblock, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, (int)batch, (int)n, (int)heads);
+    else
+        hipLaunchKernelGGL((attn_delta_kernel<float>), dgrid, dblock, 0, st, (const float*)out, (const float*)dout, delta_ws, (int)batch, (int)n, (int)heads);
+    const int nw = attn_waves(n);
+#define F(T) switch (nw) { case 1: launch_attn_bwd<T, 1>(p, st); break; case 2: launch_attn_bwd<T, 2>(p, st); break; \
+                           case 3: launch_attn_bwd<T, 3>(p, st); break; default: launch_attn_bwd<T, 4>(p, st); break; }
+    if (dtype == XCLIP_BF16) {
+        switch (nw) { case 1: launch_attn2_bwd<1>(p, st); break; case 2: launch_attn2_bwd<2>(p, st); break;
+                      case 3: launch_attn2_bwd<3>(p, st); break; default: launch_attn2_bwd<4>(p, st); break; }
+    } else { F(float) }
+#undef F
+    return check_launch(__func__);
+}
+
+}  // extern "C"
