@@ -27,6 +27,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define XC_DEV inline
+#define XC_FOUR_WAVES_PER_SIMD
 #define XC_HOST_DEV inline
 #define XC_LDS_DYNAMIC(name) unsigned char* name = xcemu::dyn_lds()
 #define XC_ALLOW_LDS(kernel, bytes) ((void)0)
@@ -265,6 +266,17 @@ inline float shfl_xor(float v, int mask) { return shfl_generic(v, lane_id() ^ ma
 inline int shfl_xor(int v, int mask) { return shfl_generic(v, lane_id() ^ mask); }
 inline float shfl(float v, int src) { return shfl_generic(v, src); }
 inline int shfl(int v, int src) { return shfl_generic(v, src); }
+
+inline bool wave_all(bool pred) {
+    int v = pred ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v &= shfl_xor(v, m);
+    return v != 0;
+}
+inline bool wave_any(bool pred) {
+    int v = pred ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v |= shfl_xor(v, m);
+    return v != 0;
+}
 
 inline float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);

@@ -9,6 +9,8 @@
 #include <stdint.h>
 
 #define XC_DEV __device__ __forceinline__
+// kernel attribute: plan for four waves per SIMD, i.e. at most 128 VGPRs per lane
+#define XC_FOUR_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(4)))
 #define XC_HOST_DEV __host__ __device__ __forceinline__
 // dynamic LDS carve base, 16-byte aligned (cdna_hip_programming.md Guideline 17)
 #define XC_LDS_DYNAMIC(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -63,6 +65,10 @@ XC_DEV float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 XC_DEV int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 XC_DEV float shfl(float v, int src) { return __shfl(v, src, 64); }
 XC_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
+
+// wave-wide votes (the result is uniform)
+XC_DEV bool wave_all(bool pred) { return __all(pred) != 0; }
+XC_DEV bool wave_any(bool pred) { return __any(pred) != 0; }
 
 XC_DEV float wave_sum(float v) {
 #pragma unroll

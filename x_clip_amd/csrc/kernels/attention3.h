@@ -41,35 +41,42 @@ XC_HOST_DEV bool a3_coop_tail(int n) { return (n & 31) != 0 && (n & 31) <= A3_TA
 XC_HOST_DEV int a3_waves(int n) { return a3_coop_tail(n) ? n / 32 : (n + 31) / 32; }
 constexpr int A3_TAIL_REC = 66;                                // floats per (wave, tail row): m, l, O[64]
 
-// one 32-key sub-tile of the online-softmax forward for the 32 queries whose fragments are qf (shared by both passes)
+// one 32-key sub-tile of the online-softmax forward for the 32 queries whose fragments are qf (shared by both passes).
+// The kernels are VALU-bound (the first version spent ~250 VALU instructions per 8 MFMAs here), so the softmax bookkeeping is
+// kept in the base-2 domain of the SCALED scores: m2 = running max of s * scale2 (scale2 = scale log2 e, the max is taken
+// over the raw accumulators), p = exp2(fma(s, scale2, -m2)) is one fma + one bare v_exp_f32 per score, and the key-validity
+// selects are only compiled into the MASKED variant -- the caller votes per sub-tile (all keys valid: plain path; none: the
+// sub-tile is skipped, its probabilities are exactly 0).
+template <bool MASKED>
 XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
-                        float scale, int lane, f32x16 (&o)[2], float& m, float& l) {
+                        float scale2, int lane, f32x16 (&o)[2], float& m2, float& l) {
     const int h = lane >> 5, c31 = lane & 31;
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) s = mma_kblock(a2_row_frag(Ks, t * 32 + c31, kb, h), qf[kb], s, (bf16_t*)nullptr);
+    bool valid[16];
     float mx = ATT_NEG;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float sv = Ms[t * 32 + mfma_row(r, lane)] ? s[r] * scale : ATT_NEG;
-        s[r] = sv;
-        mx = fmaxf(mx, sv);
+        valid[r] = !MASKED || Ms[t * 32 + mfma_row(r, lane)] != 0;
+        mx = fmaxf(mx, valid[r] ? s[r] : ATT_NEG);
     }
     mx = fmaxf(mx, shfl_xor(mx, 32));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = fast_exp(m - m_new);
+    const float m_new = fmaxf(m2, mx > 0.5f * ATT_NEG ? mx * scale2 : ATT_NEG);
+    const float alpha = fast_exp2(m2 - m_new);
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float pv = (s[r] > 0.5f * ATT_NEG) ? fast_exp(s[r] - m_new) : 0.f;
+        float pv = fast_exp2(s[r] * scale2 - m_new);
+        if (MASKED) pv = valid[r] ? pv : 0.f;
         s[r] = pv;
         rs += pv;
     }
     rs += shfl_xor(rs, 32);
     l = l * alpha + rs;
-    m = m_new;
+    m2 = m_new;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -81,9 +88,17 @@ XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const 
         for (int db = 0; db < 2; ++db) o[db] = mma_kblock(a2_col_frag(Vs, t, blk, db, lane), pf, o[db], (bf16_t*)nullptr);
     }
 }
+// votes on the sub-tile's key validity and runs the matching variant
+XC_DEV void a3_fwd_step_auto(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
+                             float scale2, int lane, f32x16 (&o)[2], float& m2, float& l) {
+    const bool kv = Ms[t * 32 + (lane & 31)] != 0;
+    if (wave_all(kv)) a3_fwd_step<false>(Ks, Vs, Ms, t, qf, scale2, lane, o, m2, l);
+    else if (wave_any(kv)) a3_fwd_step<true>(Ks, Vs, Ms, t, qf, scale2, lane, o, m2, l);
+}
 
 // ---- forward ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
+// (at most 128 VGPRs: two 8-wave work-groups of ~78 KB LDS share a CU)
+__global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(AttnParams p) {
     XC_LDS_DYNAMIC(lds);
     const int n = p.n, npad = (n + 31) & ~31;
     unsigned char* Ks = lds;
@@ -113,6 +128,7 @@ __global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
     wait_vmem();
     sync();
     const int nsub = npad >> 5;
+    const float scale2 = p.scale * 1.4426950408889634f;
     if (coop) {                                                // tail queries x this wave's share of the key sub-tiles
         const int trow = tail0 + c31 < n ? tail0 + c31 : n - 1;
 #pragma unroll
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
         float m = ATT_NEG, l = 0.f;
-        for (int t = wave; t < nsub; t += nwaves) a3_fwd_step(Ks, Vs, Ms, t, qf, p.scale, lane, o, m, l);
+        for (int t = wave; t < nsub; t += nwaves) a3_fwd_step_auto(Ks, Vs, Ms, t, qf, scale2, lane, o, m, l);
         if (c31 < ntail) {
             float* rec = Ts + ((long)wave * A3_TAIL_MAX + c31) * A3_TAIL_REC;
             if (h == 0) { rec[0] = m; rec[1] = l; }
@@ -139,11 +155,11 @@ __global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m = ATT_NEG, l = 0.f;
-    for (int t = 0; t < nsub; ++t) a3_fwd_step(Ks, Vs, Ms, t, qf, p.scale, lane, o, m, l);
+    for (int t = 0; t < nsub; ++t) a3_fwd_step_auto(Ks, Vs, Ms, t, qf, scale2, lane, o, m, l);
     sync();                                                    // every wave is done with the K / V images (and the tail partials are in)
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     a2_store_rows(lds + wave * 32 * 144, o, inv, out, (long)p.heads * ATT_DH, q0, n, lane);
-    if (h == 0 && qrow < n) lse_out[qrow] = m + logf(l);
+    if (h == 0 && qrow < n) lse_out[qrow] = m * 0.6931471805599453f + logf(l);    // m is in log2 units
     if (coop && wave == 0) {                                   // merge the nwaves partials of every tail row; lane = feature d
         for (int q = 0; q < ntail; ++q) {
             float M = ATT_NEG;
@@ -151,12 +167,12 @@ __global__ __launch_bounds__(576) void attn3_fwd_kernel(AttnParams p) {
             float L = 0.f, acc = 0.f;
             for (int w = 0; w < nwaves; ++w) {
                 const float* rec = Ts + ((long)w * A3_TAIL_MAX + q) * A3_TAIL_REC;
-                const float f = fast_exp(rec[0] - M);
+                const float f = fast_exp2(rec[0] - M);
                 L += rec[1] * f;
                 acc += rec[2 + lane] * f;
             }
             out[(long)(tail0 + q) * p.heads * ATT_DH + lane] = f2bf(L > 0.f ? acc / L : 0.f);
-            if (lane == 0) lse_out[tail0 + q] = M + logf(L);
+            if (lane == 0) lse_out[tail0 + q] = M * 0.6931471805599453f + logf(L);
         }
     }
 }

@@ -70,6 +70,7 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // head-resident kernel: one work-group per (batch, head)
+        XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         XC_ALLOW_LDS(attn3_fwd_kernel, 160 * 1024);
         const int nwq = a3_waves((int)n);
         hipLaunchKernelGGL(attn3_fwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
@@ -99,6 +100,7 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
+        XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         const int nwq = a3_bwd_waves((int)n);
         static const int abl = [] { const char* e = getenv("XCLIP_ATTN_ABL"); return e ? atoi(e) : 0; }();   // measurement only
         p.chunks = abl;
