@@ -203,10 +203,10 @@ def main():
                 traffic = round(json.load(f)["bytes_per_launch"])
         except Exception:
             pass
-        out["roofline"] = {"kernel": "xclip_gemm (gemm_kernel<bf16> NT/NN/TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
+        out["roofline"] = {"kernel": "xclip_gemm (gemm3_kernel<bf16> NT/NN/TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": traffic,
-                           "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command (profiles/r01_step9_hbm_traffic_pmc.txt)",
+                           "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command (profiles/r01_step10_hbm_traffic_pmc.txt)",
                            "algorithmic_bytes_per_launch": round(probe.algorithmic_bytes / max(launches, 1)),
                            "launches_per_step": launches // max(args.steps, 1),
                            "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
