@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 4
+#define XCLIP_ABI_VERSION 5
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -162,6 +162,13 @@ int xclip_rowlse(const float* S, int64_t lds, int64_t rows, int64_t cols, int64_
                  float* loss_accum, void* stream);
 int xclip_rowgrad(const float* S, int64_t lds, const float* lse, int64_t rows, int64_t cols, int64_t diag_off, int dcl, float coef,
                   const float* gmul, float* G, int64_t ldg, float* dtau_accum, void* stream);
+/* Similarity regularisation (x_clip.py:773-784): D[r,c] = A[r,c] - C[r,c] for two materialised similarity blocks (text-text and
+ * image-image, [rows, cols] in the model dtype, row strides lda / ldc), 0 where c == r + diag_off (the global diagonal);
+ * *sumsq_accum += sum D^2 (fp32, of the unrounded differences).  D (row stride ldd, model dtype) is the gradient factor:
+ * d loss / d text_latent[r] = (2 w / N) sum_c D[r,c] text_latent[c], the image side with the opposite sign.  cols, lda, ldc, ldd
+ * multiples of the 16-byte chunk. */
+int xclip_simreg_diff(const void* A, int64_t lda, const void* C, int64_t ldc, void* D, int64_t ldd, int64_t rows, int64_t cols,
+                      int64_t diag_off, float* sumsq_accum, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ class ClipConfig:
     decoupled_contrastive_learning: bool = False
     extra_latent_projection: bool = False
     multiview_loss_weight: float = 0.1
+    sim_reg_loss_weight: float = 0.0
 
     @property
     def num_patches(self) -> int:
@@ -231,7 +232,25 @@ def contrastive_loss(cfg: ClipConfig, temperature: Tensor,
     loss = losses[0] * (1.0 - w_mv)
     if multiview:
         loss = loss + losses[1:].mean() * w_mv
+    if cfg.sim_reg_loss_weight > 0:
+        loss = loss + sim_reg_loss(tl, il, tlx, ilx) * cfg.sim_reg_loss_weight     # x_clip.py:872-873
     return loss
+
+
+def sim_reg_loss(tl: Tensor, il: Tensor, tlx: Tensor, ilx: Tensor) -> Tensor:
+    """Similarity regularisation (x_clip.py:773-784): mean squared difference between the off-diagonal text-text and
+    image-image similarities, for the main and the CLOOB-extra latents, averaged.  The reference's boolean mask has a
+    leading dimension of 1, so it is only defined for a single view (m = n = 1), CLS-mode latents [1, B, d], and -- because
+    its `*_extra` tensors are only reshaped under `extra_latent_projection` -- only with the extra projections on."""
+    assert tl.shape[0] == 1 and il.shape[0] == 1 and tl.dim() == 3, "sim-reg loss: single view, CLS-mode latents"
+    B = tl.shape[1]
+    off = ~torch.eye(B, dtype=torch.bool)
+
+    def sim(t):
+        return (t[0] @ t[0].t())[off]
+
+    mse = torch.nn.functional.mse_loss
+    return (mse(sim(tl), sim(il)) + mse(sim(tlx), sim(ilx))) / 2
 
 
 def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Tensor,

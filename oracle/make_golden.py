@@ -60,6 +60,8 @@ CASES = {
     "cfg1_filip": (dict(use_all_token_embeds=True), 4, 0, 0, 0.0),
     "cfg1_filip_dcl": (dict(use_all_token_embeds=True, decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
     "cfg1_patchdrop": (dict(), 4, 0, 0, 0.5),
+    "cfg1_simreg_extra": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.1), 4, 0, 0, 0.0),
+    "cfg1_simreg_extra_dcl": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.5, decoupled_contrastive_learning=True), 6, 0, 0, 0.0),
     "p16_heads2": (dict(dim_text=48, dim_image=80, dim_latent=40, text_heads=2, text_dim_head=32,
                         visual_heads=3, visual_dim_head=16, visual_image_size=48, visual_patch_size=16,
                         text_seq_len=19, text_enc_depth=1, visual_enc_depth=3, num_text_tokens=257),
@@ -158,10 +160,18 @@ def run_reference_distributed(cfg: ClipConfig, sizes):
                 grad_sum_head={k: v.flatten()[:8].tolist() for k, v in summed.items()})
 
 
+DIST_CASES = (("dist2_infonce", dict()), ("dist2_dcl", dict(decoupled_contrastive_learning=True)),
+              ("dist2_simreg_extra", dict(extra_latent_projection=True, sim_reg_loss_weight=0.5)))
+
+
 def main():
+    """python oracle/make_golden.py [case ...]   (no arguments: every case)"""
+    only = set(sys.argv[1:])
     os.makedirs(GOLDEN, exist_ok=True)
     x_clip = import_reference()
     for name, (over, batch, nat, nai, pdrop) in CASES.items():
+        if only and name not in only:
+            continue
         cfg = ClipConfig(**{**CFG1.ctor_kwargs(), **over})
         out = run_reference(x_clip, cfg, batch, nat, nai, pdrop)
         rec = dict(case=name, config=cfg.ctor_kwargs(), batch=batch, n_aug_text=nat, n_aug_image=nai,
@@ -173,7 +183,9 @@ def main():
         print(f"{name}: loss={out['loss']:.9f} dtau={out['dtau']:+.9f}")
 
     # 2-rank distributed intent (uneven 5+3 split) vs. the single-process global batch
-    for name, over in (("dist2_infonce", dict()), ("dist2_dcl", dict(decoupled_contrastive_learning=True))):
+    for name, over in DIST_CASES:
+        if only and name not in only:
+            continue
         cfg = ClipConfig(**{**CFG1.ctor_kwargs(), **over})
         sizes = [5, 3]
         d = run_reference_distributed(cfg, sizes)

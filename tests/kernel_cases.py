@@ -379,3 +379,18 @@ def case_gelu_accuracy(dev, dtype):
     mu = v.mean(-1, keepdim=True)
     yr = (v - mu) * torch.rsqrt(((v - mu) ** 2).mean(-1, keepdim=True) + ops.ln_eps(dtype))
     close(y, yr, dtype, "gelu via geglu-ln")
+
+
+def case_simreg_diff(dev, dtype, rows, cols, diag_off):
+    """D = A - C off the global diagonal + sum of squares (x_clip.py:773-784)"""
+    A = rnd((rows, cols), dtype, 41)
+    Cm = rnd((rows, cols), dtype, 42)
+    acc = torch.zeros(1, dtype=torch.float32, device=dev)
+    D = ops.simreg_diff(A.to(dev).clone(), Cm.to(dev), diag_off, acc)
+    ref = ref64(A) - ref64(Cm)
+    for r in range(rows):
+        if 0 <= r + diag_off < cols:
+            ref[r, r + diag_off] = 0
+    close(D, ref, dtype, "simreg D")
+    want = float((ref ** 2).sum())
+    assert abs(float(acc) - want) <= 1e-4 * max(1.0, want), (float(acc), want)

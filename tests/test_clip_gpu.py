@@ -28,7 +28,7 @@ def hip_library():
 
 
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl"])
+                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 
@@ -57,6 +57,16 @@ def test_filip_mid_vs_oracle(dtype):
     # bf16: the token scores are rounded to bf16 before the max, so near-ties can route through a different token than the fp64
     # oracle (as the reference's own bf16 run would); the small, attention-only gradients (cls_token) show it most
     C.case_vs_oracle(DEV, dtype, cfg, 24, bf16_cos=0.9, bf16_rel=0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_mid_sim_reg_extra_vs_oracle(dtype):
+    """similarity regularisation (x_clip.py:773-784) on top of the CLOOB extra projections; batch 20 is not a whole 16-byte chunk"""
+    import dataclasses
+    cfg = dataclasses.replace(MID, extra_latent_projection=True, sim_reg_loss_weight=0.5)
+    # bf16: D is a difference of two bf16-rounded similarity matrices (the reference's einsum outputs are rounded the same way), so
+    # its relative error is larger than that of the other heads; the direction of every gradient still has to match
+    C.case_vs_oracle(DEV, dtype, cfg, 20, bf16_rel=0.35)
 
 
 def test_filip_multiview_extra_dcl_patchdrop_fp32():

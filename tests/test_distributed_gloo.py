@@ -52,7 +52,7 @@ def _worker(rank, world, port, name, sizes, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,sizes", [("dist2_infonce", [5, 3]), ("dist2_dcl", [5, 3])])
+@pytest.mark.parametrize("name,sizes", [("dist2_infonce", [5, 3]), ("dist2_dcl", [5, 3]), ("dist2_simreg_extra", [5, 3])])
 def test_two_ranks_match_reference_semantics(name, sizes, tmp_path):
     with open(os.path.join(HERE, "golden", name + ".json")) as f:
         rec = json.load(f)

@@ -134,3 +134,9 @@ def test_scatter_sorted_and_gelu(dtype):
 def test_simloss_on_gemm3_loop(dcl):
     """bf16 problems at least a tile wide run on the persistent gemm3 loop (simloss3.h): ragged rows and columns, 2 x 2 tiles"""
     K.case_simloss(DEV, torch.bfloat16, 264, 392, 64, dcl, diag_off=100)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,cols,diag_off", [(5, 16, 0), (7, 24, 8)])
+def test_simreg_diff(dtype, rows, cols, diag_off):
+    K.case_simreg_diff(DEV, dtype, rows, cols, diag_off)

@@ -133,3 +133,9 @@ def test_simloss_on_gemm3_loop(dcl):
     K.case_simloss(DEV, torch.bfloat16, 264, 392, 64, dcl, diag_off=100)
     K.case_simloss(DEV, torch.bfloat16, 1024, 4096, 512, dcl, diag_off=2048)
     K.case_simloss_closed_form(DEV, torch.bfloat16, 1032, 512, dcl)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,cols,diag_off", [(5, 16, 0), (1031, 4104, 512), (4096, 32768, 8192)])
+def test_simreg_diff(dtype, rows, cols, diag_off):
+    K.case_simreg_diff(DEV, dtype, rows, cols, diag_off)

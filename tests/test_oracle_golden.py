@@ -81,7 +81,7 @@ def test_closed_form_head_matches_reference(name):
     assert abs(out["dtau"] - rec["dtau"]) < 2e-6
 
 
-@pytest.mark.parametrize("name", ["dist2_infonce", "dist2_dcl"])
+@pytest.mark.parametrize("name", ["dist2_infonce", "dist2_dcl", "dist2_simreg_extra"])
 def test_distributed_fixture_identity(name):
     """Reference intent for the 2-rank all-gather path (distributed.py with its two missing names
     injected): every rank's loss equals the single-process global-batch loss and the rank-summed

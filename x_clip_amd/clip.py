@@ -8,7 +8,7 @@ the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is n
 on an MI355X.
 
 Not on this path yet (constructor raises NotImplementedError): rotary / causal text encoder,
-MLM and visual-SSL side losses, `downsample_image_embeds`, `sim_reg_loss_weight`.
+MLM and visual-SSL side losses, `downsample_image_embeds`.
 """
 from __future__ import annotations
 
@@ -333,9 +333,12 @@ class CLIP(nn.Module):
 
         self.sim_reg_loss_weight = sim_reg_loss_weight
         self.has_sim_reg_loss = sim_reg_loss_weight > 0.
-        if self.has_sim_reg_loss:
-            raise NotImplementedError("sim_reg_loss_weight > 0 is not on the accelerated path yet (SURVEY.md 8(f); the "
-                                      "reference path raises an einsum rank error without extra_latent_projection)")
+        if self.has_sim_reg_loss and not extra_latent_projection:
+            raise ValueError("sim_reg_loss_weight > 0 needs extra_latent_projection=True: the reference's sim-reg path fails with an "
+                             "einsum rank error otherwise (its *_extra latents are only reshaped under the extra projections, "
+                             "x_clip.py:757-758,778)")
+        if self.has_sim_reg_loss and use_all_token_embeds:
+            raise NotImplementedError("sim_reg_loss_weight > 0 with use_all_token_embeds: only the CLS-latent form is on the accelerated path")
 
     def _side_stream(self, device):
         if device.type != "cuda":
@@ -458,6 +461,11 @@ class CLIP(nn.Module):
             return XL.filip_loss(self.temperature, text_latents, image_latents,
                                  text_latents_extra if self.extra_latent_projection else None,
                                  image_latents_extra if self.extra_latent_projection else None, text_mask, spec)
-        return XL.contrastive_loss(self.temperature, text_latents, image_latents,
+        loss = XL.contrastive_loss(self.temperature, text_latents, image_latents,
                                    text_latents_extra if self.extra_latent_projection else None,
                                    image_latents_extra if self.extra_latent_projection else None, spec)
+        if self.has_sim_reg_loss:                                                          # x_clip.py:773-784, 872-873
+            assert not is_multiview, 'the similarity regularisation loss is defined for a single view (its [1, b, b] mask, x_clip.py:776-778)'
+            sim_reg = XL.sim_reg_loss(text_latents[0], image_latents[0], text_latents_extra[0], image_latents_extra[0], spec)
+            loss = loss + sim_reg * self.sim_reg_loss_weight
+        return loss

@@ -159,4 +159,37 @@ __global__ __launch_bounds__(256) void rowgrad_kernel(const float* __restrict__ 
     if (lane_id() == 0 && dtau != nullptr) atomic_add(dtau, dt);
 }
 
+// ---- similarity regularisation (x_clip.py:773-784) -----------------------------------------------------------------------------
+// D = A - C off the global diagonal, sum of squares into one fp32 accumulator.  One wave per row, 16-byte chunks, one atomic per
+// work-group.
+template <typename T>
+__global__ __launch_bounds__(256) void simreg_diff_kernel(const T* __restrict__ A, long lda, const T* __restrict__ C, long ldc,
+                                                          T* __restrict__ D, long ldd, int rows, int cols, int diag_off,
+                                                          float* __restrict__ sumsq) {
+    constexpr int VEC = Elem<T>::VEC;
+    XC_LDS_DYNAMIC(lds);
+    float* red = reinterpret_cast<float*>(lds);            // [4]
+    const int lane = lane_id(), wave = wave_id();
+    float acc = 0.f;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const int dcol = (int)row + diag_off;
+        for (int c = lane; c < cols / VEC; c += 64) {
+            float a[VEC], b[VEC];
+            load_vec<T>(A + row * lda + c * VEC, a);
+            load_vec<T>(C + row * ldc + c * VEC, b);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float d = (c * VEC + j == dcol) ? 0.f : a[j] - b[j];
+                a[j] = d;
+                acc += d * d;
+            }
+            store_vec<T>(D + row * ldd + c * VEC, a);
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    sync();
+    if (threadIdx.x == 0 && sumsq != nullptr) atomic_add(sumsq, red[0] + red[1] + red[2] + red[3]);
+}
+
 }  // namespace xc

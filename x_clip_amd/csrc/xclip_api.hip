@@ -653,4 +653,25 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
     return check_launch(__func__);
 }
 
+int xclip_simreg_diff(const void* A, int64_t lda, const void* C, int64_t ldc, void* D, int64_t ldd, int64_t rows, int64_t cols,
+                      int64_t diag_off, float* sumsq_accum, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(rows >= 0 && cols > 0 && cols % vec == 0 && lda % vec == 0 && ldc % vec == 0 && ldd % vec == 0,
+               "cols and the row strides must be multiples of the 16-byte chunk");
+    XC_REQUIRE(lda >= cols && ldc >= cols && ldd >= cols, "row stride smaller than the row");
+    XC_REQUIRE(A && C && D && aligned16(A) && aligned16(C) && aligned16(D), "null or misaligned pointer");
+    if (rows == 0) return 0;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((simreg_diff_kernel<bf16_t>), grid, block, 16, (hipStream_t)stream, (const bf16_t*)A, (long)lda, (const bf16_t*)C,
+                           (long)ldc, (bf16_t*)D, (long)ldd, (int)rows, (int)cols, (int)diag_off, sumsq_accum);
+    else
+        hipLaunchKernelGGL((simreg_diff_kernel<float>), grid, block, 16, (hipStream_t)stream, (const float*)A, (long)lda, (const float*)C,
+                           (long)ldc, (float*)D, (long)ldd, (int)rows, (int)cols, (int)diag_off, sumsq_accum);
+    return check_launch(__func__);
+}
+
 }  // extern "C"

@@ -205,6 +205,78 @@ def contrastive_loss(tau: Tensor, text_latents: Tensor, image_latents: Tensor, t
 
 
 # =========================================================================================================================
+# similarity regularisation (x_clip.py:773-784, 872-873)
+# =========================================================================================================================
+class _SimRegFn(torch.autograd.Function):
+    """(mse(offdiag(T T^T), offdiag(I I^T)) + mse(offdiag(Tx Tx^T), offdiag(Ix Ix^T))) / 2 over the GLOBAL batch.
+
+    Rank r evaluates its row block -- its b texts / images against all B -- as two MFMA GEMMs per pair, one pass that forms
+    D = TT^T - II^T off the diagonal and accumulates sum D^2 (xclip_simreg_diff), and, because D is symmetric, obtains the
+    complete gradient of its own latents from that block alone: dT_r = (2 / N) D_r T_all, dI_r = -(2 / N) D_r I_all with
+    N = B (B - 1).  The gathered latents are constants of the backward (as in the reference, whose all-gather backward keeps
+    the local slice, distributed.py:51-54)."""
+
+    @staticmethod
+    def forward(ctx, spec: ContrastiveSpec, T: Tensor, I: Tensor, Tx: Tensor, Ix: Tensor):
+        dev, dt = T.device, T.dtype
+        b, d = T.shape
+        v = ops.vec(dt)
+        mats = [ops._c(x.detach()) for x in (T, I, Tx, Ix)]
+        if spec.distributed:
+            sizes = [b] * xdist.dist.get_world_size(spec.group) if spec.assume_equal_batch else xdist.exchange_sizes(b, dev, spec.group)
+            rank = xdist.dist.get_rank(spec.group)
+            off, B = sum(sizes[:rank]), sum(sizes)
+            gathered = xdist.GatheredViews(mats, sizes, spec.group)
+            gathered.wait()
+        else:
+            off, B, gathered = 0, b, None
+        Bp = (B + v - 1) // v * v                              # GEMM N / K must be whole 16-byte chunks: zero rows contribute nothing
+        alls = []
+        for k in range(4):
+            if gathered is None and Bp == B:
+                alls.append(mats[k])
+                continue
+            full = torch.zeros(Bp, d, dtype=dt, device=dev)
+            for chunk, row0 in (gathered.chunks(k) if gathered is not None else [(mats[k], 0)]):
+                full[row0: row0 + chunk.shape[0]].copy_(chunk)
+            alls.append(full)
+        sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        Ds = []
+        for x, y in ((0, 1), (2, 3)):
+            S1 = ops.gemm(mats[x], alls[x], b, Bp, d)          # [b, Bp] = X_r X_all^T
+            S2 = ops.gemm(mats[y], alls[y], b, Bp, d)
+            Ds.append(ops.simreg_diff(S1, S2, off, sumsq))
+        N = max(B * (B - 1), 1)
+        loss = sumsq / (2.0 * N)
+        if spec.distributed:
+            xdist.all_reduce_scalars(loss, spec.group)
+        ctx.Ds, ctx.alls, ctx.geom = Ds, alls, (b, d, Bp, N, dt)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        b, d, Bp, N, dt = ctx.geom
+        g = dloss.detach().to(dt)
+        grads = [None] * 4
+        for p, (x, y) in enumerate(((0, 1), (2, 3))):
+            D = ctx.Ds[p]
+            if ctx.needs_input_grad[1 + x]:
+                grads[x] = ops.gemm(D, ctx.alls[x], b, d, Bp, b_kmajor=True, alpha=2.0 / N) * g
+            if ctx.needs_input_grad[1 + y]:
+                grads[y] = ops.gemm(D, ctx.alls[y], b, d, Bp, b_kmajor=True, alpha=-2.0 / N) * g
+        return (None, *grads)
+
+
+def sim_reg_loss(text_latents: Tensor, image_latents: Tensor, text_latents_extra: Tensor, image_latents_extra: Tensor,
+                 spec: ContrastiveSpec) -> Tensor:
+    """CLS-mode latents of ONE view, each [b, d] -> fp32 scalar (the reference's boolean mask [1, B, B] restricts it to a
+    single view and its `*_extra` reshapes to extra_latent_projection=True, x_clip.py:776-784)."""
+    assert text_latents.dim() == 2 and text_latents.shape == image_latents.shape == text_latents_extra.shape == image_latents_extra.shape
+    return _SimRegFn.apply(spec, text_latents, image_latents, text_latents_extra, image_latents_extra)
+
+
+# =========================================================================================================================
 # fine-grained (FILIP) head: use_all_token_embeds = True  (x_clip.py:797-811 + the shared InfoNCE / DCL tail :821-868)
 # =========================================================================================================================
 _FILIP_CHUNK_BYTES = 1 << 30          # workspace bound for one chunk of token similarities / routing matrix

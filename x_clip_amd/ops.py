@@ -484,3 +484,15 @@ def rowgrad(S: Tensor, lse: Tensor, diag_off: int, dcl: bool, coef: float, gmul:
     _lib.check(_lib.lib().xclip_rowgrad(S.data_ptr(), S.stride(0), lse.data_ptr(), rows, cols, diag_off, int(dcl), coef, _ptr(gmul),
                                         G.data_ptr(), cols, _ptr(dtau_accum), _stream(S)), "xclip_rowgrad")
     return G
+
+
+def simreg_diff(A: Tensor, C: Tensor, diag_off: int, sumsq_accum: Tensor) -> Tensor:
+    """D = A - C with the global diagonal (column r + diag_off of row r) zeroed, written over A; *sumsq_accum += sum D^2.
+    A, C [rows, cols] similarity blocks in the model dtype (x_clip.py:773-784)."""
+    _dev_check(A, C, sumsq_accum)
+    assert A.dim() == 2 and A.shape == C.shape and A.dtype == C.dtype and A.stride(1) == 1 and C.stride(1) == 1
+    assert sumsq_accum.dtype == torch.float32
+    rows, cols = A.shape
+    _lib.check(_lib.lib().xclip_simreg_diff(A.data_ptr(), A.stride(0), C.data_ptr(), C.stride(0), A.data_ptr(), A.stride(0), rows, cols,
+                                            diag_off, sumsq_accum.data_ptr(), dtype_code(A), _stream(A)), "xclip_simreg_diff")
+    return A
