@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 5
+#define XCLIP_ABI_VERSION 6
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -162,6 +162,12 @@ int xclip_rowlse(const float* S, int64_t lds, int64_t rows, int64_t cols, int64_
                  float* loss_accum, void* stream);
 int xclip_rowgrad(const float* S, int64_t lds, const float* lse, int64_t rows, int64_t cols, int64_t diag_off, int dcl, float coef,
                   const float* gmul, float* G, int64_t ldg, float* dtau_accum, void* stream);
+/* Rotary position embedding (RotaryEmbedding / apply_rotary_pos_emb, x_clip.py:155-176; applied to q, k and v, :221-223), in
+ * place on rows of `slots` 64-wide head slots (the packed qkv activation: slots = 3 * heads).  Token position = row % n; in
+ * every slot the first 32 features are rotated pairwise (j, j + 16) by pos * inv_freq[j]; inv_freq: 16 device fp32 values, the
+ * module's `inv_freq` buffer 10000^(-2 j / 32).  inverse != 0 applies the transposed rotation = the backward of the forward call. */
+int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, const float* inv_freq, int inverse, int dtype,
+                 void* stream);
 /* Similarity regularisation (x_clip.py:773-784): D[r,c] = A[r,c] - C[r,c] for two materialised similarity blocks (text-text and
  * image-image, [rows, cols] in the model dtype, row strides lda / ldc), 0 where c == r + diag_off (the global diagonal);
  * *sumsq_accum += sum D^2 (fp32, of the unrounded differences).  D (row stride ldd, model dtype) is the gradient factor:

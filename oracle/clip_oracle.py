@@ -44,6 +44,7 @@ class ClipConfig:
     text_dim_head: int = 64
     text_has_cls_token: bool = True
     text_pad_id: int = 0
+    text_rotary_pos_emb: bool = False
     visual_enc_depth: int = 6
     visual_heads: int = 8
     visual_dim_head: int = 64
@@ -96,8 +97,26 @@ def l2_normalize(x: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------------------
 # transformer block stack (x_clip.py:201-291)
 # --------------------------------------------------------------------------------------------------
+def rotary_freqs(seq_len: int, dim_head: int, dtype=torch.float32) -> Tensor:
+    """RotaryEmbedding(min(dim_head, 32)).forward(seq_len) (x_clip.py:155-166): [seq_len, rot] angles, the rot/2
+    frequencies repeated twice."""
+    rot = min(dim_head, 32)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))
+    f = torch.einsum("i,j->ij", torch.arange(seq_len).float(), inv_freq)
+    return torch.cat((f, f), dim=-1).to(dtype)
+
+
+def apply_rotary(freqs: Tensor, t: Tensor) -> Tensor:
+    """apply_rotary_pos_emb (x_clip.py:168-176): the first rot features are rotated pairwise (j, j + rot/2), the rest pass."""
+    rot = freqs.shape[-1]
+    a, rest = t[..., :rot], t[..., rot:]
+    x1, x2 = a[..., : rot // 2], a[..., rot // 2:]
+    half = torch.cat((-x2, x1), dim=-1)
+    return torch.cat((a * freqs.cos() + half * freqs.sin(), rest), dim=-1)
+
+
 def attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: int,
-              key_mask: Optional[Tensor]) -> Tensor:
+              key_mask: Optional[Tensor], rotary: Optional[Tensor] = None) -> Tensor:
     """Attention.forward (x_clip.py:213-245): bias-free fused qkv projection, q scaled by
     dim_head**-0.5, key padding mask, softmax in fp32 (or wider), bias-free out projection followed by a
     LayerNorm."""
@@ -105,6 +124,8 @@ def attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: 
     qkv = x @ sd[pfx + "to_qkv.weight"].t()                     # [b, n, 3*h*d]
     qkv = qkv.view(b, n, 3, heads, dim_head).permute(2, 0, 3, 1, 4)   # [3, b, h, n, d]
     q, k, v = qkv[0] * (dim_head ** -0.5), qkv[1], qkv[2]
+    if rotary is not None:                                      # x_clip.py:221-223: q, k AND v
+        q, k, v = (apply_rotary(rotary.to(x.dtype), t) for t in (q, k, v))
     scores = q @ k.transpose(-1, -2)                            # [b, h, n, n]
     if key_mask is not None:
         scores = scores.masked_fill(~key_mask[:, None, None, :], -torch.finfo(scores.dtype).max)
@@ -124,14 +145,14 @@ def feed_forward(x: Tensor, sd: Dict[str, Tensor], pfx: str) -> Tensor:
 
 
 def transformer(x: Tensor, sd: Dict[str, Tensor], pfx: str, depth: int, heads: int, dim_head: int,
-                key_mask: Optional[Tensor]) -> Tensor:
+                key_mask: Optional[Tensor], rotary: Optional[Tensor] = None) -> Tensor:
     """Transformer.forward (x_clip.py:274-291): norm_in, pre-norm residual attention + feed-forward
     blocks, norm_out."""
     x = layer_norm(x, sd[pfx + "norm_in.g"])
     for l in range(depth):
         a = f"{pfx}layers.{l}.0."
         f = f"{pfx}layers.{l}.1."
-        x = attention(layer_norm(x, sd[a + "norm.g"]), sd, a + "fn.", heads, dim_head, key_mask) + x
+        x = attention(layer_norm(x, sd[a + "norm.g"]), sd, a + "fn.", heads, dim_head, key_mask, rotary) + x
         x = feed_forward(layer_norm(x, sd[f + "norm.g"]), sd, f + "fn.") + x
     return layer_norm(x, sd[pfx + "norm_out.g"])
 
@@ -144,13 +165,18 @@ def encode_text(sd: Dict[str, Tensor], cfg: ClipConfig, tokens: Tensor, mask: Op
     prepended (its mask slot is True), then the block stack.  Returns [b, n+1, dim_text]."""
     pfx = "text_transformer."
     b, n = tokens.shape
-    x = sd[pfx + "token_emb.weight"][tokens] + sd[pfx + "abs_pos_emb.weight"][:n][None]
+    x = sd[pfx + "token_emb.weight"][tokens]
+    rotary = None
+    if cfg.text_rotary_pos_emb:                                 # x_clip.py:311-312,328-330: no absolute table, n + 1 positions
+        rotary = rotary_freqs(n + 1, cfg.text_dim_head)
+    else:
+        x = x + sd[pfx + "abs_pos_emb.weight"][:n][None]
     cls = sd[pfx + "cls_token"].expand(b, 1, -1)
     x = torch.cat([cls, x], dim=1)
     if mask is not None:
         mask = torch.cat([torch.ones(b, 1, dtype=torch.bool), mask], dim=1)
     return transformer(x, sd, pfx + "transformer.", cfg.text_enc_depth, cfg.text_heads,
-                       cfg.text_dim_head, mask)
+                       cfg.text_dim_head, mask, rotary)
 
 
 def patchify(image: Tensor, p: int) -> Tensor:
@@ -345,7 +371,10 @@ def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
     t = "text_transformer."
     shapes[t + "cls_token"] = (cfg.dim_text,)
     shapes[t + "token_emb.weight"] = (cfg.num_text_tokens, cfg.dim_text)
-    shapes[t + "abs_pos_emb.weight"] = (cfg.text_seq_len, cfg.dim_text)
+    if cfg.text_rotary_pos_emb:                                 # buffer of RotaryEmbedding (x_clip.py:158-159)
+        shapes[t + "rotary_pos_emb.inv_freq"] = (min(cfg.text_dim_head, 32) // 2,)
+    else:
+        shapes[t + "abs_pos_emb.weight"] = (cfg.text_seq_len, cfg.dim_text)
     tower(t + "transformer.", cfg.dim_text, cfg.text_enc_depth, cfg.text_heads, cfg.text_dim_head)
     v = "visual_transformer."
     pd = cfg.channels * cfg.visual_patch_size ** 2
@@ -369,6 +398,9 @@ def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str
     for key, shape in sorted(state_dict_shapes(cfg).items()):
         if key == "temperature":
             a = np.array(1.0)
+        elif key.endswith("inv_freq"):
+            rot = 2 * shape[0]
+            a = (1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))).double().numpy()
         elif key.endswith(".g"):
             a = 1.0 + 0.1 * rs.standard_normal(shape)
         elif key.endswith(".bias"):

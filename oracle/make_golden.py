@@ -60,6 +60,8 @@ CASES = {
     "cfg1_filip": (dict(use_all_token_embeds=True), 4, 0, 0, 0.0),
     "cfg1_filip_dcl": (dict(use_all_token_embeds=True, decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
     "cfg1_patchdrop": (dict(), 4, 0, 0, 0.5),
+    "cfg1_rotary": (dict(text_rotary_pos_emb=True), 4, 0, 0, 0.0),
+    "cfg1_rotary_dcl_multiview": (dict(text_rotary_pos_emb=True, decoupled_contrastive_learning=True), 4, 1, 0, 0.0),
     "cfg1_simreg_extra": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.1), 4, 0, 0, 0.0),
     "cfg1_simreg_extra_dcl": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.5, decoupled_contrastive_learning=True), 6, 0, 0, 0.0),
     "p16_heads2": (dict(dim_text=48, dim_image=80, dim_latent=40, text_heads=2, text_dim_head=32,

@@ -394,3 +394,17 @@ def case_simreg_diff(dev, dtype, rows, cols, diag_off):
     close(D, ref, dtype, "simreg D")
     want = float((ref ** 2).sum())
     assert abs(float(acc) - want) <= 1e-4 * max(1.0, want), (float(acc), want)
+
+
+def case_rotary(dev, dtype, batch, n, heads):
+    """rotary embedding on packed q | k | v head slots, forward and its transposed (backward) form (x_clip.py:155-176)"""
+    slots = 3 * heads
+    x = rnd((batch * n, slots * 64), dtype, 51)
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+    y = ops.rotary_(x.to(dev).clone(), n, inv_freq)
+    fr = O.rotary_freqs(n, 64, torch.float64)                                  # [n, 32]
+    x64 = ref64(x).view(batch, n, slots, 64)
+    ref = O.apply_rotary(fr[None, :, None, :], x64).reshape(batch * n, slots * 64)
+    close(y, ref, dtype, "rotary fwd")
+    z = ops.rotary_(y.clone(), n, inv_freq, inverse=True)                      # R^T R = identity
+    close(z, ref64(x), dtype, "rotary inverse", mult=2.0)

@@ -28,7 +28,7 @@ def hip_library():
 
 
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl"])
+                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 
@@ -67,6 +67,13 @@ def test_mid_sim_reg_extra_vs_oracle(dtype):
     # bf16: D is a difference of two bf16-rounded similarity matrices (the reference's einsum outputs are rounded the same way), so
     # its relative error is larger than that of the other heads; the direction of every gradient still has to match
     C.case_vs_oracle(DEV, dtype, cfg, 20, bf16_rel=0.35)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_mid_rotary_vs_oracle(dtype):
+    """rotary text encoder (no absolute position table; q, k and v rotated over n + 1 positions, x_clip.py:155-176,221-223,328-330)"""
+    import dataclasses
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, text_rotary_pos_emb=True), 16)
 
 
 def test_filip_multiview_extra_dcl_patchdrop_fp32():

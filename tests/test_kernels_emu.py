@@ -140,3 +140,9 @@ def test_simloss_on_gemm3_loop(dcl):
 @pytest.mark.parametrize("rows,cols,diag_off", [(5, 16, 0), (7, 24, 8)])
 def test_simreg_diff(dtype, rows, cols, diag_off):
     K.case_simreg_diff(DEV, dtype, rows, cols, diag_off)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("batch,n,heads", [(2, 5, 1), (1, 33, 2)])
+def test_rotary(dtype, batch, n, heads):
+    K.case_rotary(DEV, dtype, batch, n, heads)

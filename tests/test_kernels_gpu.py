@@ -139,3 +139,9 @@ def test_simloss_on_gemm3_loop(dcl):
 @pytest.mark.parametrize("rows,cols,diag_off", [(5, 16, 0), (1031, 4104, 512), (4096, 32768, 8192)])
 def test_simreg_diff(dtype, rows, cols, diag_off):
     K.case_simreg_diff(DEV, dtype, rows, cols, diag_off)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("batch,n,heads", [(2, 5, 1), (7, 257, 8), (3, 33, 4)])
+def test_rotary(dtype, batch, n, heads):
+    K.case_rotary(DEV, dtype, batch, n, heads)

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "xclip_rowlse": (c_int, [P, L, L, L, L, I, F, P, P, P]),
     "xclip_rowgrad": (c_int, [P, L, P, L, L, L, I, F, P, P, L, P, P]),
     "xclip_simreg_diff": (c_int, [P, L, P, L, P, L, L, L, L, P, I, P]),
+    "xclip_rotary": (c_int, [P, L, L, L, L, P, I, I, P]),
     "xclip_simloss_workspace_bytes": (c_int64, [L, L]),
     "xclip_simloss_partial": (c_int, [P, P, L, L, L, F, P, L, I, P, L, L, P, I, P]),
     "xclip_simloss_combine": (c_int, [P, L, L, P, P, P, F, P]),
@@ -57,7 +58,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def _bind(path: str):

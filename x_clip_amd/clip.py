@@ -7,7 +7,7 @@ draws the same initial weights as the reference) -- but the modules are paramete
 the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is no CPU / ATen fallback; tensors must live
 on an MI355X.
 
-Not on this path yet (constructor raises NotImplementedError): rotary / causal text encoder,
+Not on this path yet (constructor raises NotImplementedError): causal text encoder,
 MLM and visual-SSL side losses, `downsample_image_embeds`.
 """
 from __future__ import annotations
@@ -114,14 +114,38 @@ class Transformer(nn.Module):
         ps.append(self.norm_out.g)
         return ps
 
-    def spec(self) -> XF.StackSpec:
+    def spec(self, rotary: Optional[Tensor] = None) -> XF.StackSpec:
         return XF.StackSpec(depth=self.depth, heads=self.heads, dim_head=self.dim_head,
-                            checkpoint=bool(self.training and self.checkpoint_during_training))
+                            checkpoint=bool(self.training and self.checkpoint_during_training), rotary=rotary)
 
     def forward(self, x, rotary_pos_emb=None, mask=None):
         if exists(rotary_pos_emb):
-            raise NotImplementedError("rotary embeddings are not on the accelerated path yet (SURVEY.md 8(f))")
+            raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): build the TextTransformer with rotary_pos_emb=True "
+                                      "instead -- the kernels take the inv_freq buffer, not the angle table")
         return XF.transformer(x, self.stack_params(), self.spec(), mask)
+
+
+class RotaryEmbedding(nn.Module):
+    """reference RotaryEmbedding (x_clip.py:155-166): holds the `inv_freq` buffer (state_dict key parity).  The kernels
+    (xclip_rotary) regenerate the same 10000^(-2j/dim) frequencies; dim is min(dim_head, 32) = 32 on this path."""
+
+    def __init__(self, dim):
+        super().__init__()
+        if dim != 32:
+            raise NotImplementedError("rotary embedding: the kernels rotate the first 32 features of 64-wide heads")
+        self.register_buffer('inv_freq', 1. / (10000 ** (torch.arange(0, dim, 2).float() / dim)))
+
+    def frequencies(self, device) -> Tensor:
+        """the 16 fp32 frequencies the kernels take.  A model cast with .to(bfloat16) also rounds the buffer (the reference then
+        computes its angle table from the rounded values); the frequencies are regenerated in fp32 in that case."""
+        f = self.inv_freq
+        if f.dtype != torch.float32:
+            f = 1. / (10000 ** (torch.arange(0, 2 * f.numel(), 2, device=device).float() / (2 * f.numel())))
+        return f.to(device).contiguous()
+
+    def forward(self, seq_len, device):                          # [seq_len, dim] angle table (not used by the kernels)
+        pos = torch.arange(seq_len, device=device, dtype=self.inv_freq.dtype)
+        return torch.outer(pos, self.inv_freq.to(device)).repeat(1, 2)
 
 
 class TextTransformer(nn.Module):
@@ -129,20 +153,20 @@ class TextTransformer(nn.Module):
 
     def __init__(self, dim, *, num_tokens, max_seq_len, dim_head, rotary_pos_emb=None, causal=False, **kwargs):
         super().__init__()
-        if rotary_pos_emb:
-            raise NotImplementedError("text_rotary_pos_emb is not on the accelerated path yet (SURVEY.md 8(f))")
         if causal:
             raise NotImplementedError("text_causal_mask is not on the accelerated path yet (SURVEY.md 8(f); the reference "
                                       "path itself raises NameError, x_clip.py:683-684)")
         self.token_emb = nn.Embedding(num_tokens, dim)
-        self.abs_pos_emb = nn.Embedding(max_seq_len, dim)
-        self.rotary_pos_emb = None
+        self.abs_pos_emb = nn.Embedding(max_seq_len, dim) if not rotary_pos_emb else None      # x_clip.py:311-312
+        self.rotary_pos_emb = RotaryEmbedding(min(dim_head, 32)) if rotary_pos_emb else None
         self.cls_token = nn.Parameter(torch.randn(dim))
         self.transformer = Transformer(dim, dim_head=dim_head, causal=causal, **kwargs)
 
     def forward(self, x, mask=None):
         t = self.transformer
-        return XF.text_encode(x, mask, self.token_emb.weight, self.abs_pos_emb.weight, self.cls_token, t.stack_params(), t.spec())
+        pos = self.abs_pos_emb.weight if exists(self.abs_pos_emb) else None
+        return XF.text_encode(x, mask, self.token_emb.weight, pos, self.cls_token, t.stack_params(),
+                              t.spec(rotary=self.rotary_pos_emb.frequencies(x.device) if exists(self.rotary_pos_emb) else None))
 
 
 class PatchDropout(nn.Module):

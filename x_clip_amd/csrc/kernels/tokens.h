@@ -307,4 +307,41 @@ __global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restr
         dst[i] = from_f32<T>(src[i] * scale);
 }
 
+// ---- rotary position embedding on the packed qkv rows (x_clip.py:155-176, 221-223) --------------------------------------------
+// X [rows, slots * 64] (q | k | v, heads contiguous; slots = 3 * heads), token position = row % n.  In every 64-wide head slot
+// the first ROT = 32 features are rotated pairwise (j, j + 16) by the angle pos * inv_freq[j] (the module's buffer, 16 fp32 values:
+// bit-identical angles to the reference's table); the other 32 pass through
+// (the reference applies it to q, k AND v).  sign = +1: forward; -1: the transposed rotation = its backward.  In place; one
+// lane owns the two 16-byte chunks that hold a set of pairs, so no exchange is needed.
+template <typename T>
+__global__ __launch_bounds__(256) void rotary_kernel(T* __restrict__ X, long ld, long rows, int n, int slots,
+                                                     const float* __restrict__ inv_freq, float sign) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int HALF = 16;                                   // ROT / 2
+    constexpr int CPH = HALF / VEC;                            // chunks per half: 2 (bf16) / 4 (fp32)
+    const long items = rows * slots * CPH;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % CPH);
+        const long rs = it / CPH;
+        const int slot = (int)(rs % slots);
+        const long row = rs / slots;
+        const float pos = (float)(row % n);
+        T* p = X + row * ld + slot * 64 + c * VEC;
+        float a[VEC], b[VEC];
+        load_vec<T>(p, a);                                     // features j      = c VEC + (0 .. VEC-1)
+        load_vec<T>(p + HALF, b);                              // features j + 16
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float sn, cs;
+            sincosf(pos * inv_freq[c * VEC + e], &sn, &cs);
+            sn *= sign;
+            const float x1 = a[e], x2 = b[e];
+            a[e] = x1 * cs - x2 * sn;
+            b[e] = x2 * cs + x1 * sn;
+        }
+        store_vec<T>(p, a);
+        store_vec<T>(p + HALF, b);
+    }
+}
+
 }  // namespace xc

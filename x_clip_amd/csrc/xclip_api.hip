@@ -434,6 +434,24 @@ int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale,
     return check_launch(__func__);
 }
 
+int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, const float* inv_freq, int inverse, int dtype,
+                 void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(rows >= 0 && n > 0 && slots > 0 && ld >= slots * 64 && ld % vec_of(dtype) == 0, "bad shape (64-wide head slots)");
+    XC_REQUIRE(x && aligned16(x) && inv_freq, "null or misaligned pointer");
+    if (rows == 0) return 0;
+    const int64_t items = rows * slots * (16 / vec_of(dtype));
+    int64_t blocks = (items + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks), block(256);
+    const float sign = inverse ? -1.0f : 1.0f;
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((rotary_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)x, (long)ld, (long)rows, (int)n, (int)slots, inv_freq, sign);
+    else
+        hipLaunchKernelGGL((rotary_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)x, (long)ld, (long)rows, (int)n, (int)slots, inv_freq, sign);
+    return check_launch(__func__);
+}
+
 int64_t xclip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype) {
     const int s = use_gemm2(M, N, K, dtype) ? gemm2_splits(M, N, K) : gemm_splits(M, N, K, dtype);
     return s > 1 ? (int64_t)s * M * N * 4 : 0;

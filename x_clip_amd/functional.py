@@ -87,6 +87,7 @@ class StackSpec:
     heads: int
     dim_head: int = 64
     checkpoint: bool = False
+    rotary: Optional[Tensor] = None         # rotary embedding on q, k, v: the inv_freq buffer (16 fp32), x_clip.py:155-176,221-223
 
     def __post_init__(self):
         if self.dim_head != 64:
@@ -110,12 +111,14 @@ class _GainGrads:
 
 
 # ---- one pre-norm residual block pair (x_clip.py:285-289) --------------------------------------------------------------
-def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor]):
+def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor], rotary: Optional[Tensor] = None):
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     M, D = x.shape
     inner = heads * 64
     h, m1, r1 = ops.layernorm_fwd(x, g_attn)                                           # PreNorm           :126
     qkv = ops.gemm(h, w_qkv, M, 3 * inner, D)                                          # to_qkv            :216
+    if rotary is not None:
+        ops.rotary_(qkv, n, rotary)                                                            # q, k, v rotated   :221-223
     o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, 64 ** -0.5)     # scale/mask/softmax :217-244
     p = ops.gemm(o.view(M, inner), w_out, M, D, inner)                                 # to_out.0          :245
     x1, m2, r2 = ops.layernorm_fwd(p, g_out, res=x)                                    # to_out.1 + skip   :245,288
@@ -127,7 +130,7 @@ def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, m
 
 
 def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
-                    gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm"):
+                    gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm", rotary: Optional[Tensor] = None):
     """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2])"""
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     dg_attn, dg_out, dg_ff, dg_inner = gain_acc
@@ -153,6 +156,8 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     del dp
     dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, 64 ** -0.5)
     del do
+    if rotary is not None:
+        ops.rotary_(dqkv.view(M, 3 * inner), n, rotary, inverse=True)      # the saved qkv is the rotated one; R^T maps its gradient back
     dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
     d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M) if need_w[0] else None
     del dqkv
@@ -170,7 +175,7 @@ def stack_forward(x0: Tensor, B: int, n: int, spec: StackSpec, params: Sequence[
     layers = []
     for l in range(spec.depth):
         W = params[1 + LAYER_PARAMS * l: 1 + LAYER_PARAMS * (l + 1)]
-        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask)
+        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary)
         if keep_tape:
             layers.append((saved[0],) if spec.checkpoint else saved)
         x = x_next
@@ -193,9 +198,9 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
         W = params[base: base + LAYER_PARAMS]
         saved = layers[l]
         if spec.checkpoint:                      # re-run the layer forward from its saved input
-            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask)
+            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary)
         need_w = [need[base + 1], need[base + 2], need[base + 5], need[base + 7]]
-        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg)
+        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary)
         layers[l] = None                         # release this layer's activations
         sg.layer_done()
         grads[base + 1], grads[base + 2], grads[base + 5], grads[base + 7] = dws

@@ -496,3 +496,14 @@ def simreg_diff(A: Tensor, C: Tensor, diag_off: int, sumsq_accum: Tensor) -> Ten
     _lib.check(_lib.lib().xclip_simreg_diff(A.data_ptr(), A.stride(0), C.data_ptr(), C.stride(0), A.data_ptr(), A.stride(0), rows, cols,
                                             diag_off, sumsq_accum.data_ptr(), dtype_code(A), _stream(A)), "xclip_simreg_diff")
     return A
+
+
+def rotary_(x: Tensor, n: int, inv_freq: Tensor, inverse: bool = False) -> Tensor:
+    """in-place rotary position embedding on x [rows, slots * 64] (packed q | k | v head slots), position = row % n, angles
+    pos * inv_freq[j] (x_clip.py:155-176, 221-223); inverse=True is the backward of the forward call"""
+    _dev_check(x, inv_freq)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 64 == 0
+    assert inv_freq.dtype == torch.float32 and inv_freq.numel() == 16 and inv_freq.is_contiguous()
+    _lib.check(_lib.lib().xclip_rotary(x.data_ptr(), x.stride(0), x.shape[0], n, x.shape[1] // 64, inv_freq.data_ptr(), int(inverse),
+                                       dtype_code(x), _stream(x)), "xclip_rotary")
+    return x
