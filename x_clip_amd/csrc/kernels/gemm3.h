@@ -309,7 +309,7 @@ struct G3GemmEpilogue {
 // accumulators pinned to AGPRs (the compiler then splits 128 / 128 and spills), an epilogue transposed through wave-private LDS
 // so that every store is a full 128-byte line (K=512: 508 vs 510 us -- the 86 us the stores cost there are not a coalescing
 // problem), the tile's last B pieces issued before the epilogue so its stores may stay in flight one more K step (no change),
-// one fragment read in front of each MFMA instead of six up front (+1 %).
+// one fragment read in front of each MFMA instead of six up front (+1 %), non-temporal epilogue stores (K=512: 731 vs 521 us).
 template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
