@@ -309,7 +309,9 @@ struct G3GemmEpilogue {
 // accumulators pinned to AGPRs (the compiler then splits 128 / 128 and spills), an epilogue transposed through wave-private LDS
 // so that every store is a full 128-byte line (K=512: 508 vs 510 us -- the 86 us the stores cost there are not a coalescing
 // problem), the tile's last B pieces issued before the epilogue so its stores may stay in flight one more K step (no change),
-// one fragment read in front of each MFMA instead of six up front (+1 %), non-temporal epilogue stores (K=512: 731 vs 521 us).
+// one fragment read in front of each MFMA instead of six up front (+1 %), non-temporal epilogue stores (K=512: 731 vs 521 us),
+// four waves of 128 x 128 instead of eight of 128 x 64 (a third less fragment traffic, but hipcc spills ~100 of the 256 + 64
+// live registers and a lone wave per SIMD has nobody to hide behind: 626 vs 537 us at K=2048).
 template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
