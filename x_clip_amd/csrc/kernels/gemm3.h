@@ -311,7 +311,8 @@ struct G3GemmEpilogue {
 // problem), the tile's last B pieces issued before the epilogue so its stores may stay in flight one more K step (no change),
 // one fragment read in front of each MFMA instead of six up front (+1 %), non-temporal epilogue stores (K=512: 731 vs 521 us),
 // four waves of 128 x 128 instead of eight of 128 x 64 (a third less fragment traffic, but hipcc spills ~100 of the 256 + 64
-// live registers and a lone wave per SIMD has nobody to hide behind: 626 vs 537 us at K=2048).
+// live registers and a lone wave per SIMD has nobody to hide behind: 626 vs 537 us at K=2048), a 2-D blocked tile order (8 A panels
+// x 4 weight tiles per XCD round instead of 2 x 16, to keep the weights in L2: FF1 +2 %, QKV -4 %, others within noise).
 template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
