@@ -68,14 +68,32 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict
             }
         }
     }
-    float* dst = (j >= 0) ? (dP != nullptr ? dP + (long)j * D : nullptr) : dcls;
-    if (dst != nullptr) {
+    // the four waves' column sums meet in LDS; one atomic per column per work-group (gridDim.y-way contention per address
+    // instead of 4 gridDim.y: the position / CLS rows are few and every work-group of a position adds into the same one)
+    XC_LDS_DYNAMIC(lds);
+    float* red = reinterpret_cast<float*>(lds);            // [3][D]
+    const int wave = wave_id();
+    if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch)
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) atomic_add(dst + c * VEC + k, acc[i][k]);
+                for (int k = 0; k < VEC; ++k) red[(wave - 1) * D + c * VEC + k] = acc[i][k];
+        }
+    }
+    sync();
+    float* dst = (j >= 0) ? (dP != nullptr ? dP + (long)j * D : nullptr) : dcls;
+    if (dst != nullptr && wave == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const int col = c * VEC + k;
+                    atomic_add(dst + col, acc[i][k] + red[col] + red[D + col] + red[2 * D + col]);
+                }
         }
     }
 }

@@ -283,7 +283,8 @@ int xclip_text_embed_bwd(const void* dout, const int64_t* tokens, float* dE_accu
     int ysplit = (int)((batch + 31) / 32);
     if (ysplit > 16) ysplit = 16;
     dim3 grid((unsigned)(n + (has_cls ? 1 : 0)), ysplit), block(256);
-#define F(T, C) hipLaunchKernelGGL((text_embed_bwd_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)dout, (const long long*)tokens, dE_accum, dP_accum, dcls_accum, (int)batch, (int)n, (int)dim, has_cls ? 1 : 0)
+    const size_t red_bytes = (size_t)3 * dim * sizeof(float);
+#define F(T, C) hipLaunchKernelGGL((text_embed_bwd_kernel<T, C>), grid, block, red_bytes, (hipStream_t)stream, (const T*)dout, (const long long*)tokens, dE_accum, dP_accum, dcls_accum, (int)batch, (int)n, (int)dim, has_cls ? 1 : 0)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
     return check_launch(__func__);
