@@ -226,12 +226,14 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 
     (void)epi(acc, m0, n0);
     }   // tile loop
+    epi.finish();                                             // per-work-group leftovers of the epilogue (e.g. one atomic per wave)
 }
 
 // ---- the GEMM epilogue: registers -> global, one output row per lane ------------------------------------------------------------
 template <int ABL>
 struct G3GemmEpilogue {
     const Gemm2Params& p;
+    XC_DEV void finish() const {}
     XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
         const int lane = threadIdx.x & 63, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;

@@ -14,6 +14,7 @@
 namespace xc {
 
 struct Sim3LseEpilogue {
+    XC_DEV void finish() {}
     const SimParams& p;
     XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
         const int lane = threadIdx.x & 63, h = lane >> 5;
@@ -90,7 +91,13 @@ struct Sim3LseEpilogue {
 
 struct Sim3GradEpilogue {
     const SimParams& p;
-    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
+    float dt_acc = 0.f;          // this lane's share of sum G o S over ALL tiles of the work-group: one atomic per wave at the end
+                                 // (per tile it was 16k same-address atomics at 32k x 4k, each on the next barrier's critical path)
+    XC_DEV void finish() {
+        const float dt = wave_sum(dt_acc);
+        if ((threadIdx.x & 63) == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
+    }
+    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) {
         const int lane = threadIdx.x & 63, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
         const float scale = sim_scale(p);
@@ -145,8 +152,7 @@ struct Sim3GradEpilogue {
                     }
                 }
             }
-            dt = wave_sum(dt);
-            if (lane == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
+            dt_acc += dt;
             return 16;
         }
 #pragma unroll
@@ -193,8 +199,7 @@ struct Sim3GradEpilogue {
                 }
             }
         }
-        dt = wave_sum(dt);
-        if (lane == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
+        dt_acc += dt;
         return full ? 16 : 0;
     }
 };
