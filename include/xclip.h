@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 6
+#define XCLIP_ABI_VERSION 7
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -162,6 +162,14 @@ int xclip_rowlse(const float* S, int64_t lds, int64_t rows, int64_t cols, int64_
                  float* loss_accum, void* stream);
 int xclip_rowgrad(const float* S, int64_t lds, const float* lse, int64_t rows, int64_t cols, int64_t diag_off, int dcl, float coef,
                   const float* gmul, float* G, int64_t ldg, float* dtau_accum, void* stream);
+/* `downsample_image_embeds` (x_clip.py:560-568), first stage: the depthwise Conv2d(C, C, 4, stride 2, padding 1, groups C, no bias)
+ * over the image tokens laid out as an h x h grid.  x [batch, h*h, C] token-major, w [C, 16] (= the Conv2d weight [C, 1, 4, 4]),
+ * y [batch, (h/2)^2, C].  (The 1 x 1 Conv2d with bias that follows is xclip_gemm with a bias row.)  bwd: dx [batch, h*h, C] and
+ * dw_accum[C * 16] += the weight gradient (fp32), through per-wave partial rows in `workspace`. */
+int64_t xclip_dwconv4s2_workspace_bytes(int64_t batch, int64_t h, int64_t C, int dtype);
+int xclip_dwconv4s2_fwd(const void* x, const void* w, void* y, int64_t batch, int64_t h, int64_t C, int dtype, void* stream);
+int xclip_dwconv4s2_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw_accum, void* workspace, int64_t workspace_bytes,
+                        int64_t batch, int64_t h, int64_t C, int dtype, void* stream);
 /* Rotary position embedding (RotaryEmbedding / apply_rotary_pos_emb, x_clip.py:155-176; applied to q, k and v, :221-223), in
  * place on rows of `slots` 64-wide head slots (the packed qkv activation: slots = 3 * heads).  Token position = row % n; in
  * every slot the first 32 features are rotated pairwise (j, j + 16) by pos * inv_freq[j]; inv_freq: 16 device fp32 values, the

@@ -53,6 +53,7 @@ class ClipConfig:
     visual_has_cls_token: bool = True
     channels: int = 3
     use_all_token_embeds: bool = False
+    downsample_image_embeds: bool = False
     decoupled_contrastive_learning: bool = False
     extra_latent_projection: bool = False
     multiview_loss_weight: float = 0.1
@@ -279,6 +280,19 @@ def sim_reg_loss(tl: Tensor, il: Tensor, tlx: Tensor, ilx: Tensor) -> Tensor:
     return (mse(sim(tl), sim(il)) + mse(sim(tlx), sim(ilx))) / 2
 
 
+def downsample_latents(tokens: Tensor, w_dw: Tensor, w_pw: Tensor, b_pw: Tensor) -> Tensor:
+    """`downsample_image_embeds` projection (x_clip.py:560-568): the image tokens [b, n, C] (n a perfect square) are laid out as
+    a sqrt(n) x sqrt(n) grid, filtered per channel by a 4 x 4 stride-2 pad-1 convolution (weight [C, 1, 4, 4], no bias), then mapped
+    to the latent width by a 1 x 1 convolution (weight [L, C, 1, 1] + bias): [b, n / 4, L]."""
+    b, n, C = tokens.shape
+    h = int(math.isqrt(n))
+    assert h * h == n, "downsample_image_embeds needs a square token grid"
+    x = tokens.transpose(1, 2).reshape(b, C, h, h)
+    x = torch.nn.functional.conv2d(x, w_dw, None, stride=2, padding=1, groups=C)
+    x = torch.nn.functional.conv2d(x, w_pw, b_pw)
+    return x.flatten(2).transpose(1, 2)
+
+
 def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Tensor,
                  aug_text: Sequence[Tensor] = (), aug_image: Sequence[Tensor] = (),
                  keep_idx: Optional[Tensor] = None, return_latents: bool = False):
@@ -294,12 +308,17 @@ def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Te
         ei = enc_i[:, 1:] if cfg.visual_has_cls_token else enc_i
     else:
         et, ei = enc_t[:, 0], enc_i[:, 0]
+    def visual_latent(pfx):
+        if cfg.downsample_image_embeds:                                   # x_clip.py:560-568
+            return downsample_latents(ei, sd[pfx + ".1.weight"], sd[pfx + ".2.weight"], sd[pfx + ".2.bias"])
+        return ei @ sd[pfx + ".weight"].t()
+
     tl = l2_normalize(et @ sd["to_text_latent.weight"].t())               # x_clip.py:713-715
-    il = l2_normalize(ei @ sd["to_visual_latent.weight"].t())
+    il = l2_normalize(visual_latent("to_visual_latent"))
     tlx = ilx = None
     if cfg.extra_latent_projection:                                       # x_clip.py:720-724
         tlx = l2_normalize(et @ sd["to_text_latent_extra.weight"].t())
-        ilx = l2_normalize(ei @ sd["to_visual_latent_extra.weight"].t())
+        ilx = l2_normalize(visual_latent("to_visual_latent_extra"))
     if return_latents:
         return (tl, il) if tlx is None else (tl, il, tlx, ilx)
     return contrastive_loss(cfg, sd["temperature"], tl, il, tlx, ilx, text_mask, m, n)
@@ -384,8 +403,13 @@ def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
     tower(v + "transformer.", cfg.dim_image, cfg.visual_enc_depth, cfg.visual_heads, cfg.visual_dim_head)
     shapes[v + "to_cls_tokens.1.weight"] = (cfg.dim_image, cfg.dim_image)
     for k, d in (("to_text_latent", cfg.dim_text), ("to_visual_latent", cfg.dim_image)):
-        shapes[k + ".weight"] = (cfg.dim_latent, d)
-        shapes[k + "_extra.weight"] = (cfg.dim_latent, d)
+        for sfx in ("", "_extra"):
+            if k == "to_visual_latent" and cfg.downsample_image_embeds:   # Sequential(RearrangeImage, Conv2d dw, Conv2d 1x1, Rearrange)
+                shapes[k + sfx + ".1.weight"] = (d, 1, 4, 4)
+                shapes[k + sfx + ".2.weight"] = (cfg.dim_latent, d, 1, 1)
+                shapes[k + sfx + ".2.bias"] = (cfg.dim_latent,)
+            else:
+                shapes[k + sfx + ".weight"] = (cfg.dim_latent, d)
     return shapes
 
 
@@ -408,7 +432,8 @@ def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str
         elif "emb" in key or key.endswith("cls_token"):
             a = rs.standard_normal(shape)
         else:
-            bound = 1.0 / math.sqrt(shape[-1])
+            fan_in = int(np.prod(shape[1:])) if len(shape) == 4 else shape[-1]     # conv weights: in/groups * kh * kw
+            bound = 1.0 / math.sqrt(fan_in)
             a = rs.uniform(-bound, bound, shape)
         sd[key] = torch.tensor(a, dtype=torch.float64).to(dtype)
     return sd

@@ -60,6 +60,9 @@ CASES = {
     "cfg1_filip": (dict(use_all_token_embeds=True), 4, 0, 0, 0.0),
     "cfg1_filip_dcl": (dict(use_all_token_embeds=True, decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
     "cfg1_patchdrop": (dict(), 4, 0, 0, 0.5),
+    "cfg1_filip_downsample": (dict(use_all_token_embeds=True, downsample_image_embeds=True, visual_patch_size=16), 4, 0, 0, 0.0),
+    "cfg1_filip_downsample_extra_dcl": (dict(use_all_token_embeds=True, downsample_image_embeds=True, visual_patch_size=16,
+                                             extra_latent_projection=True, decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
     "cfg1_rotary": (dict(text_rotary_pos_emb=True), 4, 0, 0, 0.0),
     "cfg1_rotary_dcl_multiview": (dict(text_rotary_pos_emb=True, decoupled_contrastive_learning=True), 4, 1, 0, 0.0),
     "cfg1_simreg_extra": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.1), 4, 0, 0, 0.0),

@@ -408,3 +408,21 @@ def case_rotary(dev, dtype, batch, n, heads):
     close(y, ref, dtype, "rotary fwd")
     z = ops.rotary_(y.clone(), n, inv_freq, inverse=True)                      # R^T R = identity
     close(z, ref64(x), dtype, "rotary inverse", mult=2.0)
+
+
+def case_dwconv(dev, dtype, batch, h, C):
+    """depthwise 4x4 / stride 2 / pad 1 convolution over the token grid, forward and both gradients (x_clip.py:560-568)"""
+    x = rnd((batch, h * h, C), dtype, 61)
+    w = rnd((C, 1, 4, 4), dtype, 62) * 0.25
+    dy = rnd((batch, (h // 2) ** 2, C), dtype, 63)
+    y = ops.dwconv4s2_fwd(x.to(dev), w.to(dev).view(C, 16))
+    dwa = torch.zeros(C * 16, dtype=torch.float32, device=dev)
+    dx = ops.dwconv4s2_bwd(dy.to(dev), x.to(dev), w.to(dev).view(C, 16), dwa)
+    x64 = ref64(x).requires_grad_(True)
+    w64 = ref64(w).requires_grad_(True)
+    img = x64.transpose(1, 2).reshape(batch, C, h, h)
+    ref = torch.nn.functional.conv2d(img, w64, None, stride=2, padding=1, groups=C).flatten(2).transpose(1, 2)
+    ref.backward(ref64(dy))
+    close(y, ref, dtype, "dwconv y", mult=2.0)
+    close(dx, x64.grad, dtype, "dwconv dx", mult=2.0)
+    close(dwa.view(C, 1, 4, 4), w64.grad, torch.float32 if dtype == torch.float32 else dtype, "dwconv dw", mult=4.0)

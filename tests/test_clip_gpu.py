@@ -28,7 +28,7 @@ def hip_library():
 
 
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview"])
+                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 

@@ -146,3 +146,9 @@ def test_simreg_diff(dtype, rows, cols, diag_off):
 @pytest.mark.parametrize("batch,n,heads", [(2, 5, 1), (1, 33, 2)])
 def test_rotary(dtype, batch, n, heads):
     K.case_rotary(DEV, dtype, batch, n, heads)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("batch,h,C", [(2, 4, 64), (1, 2, 16)])
+def test_dwconv(dtype, batch, h, C):
+    K.case_dwconv(DEV, dtype, batch, h, C)

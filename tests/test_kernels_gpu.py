@@ -145,3 +145,9 @@ def test_simreg_diff(dtype, rows, cols, diag_off):
 @pytest.mark.parametrize("batch,n,heads", [(2, 5, 1), (7, 257, 8), (3, 33, 4)])
 def test_rotary(dtype, batch, n, heads):
     K.case_rotary(DEV, dtype, batch, n, heads)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("batch,h,C", [(2, 4, 64), (3, 14, 512), (5, 8, 1024)])
+def test_dwconv(dtype, batch, h, C):
+    K.case_dwconv(DEV, dtype, batch, h, C)

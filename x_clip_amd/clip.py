@@ -8,7 +8,7 @@ the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is n
 on an MI355X.
 
 Not on this path yet (constructor raises NotImplementedError): causal text encoder,
-MLM and visual-SSL side losses, `downsample_image_embeds`.
+MLM and visual-SSL side losses.
 """
 from __future__ import annotations
 
@@ -332,10 +332,18 @@ class CLIP(nn.Module):
 
         self.to_text_latent = nn.Linear(dim_text, dim_latent, bias=False)
 
-        if downsample_image_embeds:
+        self.downsample_image_embeds = downsample_image_embeds
+        if downsample_image_embeds:                                                        # x_clip.py:560-568
             assert use_all_token_embeds, 'must be using all token embeds for contrastive learning in order to downsampling'
-            raise NotImplementedError("downsample_image_embeds is not on the accelerated path yet (SURVEY.md 8(f))")
-        self.to_visual_latent = nn.Linear(dim_image, dim_latent, bias=False)
+            # parameter containers with the reference's Sequential indices (.1 = depthwise 4x4 / stride 2, .2 = 1x1 + bias); the
+            # arithmetic runs in xclip_dwconv4s2 + xclip_gemm (functional.downsample_latents)
+            self.to_visual_latent = nn.Sequential(
+                nn.Identity(),
+                nn.Conv2d(dim_image, dim_image, 4, stride=2, padding=1, bias=False, groups=dim_image),
+                nn.Conv2d(dim_image, dim_latent, 1),
+                nn.Identity())
+        else:
+            self.to_visual_latent = nn.Linear(dim_image, dim_latent, bias=False)
 
         self.temperature = nn.Parameter(torch.tensor(1.))
 
@@ -445,12 +453,17 @@ class CLIP(nn.Module):
             image_embeds = XF.select_row(enc_image, 0) if enc_image.ndim == 3 else enc_image
 
         text_latents = XF.l2norm(XF.linear(text_embeds, self.to_text_latent.weight))       # x_clip.py:713-715
-        image_latents = XF.l2norm(XF.linear(image_embeds, self.to_visual_latent.weight))
+        def visual_latents(proj):
+            if self.downsample_image_embeds:
+                return XF.downsample_latents(image_embeds, proj[1].weight, proj[2].weight, proj[2].bias)
+            return XF.linear(image_embeds, proj.weight)
+
+        image_latents = XF.l2norm(visual_latents(self.to_visual_latent))
 
         text_latents_extra, image_latents_extra = text_latents, image_latents              # x_clip.py:720-724
         if self.extra_latent_projection:
             text_latents_extra = XF.l2norm(XF.linear(text_embeds, self.to_text_latent_extra.weight))
-            image_latents_extra = XF.l2norm(XF.linear(image_embeds, self.to_visual_latent_extra.weight))
+            image_latents_extra = XF.l2norm(visual_latents(self.to_visual_latent_extra))
 
         if return_latents:                                                                 # x_clip.py:728-732
             if self.extra_latent_projection:

@@ -362,4 +362,130 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* __restrict__ X, long ld,
     }
 }
 
+// ---- depthwise 4 x 4 / stride 2 / pad 1 convolution over a square token grid (`downsample_image_embeds`, x_clip.py:560-568) ----
+// x [batch, h * h, C] token-major (channels contiguous), w [C, 16] (the Conv2d weight [C, 1, 4, 4]), y [batch, (h/2)^2, C]:
+//   y[b, (i, j), c] = sum_{u, v} w[c, 4 u + v] x[b, (2 i - 1 + u, 2 j - 1 + v), c]      (out-of-range taps are zero padding)
+// A lane owns one 16-byte channel chunk: every x / y access is a coalesced row segment, and the chunk's 16 x VEC weights are one
+// contiguous run of w.
+template <typename T>
+XC_DEV void dwconv_load_w(const T* __restrict__ w, int c0, float (&wf)[Elem<T>::VEC][16]) {
+    constexpr int VEC = Elem<T>::VEC;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                             // flat element e = k * 16 + tap, VEC elements per load
+        float t[VEC];
+        load_vec<T>(w + (long)c0 * 16 + q * VEC, t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) wf[(q * VEC + e) / 16][(q * VEC + e) % 16] = t[e];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int batch,
+                                                         int h, int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int ho = h / 2, nch = C / VEC;
+    const long items = (long)batch * ho * ho * nch;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % nch);
+        const long t = it / nch;
+        const int j = (int)(t % ho), i = (int)((t / ho) % ho);
+        const long b = t / ((long)ho * ho);
+        float wf[VEC][16];
+        dwconv_load_w<T>(w, c * VEC, wf);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = 2 * i - 1 + u;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int q = 2 * j - 1 + v;
+                if (p >= 0 && p < h && q >= 0 && q < h) {
+                    float xv[VEC];
+                    load_vec<T>(x + ((b * h + p) * h + q) * (long)C + c * VEC, xv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += wf[e][u * 4 + v] * xv[e];
+                }
+            }
+        }
+        store_vec<T>(y + t * (long)C + c * VEC, acc);
+    }
+}
+// backward: dx (gather form: an input token feeds at most 2 x 2 outputs) and per-wave partial rows of dw [C * 16] (fp32) that the
+// caller folds with colsum_fold_kernel.  partial: [gridDim.x * 4, C * 16], zero-initialised by the caller.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
+                                                         T* __restrict__ dx, float* __restrict__ partial, int batch, int h, int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int ho = h / 2, nch = C / VEC;
+    // ---- dx ----
+    const long in_items = (long)batch * h * h * nch;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < in_items; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % nch);
+        const long t = it / nch;
+        const int q = (int)(t % h), p = (int)((t / h) % h);
+        const long b = t / ((long)h * h);
+        float wf[VEC][16];
+        dwconv_load_w<T>(w, c * VEC, wf);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int di = 0; di < 2; ++di) {
+            const int i = (p + 1) / 2 - di, u = p + 1 - 2 * i;                 // 2 i - 1 + u = p
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const int j = (q + 1) / 2 - dj, v = q + 1 - 2 * j;
+                if (i >= 0 && i < ho && u >= 0 && u < 4 && j >= 0 && j < ho && v >= 0 && v < 4) {
+                    float g[VEC];
+                    load_vec<T>(dy + ((b * ho + i) * ho + j) * (long)C + c * VEC, g);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        float wsel = 0.f;                                      // w[e][4 u + v] with a run-time tap: select over the 16 registers
+#pragma unroll
+                        for (int tap = 0; tap < 16; ++tap) wsel = (tap == u * 4 + v) ? wf[e][tap] : wsel;
+                        acc[e] += wsel * g[e];
+                    }
+                }
+            }
+        }
+        store_vec<T>(dx + t * (long)C + c * VEC, acc);
+    }
+    // ---- dw partials: lane <-> channel chunk, (work-group, wave) <-> a strided share of the (b, i, j) outputs ----
+    const int lane = lane_id(), wave = wave_id();
+    const long outs = (long)batch * ho * ho;
+    float* prow = partial + ((long)blockIdx.x * 4 + wave) * C * 16;
+    for (int c = lane; c < nch; c += 64) {
+        float wacc[VEC][16];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+#pragma unroll
+            for (int tap = 0; tap < 16; ++tap) wacc[e][tap] = 0.f;
+        for (long t = (long)blockIdx.x * 4 + wave; t < outs; t += (long)gridDim.x * 4) {
+            const int j = (int)(t % ho), i = (int)((t / ho) % ho);
+            const long b = t / ((long)ho * ho);
+            float g[VEC];
+            load_vec<T>(dy + t * (long)C + c * VEC, g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = 2 * i - 1 + u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int q = 2 * j - 1 + v;
+                    if (p >= 0 && p < h && q >= 0 && q < h) {
+                        float xv[VEC];
+                        load_vec<T>(x + ((b * h + p) * h + q) * (long)C + c * VEC, xv);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) wacc[e][u * 4 + v] += g[e] * xv[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+#pragma unroll
+            for (int tap = 0; tap < 16; ++tap) prow[(long)(c * VEC + e) * 16 + tap] = wacc[e][tap];
+    }
+}
+
 }  // namespace xc

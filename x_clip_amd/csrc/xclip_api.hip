@@ -435,6 +435,50 @@ int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale,
     return check_launch(__func__);
 }
 
+namespace {
+inline int dwconv_bwd_blocks(int64_t batch, int64_t h, int64_t C, int dtype) {
+    const int64_t items = batch * h * h * (C / vec_of(dtype));
+    int64_t b = (items + 255) / 256;
+    return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+}  // namespace
+int64_t xclip_dwconv4s2_workspace_bytes(int64_t batch, int64_t h, int64_t C, int dtype) {
+    return (int64_t)dwconv_bwd_blocks(batch, h, C, dtype) * 4 * C * 16 * 4;
+}
+int xclip_dwconv4s2_fwd(const void* x, const void* w, void* y, int64_t batch, int64_t h, int64_t C, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(batch >= 0 && h >= 2 && h % 2 == 0 && C > 0 && C % vec_of(dtype) == 0, "token grid must be even-sided, channels whole 16-byte chunks");
+    XC_REQUIRE(x && w && y && aligned16(x) && aligned16(w) && aligned16(y), "null or misaligned pointer");
+    if (batch == 0) return 0;
+    const int64_t items = batch * (h / 2) * (h / 2) * (C / vec_of(dtype));
+    int64_t blocks = (items + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (int)batch, (int)h, (int)C);
+    else
+        hipLaunchKernelGGL((dwconv_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (const float*)w, (float*)y, (int)batch, (int)h, (int)C);
+    return check_launch(__func__);
+}
+int xclip_dwconv4s2_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw_accum, void* workspace, int64_t workspace_bytes,
+                        int64_t batch, int64_t h, int64_t C, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(batch >= 0 && h >= 2 && h % 2 == 0 && C > 0 && C % vec_of(dtype) == 0, "token grid must be even-sided, channels whole 16-byte chunks");
+    XC_REQUIRE(dy && x && w && dx && dw_accum && aligned16(dy) && aligned16(x) && aligned16(w) && aligned16(dx), "null or misaligned pointer");
+    XC_REQUIRE(workspace != nullptr && workspace_bytes >= xclip_dwconv4s2_workspace_bytes(batch, h, C, dtype), "workspace too small");
+    if (batch == 0) return 0;
+    const int blocks = dwconv_bwd_blocks(batch, h, C, dtype);
+    dim3 grid((unsigned)blocks), block(256);
+    float* partial = (float*)workspace;
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((dwconv_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)dx, partial, (int)batch, (int)h, (int)C);
+    else
+        hipLaunchKernelGGL((dwconv_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dy, (const float*)x, (const float*)w, (float*)dx, partial, (int)batch, (int)h, (int)C);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((C * 16 + 63) / 64), 4), dim3(256), 1024, (hipStream_t)stream,
+                       (const float*)partial, dw_accum, blocks * 4, (int)(C * 16));
+    return check_launch(__func__);
+}
+
 int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, const float* inv_freq, int inverse, int dtype,
                  void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");

@@ -407,6 +407,48 @@ def linear(x: Tensor, w: Tensor) -> Tensor:
     return _LinearFn.apply(x, w)
 
 
+class _DownsampleFn(torch.autograd.Function):
+    """`downsample_image_embeds` projection (x_clip.py:560-568): depthwise 4 x 4 / stride 2 / pad 1 convolution over the square token
+    grid, then the 1 x 1 convolution with bias = a GEMM with a bias row.  tokens [b, n, C] -> [b, n / 4, L]."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w_dw: Tensor, w_pw: Tensor, b_pw: Tensor):
+        x = ops._c(x)
+        b, n, C = x.shape
+        L = w_pw.shape[0]
+        wd = ops._c(w_dw).view(C, 16)
+        wp = ops._c(w_pw).view(L, C)
+        y = ops.dwconv4s2_fwd(x, wd)                                           # [b, n/4, C]
+        M = y.shape[0] * y.shape[1]
+        z = ops.gemm(y.view(M, C), wp, M, L, C, bias=ops._c(b_pw))
+        ctx.save_for_backward(x, wd, y, wp)
+        ctx.meta = (b, n, C, L, w_dw.shape, w_pw.shape, b_pw.dtype)
+        return z.view(b, y.shape[1], L)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        x, wd, y, wp = ctx.saved_tensors
+        b, n, C, L, dw_shape, pw_shape, bdt = ctx.meta
+        M = y.shape[0] * y.shape[1]
+        dz2 = ops._c(dz).view(M, L)
+        dy = ops.gemm(dz2, wp, M, C, L, b_kmajor=True)                         # [M, C]
+        d_pw = ops.gemm(dz2, y.view(M, C), L, C, M, a_kmajor=True, b_kmajor=True).view(pw_shape) if ctx.needs_input_grad[2] else None
+        d_b = None
+        if ctx.needs_input_grad[3]:
+            acc = torch.zeros(L, dtype=torch.float32, device=dz.device)
+            ops.rows_scatter_add(dz2, None, None, acc)                         # column sums
+            d_b = acc.to(bdt)
+        dwa = torch.zeros(C * 16, dtype=torch.float32, device=dz.device)
+        dx = ops.dwconv4s2_bwd(dy.view(b, M // b, C), x, wd, dwa)
+        d_dw = dwa.to(wd.dtype).view(dw_shape) if ctx.needs_input_grad[1] else None
+        return (dx if ctx.needs_input_grad[0] else None), d_dw, d_pw, d_b
+
+
+def downsample_latents(tokens: Tensor, w_dw: Tensor, w_pw: Tensor, b_pw: Tensor) -> Tensor:
+    return _DownsampleFn.apply(tokens, w_dw, w_pw, b_pw)
+
+
 class _L2NormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor):

@@ -4,6 +4,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import math
+
 import torch
 
 from . import _lib
@@ -507,3 +509,31 @@ def rotary_(x: Tensor, n: int, inv_freq: Tensor, inverse: bool = False) -> Tenso
     _lib.check(_lib.lib().xclip_rotary(x.data_ptr(), x.stride(0), x.shape[0], n, x.shape[1] // 64, inv_freq.data_ptr(), int(inverse),
                                        dtype_code(x), _stream(x)), "xclip_rotary")
     return x
+
+
+def dwconv4s2_fwd(x: Tensor, w: Tensor) -> Tensor:
+    """depthwise 4x4 / stride 2 / pad 1 convolution over the token grid: x [b, h*h, C], w [C, 1, 4, 4] -> [b, (h/2)^2, C]
+    (first stage of `downsample_image_embeds`, x_clip.py:560-568)"""
+    _dev_check(x, w)
+    b, n, C = x.shape
+    h = math.isqrt(n)
+    assert h * h == n and h % 2 == 0, "downsample_image_embeds needs an even-sided square token grid"
+    assert x.is_contiguous() and w.is_contiguous() and w.numel() == C * 16 and w.dtype == x.dtype
+    y = torch.empty(b, (h // 2) ** 2, C, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().xclip_dwconv4s2_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), b, h, C, dtype_code(x), _stream(x)), "xclip_dwconv4s2_fwd")
+    return y
+
+
+def dwconv4s2_bwd(dy: Tensor, x: Tensor, w: Tensor, dw_accum: Tensor) -> Tensor:
+    """-> dx [b, h*h, C]; dw_accum (fp32 [C * 16]) += the weight gradient"""
+    _dev_check(dy, x, w, dw_accum)
+    b, n, C = x.shape
+    h = math.isqrt(n)
+    assert dy.is_contiguous() and x.is_contiguous() and dw_accum.dtype == torch.float32 and dw_accum.numel() == C * 16
+    L = _lib.lib()
+    wbytes = L.xclip_dwconv4s2_workspace_bytes(b, h, C, dtype_code(x))
+    ws = workspace(x.device, wbytes)
+    dx = torch.empty_like(x)
+    _lib.check(L.xclip_dwconv4s2_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), dw_accum.data_ptr(), ws.data_ptr(), wbytes,
+                                     b, h, C, dtype_code(x), _stream(x)), "xclip_dwconv4s2_bwd")
+    return dx
