@@ -24,8 +24,10 @@ def emulator_library():
     _lib._use_library_for_tests(None)
 
 
-@pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl"])      # p16_heads2 uses dim_head 32: kernels are built for 64
+# the emulator runs every fixture in 15-20 s; the plain variants whose code paths are a subset of a combined fixture below
+# (cfg1_dcl, cfg1_multiview, cfg1_filip, cfg1_simreg_extra, cfg1_rotary, cfg1_filip_downsample) are exercised on the GPU only
+@pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_extra_dcl", "cfg1_multiview_m3n1", "cfg1_patchdrop", "cfg1_filip_dcl",
+                                  "cfg1_simreg_extra_dcl", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample_extra_dcl"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 
