@@ -315,6 +315,8 @@ struct G3GemmEpilogue {
 // four waves of 128 x 128 instead of eight of 128 x 64 (a third less fragment traffic, but hipcc spills ~100 of the 256 + 64
 // live registers and a lone wave per SIMD has nobody to hide behind: 626 vs 537 us at K=2048), a 2-D blocked tile order (8 A panels
 // x 4 weight tiles per XCD round instead of 2 x 16, to keep the weights in L2: FF1 +2 %, QKV -4 %, others within noise).
+// Where the K=512 epilogue goes (M=263168 N=1536): 529 us as is, 452 with every tile storing into the same L2-resident 128 KiB, 410
+// with no stores -- 42 us of store issue / L2 acceptance, 77 us of the 808 MB write stream reaching HBM next to the A reads.
 template <bool A_KMAJOR, bool B_KMAJOR, int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm3_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
