@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 7
+#define XCLIP_ABI_VERSION 8
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -162,6 +162,17 @@ int xclip_rowlse(const float* S, int64_t lds, int64_t rows, int64_t cols, int64_
                  float* loss_accum, void* stream);
 int xclip_rowgrad(const float* S, int64_t lds, const float* lse, int64_t rows, int64_t cols, int64_t diag_off, int dcl, float coef,
                   const float* gmul, float* G, int64_t ldg, float* dtau_accum, void* stream);
+/* Masked-language-model head (MLM.forward, mlm.py:96-109; `to_logits` itself is xclip_gemm with a bias row).
+ * gather_rows: out[r, :] = src[idx[r], :] -- only the masked positions of the encoder output are projected onto the vocabulary.
+ * cross_entropy_fwd: lse[r] = log sum_{c < cols} exp(x[r, c]); *loss_accum += sum_r (lse[r] - x[r, labels[r]]) (the caller
+ *   divides by the number of rows: F.cross_entropy(..., ignore_index) averages over the non-ignored positions).
+ * cross_entropy_bwd: in place, x[r, c] <- (*gmul / rows) (softmax(x[r])[c] - [c == labels[r]]) for c < cols, 0 in the padding
+ *   columns [cols, ld). */
+int xclip_gather_rows(const void* src, int64_t lds, const int32_t* idx, void* out, int64_t rows, int64_t dim, int dtype, void* stream);
+int xclip_cross_entropy_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t rows, int64_t cols, float* lse, float* loss_accum,
+                            int dtype, void* stream);
+int xclip_cross_entropy_bwd(void* logits, int64_t ld, const int64_t* labels, const float* lse, const float* gmul, int64_t rows, int64_t cols,
+                            int dtype, void* stream);
 /* `downsample_image_embeds` (x_clip.py:560-568), first stage: the depthwise Conv2d(C, C, 4, stride 2, padding 1, groups C, no bias)
  * over the image tokens laid out as an h x h grid.  x [batch, h*h, C] token-major, w [C, 16] (= the Conv2d weight [C, 1, 4, 4]),
  * y [batch, (h/2)^2, C].  (The 1 x 1 Conv2d with bias that follows is xclip_gemm with a bias row.)  bwd: dx [batch, h*h, C] and

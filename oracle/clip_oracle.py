@@ -58,6 +58,8 @@ class ClipConfig:
     extra_latent_projection: bool = False
     multiview_loss_weight: float = 0.1
     sim_reg_loss_weight: float = 0.0
+    use_mlm: bool = False
+    text_ssl_loss_weight: float = 0.05
 
     @property
     def num_patches(self) -> int:
@@ -227,7 +229,7 @@ def _info_nce(t2i: Tensor, i2t: Tensor, dcl: bool) -> Tensor:
 def contrastive_loss(cfg: ClipConfig, temperature: Tensor,
                      t_lat: Tensor, i_lat: Tensor,
                      t_lat_x: Optional[Tensor], i_lat_x: Optional[Tensor],
-                     text_mask: Optional[Tensor], m: int, n: int) -> Tensor:
+                     text_mask: Optional[Tensor], m: int, n: int, ssl_weight: float = 0.0) -> Tensor:
     """x_clip.py:736,750-755,797-868.  `t_lat` is [(m b), d] (CLS mode) or [(m b), nt, d] (FILIP);
     `i_lat` likewise with n views.  `*_x` are the CLOOB extra-projection latents or None."""
     temp = temperature.exp()
@@ -256,7 +258,7 @@ def contrastive_loss(cfg: ClipConfig, temperature: Tensor,
                        cfg.decoupled_contrastive_learning)
     multiview = (m > 1) or (n > 1)
     w_mv = cfg.multiview_loss_weight if multiview else 0.0
-    loss = losses[0] * (1.0 - w_mv)
+    loss = losses[0] * (1.0 - (ssl_weight + w_mv))                        # cl_loss_weight, x_clip.py:855
     if multiview:
         loss = loss + losses[1:].mean() * w_mv
     if cfg.sim_reg_loss_weight > 0:
@@ -293,10 +295,24 @@ def downsample_latents(tokens: Tensor, w_dw: Tensor, w_pw: Tensor, b_pw: Tensor)
     return x.flatten(2).transpose(1, 2)
 
 
+def mlm_loss(sd: Dict[str, Tensor], cfg: ClipConfig, masked_seq: Tensor, labels: Tensor, text_mask: Tensor) -> Tensor:
+    """MLM.forward after the random masking (mlm.py:96-109): the SAME text transformer encodes the masked sequence, `to_logits`
+    (Linear with bias, vocabulary = num_text_tokens) scores every non-CLS position, cross-entropy averaged over the positions
+    whose label is not the pad id.  The masking itself (mlm.py:70-94) is random; callers pass its outcome."""
+    emb = encode_text(sd, cfg, masked_seq, text_mask)
+    logits = emb[:, 1:] @ sd["mlm.to_logits.weight"].t() + sd["mlm.to_logits.bias"]
+    return torch.nn.functional.cross_entropy(logits.transpose(1, 2), labels, ignore_index=cfg.text_pad_id)
+
+
 def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Tensor,
                  aug_text: Sequence[Tensor] = (), aug_image: Sequence[Tensor] = (),
-                 keep_idx: Optional[Tensor] = None, return_latents: bool = False):
-    """CLIP.forward(return_loss=True) (x_clip.py:597-875) without the SSL side losses."""
+                 keep_idx: Optional[Tensor] = None, return_latents: bool = False,
+                 mlm_masked: Optional[Tuple[Tensor, Tensor]] = None):
+    """CLIP.forward(return_loss=True) (x_clip.py:597-875); of the SSL side losses only MLM (`mlm_masked` = the masked sequence
+    and labels the random masking produced, x_clip.py:620-622)."""
+    text_ssl = None
+    if cfg.use_mlm and not return_latents:
+        text_ssl = mlm_loss(sd, cfg, mlm_masked[0], mlm_masked[1], text != cfg.text_pad_id)
     m, n = 1 + len(aug_text), 1 + len(aug_image)
     text = torch.cat([text, *aug_text], dim=0)
     image = torch.cat([image, *aug_image], dim=0)
@@ -321,7 +337,11 @@ def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Te
         ilx = l2_normalize(visual_latent("to_visual_latent_extra"))
     if return_latents:
         return (tl, il) if tlx is None else (tl, il, tlx, ilx)
-    return contrastive_loss(cfg, sd["temperature"], tl, il, tlx, ilx, text_mask, m, n)
+    loss = contrastive_loss(cfg, sd["temperature"], tl, il, tlx, ilx, text_mask, m, n,
+                            ssl_weight=cfg.text_ssl_loss_weight if cfg.use_mlm else 0.0)
+    if text_ssl is not None:
+        loss = loss + text_ssl * cfg.text_ssl_loss_weight                 # x_clip.py:857-860
+    return loss
 
 
 # --------------------------------------------------------------------------------------------------
@@ -389,7 +409,7 @@ def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
 
     t = "text_transformer."
     shapes[t + "cls_token"] = (cfg.dim_text,)
-    shapes[t + "token_emb.weight"] = (cfg.num_text_tokens, cfg.dim_text)
+    shapes[t + "token_emb.weight"] = (cfg.num_text_tokens + (1 if cfg.use_mlm else 0), cfg.dim_text)     # x_clip.py:487
     if cfg.text_rotary_pos_emb:                                 # buffer of RotaryEmbedding (x_clip.py:158-159)
         shapes[t + "rotary_pos_emb.inv_freq"] = (min(cfg.text_dim_head, 32) // 2,)
     else:
@@ -402,6 +422,11 @@ def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
     shapes[v + "pos_emb.weight"] = (cfg.num_patches, cfg.dim_image)
     tower(v + "transformer.", cfg.dim_image, cfg.visual_enc_depth, cfg.visual_heads, cfg.visual_dim_head)
     shapes[v + "to_cls_tokens.1.weight"] = (cfg.dim_image, cfg.dim_image)
+    if cfg.use_mlm:                                             # MLM head (mlm.py:65); its `transformer` IS text_transformer: the
+        shapes["mlm.to_logits.weight"] = (cfg.num_text_tokens, cfg.dim_text)      # state_dict lists those tensors a second time
+        shapes["mlm.to_logits.bias"] = (cfg.num_text_tokens,)
+        for k in [k for k in shapes if k.startswith(t)]:
+            shapes["mlm.transformer." + k[len(t):]] = shapes[k]
     for k, d in (("to_text_latent", cfg.dim_text), ("to_visual_latent", cfg.dim_image)):
         for sfx in ("", "_extra"):
             if k == "to_visual_latent" and cfg.downsample_image_embeds:   # Sequential(RearrangeImage, Conv2d dw, Conv2d 1x1, Rearrange)
@@ -420,6 +445,8 @@ def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str
     rs = np.random.RandomState(seed)
     sd: Dict[str, Tensor] = {}
     for key, shape in sorted(state_dict_shapes(cfg).items()):
+        if key.startswith("mlm.transformer."):
+            continue                                            # aliases of text_transformer.*, filled in below
         if key == "temperature":
             a = np.array(1.0)
         elif key.endswith("inv_freq"):
@@ -436,6 +463,9 @@ def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str
             bound = 1.0 / math.sqrt(fan_in)
             a = rs.uniform(-bound, bound, shape)
         sd[key] = torch.tensor(a, dtype=torch.float64).to(dtype)
+    if cfg.use_mlm:
+        for k in [k for k in sd if k.startswith("text_transformer.")]:
+            sd["mlm.transformer." + k[len("text_transformer."):]] = sd[k]
     return sd
 
 

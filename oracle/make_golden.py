@@ -63,6 +63,8 @@ CASES = {
     "cfg1_filip_downsample": (dict(use_all_token_embeds=True, downsample_image_embeds=True, visual_patch_size=16), 4, 0, 0, 0.0),
     "cfg1_filip_downsample_extra_dcl": (dict(use_all_token_embeds=True, downsample_image_embeds=True, visual_patch_size=16,
                                              extra_latent_projection=True, decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
+    "cfg1_mlm": (dict(use_mlm=True), 4, 0, 0, 0.0),
+    "cfg1_mlm_dcl_multiview": (dict(use_mlm=True, text_ssl_loss_weight=0.2, decoupled_contrastive_learning=True), 4, 1, 1, 0.0),
     "cfg1_rotary": (dict(text_rotary_pos_emb=True), 4, 0, 0, 0.0),
     "cfg1_rotary_dcl_multiview": (dict(text_rotary_pos_emb=True, decoupled_contrastive_learning=True), 4, 1, 0, 0.0),
     "cfg1_simreg_extra": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.1), 4, 0, 0, 0.0),
@@ -94,6 +96,21 @@ def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropou
         torch.manual_seed(drop_seed)
         keep_idx = torch.randn(batch * (1 + n_aug_i), n).topk(keep, dim=-1).indices
         torch.manual_seed(drop_seed)
+    mlm_rec = None
+    if cfg.use_mlm:
+        # reproduce the draws MLM.forward will make (mlm.py:70-94: rand for the subset, uniform_ for the replace mask) with the
+        # reference's own helpers, so the masked sequence and the labels can be recorded; then rewind the generator
+        import x_clip.mlm as xm
+        torch.manual_seed(drop_seed)
+        m = ref.mlm
+        no_mask = xm.mask_with_tokens(text, m.mask_ignore_token_ids)
+        msk = xm.get_mask_subset_with_prob(~no_mask, m.mask_prob)
+        labels = text.masked_fill(~msk, m.pad_token_id)
+        assert m.random_token_prob == 0
+        replace = xm.prob_mask_like(text, m.replace_prob)
+        masked_seq = text.clone().masked_fill(msk * replace, m.mask_token_id)
+        mlm_rec = (masked_seq, labels)
+        torch.manual_seed(drop_seed)
     kw = {}
     if aug_t:
         kw["aug_text"] = tuple(aug_t)
@@ -116,6 +133,9 @@ def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropou
             out[nme + "_shape"] = list(l.shape)
     if keep_idx is not None:
         out["keep_idx"] = keep_idx.tolist()
+    if mlm_rec is not None:
+        out["mlm_masked_seq"] = mlm_rec[0].tolist()
+        out["mlm_labels"] = mlm_rec[1].tolist()
     return out
 
 

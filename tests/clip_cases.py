@@ -37,9 +37,11 @@ def build_clip(cfg: O.ClipConfig, sd, dev, dtype, patch_dropout=0.0, **extra):
     return model
 
 
-def run_product(model, text, image, aug_t, aug_i, dev, dtype, keep=None):
+def run_product(model, text, image, aug_t, aug_i, dev, dtype, keep=None, mlm=None):
     if keep is not None:
         model.visual_transformer.keep_indices_override = keep.to(torch.int32).to(dev)
+    if mlm is not None:
+        model.mlm.masked_override = (mlm[0].to(dev), mlm[1].to(dev))
     kw = {}
     if aug_t:
         kw["aug_text"] = [a.to(dev) for a in aug_t]
@@ -57,8 +59,9 @@ def case_golden(dev, name, dtype=torch.float32):
     sd = O.make_state_dict(cfg, rec["param_seed"], torch.float32)
     text, image, aug_t, aug_i = O.make_inputs(cfg, rec["batch"], rec["input_seed"], rec["n_aug_text"], rec["n_aug_image"])
     keep = torch.tensor(rec["keep_idx"]) if "keep_idx" in rec else None
+    mlm = (torch.tensor(rec["mlm_masked_seq"]), torch.tensor(rec["mlm_labels"])) if "mlm_masked_seq" in rec else None
     model = build_clip(cfg, sd, dev, dtype, patch_dropout=rec.get("visual_patch_dropout", 0.0))
-    loss = run_product(model, text, image.float(), aug_t, [a.float() for a in aug_i], dev, dtype, keep)
+    loss = run_product(model, text, image.float(), aug_t, [a.float() for a in aug_i], dev, dtype, keep, mlm)
     assert loss.dtype == torch.float32
     assert abs(float(loss.detach()) - rec["loss"]) < 1e-5 * max(1.0, abs(rec["loss"])), (float(loss.detach()), rec["loss"])
     assert abs(float(model.temperature.grad) - rec["dtau"]) < 2e-5, (float(model.temperature.grad), rec["dtau"])
@@ -84,9 +87,9 @@ def case_golden(dev, name, dtype=torch.float32):
             np.testing.assert_allclose(l.double().flatten().cpu().numpy(), np.asarray(rec[nme]), atol=1e-5, err_msg=nme)
 
 
-def oracle_run(cfg, sd64, text, image64, aug_t, aug_i64, keep):
+def oracle_run(cfg, sd64, text, image64, aug_t, aug_i64, keep, mlm=None):
     sd = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
-    loss = O.clip_forward(sd, cfg, text, image64, aug_t, aug_i64, keep)
+    loss = O.clip_forward(sd, cfg, text, image64, aug_t, aug_i64, keep, mlm_masked=mlm)
     loss.backward()
     return loss.detach(), {k: v.grad for k, v in sd.items()}
 
@@ -105,9 +108,13 @@ def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_ima
         keep = torch.randn(batch * (1 + n_aug_image), cfg.num_patches, generator=g).topk(patch_keep, dim=-1).indices
     model = build_clip(cfg, {k: v.float() for k, v in sd.items()}, dev, dtype, patch_dropout=0.5 if keep is not None else 0.0,
                        **extra)
-    loss = run_product(model, text, image, aug_t, aug_i, dev, dtype, keep)
+    mlm = None
+    if cfg.use_mlm:                                             # a deterministic stand-in for the random masking: every 5th real token
+        chosen = (text != cfg.text_pad_id) & ((torch.arange(text.shape[1])[None] + torch.arange(text.shape[0])[:, None]) % 5 == 0)
+        mlm = (text.masked_fill(chosen, 2), text.masked_fill(~chosen, cfg.text_pad_id))
+    loss = run_product(model, text, image, aug_t, aug_i, dev, dtype, keep, mlm)
     sd64 = {k: v.double() for k, v in sd.items()}
-    ref_loss, ref_grads = oracle_run(cfg, sd64, text, image.double(), aug_t, [a.double() for a in aug_i], keep)
+    ref_loss, ref_grads = oracle_run(cfg, sd64, text, image.double(), aug_t, [a.double() for a in aug_i], keep, mlm)
     fp32 = dtype == torch.float32
     assert abs(float(loss.detach()) - float(ref_loss)) < (1e-5 if fp32 else 2e-2) * max(1.0, abs(float(ref_loss))), (float(loss.detach()), float(ref_loss))
     for k, p in model.named_parameters():

@@ -426,3 +426,23 @@ def case_dwconv(dev, dtype, batch, h, C):
     close(y, ref, dtype, "dwconv y", mult=2.0)
     close(dx, x64.grad, dtype, "dwconv dx", mult=2.0)
     close(dwa.view(C, 1, 4, 4), w64.grad, torch.float32 if dtype == torch.float32 else dtype, "dwconv dw", mult=4.0)
+
+
+def case_cross_entropy(dev, dtype, rows, cols, ld):
+    """gathered rows -> softmax cross-entropy with labels, forward + in-place gradient; padding columns [cols, ld) ignored / zeroed"""
+    g = torch.Generator().manual_seed(71)
+    src = rnd((rows * 3, ld), dtype, 72) * 3.0
+    idx = torch.randperm(rows * 3, generator=g)[:rows].to(torch.int32)
+    x = ops.gather_rows(src.to(dev), idx.to(dev))
+    assert torch.equal(x.cpu(), src[idx.long()])
+    labels = torch.randint(0, cols, (rows,), generator=g)
+    acc = torch.zeros(1, dtype=torch.float32, device=dev)
+    lse = ops.cross_entropy_fwd(x, cols, labels.to(dev), acc)
+    x64 = ref64(src)[idx.long()][:, :cols].clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(x64, labels, reduction="sum")
+    assert abs(float(acc) - float(ref)) <= 2e-4 * max(1.0, abs(float(ref))), (float(acc), float(ref))
+    (ref / rows * 0.7).backward()
+    gm = torch.full((1,), 0.7, dtype=torch.float32, device=dev)
+    d = ops.cross_entropy_bwd_(x, cols, labels.to(dev), lse, gm)
+    close(d[:, :cols], x64.grad, dtype, "ce grad", mult=2.0)
+    assert float(d[:, cols:].abs().max()) == 0.0 if ld > cols else True

@@ -28,7 +28,7 @@ def hip_library():
 
 
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl"])
+                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm", "cfg1_mlm_dcl_multiview"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 
@@ -74,6 +74,14 @@ def test_mid_rotary_vs_oracle(dtype):
     """rotary text encoder (no absolute position table; q, k and v rotated over n + 1 positions, x_clip.py:155-176,221-223,328-330)"""
     import dataclasses
     C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, text_rotary_pos_emb=True), 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_mid_mlm_vs_oracle(dtype):
+    """masked-language-model side loss through the shared text tower (mlm.py:96-109; x_clip.py:620-622, 857-860)"""
+    import dataclasses
+    # (bf16: the scalar temperature gradient -- a difference of O(1) sums over 16 x 16 bf16-rounded logits -- sits at 20 % of its fp64 value)
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, use_mlm=True, text_ssl_loss_weight=0.3), 16, bf16_rel=0.3)
 
 
 def test_filip_multiview_extra_dcl_patchdrop_fp32():

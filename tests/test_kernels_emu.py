@@ -152,3 +152,9 @@ def test_rotary(dtype, batch, n, heads):
 @pytest.mark.parametrize("batch,h,C", [(2, 4, 64), (1, 2, 16)])
 def test_dwconv(dtype, batch, h, C):
     K.case_dwconv(DEV, dtype, batch, h, C)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,cols,ld", [(5, 24, 24), (9, 1000, 1000), (3, 13, 16)])
+def test_cross_entropy(dtype, rows, cols, ld):
+    K.case_cross_entropy(DEV, dtype, rows, cols, ld)

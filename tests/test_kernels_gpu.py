@@ -151,3 +151,9 @@ def test_rotary(dtype, batch, n, heads):
 @pytest.mark.parametrize("batch,h,C", [(2, 4, 64), (3, 14, 512), (5, 8, 1024)])
 def test_dwconv(dtype, batch, h, C):
     K.case_dwconv(DEV, dtype, batch, h, C)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,cols,ld", [(5, 24, 24), (700, 10000, 10000), (33, 1003, 1008)])
+def test_cross_entropy(dtype, rows, cols, ld):
+    K.case_cross_entropy(DEV, dtype, rows, cols, ld)

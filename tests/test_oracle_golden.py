@@ -28,7 +28,8 @@ def run_oracle(rec, dtype):
     # fixtures were produced from fp32 images: round through fp32 first
     image = image.float().to(dtype)
     aug_i = [a.float().to(dtype) for a in aug_i]
-    loss = clip_forward(sd, cfg, text, image, aug_t, aug_i, keep)
+    mlm = (torch.tensor(rec["mlm_masked_seq"]), torch.tensor(rec["mlm_labels"])) if "mlm_masked_seq" in rec else None
+    loss = clip_forward(sd, cfg, text, image, aug_t, aug_i, keep, mlm_masked=mlm)
     loss.backward()
     return cfg, sd, loss, (text, image)
 

@@ -7,8 +7,8 @@ draws the same initial weights as the reference) -- but the modules are paramete
 the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is no CPU / ATen fallback; tensors must live
 on an MI355X.
 
-Not on this path yet (constructor raises NotImplementedError): causal text encoder,
-MLM and visual-SSL side losses.
+Not on this path (constructor raises NotImplementedError): causal text encoder (broken in the
+reference itself), visual-SSL side losses (their augmentations need torchvision).
 """
 from __future__ import annotations
 
@@ -21,6 +21,7 @@ from torch import nn
 
 from . import functional as XF
 from . import losses as XL
+from .mlm import MLM
 
 Tensor = torch.Tensor
 
@@ -321,12 +322,13 @@ class CLIP(nn.Module):
             )
 
         # side losses of the reference that are outside the accelerated path
-        if use_mlm:
-            raise NotImplementedError("use_mlm: the MLM side loss (x_clip/mlm.py) is outside the accelerated contrastive path")
         if use_visual_ssl or exists(visual_ssl):
             raise NotImplementedError("use_visual_ssl / visual_ssl: SimSiam / SimCLR (x_clip/visual_ssl.py) are outside the accelerated contrastive path")
-        self.use_mlm = False
-        self.text_ssl_loss_weight = 0
+        self.use_mlm = use_mlm                                                             # x_clip.py:516-527
+        self.text_ssl_loss_weight = text_ssl_loss_weight if use_mlm else 0
+        if use_mlm:
+            mlm_kwargs = {k[len('mlm_'):]: v for k, v in kwargs.items() if k.startswith('mlm_')}
+            self.mlm = MLM(self.text_transformer, dim=dim_text, num_tokens=num_text_tokens, **mlm_kwargs)
         self.use_visual_ssl = False
         self.image_ssl_loss_weight = 0
 
@@ -397,6 +399,10 @@ class CLIP(nn.Module):
         batch, device = text.shape[0], text.device
 
         text_mask = text != self.text_pad_id                                               # x_clip.py:614
+
+        text_ssl_loss = 0                                                                  # x_clip.py:618-622
+        if return_loss and self.use_mlm:
+            text_ssl_loss = self.mlm(text, mask=text_mask)
 
         num_batch_texts = num_batch_images = 1
 
@@ -495,12 +501,15 @@ class CLIP(nn.Module):
                                   multiview_weight=multiview_loss_weight, distributed=self.requires_all_gather,
                                   assume_equal_batch=self.assume_equal_batch)
         if self.use_all_token_embeds:                                                      # x_clip.py:797-811
-            return XL.filip_loss(self.temperature, text_latents, image_latents,
+            loss = XL.filip_loss(self.temperature, text_latents, image_latents,
                                  text_latents_extra if self.extra_latent_projection else None,
                                  image_latents_extra if self.extra_latent_projection else None, text_mask, spec)
-        loss = XL.contrastive_loss(self.temperature, text_latents, image_latents,
-                                   text_latents_extra if self.extra_latent_projection else None,
-                                   image_latents_extra if self.extra_latent_projection else None, spec)
+        else:
+            loss = XL.contrastive_loss(self.temperature, text_latents, image_latents,
+                                       text_latents_extra if self.extra_latent_projection else None,
+                                       image_latents_extra if self.extra_latent_projection else None, spec)
+        if self.use_mlm:                                                                   # x_clip.py:857-860
+            loss = loss + text_ssl_loss * self.text_ssl_loss_weight
         if self.has_sim_reg_loss:                                                          # x_clip.py:773-784, 872-873
             assert not is_multiview, 'the similarity regularisation loss is defined for a single view (its [1, b, b] mask, x_clip.py:776-778)'
             sim_reg = XL.sim_reg_loss(text_latents[0], image_latents[0], text_latents_extra[0], image_latents_extra[0], spec)

@@ -488,4 +488,77 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
     }
 }
 
+// ---- masked-language-model head (mlm.py:96-109) ---------------------------------------------------------------------------------
+// gather: out[r, :] = src[idx[r], :]   (only the masked positions of the encoder output go through the vocabulary projection)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, long lds_, const int* __restrict__ idx,
+                                                          T* __restrict__ out, long rows, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int nch = D / VEC;
+    const long total = rows * nch;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        const long r = id / nch;
+        const int c = (int)(id % nch);
+        st16(out + r * (long)D + c * VEC, ld16(src + (long)idx[r] * lds_ + c * VEC));
+    }
+}
+// cross-entropy over the first `cols` columns of logits [rows, ld] (any padding columns up to ld are ignored) with one int64 label
+// per row: lse[r] = log sum_c exp(x[r, c]);  *loss_accum += sum_r (lse[r] - x[r, label[r]]).  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ x, long ld, const long long* __restrict__ label, int rows,
+                                                     int cols, float* __restrict__ lse, float* __restrict__ loss) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long r = (long)blockIdx.x * 4 + wave_id();
+    if (r >= rows) return;
+    const T* row = x + r * ld;
+    const int nch = (cols + VEC - 1) / VEC;
+    float m = -3.0e38f;
+    for (int c = lane; c < nch; c += 64) {
+        float v[VEC];
+        load_vec<T>(row + c * VEC, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (c * VEC + e < cols) m = fmaxf(m, v[e]);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+        float v[VEC];
+        load_vec<T>(row + c * VEC, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (c * VEC + e < cols) l += fast_exp(v[e] - m);
+    }
+    l = wave_sum(l);
+    if (lane == 0) {
+        const float v = m + logf(l);
+        lse[r] = v;
+        atomic_add(loss, v - to_f32(row[label[r]]));
+    }
+}
+// in place: x[r, c] <- scale * (exp(x[r, c] - lse[r]) - [c == label[r]]) for c < cols, 0 for the padding columns;  scale = *gmul / rows
+// (mean over the selected rows times the upstream gradient, a device scalar)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(T* __restrict__ x, long ld, const long long* __restrict__ label,
+                                                     const float* __restrict__ lse, const float* __restrict__ gmul, int rows, int cols) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long r = (long)blockIdx.x * 4 + wave_id();
+    if (r >= rows) return;
+    T* row = x + r * ld;
+    const float scale = *gmul / (float)rows, L = lse[r];
+    const int lab = (int)label[r];
+    for (int c = lane; c < (int)(ld / VEC); c += 64) {
+        float v[VEC];
+        load_vec<T>(row + c * VEC, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int col = c * VEC + e;
+            v[e] = col < cols ? scale * (fast_exp(v[e] - L) - (col == lab ? 1.f : 0.f)) : 0.f;
+        }
+        store_vec<T>(row + c * VEC, v);
+    }
+}
+
 }  // namespace xc

@@ -479,6 +479,47 @@ int xclip_dwconv4s2_bwd(const void* dy, const void* x, const void* w, void* dx, 
     return check_launch(__func__);
 }
 
+int xclip_gather_rows(const void* src, int64_t lds, const int32_t* idx, void* out, int64_t rows, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec_of(dtype) == 0 && lds % vec_of(dtype) == 0, "dim / row stride must be whole 16-byte chunks");
+    XC_REQUIRE(src && idx && out && aligned16(src) && aligned16(out), "null or misaligned pointer");
+    if (rows == 0) return 0;
+    int64_t blocks = (rows * (dim / vec_of(dtype)) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (long)lds, idx, (bf16_t*)out, (long)rows, (int)dim);
+    else
+        hipLaunchKernelGGL((gather_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, (long)lds, idx, (float*)out, (long)rows, (int)dim);
+    return check_launch(__func__);
+}
+int xclip_cross_entropy_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t rows, int64_t cols, float* lse, float* loss_accum,
+                            int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && ld % vec_of(dtype) == 0, "row stride must cover the columns in whole 16-byte chunks");
+    XC_REQUIRE(logits && labels && lse && loss_accum && aligned16(logits), "null or misaligned pointer");
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((ce_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)logits, (long)ld, (const long long*)labels, (int)rows, (int)cols, lse, loss_accum);
+    else
+        hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)logits, (long)ld, (const long long*)labels, (int)rows, (int)cols, lse, loss_accum);
+    return check_launch(__func__);
+}
+int xclip_cross_entropy_bwd(void* logits, int64_t ld, const int64_t* labels, const float* lse, const float* gmul, int64_t rows, int64_t cols,
+                            int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && ld % vec_of(dtype) == 0, "row stride must cover the columns in whole 16-byte chunks");
+    XC_REQUIRE(logits && labels && lse && gmul && aligned16(logits), "null or misaligned pointer");
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)logits, (long)ld, (const long long*)labels, lse, gmul, (int)rows, (int)cols);
+    else
+        hipLaunchKernelGGL((ce_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)logits, (long)ld, (const long long*)labels, lse, gmul, (int)rows, (int)cols);
+    return check_launch(__func__);
+}
+
 int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, const float* inv_freq, int inverse, int dtype,
                  void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");

@@ -537,3 +537,33 @@ def dwconv4s2_bwd(dy: Tensor, x: Tensor, w: Tensor, dw_accum: Tensor) -> Tensor:
     _lib.check(L.xclip_dwconv4s2_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), dw_accum.data_ptr(), ws.data_ptr(), wbytes,
                                      b, h, C, dtype_code(x), _stream(x)), "xclip_dwconv4s2_bwd")
     return dx
+
+
+def gather_rows(src: Tensor, idx: Tensor) -> Tensor:
+    """out[r] = src[idx[r]] for src [rows_in, D] (row stride free), idx int32 [rows]"""
+    _dev_check(src, idx)
+    assert src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32 and idx.is_contiguous()
+    out = torch.empty(idx.numel(), src.shape[1], dtype=src.dtype, device=src.device)
+    _lib.check(_lib.lib().xclip_gather_rows(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), idx.numel(), src.shape[1],
+                                            dtype_code(src), _stream(src)), "xclip_gather_rows")
+    return out
+
+
+def cross_entropy_fwd(logits: Tensor, cols: int, labels: Tensor, loss_accum: Tensor) -> Tensor:
+    """lse [rows] of logits[:, :cols]; *loss_accum += sum_r (lse[r] - logits[r, labels[r]])   (mlm.py:103-107)"""
+    _dev_check(logits, labels, loss_accum)
+    assert logits.dim() == 2 and logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.is_contiguous()
+    rows = logits.shape[0]
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.lib().xclip_cross_entropy_fwd(logits.data_ptr(), logits.stride(0), labels.data_ptr(), rows, cols, lse.data_ptr(),
+                                                  loss_accum.data_ptr(), dtype_code(logits), _stream(logits)), "xclip_cross_entropy_fwd")
+    return lse
+
+
+def cross_entropy_bwd_(logits: Tensor, cols: int, labels: Tensor, lse: Tensor, gmul: Tensor) -> Tensor:
+    """in place: logits <- (gmul / rows) (softmax - onehot), padding columns zeroed"""
+    _dev_check(logits, labels, lse, gmul)
+    assert gmul.dtype == torch.float32 and gmul.numel() == 1
+    _lib.check(_lib.lib().xclip_cross_entropy_bwd(logits.data_ptr(), logits.stride(0), labels.data_ptr(), lse.data_ptr(), gmul.data_ptr(),
+                                                  logits.shape[0], cols, dtype_code(logits), _stream(logits)), "xclip_cross_entropy_bwd")
+    return logits
