@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side streams for the vision tower / weight gradients "
                     "(use this for rocprofv3 kernel-trace runs whose per-kernel averages should be of kernels running alone)")
     ap.add_argument("--dcl", action="store_true")
+    ap.add_argument("--filip", action="store_true", help="BASELINE configs[3] instead of the headline configs[1]: use_all_token_embeds, "
+                    "image 224 / patch 16, text length 77 (own measurements; the driver's line is the default configuration)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -112,7 +114,8 @@ def main():
     from x_clip_amd.distributed import GradSync
 
     torch.manual_seed(0)
-    model = CLIP(decoupled_contrastive_learning=args.dcl).to(torch.bfloat16).to(dev)
+    extra = dict(use_all_token_embeds=True, visual_image_size=224, visual_patch_size=16, text_seq_len=77) if args.filip else {}
+    model = CLIP(decoupled_contrastive_learning=args.dcl, **extra).to(torch.bfloat16).to(dev)
     model.train()
     model.assume_equal_batch = True
     sync = GradSync(model) if world > 1 else None
@@ -172,7 +175,8 @@ def main():
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (randint tokens, randn images, random-init weights)",
-        "config": {"workload": "BASELINE configs[1]: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, "
+        "config": {"workload": ("BASELINE configs[3] (FILIP): dim 512 depth 6/6 image 224 patch 16 text seq 77, " if args.filip else
+                                "BASELINE configs[1]: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, ") +
                                "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ", fwd+bwd",
                    "local_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                    "gflop_per_pair_fwd_bwd": round(3 * fwd_flops / 1e9, 3)},

@@ -13,6 +13,7 @@ Closed form: with S = e^tau X Y^T, L = sum over view pair
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -296,7 +297,10 @@ class _FilipBlock:
         per_img = self.bx * self.nt * self.ni * esize
         yc = max(1, min(self.by, _FILIP_CHUNK_BYTES // max(per_img, 1)))
         if yc < self.by:
-            yc = max(8, yc // 8 * 8)                      # keeps chunk row strides / GEMM K 16-byte aligned
+            # the chunk width yc * ni is the contraction length of the backward GEMM dX = P Y: a multiple of the 64-deep K step keeps
+            # it on the MFMA / LDS-DMA kernel (136 images x 98 tokens fell back to the register-staged 128^2 kernel: 1.47 ms per call)
+            q = 64 // math.gcd(self.ni, 64)
+            yc = max(q, yc // q * q)
         self.yc = yc
         self.ld = (yc * self.ni + v - 1) // v * v
         dev = X.device
