@@ -77,6 +77,153 @@ __global__ __launch_bounds__(256) void filip_reduce_kernel(const T* __restrict__
     }
 }
 
+// Row-coalesced form of the same reductions for chunk rows of at most 256 * VEC * FILIP_MAXCH columns and ni >= VEC (the host sizes
+// its chunks for it): ONE work-group per text sample walks that sample's real rows, always one row of raw chunks ahead of the
+// arithmetic; every row is read once as whole 16-byte chunks by all 256 threads (the per-pair kernel above reads 2 ni-byte pieces
+// at a row stride of the whole chunk: 0.8 TB/s).  A thread keeps the running column maxima (max over t, for i2t) of its own
+// columns in registers.  The per-row segment maxima (max over k, for t2i): a chunk overlaps at most two image segments, so every
+// thread leaves a (max, arg) pair per portion in LDS (plain stores, double-buffered by row parity: one barrier per row) and the
+// thread that owns segment y scans the ~ni / VEC + 1 chunks overlapping it in column order (first index wins, like torch.max).
+constexpr int FILIP_MAXCH = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void filip_reduce_rows_kernel(const T* __restrict__ S, long lds_, const unsigned char* __restrict__ mask,
+                                                                const float* __restrict__ log_temp, float* __restrict__ t2i,
+                                                                float* __restrict__ i2t, long ldo, short* __restrict__ kmax,
+                                                                short* __restrict__ tmax, float* __restrict__ cnt, int bx, int nt,
+                                                                int yc_all, int ni, int y0_all, int ytotal, int ysplit) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int SEGS = 8;                                        // segments per thread: yc <= 2048
+    XC_LDS_DYNAMIC(lds);
+    const int x = blockIdx.x, tid = threadIdx.x;
+    // blockIdx.y selects a sub-range of `ysplit` images of the chunk (ysplit * ni is a whole number of 16-byte chunks): more
+    // work-groups in flight than text samples, shorter rows per work-group
+    const int ysub = blockIdx.y * ysplit;
+    const int yc = (yc_all - ysub) < ysplit ? (yc_all - ysub) : ysplit;
+    const int y0 = y0_all + ysub;
+    S += (long)ysub * ni;
+    const int ncols = yc * ni, nch = (ncols + VEC - 1) / VEC;
+    float* pval = reinterpret_cast<float*>(lds);                   // [2 buffers][nch][2 portions] portion maxima of a row
+    int* parg = reinterpret_cast<int*>(pval + 4 * nch);            // same shape: k of the portion maximum
+    float* seg_sum = reinterpret_cast<float*>(parg + 4 * nch);     // [yc] sum over k of the column maxima (epilogue)
+    const float temp = expf(*log_temp);
+    float cmax[FILIP_MAXCH][VEC];
+    short carg[FILIP_MAXCH][VEC];
+    int ys[FILIP_MAXCH], ks[FILIP_MAXCH];                          // (image, token) of the first column of each owned chunk
+#pragma unroll
+    for (int i = 0; i < FILIP_MAXCH; ++i) {
+        const int col0 = (tid + 256 * i) * VEC;
+        ys[i] = col0 / ni;
+        ks[i] = col0 - ys[i] * ni;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { cmax[i][e] = FILIP_NEG; carg[i][e] = 0; }
+    }
+    float t2i_acc[SEGS];
+#pragma unroll
+    for (int j = 0; j < SEGS; ++j) t2i_acc[j] = 0.f;
+    float wsum = 0.f;
+    auto next_live = [&](int t) {                                  // rows of padding tokens take no part in either direction
+        while (t < nt && mask[(long)x * nt + t] == 0) ++t;
+        return t;
+    };
+    u32x4 cur[FILIP_MAXCH], nxt[FILIP_MAXCH];
+    auto fetch = [&](int t) {
+        const T* row = S + ((long)x * nt + t) * lds_;
+#pragma unroll
+        for (int i = 0; i < FILIP_MAXCH; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nch) nxt[i] = ld16(row + c * VEC);
+        }
+    };
+    int t = next_live(0);
+    if (t < nt) fetch(t);
+    int par = 0;
+    while (t < nt) {
+        wsum += 1.f;
+#pragma unroll
+        for (int i = 0; i < FILIP_MAXCH; ++i) cur[i] = nxt[i];
+        const int tn = next_live(t + 1);
+        if (tn < nt) fetch(tn);                                    // a whole row of arithmetic covers the next row's latency
+        float* pv = pval + par * 2 * nch;
+        int* pa = parg + par * 2 * nch;
+#pragma unroll
+        for (int i = 0; i < FILIP_MAXCH; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nch) {
+                float v[VEC];
+                unpack(cur[i], v, (T*)nullptr);
+                int k = ks[i], portion = 0;
+                float smax = FILIP_NEG;
+                int sarg = 0;
+                pv[2 * c + 1] = FILIP_NEG;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (c * VEC + e < ncols) {
+                        const float val = v[e] * temp;
+                        if (val > cmax[i][e]) { cmax[i][e] = val; carg[i][e] = (short)t; }
+                        if (val > smax) { smax = val; sarg = k; }
+                        if (++k == ni) {                           // the first segment of the chunk ends here
+                            pv[2 * c + portion] = smax; pa[2 * c + portion] = sarg;
+                            smax = FILIP_NEG; sarg = 0; k = 0; portion = 1;
+                        }
+                    }
+                }
+                if (portion < 2 && (k != 0 || portion == 0)) { pv[2 * c + portion] = smax; pa[2 * c + portion] = sarg; }
+            }
+        }
+        sync();
+#pragma unroll
+        for (int j = 0; j < SEGS; ++j) {
+            const int y = tid + 256 * j;
+            if (y < yc) {
+                const int c_lo = (y * ni) / VEC, c_hi = ((y + 1) * ni - 1) / VEC;
+                int c = c_lo;
+                int portion = ((y * ni) % VEC == 0) ? 0 : 1;
+                float best = FILIP_NEG;
+                int bk = 0;
+                for (; c <= c_hi; ++c, portion = 0) {
+                    const float pvv = pv[2 * c + portion];
+                    if (pvv > best) { best = pvv; bk = pa[2 * c + portion]; }
+                }
+                kmax[((long)x * nt + t) * ytotal + y0 + y] = (short)bk;
+                t2i_acc[j] += best;
+            }
+        }
+        par ^= 1;                                                  // the next row writes the other buffer: no second barrier
+        t = tn;
+    }
+    for (int y = tid; y < yc; y += 256) seg_sum[y] = 0.f;
+    sync();
+#pragma unroll
+    for (int i = 0; i < FILIP_MAXCH; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nch) {
+            int y = ys[i], k = ks[i];
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int col = c * VEC + e;
+                if (col < ncols) {
+                    tmax[((long)x * ytotal + y0) * ni + col] = carg[i][e];
+                    part += cmax[i][e];
+                    if (++k == ni) { atomic_add(seg_sum + y, part); part = 0.f; k = 0; ++y; }
+                }
+            }
+            if (k != 0 && y < yc) atomic_add(seg_sum + y, part);
+        }
+    }
+    sync();
+#pragma unroll
+    for (int j = 0; j < SEGS; ++j) {
+        const int y = tid + 256 * j;
+        if (y < yc) {
+            t2i[(long)x * ldo + y0 + y] = t2i_acc[j] / fmaxf(wsum, 1e-6f);
+            i2t[(long)x * ldo + y0 + y] = seg_sum[y] / (float)ni;
+        }
+    }
+    if (tid == 0 && y0 == 0) cnt[x] = wsum;
+}
+
 // P[(x,t),(y,k)] = temp * ( g1[x,y0+y] * w[x,t] / cnt[x] * [k == kmax] + g2[x,y0+y] / ni * [t == tmax[.., k]] )
 // one thread per 16-byte output chunk of a row; rows are padded with zeros up to ldp
 template <typename T>
@@ -89,25 +236,39 @@ __global__ __launch_bounds__(256) void filip_route_kernel(T* __restrict__ P, lon
     const float temp = expf(*log_temp);
     const int nch = (int)(ldp / VEC);
     const long total = (long)bx * nt * nch;
+    const float inv_ni = 1.0f / (float)ni;
     for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(id % nch);
         const long row = id / nch;
         const int x = (int)(row / nt), t = (int)(row % nt);
         const bool w = mask[row] != 0;
-        const float invc = 1.0f / fmaxf(cnt[x], 1e-6f);
         float v[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const int col = ch * VEC + e;
-            float val = 0.f;
-            if (col < yc * ni) {
-                const int y = col / ni, k = col % ni;
-                const long gy = (long)x * ldg + y0 + y;
-                if (w && kmax[((long)x * nt + t) * ytotal + y0 + y] == k) val += g1[gy] * invc;
-                if (tmax[((long)x * ytotal + y0 + y) * ni + k] == t && w) val += g2[gy] / (float)ni;
-                val *= temp;
+        for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+        const int col0 = ch * VEC;
+        if (w && col0 < yc * ni) {                              // (rows of padding tokens and the padding columns stay zero)
+            // one division per chunk; the chunk's columns walk (y, k) from there.  Per image y: the arg-max token of this text row
+            // (kmax) and the two upstream gradients are loaded once, the per-column arg-max rows (tmax) are contiguous in the column
+            int y = col0 / ni, k = col0 - y * ni;
+            const float invc = temp / fmaxf(cnt[x], 1e-6f);
+            const short* tm = tmax + ((long)x * ytotal + y0) * ni + col0;
+            const short* km = kmax + ((long)x * nt + t) * ytotal + y0;
+            const float* g1r = g1 + (long)x * ldg + y0;
+            const float* g2r = g2 + (long)x * ldg + y0;
+            int kbest = km[y];
+            float a1 = g1r[y] * invc, a2 = g2r[y] * inv_ni * temp;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (col0 + e < yc * ni) {
+                    float val = (k == kbest) ? a1 : 0.f;
+                    if (tm[e] == t) val += a2;
+                    v[e] = val;
+                    if (++k == ni && col0 + e + 1 < yc * ni) {
+                        k = 0; ++y;
+                        kbest = km[y]; a1 = g1r[y] * invc; a2 = g2r[y] * inv_ni * temp;
+                    }
+                }
             }
-            v[e] = val;
         }
         store_vec<T>(P + row * ldp + ch * VEC, v);
     }

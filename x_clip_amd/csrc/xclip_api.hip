@@ -626,6 +626,29 @@ int xclip_filip_reduce(const void* S, int64_t lds, const uint8_t* mask, const fl
     XC_REQUIRE(bx > 0 && nt > 0 && yc > 0 && ni > 0 && ni <= 256, "FILIP reductions support up to 256 image tokens");
     XC_REQUIRE(lds >= yc * ni && y0 >= 0 && y0 + yc <= ytotal && ldo >= ytotal, "bad chunk geometry");
     XC_REQUIRE(S && mask && log_temp && t2i && i2t && kmax && tmax && cnt, "null pointer");
+    // chunk rows that fit the register budget of the row-coalesced kernel (the host sizes its chunks for it) take that one
+    if (yc * ni <= 256 * vec_of(dtype) * FILIP_MAXCH && yc <= 2048 && ni >= vec_of(dtype) && lds % vec_of(dtype) == 0 && aligned16(S)) {
+        // split the chunk's images over blockIdx.y only when there are fewer text samples than CUs; sub-ranges start on 16-byte chunks
+        const int vec = vec_of(dtype);
+        int64_t g = ni, h = vec;
+        while (h) { const int64_t r = g % h; g = h; h = r; }          // gcd(ni, vec)
+        const int64_t step = vec / g;
+        int64_t nsplit = ((int64_t)xc_num_cus() + bx - 1) / bx;          // (more, shorter rows per work-group measured slower: the per-row cost is fixed)
+        if (nsplit < 1) nsplit = 1;
+        int64_t ysplit = ((yc + nsplit - 1) / nsplit + step - 1) / step * step;
+        if (ysplit < step) ysplit = step;
+        nsplit = (yc + ysplit - 1) / ysplit;
+        const int64_t nchunks = (ysplit * ni + vec - 1) / vec;
+        const size_t shm = (size_t)nchunks * 32 + (size_t)ysplit * 4;
+        XC_ALLOW_LDS((filip_reduce_rows_kernel<bf16_t>), 96 * 1024);
+        XC_ALLOW_LDS((filip_reduce_rows_kernel<float>), 96 * 1024);
+        dim3 g2((unsigned)bx, (unsigned)nsplit), b2(256);
+        if (dtype == XCLIP_BF16)
+            hipLaunchKernelGGL((filip_reduce_rows_kernel<bf16_t>), g2, b2, shm, (hipStream_t)stream, (const bf16_t*)S, (long)lds, mask, log_temp, t2i, i2t, (long)ldo, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal, (int)ysplit);
+        else
+            hipLaunchKernelGGL((filip_reduce_rows_kernel<float>), g2, b2, shm, (hipStream_t)stream, (const float*)S, (long)lds, mask, log_temp, t2i, i2t, (long)ldo, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal, (int)ysplit);
+        return check_launch(__func__);
+    }
     dim3 grid((unsigned)((bx * yc + 3) / 4)), block(256);
     if (dtype == XCLIP_BF16)
         hipLaunchKernelGGL((filip_reduce_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)S, (long)lds, mask, log_temp, t2i, i2t, (long)ldo, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal);

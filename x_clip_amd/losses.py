@@ -296,6 +296,7 @@ class _FilipBlock:
         esize = X.element_size()
         per_img = self.bx * self.nt * self.ni * esize
         yc = max(1, min(self.by, _FILIP_CHUNK_BYTES // max(per_img, 1)))
+        yc = max(1, min(yc, (256 * v * 8) // self.ni, 2048))   # rows the row-coalesced reduction keeps in registers (filip.h: FILIP_MAXCH)
         if yc < self.by:
             # the chunk width yc * ni is the contraction length of the backward GEMM dX = P Y: a multiple of the 64-deep K step keeps
             # it on the MFMA / LDS-DMA kernel (136 images x 98 tokens fell back to the register-staged 128^2 kernel: 1.47 ms per call)
