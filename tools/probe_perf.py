@@ -1,6 +1,6 @@
 """GPU micro-benchmarks of the hot kernels at the BASELINE cfg2 shapes (b=1024): prints achieved TFLOP/s / GB/s.
     python tools/probe_perf.py            (on the MI355X)"""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from x_clip_amd import ops

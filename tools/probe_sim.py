@@ -1,6 +1,6 @@
 """contrastive-head kernels at the BASELINE configs[2] per-rank block shape: b = 4096 local rows against B = 32768 gathered
 columns, d = 512, bf16 (row block of the rank-sharded loss)."""
-import sys, os, math
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from x_clip_amd import ops

@@ -52,30 +52,9 @@ XC_DEV void g3_add4(float (&v)[4], const bf16_t* p) {
     v[0] += u2f(t[0] << 16); v[1] += u2f(t[0] & 0xffff0000u); v[2] += u2f(t[1] << 16); v[3] += u2f(t[1] & 0xffff0000u);
 }
 
-// L2 prefetch stream (one 4-byte LDS-DMA touch per future 128-byte line, G3_PD K steps ahead).  MEASURED SLOWER on MI355X
-// (qkv fwd 644 -> 603 TF/s, wgrad 900 -> 742): vmcnt retires in order, so every K step then waits on a one-step-old HBM
-// access.  Kept behind this switch as a documented negative result.
-constexpr bool G3_L2_PREFETCH = false;
-constexpr int G3_PD = 3;                                      // L2 prefetch distance in K steps
-constexpr int G3_LDS_BYTES = G2_LDS_BYTES + 8 * 256;          // + one 256-byte prefetch sink per wave
-
-// one 4-byte touch per lane = one 128-byte line of a future operand tile (256 lines per tile): pulls the line into this
-// XCD's L2 ~G3_PD K steps before the 16-byte DMA asks for it (first touches otherwise pay HBM latency EVERY K step, in all
-// the N-tiles that share the A panel at once)
-template <bool KMAJOR>
-XC_DEV void g3_prefetch(const bf16_t* X, long ld, int outer0, int nouter, int k0, int line, unsigned char* sink) {
-    const bf16_t* src;
-    if (!KMAJOR) {
-        int g = outer0 + line;
-        g = g < nouter ? g : nouter - 1;
-        src = X + (long)g * ld + k0;
-    } else {
-        int g = outer0 + (line & 3) * 64;
-        g = g < nouter ? g : nouter - 8;
-        src = X + (long)(k0 + (line >> 2)) * ld + g;
-    }
-    glds4(src, sink);
-}
+// (An L2 prefetch stream -- one 4-byte LDS-DMA touch per future 128-byte line, three K steps ahead -- measured SLOWER: qkv fwd
+// 644 -> 603 TF/s, wgrad 900 -> 742; vmcnt retires in order, so every K step then waits on a one-step-old HBM access.)
+constexpr int G3_LDS_BYTES = G2_LDS_BYTES;                    // the two 64 KiB stages; the epilogue goes straight from registers
 
 // The persistent tile loop shared by the GEMM and by the contrastive-head kernels (simloss3.h): `epi(acc, m0, n0, full)` is
 // called once per finished 256 x 256 tile with the TRANSPOSED accumulators (see below) and must report how many global

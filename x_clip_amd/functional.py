@@ -17,7 +17,7 @@ inputs of a layer and re-runs that layer's forward inside the backward.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence
 
 import torch
 from torch.autograd.function import once_differentiable
