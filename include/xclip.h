@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 8
+#define XCLIP_ABI_VERSION 9
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -41,6 +41,18 @@ int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* 
                         const void* dres, void* dx, int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes,
                         int64_t rows, int64_t dim, int geglu, int dtype, void* stream);
 
+/* The residual-block boundary of the Transformer as ONE pass over the rows (x_clip.py:245,288-289 followed by :126):
+ *   x1 = LayerNorm(p) g1 + res   (to_out's LayerNorm + skip),   h2 = LayerNorm(x1) g2   (the feed-forward PreNorm),
+ * contiguous [rows, dim] tensors, both pairs of statistics out.  The second LayerNorm sees x1 as stored (rounded to the dtype), so
+ * the results equal two xclip_layernorm_fwd calls; the pass saves re-reading x1.  chain_bwd: dx1 = LN2'(dh2) + dres and
+ * dp = LN1'(dx1) in one pass (dx1 is still written: the next residual junction adds it), gain gradients into dg2_accum / dg1_accum
+ * (fp32 [dim] each) through per-work-group partial rows in `workspace`. */
+int xclip_layernorm_chain_fwd(const void* p, const void* g1, const void* res, void* x1, float* mean1, float* rstd1, const void* g2,
+                              void* h2, float* mean2, float* rstd2, int64_t rows, int64_t dim, float eps, int dtype, void* stream);
+int64_t xclip_layernorm_chain_bwd_workspace_bytes(int64_t rows, int64_t dim);
+int xclip_layernorm_chain_bwd(const void* dh2, const void* x1, const void* g2, const float* mean2, const float* rstd2, const void* dres,
+                              void* dx1, const void* p, const void* g1, const float* mean1, const float* rstd1, void* dp, float* dg2_accum,
+                              float* dg1_accum, void* workspace, int64_t workspace_bytes, int64_t rows, int64_t dim, int dtype, void* stream);
 /* ---- l2 normalisation (reference l2norm = F.normalize, x_clip.py:54-55,715) ------------------------------------ */
 int xclip_l2norm_fwd(const void* x, void* y, float* rnorm, int64_t rows, int64_t dim, int dtype, void* stream);
 int xclip_l2norm_bwd(const void* dy, const void* y, const float* rnorm, void* dx, int64_t rows, int64_t dim, int dtype, void* stream);

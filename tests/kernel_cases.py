@@ -446,3 +446,37 @@ def case_cross_entropy(dev, dtype, rows, cols, ld):
     d = ops.cross_entropy_bwd_(x, cols, labels.to(dev), lse, gm)
     close(d[:, :cols], x64.grad, dtype, "ce grad", mult=2.0)
     assert float(d[:, cols:].abs().max()) == 0.0 if ld > cols else True
+
+
+def case_layernorm_chain(dev, dtype, rows, dim):
+    """x1 = LN(p) g1 + res, h2 = LN(x1) g2 in one pass, and its backward, against the two-call composition in fp64"""
+    p_ = rnd((rows, dim), dtype, 81)
+    res = rnd((rows, dim), dtype, 82)
+    g1 = (1.0 + 0.1 * rnd((dim,), torch.float32, 83)).to(dtype)
+    g2 = (1.0 + 0.1 * rnd((dim,), torch.float32, 84)).to(dtype)
+    dh2 = rnd((rows, dim), dtype, 85)
+    dres = rnd((rows, dim), dtype, 86)
+    x1, m1, r1, h2, m2, r2 = ops.layernorm_chain_fwd(p_.to(dev), g1.to(dev), res.to(dev), g2.to(dev))
+    dg2 = torch.zeros(dim, dtype=torch.float32, device=dev)
+    dg1 = torch.zeros(dim, dtype=torch.float32, device=dev)
+    dx1, dp = ops.layernorm_chain_bwd(dh2.to(dev), x1, g2.to(dev), m2, r2, dres.to(dev), p_.to(dev), g1.to(dev), m1, r1, dg2, dg1)
+    eps = 1e-5 if dtype == torch.float32 else 1e-3
+    p64, g164, g264 = ref64(p_).requires_grad_(True), ref64(g1).requires_grad_(True), ref64(g2).requires_grad_(True)
+
+    def ln(t, g):
+        return (t - t.mean(-1, keepdim=True)) * torch.rsqrt(t.var(-1, unbiased=False, keepdim=True) + eps) * g
+
+    x1r = ln(p64, g164) + ref64(res)
+    x1r.retain_grad()
+    h2r = ln(x1r, g264)
+    (h2r * ref64(dh2)).sum().backward(retain_graph=True)
+    close(x1, x1r, dtype, "chain x1")
+    close(h2, h2r, dtype, "chain h2", mult=3.0)                    # (h2 is computed from the ROUNDED x1, like two separate calls)
+    # total gradient of x1 = through LN2 + the skip path; dp = through LN1
+    want_dx1 = x1r.grad + ref64(dres)
+    close(dx1, want_dx1, dtype, "chain dx1", mult=3.0)
+    gp, = torch.autograd.grad((ln(p64, g164) * want_dx1.detach()).sum(), p64)
+    close(dp, gp, dtype, "chain dp", mult=4.0)
+    close(dg2, g264.grad, torch.float32 if dtype == torch.float32 else dtype, "chain dg2", mult=4.0)
+    xh1 = ((p64 - p64.mean(-1, keepdim=True)) * torch.rsqrt(p64.var(-1, unbiased=False, keepdim=True) + eps)).detach()
+    close(dg1, (want_dx1.detach() * xh1).sum(0), torch.float32 if dtype == torch.float32 else dtype, "chain dg1", mult=4.0)

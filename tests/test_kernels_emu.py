@@ -158,3 +158,9 @@ def test_dwconv(dtype, batch, h, C):
 @pytest.mark.parametrize("rows,cols,ld", [(5, 24, 24), (9, 1000, 1000), (3, 13, 16)])
 def test_cross_entropy(dtype, rows, cols, ld):
     K.case_cross_entropy(DEV, dtype, rows, cols, ld)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,dim", [(5, 64), (9, 512)])
+def test_layernorm_chain(dtype, rows, dim):
+    K.case_layernorm_chain(DEV, dtype, rows, dim)

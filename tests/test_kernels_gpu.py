@@ -157,3 +157,9 @@ def test_dwconv(dtype, batch, h, C):
 @pytest.mark.parametrize("rows,cols,ld", [(5, 24, 24), (700, 10000, 10000), (33, 1003, 1008)])
 def test_cross_entropy(dtype, rows, cols, ld):
     K.case_cross_entropy(DEV, dtype, rows, cols, ld)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("rows,dim", [(5, 64), (1031, 512), (4100, 1024)])
+def test_layernorm_chain(dtype, rows, dim):
+    K.case_layernorm_chain(DEV, dtype, rows, dim)

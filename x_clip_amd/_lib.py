@@ -51,6 +51,9 @@ _SIGNATURES = {
     "xclip_rowgrad": (c_int, [P, L, P, L, L, L, I, F, P, P, L, P, P]),
     "xclip_simreg_diff": (c_int, [P, L, P, L, P, L, L, L, L, P, I, P]),
     "xclip_rotary": (c_int, [P, L, L, L, L, P, I, I, P]),
+    "xclip_layernorm_chain_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, L, F, I, P]),
+    "xclip_layernorm_chain_bwd_workspace_bytes": (c_int64, [L, L]),
+    "xclip_layernorm_chain_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, L, I, P]),
     "xclip_gather_rows": (c_int, [P, L, P, P, L, L, I, P]),
     "xclip_cross_entropy_fwd": (c_int, [P, L, P, L, L, P, P, I, P]),
     "xclip_cross_entropy_bwd": (c_int, [P, L, P, P, P, L, L, I, P]),
@@ -64,7 +67,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def _bind(path: str):

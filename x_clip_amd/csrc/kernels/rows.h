@@ -106,6 +106,173 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
     }
 }
 
+// ---- two chained LayerNorms in one pass over the rows ----------------------------------------------------------------------------
+// The residual block boundary of the Transformer (x_clip.py:245,288-289 then :126): x1 = LN(p) g1 + res (the attention block's
+// to_out LayerNorm + skip) is immediately followed by h2 = LN(x1) g2 (the feed-forward PreNorm).  Both are row-wise over the same
+// rows, so one kernel reads p and res once and writes x1, h2 and both pairs of statistics: the second LayerNorm no longer
+// re-reads x1.  The second one sees x1 exactly as stored (rounded to T), so results are those of the two separate calls.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void ln_chain_fwd_kernel(const T* __restrict__ p, const T* __restrict__ g1, const T* __restrict__ res,
+                                                           T* __restrict__ x1, float* __restrict__ mean1, float* __restrict__ rstd1,
+                                                           const T* __restrict__ g2, T* __restrict__ h2, float* __restrict__ mean2,
+                                                           float* __restrict__ rstd2, int rows, int D, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= rows) return;
+    const int nch = D / VEC;
+    float v[MAXC][VEC], rv[MAXC][VEC];
+    load_row<T, MAXC, false>(p + row * (long)D, D, lane, v);
+    load_row<T, MAXC, false>(res + row * (long)D, D, lane, rv);    // (both rows requested before the first reduction)
+    float mean, var;
+    row_stats<T, MAXC>(v, D, lane, mean, var);
+    const float rstd = fast_rsqrt(var + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float gv[VEC];
+            load_vec<T>(g1 + c * VEC, gv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[i][j] = to_f32(from_f32<T>((v[i][j] - mean) * rstd * gv[j] + rv[i][j]));   // x1 as stored
+            store_vec<T>(x1 + row * (long)D + c * VEC, v[i]);
+        }
+    }
+    float m2, var2;
+    row_stats<T, MAXC>(v, D, lane, m2, var2);                  // (padding chunks still hold zeros)
+    const float r2 = fast_rsqrt(var2 + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float gv[VEC], o[VEC];
+            load_vec<T>(g2 + c * VEC, gv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - m2) * r2 * gv[j];
+            store_vec<T>(h2 + row * (long)D + c * VEC, o);
+        }
+    }
+    if (lane == 0) {
+        mean1[row] = mean; rstd1[row] = rstd;
+        mean2[row] = m2; rstd2[row] = r2;
+    }
+}
+
+// backward of the same pair: dx1 = LN2'(dh2) + dres (the gradient of x1: still written, the next residual junction adds it), then
+// dp = LN1'(dx1) from the registers.  dg2 / dg1 partial rows per work-group as in ln_bwd_kernel: partial [gridDim.x, 2 D].
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void ln_chain_bwd_kernel(const T* __restrict__ dh2, const T* __restrict__ x1, const T* __restrict__ g2,
+                                                           const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                           const T* __restrict__ dres, T* __restrict__ dx1, const T* __restrict__ p,
+                                                           const T* __restrict__ g1, const float* __restrict__ mean1,
+                                                           const float* __restrict__ rstd1, T* __restrict__ dp,
+                                                           float* __restrict__ dg_partial, int rows, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    XC_LDS_DYNAMIC(lds);
+    float* red = reinterpret_cast<float*>(lds);            // [3][2 D]
+    const int lane = lane_id(), wave = wave_id();
+    const int nch = D / VEC;
+    float g2v[MAXC][VEC], g1v[MAXC][VEC], dg2[MAXC][VEC], dg1[MAXC][VEC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { g2v[i][j] = 0.f; g1v[i][j] = 0.f; dg2[i][j] = 0.f; dg1[i][j] = 0.f; }
+        if (c < nch) { load_vec<T>(g2 + c * VEC, g2v[i]); load_vec<T>(g1 + c * VEC, g1v[i]); }
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float m2 = mean2[row], r2 = rstd2[row], m1 = mean1[row], r1 = rstd1[row];
+        float xh[MAXC][VEC], dy[MAXC][VEC], rv[MAXC][VEC], pv[MAXC][VEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {                           // all four rows requested before the first reduction
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                load_vec<T>(dres + row * (long)D + c * VEC, rv[i]);
+                load_vec<T>(p + row * (long)D + c * VEC, pv[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { xh[i][j] = 0.f; dy[i][j] = 0.f; }
+            if (c < nch) {
+                load_vec<T>(x1 + row * (long)D + c * VEC, xh[i]);
+                load_vec<T>(dh2 + row * (long)D + c * VEC, dy[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    xh[i][j] = (xh[i][j] - m2) * r2;
+                    dg2[i][j] += dy[i][j] * xh[i][j];
+                    dy[i][j] *= g2v[i][j];
+                    s1 += dy[i][j];
+                    s2 += dy[i][j] * xh[i][j];
+                }
+            }
+        }
+        float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        s1 = 0.f; s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float d1 = r2 * (dy[i][j] - c1 - xh[i][j] * c2) + rv[i][j];  // gradient of x1
+                    dy[i][j] = d1;
+                    const float ph = (pv[i][j] - m1) * r1;
+                    xh[i][j] = ph;
+                    dg1[i][j] += d1 * ph;
+                    const float dyg = d1 * g1v[i][j];
+                    s1 += dyg;
+                    s2 += dyg * ph;
+                }
+                store_vec<T>(dx1 + row * (long)D + c * VEC, dy[i]);
+            }
+        }
+        c1 = wave_sum(s1) / (float)D;
+        c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = r1 * (dy[i][j] * g1v[i][j] - c1 - xh[i][j] * c2);
+                store_vec<T>(dp + row * (long)D + c * VEC, o);
+            }
+        }
+    }
+    // fold the 4 waves' partials: columns [0, D) = dg2, [D, 2 D) = dg1; row blockIdx.x of dg_partial [gridDim.x, 2 D]
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    red[(wave - 1) * 2 * D + c * VEC + j] = dg2[i][j];
+                    red[(wave - 1) * 2 * D + D + c * VEC + j] = dg1[i][j];
+                }
+        }
+    }
+    sync();
+    if (wave == 0) {
+        float* out = dg_partial + (long)blockIdx.x * 2 * D;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int col = c * VEC + j;
+                    out[col] = dg2[i][j] + red[col] + red[2 * D + col] + red[4 * D + col];
+                    out[D + col] = dg1[i][j] + red[D + col] + red[3 * D + col] + red[5 * D + col];
+                }
+        }
+    }
+}
+
 // ---- LayerNorm backward --------------------------------------------------------------------------------
 // xhat = (x - mean) rstd ; dyg = dy g ; dx = rstd (dyg - mean(dyg) - xhat mean(dyg xhat)) ; dg += dy xhat.
 // With GEGLU the LayerNorm input was a = u gelu(t): du = da gelu(t), dt = da u gelu'(t), written to the
@@ -322,11 +489,11 @@ __global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const T* __restrict__
     }
 }
 
-// accum[c] += sum_r partial[r, c]  for partial [nrows, D] fp32.  grid = (ceil(D / 64), slices); each wave sums a strip
+// accum[c] += sum_r partial[r, c]  for partial [nrows, D] fp32 (row stride ldp).  grid = (ceil(D / 64), slices); each wave sums a strip
 // of rows for 64 columns (coalesced 256-byte row segments), the 4 waves fold through LDS, one atomic per column per
 // work-group (slices-way contention only).
-__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, float* __restrict__ accum, int nrows,
-                                                          int D) {
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, long ldp, float* __restrict__ accum,
+                                                          int nrows, int D) {
     XC_LDS_DYNAMIC(lds);                                 // 4 x 64 floats
     float (*red)[64] = reinterpret_cast<float (*)[64]>(lds);
     const int lane = lane_id(), wave = wave_id();
@@ -337,7 +504,7 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restric
     const int r1 = r0 + per < nrows ? r0 + per : nrows;
     float s = 0.f;
     if (col < D)
-        for (int r = r0; r < r1; ++r) s += partial[(long)r * D + col];
+        for (int r = r0; r < r1; ++r) s += partial[(long)r * ldp + col];
     red[wave][lane] = s;
     sync();
     if (wave == 0 && col < D) atomic_add(accum + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);

@@ -55,7 +55,7 @@ void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, v
         hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, false>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g,
                            (const T*)res, (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
 }
-constexpr int LN_BWD_MAX_BLOCKS = 2048;
+constexpr int LN_BWD_MAX_BLOCKS = 4096;          // MI355X, 263k x 512 rows: 1024 work-groups 180 us, 2048: 189, 4096: 163, 8192: 165
 inline int ln_bwd_blocks(int64_t rows) {
     const int64_t b = (rows + 3) / 4;
     return (int)(b > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : b);
@@ -222,7 +222,53 @@ int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* 
     int slices = nblk / 64;
     if (slices < 1) slices = 1;
     hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices), dim3(256), 1024, (hipStream_t)stream,
-                       (const float*)partial, dg_accum, nblk, (int)dim);
+                       (const float*)partial, (long)dim, dg_accum, nblk, (int)dim);
+    return check_launch(__func__);
+}
+
+int xclip_layernorm_chain_fwd(const void* p, const void* g1, const void* res, void* x1, float* mean1, float* rstd1, const void* g2,
+                              void* h2, float* mean2, float* rstd2, int64_t rows, int64_t dim, float eps, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec == 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(p && g1 && res && x1 && g2 && h2 && mean1 && rstd1 && mean2 && rstd2, "null pointer");
+    XC_REQUIRE(aligned16(p) && aligned16(g1) && aligned16(res) && aligned16(x1) && aligned16(g2) && aligned16(h2), "pointers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define F(T, C) hipLaunchKernelGGL((ln_chain_fwd_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)p, (const T*)g1, (const T*)res, (T*)x1, mean1, rstd1, (const T*)g2, (T*)h2, mean2, rstd2, (int)rows, (int)dim, eps)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    return check_launch(__func__);
+}
+
+int64_t xclip_layernorm_chain_bwd_workspace_bytes(int64_t rows, int64_t dim) { return (int64_t)ln_bwd_blocks(rows) * 2 * dim * 4; }
+
+int xclip_layernorm_chain_bwd(const void* dh2, const void* x1, const void* g2, const float* mean2, const float* rstd2, const void* dres,
+                              void* dx1, const void* p, const void* g1, const float* mean1, const float* rstd1, void* dp, float* dg2_accum,
+                              float* dg1_accum, void* workspace, int64_t workspace_bytes, int64_t rows, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec == 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(dh2 && x1 && g2 && mean2 && rstd2 && dres && dx1 && p && g1 && mean1 && rstd1 && dp && dg2_accum && dg1_accum, "null pointer");
+    XC_REQUIRE(aligned16(dh2) && aligned16(x1) && aligned16(dres) && aligned16(dx1) && aligned16(p) && aligned16(dp) && aligned16(g1) && aligned16(g2),
+               "pointers must be 16-byte aligned");
+    XC_REQUIRE(workspace != nullptr && workspace_bytes >= xclip_layernorm_chain_bwd_workspace_bytes(rows, dim), "workspace too small");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+    const int nblk = ln_bwd_blocks(rows);
+    dim3 grid((unsigned)nblk), block(256);
+    float* partial = (float*)workspace;
+    const size_t lds = (size_t)6 * dim * sizeof(float);
+#define F(T, C) do { XC_ALLOW_LDS((ln_chain_bwd_kernel<T, C>), lds); hipLaunchKernelGGL((ln_chain_bwd_kernel<T, C>), grid, block, lds, (hipStream_t)stream, (const T*)dh2, (const T*)x1, (const T*)g2, mean2, rstd2, (const T*)dres, (T*)dx1, (const T*)p, (const T*)g1, mean1, rstd1, (T*)dp, partial, (int)rows, (int)dim); } while (0)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    int slices = nblk / 64;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices), dim3(256), 1024, (hipStream_t)stream,
+                       (const float*)partial, (long)(2 * dim), dg2_accum, nblk, (int)dim);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices), dim3(256), 1024, (hipStream_t)stream,
+                       (const float*)(partial + dim), (long)(2 * dim), dg1_accum, nblk, (int)dim);
     return check_launch(__func__);
 }
 
@@ -398,7 +444,7 @@ int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, flo
     if (partial != nullptr) {
         // every wave writes its row (waves without rows write zeros), so all blocks * 4 rows are defined
         hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), 4), dim3(256), 1024, (hipStream_t)stream,
-                           (const float*)partial, colsum_accum, (int)(blocks * 4), (int)dim);
+                           (const float*)partial, (long)dim, colsum_accum, (int)(blocks * 4), (int)dim);
     }
     return check_launch(__func__);
 }
@@ -475,7 +521,7 @@ int xclip_dwconv4s2_bwd(const void* dy, const void* x, const void* w, void* dx, 
     else
         hipLaunchKernelGGL((dwconv_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dy, (const float*)x, (const float*)w, (float*)dx, partial, (int)batch, (int)h, (int)C);
     hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((C * 16 + 63) / 64), 4), dim3(256), 1024, (hipStream_t)stream,
-                       (const float*)partial, dw_accum, blocks * 4, (int)(C * 16));
+                       (const float*)partial, (long)(C * 16), dw_accum, blocks * 4, (int)(C * 16));
     return check_launch(__func__);
 }
 

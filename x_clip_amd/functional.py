@@ -121,8 +121,7 @@ def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, m
         ops.rotary_(qkv, n, rotary)                                                            # q, k, v rotated   :221-223
     o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, 64 ** -0.5)     # scale/mask/softmax :217-244
     p = ops.gemm(o.view(M, inner), w_out, M, D, inner)                                 # to_out.0          :245
-    x1, m2, r2 = ops.layernorm_fwd(p, g_out, res=x)                                    # to_out.1 + skip   :245,288
-    h2, m3, r3 = ops.layernorm_fwd(x1, g_ff)                                           # PreNorm           :126
+    x1, m2, r2, h2, m3, r3 = ops.layernorm_chain_fwd(p, g_out, x, g_ff)                # to_out.1 + skip :245,288 and PreNorm :126, one pass
     u = ops.gemm(h2, w_ff1, M, w_ff1.shape[0], D)                                      # net.0             :191
     a, m4, r4 = ops.layernorm_fwd(u, g_inner, geglu=True)                              # GEGLU + net.2     :192-193
     x2 = ops.gemm(a, w_ff2, M, D, a.shape[1], residual=x1)                             # net.4 + skip      :195,289
@@ -147,10 +146,9 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     dh2 = ops.gemm(du, w_ff1, M, D, F2, b_kmajor=True)
     d_ff1 = sg.wgrad(du, h2, F2, D, M) if need_w[2] else None
     del du
-    dx1, _ = ops.layernorm_bwd(dh2, x1, g_ff, m3, r3, dres=dx2, dg=dg_ff)
+    # PreNorm backward + skip, then to_out's LayerNorm backward (the attention block), one pass over the rows
+    dx1, dp = ops.layernorm_chain_bwd(dh2, x1, g_ff, m3, r3, dx2, p, g_out, m2, r2, dg_ff, dg_out)
     del dh2
-    # attention block
-    dp, _ = ops.layernorm_bwd(dx1, p, g_out, m2, r2, dg=dg_out)
     do = ops.gemm(dp, w_out, M, inner, D, b_kmajor=True)
     d_out = sg.wgrad(dp, o.view(M, inner), D, inner, M) if need_w[1] else None
     del dp

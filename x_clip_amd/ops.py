@@ -567,3 +567,37 @@ def cross_entropy_bwd_(logits: Tensor, cols: int, labels: Tensor, lse: Tensor, g
     _lib.check(_lib.lib().xclip_cross_entropy_bwd(logits.data_ptr(), logits.stride(0), labels.data_ptr(), lse.data_ptr(), gmul.data_ptr(),
                                                   logits.shape[0], cols, dtype_code(logits), _stream(logits)), "xclip_cross_entropy_bwd")
     return logits
+
+
+def layernorm_chain_fwd(p: Tensor, g1: Tensor, res: Tensor, g2: Tensor):
+    """x1 = LN(p) g1 + res, h2 = LN(x1) g2 in one pass (x_clip.py:245,288-289 + :126) -> (x1, mean1, rstd1, h2, mean2, rstd2)"""
+    _dev_check(p, g1, res, g2)
+    p, res = _c(p), _c(res)
+    dim = p.shape[-1]
+    rows = p.numel() // dim
+    assert res.shape == p.shape and res.dtype == p.dtype and g1.numel() == dim and g2.numel() == dim
+    x1, h2 = torch.empty_like(p), torch.empty_like(p)
+    st = [torch.empty(rows, dtype=torch.float32, device=p.device) for _ in range(4)]
+    _lib.check(_lib.lib().xclip_layernorm_chain_fwd(p.data_ptr(), _c(g1).data_ptr(), res.data_ptr(), x1.data_ptr(), st[0].data_ptr(),
+                                                    st[1].data_ptr(), _c(g2).data_ptr(), h2.data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                                    rows, dim, ln_eps(p.dtype), dtype_code(p), _stream(p)), "xclip_layernorm_chain_fwd")
+    return x1, st[0], st[1], h2, st[2], st[3]
+
+
+def layernorm_chain_bwd(dh2: Tensor, x1: Tensor, g2: Tensor, mean2: Tensor, rstd2: Tensor, dres: Tensor, p: Tensor, g1: Tensor,
+                        mean1: Tensor, rstd1: Tensor, dg2: Tensor, dg1: Tensor):
+    """-> (dx1 = LN2'(dh2) + dres, dp = LN1'(dx1)); dg2 / dg1 (fp32 [dim]) accumulate the gain gradients"""
+    _dev_check(dh2, x1, g2, mean2, rstd2, dres, p, g1, mean1, rstd1, dg2, dg1)
+    dh2, dres = _c(dh2), _c(dres)
+    dim = x1.shape[-1]
+    rows = x1.numel() // dim
+    assert x1.is_contiguous() and p.is_contiguous() and dg2.dtype == torch.float32 and dg1.dtype == torch.float32
+    dx1, dp = torch.empty_like(x1), torch.empty_like(x1)
+    L = _lib.lib()
+    wbytes = L.xclip_layernorm_chain_bwd_workspace_bytes(rows, dim)
+    ws = workspace(x1.device, wbytes)
+    _lib.check(L.xclip_layernorm_chain_bwd(dh2.data_ptr(), x1.data_ptr(), _c(g2).data_ptr(), mean2.data_ptr(), rstd2.data_ptr(),
+                                           dres.data_ptr(), dx1.data_ptr(), p.data_ptr(), _c(g1).data_ptr(), mean1.data_ptr(),
+                                           rstd1.data_ptr(), dp.data_ptr(), dg2.data_ptr(), dg1.data_ptr(), ws.data_ptr(), wbytes, rows, dim,
+                                           dtype_code(x1), _stream(x1)), "xclip_layernorm_chain_bwd")
+    return dx1, dp
