@@ -141,7 +141,9 @@ def main():
         set_overlap(False)
     elif args.overlap != "both":
         set_overlap(True, args.overlap)
-    for _ in range(args.warmup):
+    # two untimed steps in front of the W warm-up steps: the caching allocator reaches its steady state (no hipMalloc in the
+    # timed region, see "allocator" in the output), kernels get their dynamic-LDS attribute, RCCL builds its channels
+    for _ in range(2 + args.warmup):
         step()
 
     def fence():
