@@ -131,3 +131,65 @@ def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_ima
         else:
             assert cos > bf16_cos and rel < bf16_rel, (k, rel, cos)
     return float(loss.detach())
+
+
+def case_short_and_padded_text(dev, dtype=torch.float32):
+    """texts shorter than text_seq_len, one of them nothing but padding (only its CLS slot is attended): finite, and equal to the oracle"""
+    cfg = O.CFG1
+    sd = O.make_state_dict(cfg, 21, torch.float32)
+    text, image, _, _ = O.make_inputs(cfg, 4, 22)
+    text = text[:, :20].clone()
+    text[1] = cfg.text_pad_id
+    model = build_clip(cfg, sd, dev, dtype)
+    loss = run_product(model, text, image.float(), [], [], dev, dtype)
+    ref_loss, ref_grads = oracle_run(cfg, {k: v.double() for k, v in sd.items()}, text, image.double(), [], [], None)
+    assert torch.isfinite(loss).all()
+    assert abs(float(loss.detach()) - float(ref_loss)) < 1e-5 * max(1.0, abs(float(ref_loss))), (float(loss.detach()), float(ref_loss))
+    for k, p in model.named_parameters():
+        rg = ref_grads[k]
+        if rg is None or float(rg.abs().max()) == 0.0:
+            continue
+        g = p.grad.double().cpu()
+        assert torch.isfinite(g).all(), k
+        rel = float((g - rg).norm() / rg.norm())
+        assert rel < 3e-4, (k, rel)
+
+
+def case_freeze_and_early_returns(dev, cfg):
+    """LiT-style frozen tower (x_clip.py:394-408), return_encodings / return_latents / inference similarity (:697-698,728-746)"""
+    import math
+    import pytest
+    m = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0).to(dev).train()
+    text, image, _, _ = O.make_inputs(cfg, 8, 6)
+    text, image = text.to(dev), image.float().to(dev)
+    m(text, image, return_loss=True, freeze_text_encoder=True).backward()
+    assert all(p.grad is None for p in m.text_transformer.parameters())
+    assert all(p.grad is not None for p in m.visual_transformer.parameters())
+    assert m.to_text_latent.weight.grad is not None
+    et, ei = m(text, image, return_encodings=True)
+    assert et.shape == (8, cfg.text_seq_len + 1, cfg.dim_text) and ei.shape == (8, 1 + cfg.num_patches, cfg.dim_image)
+    tl, il = m(text, image, return_latents=True)
+    m.eval()
+    sim = m(text, image)
+    want = (tl.double() * il.double()).sum(-1) * math.e
+    torch.testing.assert_close(sim.double(), want, rtol=1e-4, atol=1e-5)
+    with pytest.raises(AssertionError, match="loss cannot be used if not training"):
+        m(text, image, return_loss=True)
+
+
+def case_pluggable_encoders_head_only(dev, B=24, d=64):
+    """the reference's encoder hooks (x_clip.py:482-514): any nn.Module; nn.Identity + float 'text' exercises only projections + head"""
+    m = CLIP(dim_text=d, dim_image=d, dim_latent=d, text_encoder=torch.nn.Identity(), image_encoder=torch.nn.Identity(),
+             text_encode_without_mask=True, decoupled_contrastive_learning=True).to(dev).train()
+    g = torch.Generator().manual_seed(9)
+    xt = torch.randn(B, d, generator=g).to(dev).requires_grad_(True)
+    xi = torch.randn(B, d, generator=g).to(dev).requires_grad_(True)
+    loss = m(xt, xi, return_loss=True)
+    loss.backward()
+    Wt, Wi = m.to_text_latent.weight.detach().double().cpu(), m.to_visual_latent.weight.detach().double().cpu()
+    T = O.l2_normalize(xt.detach().double().cpu() @ Wt.t())
+    I = O.l2_normalize(xi.detach().double().cpu() @ Wi.t())
+    want = O.simloss_closed_form(T.numpy(), I.numpy(), 1.0, True)
+    assert abs(float(loss.detach()) - want["loss"]) < 1e-5
+    assert abs(float(m.temperature.grad) - want["dtau"]) < 1e-5
+    assert xt.grad is not None and torch.isfinite(xt.grad).all()

@@ -55,3 +55,15 @@ def test_no_cpu_fallback_without_library():
             ops.l2norm_fwd(torch.randn(4, 64))
     finally:
         _lib._use_library_for_tests(build())
+
+
+def test_short_and_fully_padded_text():
+    C.case_short_and_padded_text(DEV)
+
+
+def test_freeze_and_early_returns():
+    C.case_freeze_and_early_returns(DEV, O.CFG1)
+
+
+def test_pluggable_encoders_head_only():
+    C.case_pluggable_encoders_head_only(DEV)

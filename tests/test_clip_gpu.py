@@ -154,44 +154,11 @@ def test_checkpointing_is_bit_identical():
 
 
 def test_freeze_and_early_returns():
-    from x_clip_amd import CLIP
-    m = CLIP(**MID.ctor_kwargs(), visual_patch_dropout=0.0).to(DEV).train()
-    text, image, _, _ = O.make_inputs(MID, 8, 6)
-    text, image = text.to(DEV), image.float().to(DEV)
-    m(text, image, return_loss=True, freeze_text_encoder=True).backward()
-    assert all(p.grad is None for p in m.text_transformer.parameters())
-    assert all(p.grad is not None for p in m.visual_transformer.parameters())
-    assert m.to_text_latent.weight.grad is not None
-    et, ei = m(text, image, return_encodings=True)
-    assert et.shape == (8, MID.text_seq_len + 1, 512) and ei.shape == (8, 1 + MID.num_patches, 512)
-    tl, il = m(text, image, return_latents=True)
-    m.eval()
-    sim = m(text, image)
-    want = (tl.double() * il.double()).sum(-1) * math.e
-    torch.testing.assert_close(sim.double(), want, rtol=1e-4, atol=1e-5)
-    with pytest.raises(AssertionError, match="loss cannot be used if not training"):
-        m(text, image, return_loss=True)
+    C.case_freeze_and_early_returns(DEV, MID)
 
 
 def test_pluggable_encoders_head_only():
-    """the reference's encoder hooks: any nn.Module; nn.Identity + float 'text' exercises only projections + head"""
-    from x_clip_amd import CLIP
-    import numpy as np
-    B, d = 96, 128
-    m = CLIP(dim_text=d, dim_image=d, dim_latent=d, text_encoder=torch.nn.Identity(), image_encoder=torch.nn.Identity(),
-             text_encode_without_mask=True, decoupled_contrastive_learning=True).to(DEV).train()
-    g = torch.Generator().manual_seed(9)
-    xt = torch.randn(B, d, generator=g).to(DEV).requires_grad_(True)
-    xi = torch.randn(B, d, generator=g).to(DEV).requires_grad_(True)
-    loss = m(xt, xi, return_loss=True)
-    loss.backward()
-    Wt, Wi = m.to_text_latent.weight.detach().double().cpu(), m.to_visual_latent.weight.detach().double().cpu()
-    T = O.l2_normalize(xt.detach().double().cpu() @ Wt.t())
-    I = O.l2_normalize(xi.detach().double().cpu() @ Wi.t())
-    want = O.simloss_closed_form(T.numpy(), I.numpy(), 1.0, True)
-    assert abs(float(loss.detach()) - want["loss"]) < 1e-5
-    assert abs(float(m.temperature.grad) - want["dtau"]) < 1e-5
-    assert xt.grad is not None and torch.isfinite(xt.grad).all()
+    C.case_pluggable_encoders_head_only(DEV, B=96, d=128)
 
 
 def test_full_size_properties_bf16():
@@ -222,3 +189,7 @@ def test_full_size_properties_bf16():
     m.zero_grad()
     m(text, image, return_loss=True).backward()
     assert torch.equal(g1, m.to_text_latent.weight.grad)
+
+
+def test_short_and_fully_padded_text():
+    C.case_short_and_padded_text(DEV)

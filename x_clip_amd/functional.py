@@ -254,6 +254,7 @@ class _TextEncodeFn(torch.autograd.Function):
         npos = n + (1 if cls is not None else 0)
         D = E.shape[1]
         keep = any(ctx.needs_input_grad)
+        ctx_pos_rows = P.shape[0] if P is not None else 0              # rows of the full table (its gradient keeps that shape)
         if P is not None and P.shape[0] != n:
             P = P[:n]                                                   # abs_pos_emb(arange(n))      x_clip.py:323
         x0 = ops.text_embed_fwd(tokens, E, P, cls)                      # token_emb + pos, cls concat  :320-331
@@ -264,6 +265,7 @@ class _TextEncodeFn(torch.autograd.Function):
         y, tape = stack_forward(x0.view(B * npos, D), B, npos, spec, stack, kmask, keep_tape=keep)
         ctx.spec, ctx.kmask, ctx.tape, ctx.stack = spec, kmask, tape, stack
         ctx.tokens, ctx.meta = tokens, (B, n, npos, D, E.shape[0], P is not None, cls is not None, E.dtype)
+        ctx.pos_rows = ctx_pos_rows
         return y.view(B, npos, D)
 
     @staticmethod
@@ -281,6 +283,10 @@ class _TextEncodeFn(torch.autograd.Function):
                                               sorted_tokens=(st.values, st.indices) if need[3] else None)
             dE = ops.cast_from_f32(aE, dtype) if need[3] else None
             dP = ops.cast_from_f32(aP, dtype) if (need[4] and has_pos) else None
+            if dP is not None and dP.shape[0] != ctx.pos_rows:           # text shorter than max_seq_len: the unused positions get zero
+                full = torch.zeros(ctx.pos_rows, D, dtype=dP.dtype, device=dP.device)
+                full[:dP.shape[0]].copy_(dP)
+                dP = full
             dcls = ops.cast_from_f32(acls, dtype) if (need[5] and has_cls) else None
         return (None, None, None, dE, dP, dcls, *sgrads)
 
