@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 9
+#define XCLIP_ABI_VERSION 10
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -206,6 +206,31 @@ int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, co
  * multiples of the 16-byte chunk. */
 int xclip_simreg_diff(const void* A, int64_t lda, const void* C, int64_t ldc, void* D, int64_t ldd, int64_t rows, int64_t cols,
                       int64_t diag_off, float* sumsq_accum, int dtype, void* stream);
+
+/* ---- visual self-supervision head (reference x_clip/visual_ssl.py; the Linear layers of its MLPs are xclip_gemm) -----------------
+ * BatchNorm1d over the rows of x [rows, cols] (contiguous, model dtype), optionally with the ReLU that follows it in SimSiamMLP / MLP
+ * (visual_ssl.py:112-136):  y = relu?((x - mean) rstd gamma + beta).  gamma / beta / running_* / mean / rstd are fp32 [cols];
+ * gamma, beta NULL = BatchNorm1d(affine = False) (visual_ssl.py:135).
+ *   training != 0: mean / rstd are the batch statistics (biased variance, written out for the backward) and, when running_mean is
+ *     given, running = (1 - momentum) running + momentum stat with the unbiased variance -- nn.BatchNorm1d in train() mode;
+ *     rows must be > 1 (the reference asserts the same, visual_ssl.py:238).
+ *   training == 0: mean = running_mean, rstd = 1 / sqrt(running_var + eps).
+ * bwd: dx, and dgamma / dbeta [cols] fp32 WRITTEN (either may be NULL); x, dy as in the forward call, the ReLU mask is re-evaluated
+ *   from x.  workspace: xclip_batchnorm_workspace_bytes(rows, cols) bytes (per-slice column sums; no atomics, deterministic). */
+int64_t xclip_batchnorm_workspace_bytes(int64_t rows, int64_t cols);
+int xclip_batchnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean,
+                        float* running_var, float momentum, float eps, int training, int relu, int64_t rows, int64_t cols,
+                        void* workspace, int64_t workspace_bytes, int dtype, void* stream);
+int xclip_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        void* dx, float* dgamma, float* dbeta, int training, int relu, int64_t rows, int64_t cols, void* workspace,
+                        int64_t workspace_bytes, int dtype, void* stream);
+/* SimSiam's loss_fn (visual_ssl.py:104-107): *loss_accum += coef sum_r (2 - 2 cos(p_r, z_r)), cos over F.normalize'd rows (eps 1e-12);
+ * cosv / rp / rz [rows] fp32 (the cosine and the two reciprocal norms) are kept for the backward.  z is the stop-gradient target
+ * (visual_ssl.py:243-249): bwd writes dp = *gmul coef d(2 - 2 cos) / dp only. */
+int xclip_neg_cosine_fwd(const void* p, const void* z, int64_t rows, int64_t dim, float coef, float* cosv, float* rp, float* rz,
+                         float* loss_accum, int dtype, void* stream);
+int xclip_neg_cosine_bwd(const void* p, const void* z, const float* cosv, const float* rp, const float* rz, const float* gmul, float coef,
+                         void* dp, int64_t rows, int64_t dim, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,10 @@ class ClipConfig:
     sim_reg_loss_weight: float = 0.0
     use_mlm: bool = False
     text_ssl_loss_weight: float = 0.05
+    use_visual_ssl: bool = False                # SimSiam side loss (visual_ssl.py:207-259) through CLIP(visual_ssl = module)
+    image_ssl_loss_weight: float = 0.05
+    ssl_projection_size: int = 256              # SimSiam(projection_size, projection_hidden_size): not CLIP keywords (the CLIP
+    ssl_projection_hidden_size: int = 4096      # constructors swallow them in **kwargs)
 
     @property
     def num_patches(self) -> int:
@@ -67,6 +71,13 @@ class ClipConfig:
     def ctor_kwargs(self) -> dict:
         """kwargs for the reference / product constructor (patch dropout is passed separately)."""
         return asdict(self)
+
+    def vit_kwargs(self, patch_dropout: float = 0.0) -> dict:
+        """VisionTransformer(**...) as CLIP builds it (x_clip.py:496-507): the visual-SSL cases construct the encoder first and
+        hand it to both SimSiam(net) and CLIP(image_encoder =)"""
+        return dict(dim=self.dim_image, image_size=self.visual_image_size, patch_size=self.visual_patch_size,
+                    channels=self.channels, depth=self.visual_enc_depth, heads=self.visual_heads,
+                    dim_head=self.visual_dim_head, patch_dropout=patch_dropout)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -303,15 +314,83 @@ def mlm_loss(sd: Dict[str, Tensor], cfg: ClipConfig, masked_seq: Tensor, labels:
     return torch.nn.functional.cross_entropy(logits.transpose(1, 2), labels, ignore_index=cfg.text_pad_id)
 
 
+def ssl_aug_one(x: Tensor) -> Tensor:
+    """deterministic stand-ins for the two random augmentations of SimSiam (augment_fn / augment_fn2, visual_ssl.py:216-226):
+    the fixtures, the oracle and the product tests all pass these two callables"""
+    return x.flip(-1)
+
+
+def ssl_aug_two(x: Tensor) -> Tensor:
+    return 0.8 * x + 0.2 * x.roll(3, dims=-2)
+
+
+SSL_PROJECTOR = "visual_ssl.online_encoder.projector."
+SSL_PREDICTOR = "visual_ssl.online_predictor."
+
+
+def batch_norm_rows(x: Tensor, g: Optional[Tensor], b: Optional[Tensor], stats: Optional[list] = None) -> Tensor:
+    """nn.BatchNorm1d in train() mode over the rows of x [R, C] (biased variance, eps 1e-5); `stats` collects (mean, unbiased
+    variance) -- what the running statistics are updated with"""
+    mean = x.mean(dim=0)
+    var = x.var(dim=0, unbiased=False)
+    if stats is not None:
+        stats.append((mean.detach(), x.var(dim=0, unbiased=True).detach()))
+    y = (x - mean) * torch.rsqrt(var + 1e-5)
+    if g is not None:
+        y = y * g + b
+    return y
+
+
+def simsiam_loss(sd: Dict[str, Tensor], cfg: ClipConfig, image: Tensor, running: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """SimSiam.forward (visual_ssl.py:237-259) around the CLIP vision tower with hidden_layer = -1 (the CLIP default, x_clip.py:551):
+    the representation is the encoder output [b, 1 + n, dim], every token row is projected (NetWrapper.forward :197-203,
+    SimSiamMLP :122-135: Linear - BN - ReLU - Linear - BN - ReLU - Linear - BN(affine = False)), the predictor is MLP :112-120
+    (Linear - BN - ReLU - Linear, with biases), loss_fn :104-107 is 2 - 2 cos, the targets are the projections themselves under
+    no_grad (the target encoder IS the online encoder, :243-249; equal values because the encoder is deterministic without patch
+    dropout).  `running`: if given, receives the BatchNorm running statistics after the step (four passes through the projector
+    -- view one, view two, and both again for the targets -- and two through the predictor, momentum 0.1)."""
+    P, Q = SSL_PROJECTOR, SSL_PREDICTOR
+    stats: Dict[str, list] = {P + "1": [], P + "4": [], P + "7": [], Q + "1": []}
+
+    def project(img):
+        rep = encode_image(sd, cfg, img)
+        x = rep.reshape(-1, rep.shape[-1])
+        x = torch.relu(batch_norm_rows(x @ sd[P + "0.weight"].t(), sd[P + "1.weight"], sd[P + "1.bias"], stats[P + "1"]))
+        x = torch.relu(batch_norm_rows(x @ sd[P + "3.weight"].t(), sd[P + "4.weight"], sd[P + "4.bias"], stats[P + "4"]))
+        return batch_norm_rows(x @ sd[P + "6.weight"].t(), None, None, stats[P + "7"])
+
+    def predict(x):
+        x = torch.relu(batch_norm_rows(x @ sd[Q + "0.weight"].t() + sd[Q + "0.bias"], sd[Q + "1.weight"], sd[Q + "1.bias"], stats[Q + "1"]))
+        return x @ sd[Q + "3.weight"].t() + sd[Q + "3.bias"]
+
+    one, two = ssl_aug_one(image), ssl_aug_two(image)
+    proj_one, proj_two = project(one), project(two)
+    pred_one, pred_two = predict(proj_one), predict(proj_two)
+    for k in (P + "1", P + "4", P + "7"):                                  # the two target passes see the same batches again
+        stats[k] = stats[k] + stats[k]
+    cos = torch.nn.functional.cosine_similarity
+    loss = (2 - 2 * cos(pred_one, proj_two.detach(), dim=-1, eps=1e-12)) + (2 - 2 * cos(pred_two, proj_one.detach(), dim=-1, eps=1e-12))
+    if running is not None:
+        for k, seq in stats.items():
+            rm, rv = sd[k + ".running_mean"].detach().clone(), sd[k + ".running_var"].detach().clone()
+            for mean, var in seq:
+                rm = 0.9 * rm + 0.1 * mean
+                rv = 0.9 * rv + 0.1 * var
+            running[k + ".running_mean"], running[k + ".running_var"] = rm, rv
+    return loss.mean()
+
+
 def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Tensor,
                  aug_text: Sequence[Tensor] = (), aug_image: Sequence[Tensor] = (),
                  keep_idx: Optional[Tensor] = None, return_latents: bool = False,
-                 mlm_masked: Optional[Tuple[Tensor, Tensor]] = None):
-    """CLIP.forward(return_loss=True) (x_clip.py:597-875); of the SSL side losses only MLM (`mlm_masked` = the masked sequence
-    and labels the random masking produced, x_clip.py:620-622)."""
-    text_ssl = None
+                 mlm_masked: Optional[Tuple[Tensor, Tensor]] = None, ssl_running: Optional[Dict[str, Tensor]] = None):
+    """CLIP.forward(return_loss=True) (x_clip.py:597-875) with its two side losses: MLM (`mlm_masked` = the masked sequence and
+    labels the random masking produced, x_clip.py:620-622) and SimSiam (x_clip.py:623, deterministic augmentations)."""
+    text_ssl = image_ssl = None
     if cfg.use_mlm and not return_latents:
         text_ssl = mlm_loss(sd, cfg, mlm_masked[0], mlm_masked[1], text != cfg.text_pad_id)
+    if cfg.use_visual_ssl and not return_latents:
+        image_ssl = simsiam_loss(sd, cfg, image, ssl_running)
     m, n = 1 + len(aug_text), 1 + len(aug_image)
     text = torch.cat([text, *aug_text], dim=0)
     image = torch.cat([image, *aug_image], dim=0)
@@ -337,9 +416,12 @@ def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Te
     if return_latents:
         return (tl, il) if tlx is None else (tl, il, tlx, ilx)
     loss = contrastive_loss(cfg, sd["temperature"], tl, il, tlx, ilx, text_mask, m, n,
-                            ssl_weight=cfg.text_ssl_loss_weight if cfg.use_mlm else 0.0)
+                            ssl_weight=(cfg.text_ssl_loss_weight if cfg.use_mlm else 0.0)
+                            + (cfg.image_ssl_loss_weight if cfg.use_visual_ssl else 0.0))
     if text_ssl is not None:
         loss = loss + text_ssl * cfg.text_ssl_loss_weight                 # x_clip.py:857-860
+    if image_ssl is not None:
+        loss = loss + image_ssl * cfg.image_ssl_loss_weight
     return loss
 
 
@@ -426,6 +508,32 @@ def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
         shapes["mlm.to_logits.bias"] = (cfg.num_text_tokens,)
         for k in [k for k in shapes if k.startswith(t)]:
             shapes["mlm.transformer." + k[len(t):]] = shapes[k]
+    if cfg.use_visual_ssl:                                      # SimSiam (visual_ssl.py:122-135 projector, :112-120 predictor); `net` and
+        H, ps = cfg.ssl_projection_hidden_size, cfg.ssl_projection_size   # `online_encoder.net` list the vision tower again
+        P, Q = SSL_PROJECTOR, SSL_PREDICTOR
+
+        def bn(pfx, width, affine=True):
+            if affine:
+                shapes[pfx + ".weight"] = (width,)
+                shapes[pfx + ".bias"] = (width,)
+            shapes[pfx + ".running_mean"] = (width,)
+            shapes[pfx + ".running_var"] = (width,)
+            shapes[pfx + ".num_batches_tracked"] = ()
+
+        shapes[P + "0.weight"] = (H, cfg.dim_image)
+        bn(P + "1", H)
+        shapes[P + "3.weight"] = (H, H)
+        bn(P + "4", H)
+        shapes[P + "6.weight"] = (ps, H)
+        bn(P + "7", ps, affine=False)
+        shapes[Q + "0.weight"] = (H, ps)
+        shapes[Q + "0.bias"] = (H,)
+        bn(Q + "1", H)
+        shapes[Q + "3.weight"] = (ps, H)
+        shapes[Q + "3.bias"] = (ps,)
+        for k in [k for k in shapes if k.startswith(v)]:
+            shapes["visual_ssl.net." + k[len(v):]] = shapes[k]
+            shapes["visual_ssl.online_encoder.net." + k[len(v):]] = shapes[k]
     for k, d in (("to_text_latent", cfg.dim_text), ("to_visual_latent", cfg.dim_image)):
         for sfx in ("", "_extra"):
             if k == "to_visual_latent" and cfg.downsample_image_embeds:   # Sequential(RearrangeImage, Conv2d dw, Conv2d 1x1, Rearrange)
@@ -444,9 +552,19 @@ def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str
     rs = np.random.RandomState(seed)
     sd: Dict[str, Tensor] = {}
     for key, shape in sorted(state_dict_shapes(cfg).items()):
-        if key.startswith("mlm.transformer."):
-            continue                                            # aliases of text_transformer.*, filled in below
-        if key == "temperature":
+        if key.startswith("mlm.transformer.") or key.startswith("visual_ssl.net.") or key.startswith("visual_ssl.online_encoder.net."):
+            continue                                            # aliases of text_transformer.* / visual_transformer.*, filled in below
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.tensor(0, dtype=torch.long)
+            continue
+        if key.startswith("visual_ssl.") and len(shape) == 1 and not key.endswith(".0.bias") and not key.endswith(".3.bias"):
+            if key.endswith("running_var"):                     # BatchNorm1d tensors: gains ~1, shifts / running means small
+                a = 1.0 + 0.2 * np.abs(rs.standard_normal(shape))
+            elif key.endswith(".weight"):
+                a = 1.0 + 0.1 * rs.standard_normal(shape)
+            else:
+                a = 0.1 * rs.standard_normal(shape)
+        elif key == "temperature":
             a = np.array(1.0)
         elif key.endswith("inv_freq"):
             rot = 2 * shape[0]
@@ -465,6 +583,10 @@ def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str
     if cfg.use_mlm:
         for k in [k for k in sd if k.startswith("text_transformer.")]:
             sd["mlm.transformer." + k[len("text_transformer."):]] = sd[k]
+    if cfg.use_visual_ssl:
+        for k in [k for k in sd if k.startswith("visual_transformer.")]:
+            sd["visual_ssl.net." + k[len("visual_transformer."):]] = sd[k]
+            sd["visual_ssl.online_encoder.net." + k[len("visual_transformer."):]] = sd[k]
     return sd
 
 

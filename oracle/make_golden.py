@@ -14,7 +14,8 @@ tiny), the reference's fp32 loss, latents, d(temperature), and for every paramet
 first 8 entries of its gradient.
 
 The reference needs two work-arounds that do not touch the hot path:
-  * `torchvision` (only used by the out-of-scope visual_ssl.py) is stubbed in sys.modules;
+  * `torchvision` (only used by visual_ssl.py's default augmentation pipeline) is stubbed in sys.modules; the SimSiam cases
+    pass the oracle's two deterministic augmentation callables instead;
   * x_clip/distributed.py references `F` and `exists` without defining them; for the 2-rank case they
     are injected into that module's namespace before use.
 """
@@ -34,13 +35,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFERENCE = "/root/reference"
 
 sys.path.insert(0, ROOT)
-from oracle.clip_oracle import CFG1, ClipConfig, make_inputs, make_state_dict  # noqa: E402
+from oracle.clip_oracle import CFG1, ClipConfig, make_inputs, make_state_dict, ssl_aug_one, ssl_aug_two  # noqa: E402
 
 
 def import_reference():
     tv = types.ModuleType("torchvision")
     tvt = types.ModuleType("torchvision.transforms")
     tv.transforms = tvt
+    # SimSiam.__init__ builds the default torchvision pipeline even when augment_fn is given (visual_ssl.py:224 evaluates the
+    # default eagerly): every transform name resolves to a factory of nn.Identity placeholders, which are never called
+    tvt.__getattr__ = lambda name: (lambda *a, **k: torch.nn.Identity())
     sys.modules.setdefault("torchvision", tv)
     sys.modules.setdefault("torchvision.transforms", tvt)
     if REFERENCE not in sys.path:
@@ -65,6 +69,9 @@ CASES = {
                                              extra_latent_projection=True, decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
     "cfg1_mlm": (dict(use_mlm=True), 4, 0, 0, 0.0),
     "cfg1_mlm_dcl_multiview": (dict(use_mlm=True, text_ssl_loss_weight=0.2, decoupled_contrastive_learning=True), 4, 1, 1, 0.0),
+    "cfg1_simsiam": (dict(use_visual_ssl=True, ssl_projection_size=32, ssl_projection_hidden_size=64), 4, 0, 0, 0.0),
+    "cfg1_simsiam_mlm_dcl": (dict(use_visual_ssl=True, image_ssl_loss_weight=0.3, ssl_projection_size=24, ssl_projection_hidden_size=48,
+                                  use_mlm=True, decoupled_contrastive_learning=True), 5, 0, 0, 0.0),
     "cfg1_rotary": (dict(text_rotary_pos_emb=True), 4, 0, 0, 0.0),
     "cfg1_rotary_dcl_multiview": (dict(text_rotary_pos_emb=True, decoupled_contrastive_learning=True), 4, 1, 0, 0.0),
     "cfg1_simreg_extra": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.1), 4, 0, 0, 0.0),
@@ -80,7 +87,20 @@ INPUT_SEED = 1234
 
 def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropout, want_latents=True):
     torch.manual_seed(0)
-    ref = x_clip.CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=patch_dropout)
+    if cfg.use_visual_ssl:
+        # SimSiam around the vision tower, handed to CLIP through its `visual_ssl` / `image_encoder` keywords (README "custom vision
+        # self-supervised learning module"): the two augmentations are the oracle's deterministic callables -- the default pipeline
+        # is torchvision's, which this container does not have -- and the projector sizes are kept small
+        assert patch_dropout == 0, "the recorded SimSiam cases use a deterministic encoder"
+        from x_clip.x_clip import VisionTransformer
+        from x_clip.visual_ssl import SimSiam
+        vit = VisionTransformer(**cfg.vit_kwargs(patch_dropout))
+        ssl = SimSiam(vit, image_size=cfg.visual_image_size, channels=cfg.channels, hidden_layer=-1,
+                      projection_size=cfg.ssl_projection_size, projection_hidden_size=cfg.ssl_projection_hidden_size,
+                      augment_fn=ssl_aug_one, augment_fn2=ssl_aug_two)
+        ref = x_clip.CLIP(**cfg.ctor_kwargs(), image_encoder=vit, visual_ssl=ssl)
+    else:
+        ref = x_clip.CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=patch_dropout)
     sd = make_state_dict(cfg, PARAM_SEED)
     ref.load_state_dict(sd, strict=True)          # strict: pins the key/shape map of Appendix A
     ref.train()
@@ -131,6 +151,12 @@ def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropou
         for nme, l in zip(names, lat):
             out[nme] = l.double().flatten().tolist()
             out[nme + "_shape"] = list(l.shape)
+    if cfg.use_visual_ssl:
+        # BatchNorm running statistics after the step (SimSiam runs every projector BatchNorm four times, the predictor's twice)
+        after = ref.state_dict()
+        out["ssl_running"] = {k: dict(norm=float(v.double().norm()), head=v.flatten()[:4].double().tolist())
+                              for k, v in after.items() if k.startswith("visual_ssl.online") and ("running_" in k)}
+        out["ssl_num_batches_tracked"] = {k: int(v) for k, v in after.items() if k.startswith("visual_ssl.online") and k.endswith("num_batches_tracked")}
     if keep_idx is not None:
         out["keep_idx"] = keep_idx.tolist()
     if mlm_rec is not None:

@@ -480,3 +480,56 @@ def case_layernorm_chain(dev, dtype, rows, dim):
     close(dg2, g264.grad, torch.float32 if dtype == torch.float32 else dtype, "chain dg2", mult=4.0)
     xh1 = ((p64 - p64.mean(-1, keepdim=True)) * torch.rsqrt(p64.var(-1, unbiased=False, keepdim=True) + eps)).detach()
     close(dg1, (want_dx1.detach() * xh1).sum(0), torch.float32 if dtype == torch.float32 else dtype, "chain dg1", mult=4.0)
+
+
+def case_batchnorm(dev, dtype, rows, cols, relu, affine, training, offset=0.0):
+    """BatchNorm1d (+ReLU) over the rows, forward, running-statistics update and backward against torch's F.batch_norm in fp64
+    (reference visual_ssl.py:112-136).  `offset` shifts the columns far from zero (the shifted-variance accumulation)."""
+    F = torch.nn.functional
+    x = (rnd((rows, cols), dtype, 91).float() * (0.5 + rnd((cols,), torch.float32, 92).abs()) + offset + rnd((cols,), torch.float32, 93)).to(dtype)
+    dy = rnd((rows, cols), dtype, 94)
+    gamma = (1.0 + 0.2 * rnd((cols,), torch.float32, 95)) if affine else None
+    beta = 0.3 * rnd((cols,), torch.float32, 96) if affine else None
+    rm0 = 0.1 * rnd((cols,), torch.float32, 97) + offset
+    rv0 = 1.0 + 0.2 * rnd((cols,), torch.float32, 98).abs()
+    rm, rv = rm0.clone().to(dev), rv0.clone().to(dev)
+    eps, mom = 1e-5, 0.1
+    to = lambda t: None if t is None else t.to(dev)
+    y, mean, rstd = ops.batchnorm_fwd(x.to(dev), to(gamma), to(beta), rm, rv, mom, eps, training, relu)
+    dx, dg, db = ops.batchnorm_bwd(x.to(dev), dy.to(dev), to(gamma), to(beta), mean, rstd, training, relu, affine)
+    x64 = ref64(x).requires_grad_(True)
+    g64 = None if gamma is None else ref64(gamma).requires_grad_(True)
+    b64 = None if beta is None else ref64(beta).requires_grad_(True)
+    rm64, rv64 = ref64(rm0).clone(), ref64(rv0).clone()
+    z = F.batch_norm(x64, rm64, rv64, g64, b64, training, mom, eps)
+    want = torch.relu(z) if relu else z
+    (want * ref64(dy)).sum().backward()
+    close(y, want, dtype, "bn y", mult=2.0)
+    if training:
+        close(rm, rm64, torch.float32, "bn running_mean", scale=max(1.0, abs(offset)))
+        close(rv, rv64, torch.float32, "bn running_var", mult=5.0)
+    else:
+        assert torch.equal(rm.cpu(), rm0) and torch.equal(rv.cpu(), rv0)
+    # elements whose pre-activation sits within rounding of 0 may take either side of the ReLU: exclude them from the comparison
+    live = torch.ones_like(want, dtype=torch.bool) if not relu else (z.detach().abs() > 1e-4)
+    gscale = float(x64.grad.abs().max())
+    close(torch.where(live, dx.detach().cpu().double(), x64.grad), x64.grad, dtype, "bn dx", scale=gscale, mult=4.0)
+    if affine:
+        close(dg, g64.grad, dtype, "bn dgamma", mult=4.0)
+        close(db, b64.grad, dtype, "bn dbeta", mult=4.0)
+
+
+def case_neg_cosine(dev, dtype, rows, dim):
+    """SimSiam loss_fn (visual_ssl.py:104-107), mean over rows accumulated through coef, and its gradient w.r.t. the prediction"""
+    F = torch.nn.functional
+    p_, z_ = rnd((rows, dim), dtype, 101), rnd((rows, dim), dtype, 102)
+    acc = torch.zeros(1, dtype=torch.float32, device=dev)
+    coef = 1.0 / rows
+    st = ops.neg_cosine_fwd(p_.to(dev), z_.to(dev), coef, acc)
+    p64 = ref64(p_).requires_grad_(True)
+    want = (2 - 2 * (F.normalize(p64, dim=-1) * F.normalize(ref64(z_), dim=-1)).sum(-1)).mean()
+    assert abs(float(acc) - float(want.detach())) < 2e-5 * max(1.0, abs(float(want.detach()))), (float(acc), float(want.detach()))
+    (want * 0.6).backward()
+    gm = torch.full((1,), 0.6, dtype=torch.float32, device=dev)
+    dp = ops.neg_cosine_bwd(p_.to(dev), z_.to(dev), st, gm, coef)
+    close(dp, p64.grad, dtype, "cosine dp", mult=2.0)

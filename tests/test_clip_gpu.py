@@ -28,7 +28,7 @@ def hip_library():
 
 
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm", "cfg1_mlm_dcl_multiview"])
+                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm", "cfg1_mlm_dcl_multiview", "cfg1_simsiam", "cfg1_simsiam_mlm_dcl"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 
@@ -82,6 +82,41 @@ def test_mid_mlm_vs_oracle(dtype):
     import dataclasses
     # (bf16: the scalar temperature gradient -- a difference of O(1) sums over 16 x 16 bf16-rounded logits -- sits at 20 % of its fp64 value)
     C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, use_mlm=True, text_ssl_loss_weight=0.3), 16, bf16_rel=0.3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_mid_simsiam_vs_oracle(dtype):
+    """SimSiam side loss around the shared vision tower (visual_ssl.py:207-259; x_clip.py:623): BatchNorm MLP projector / predictor,
+    negative-cosine loss, running statistics"""
+    import dataclasses
+    cfg = dataclasses.replace(MID, use_visual_ssl=True, image_ssl_loss_weight=0.3, ssl_projection_size=256, ssl_projection_hidden_size=1024)
+    C.case_vs_oracle(DEV, dtype, cfg, 16, bf16_rel=0.3)
+
+
+def test_simsiam_default_construction_and_patch_dropout():
+    """CLIP(use_visual_ssl = True) builds SimSiam around its own vision tower (x_clip.py:536-552; default sizes 256 / 4096), which needs
+    torchvision for the default augmentations -- absent here, so the constructor must say so; with augmentations supplied the side loss
+    runs with the tower's random patch dropout (the target passes draw their own patches, as in the reference) and reaches every parameter"""
+    from x_clip_amd import CLIP, VisionTransformer
+    from x_clip_amd.visual_ssl import SimSiam
+    try:
+        import torchvision  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="torchvision"):
+            CLIP(**MID.ctor_kwargs(), use_visual_ssl=True)
+    vit = VisionTransformer(**MID.vit_kwargs(0.5))
+    ssl = SimSiam(vit, image_size=MID.visual_image_size, hidden_layer=-1, augment_fn=O.ssl_aug_one, augment_fn2=O.ssl_aug_two)
+    kw = {k: v for k, v in MID.ctor_kwargs().items() if k != "use_visual_ssl"}
+    m = CLIP(**kw, image_encoder=vit, visual_ssl=ssl, use_visual_ssl=True).to(torch.bfloat16).to(DEV).train()
+    assert ssl.online_encoder.projector[0].weight.shape == (4096, MID.dim_image)
+    text, image, _, _ = O.make_inputs(MID, 8, 3)
+    loss = m(text.to(DEV), image.to(torch.bfloat16).to(DEV), return_loss=True)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in m.named_parameters():
+        if "_extra" not in k:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert int(ssl.online_encoder.projector[1].num_batches_tracked) == 4 and int(ssl.online_predictor[1].num_batches_tracked) == 2
 
 
 def test_filip_multiview_extra_dcl_patchdrop_fp32():

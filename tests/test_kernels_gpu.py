@@ -163,3 +163,17 @@ def test_cross_entropy(dtype, rows, cols, ld):
 @pytest.mark.parametrize("rows,dim", [(5, 64), (1031, 512), (4100, 1024)])
 def test_layernorm_chain(dtype, rows, dim):
     K.case_layernorm_chain(DEV, dtype, rows, dim)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,cols,relu,affine,training,offset", [(70000, 4096, True, True, True, 0.0), (130, 512, True, True, True, 0.0), (37, 64, False, False, True, 50.0),
+                                                                    (8, 96, True, True, True, 0.0), (50, 256, True, True, False, 0.0),
+                                                                    (2, 1024, False, True, True, 0.0)])
+def test_batchnorm(dtype, rows, cols, relu, affine, training, offset):
+    K.case_batchnorm(DEV, dtype, rows, cols, relu, affine, training, offset)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,dim", [(130, 256), (3, 64), (17, 1024)])
+def test_neg_cosine(dtype, rows, dim):
+    K.case_neg_cosine(DEV, dtype, rows, dim)

@@ -22,15 +22,20 @@ def load(path):
 
 def run_oracle(rec, dtype):
     cfg = ClipConfig(**rec["config"])
-    sd = {k: v.clone().requires_grad_(True) for k, v in make_state_dict(cfg, rec["param_seed"], dtype).items()}
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in make_state_dict(cfg, rec["param_seed"], dtype).items()}
     text, image, aug_t, aug_i = make_inputs(cfg, rec["batch"], rec["input_seed"], rec["n_aug_text"], rec["n_aug_image"])
     keep = torch.tensor(rec["keep_idx"]) if "keep_idx" in rec else None
     # fixtures were produced from fp32 images: round through fp32 first
     image = image.float().to(dtype)
     aug_i = [a.float().to(dtype) for a in aug_i]
     mlm = (torch.tensor(rec["mlm_masked_seq"]), torch.tensor(rec["mlm_labels"])) if "mlm_masked_seq" in rec else None
-    loss = clip_forward(sd, cfg, text, image, aug_t, aug_i, keep, mlm_masked=mlm)
+    running = {}
+    loss = clip_forward(sd, cfg, text, image, aug_t, aug_i, keep, mlm_masked=mlm, ssl_running=running)
     loss.backward()
+    for k, want in rec.get("ssl_running", {}).items():             # BatchNorm running statistics after the reference's step
+        got = running[k].double()
+        assert abs(float(got.norm()) - want["norm"]) <= 2e-5 * want["norm"], k
+        np.testing.assert_allclose(got[:4].numpy(), np.asarray(want["head"]), rtol=1e-4, atol=1e-6, err_msg=k)
     return cfg, sd, loss, (text, image)
 
 

@@ -57,6 +57,11 @@ _SIGNATURES = {
     "xclip_gather_rows": (c_int, [P, L, P, P, L, L, I, P]),
     "xclip_cross_entropy_fwd": (c_int, [P, L, P, L, L, P, P, I, P]),
     "xclip_cross_entropy_bwd": (c_int, [P, L, P, P, P, L, L, I, P]),
+    "xclip_batchnorm_workspace_bytes": (c_int64, [L, L]),
+    "xclip_batchnorm_fwd": (c_int, [P, P, P, P, P, P, P, P, F, F, I, I, L, L, P, L, I, P]),
+    "xclip_batchnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, L, L, P, L, I, P]),
+    "xclip_neg_cosine_fwd": (c_int, [P, P, L, L, F, P, P, P, P, I, P]),
+    "xclip_neg_cosine_bwd": (c_int, [P, P, P, P, P, P, F, P, L, L, I, P]),
     "xclip_dwconv4s2_workspace_bytes": (c_int64, [L, L, L, I]),
     "xclip_dwconv4s2_fwd": (c_int, [P, P, P, L, L, L, I, P]),
     "xclip_dwconv4s2_bwd": (c_int, [P, P, P, P, P, P, L, L, L, L, I, P]),
@@ -67,7 +72,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def _bind(path: str):

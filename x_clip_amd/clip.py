@@ -8,7 +8,7 @@ the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is n
 on an MI355X.
 
 Not on this path (constructor raises NotImplementedError): causal text encoder (broken in the
-reference itself), visual-SSL side losses (their augmentations need torchvision).
+reference itself), the SimCLR variant of the visual-SSL side loss.
 """
 from __future__ import annotations
 
@@ -22,6 +22,7 @@ from torch import nn
 from . import functional as XF
 from . import losses as XL
 from .mlm import MLM
+from .visual_ssl import SimCLR, SimSiam
 
 Tensor = torch.Tensor
 
@@ -194,6 +195,7 @@ class VisionTransformer(nn.Module):
         assert image_size % patch_size == 0, 'Image dimensions must be divisible by the patch size.'
         num_patches = (image_size // patch_size) ** 2
         patch_dim = channels * patch_size ** 2
+        self.dim = dim                                           # output width (the visual-SSL projector is sized from it)
         self.patch_size = patch_size
         self.num_patches = num_patches
         # index 0 of the reference Sequential is the einops Rearrange (no parameters): keep `to_tokens.1.*` key names
@@ -321,16 +323,24 @@ class CLIP(nn.Module):
                 checkpoint_during_training=checkpoint_during_training
             )
 
-        # side losses of the reference that are outside the accelerated path
-        if use_visual_ssl or exists(visual_ssl):
-            raise NotImplementedError("use_visual_ssl / visual_ssl: SimSiam / SimCLR (x_clip/visual_ssl.py) are outside the accelerated contrastive path")
         self.use_mlm = use_mlm                                                             # x_clip.py:516-527
         self.text_ssl_loss_weight = text_ssl_loss_weight if use_mlm else 0
         if use_mlm:
             mlm_kwargs = {k[len('mlm_'):]: v for k, v in kwargs.items() if k.startswith('mlm_')}
             self.mlm = MLM(self.text_transformer, dim=dim_text, num_tokens=num_text_tokens, **mlm_kwargs)
-        self.use_visual_ssl = False
-        self.image_ssl_loss_weight = 0
+        self.use_visual_ssl = use_visual_ssl or exists(visual_ssl)                          # x_clip.py:531-552
+        self.image_ssl_loss_weight = image_ssl_loss_weight if use_visual_ssl else 0
+        if self.use_visual_ssl:
+            if exists(visual_ssl):
+                self.visual_ssl = visual_ssl
+            elif visual_ssl_type == 'simsiam':
+                self.visual_ssl = SimSiam(self.visual_transformer, image_size=visual_image_size, channels=channels,
+                                          hidden_layer=visual_ssl_hidden_layer)
+            elif visual_ssl_type == 'simclr':
+                self.visual_ssl = SimCLR(self.visual_transformer, image_size=visual_image_size, channels=channels,
+                                         hidden_layer=visual_ssl_hidden_layer, temperature=simclr_temperature)
+            else:
+                raise ValueError(f'unknown visual_ssl_type')
 
         self.to_text_latent = nn.Linear(dim_text, dim_latent, bias=False)
 
@@ -403,6 +413,9 @@ class CLIP(nn.Module):
         text_ssl_loss = 0                                                                  # x_clip.py:618-622
         if return_loss and self.use_mlm:
             text_ssl_loss = self.mlm(text, mask=text_mask)
+        image_ssl_loss = 0
+        if return_loss and self.use_visual_ssl:
+            image_ssl_loss = self.visual_ssl(image)
 
         num_batch_texts = num_batch_images = 1
 
@@ -510,6 +523,8 @@ class CLIP(nn.Module):
                                        image_latents_extra if self.extra_latent_projection else None, spec)
         if self.use_mlm:                                                                   # x_clip.py:857-860
             loss = loss + text_ssl_loss * self.text_ssl_loss_weight
+        if self.use_visual_ssl:
+            loss = loss + image_ssl_loss * self.image_ssl_loss_weight
         if self.has_sim_reg_loss:                                                          # x_clip.py:773-784, 872-873
             assert not is_multiview, 'the similarity regularisation loss is defined for a single view (its [1, b, b] mask, x_clip.py:776-778)'
             sim_reg = XL.sim_reg_loss(text_latents[0], image_latents[0], text_latents_extra[0], image_latents_extra[0], spec)

@@ -3,6 +3,7 @@
 #include "xc_device.h"
 
 #include "api_common.h"
+#include "kernels/colnorm.h"
 #include "kernels/filip.h"
 #include "kernels/gemm.h"
 #include "kernels/gemm2.h"
@@ -844,6 +845,122 @@ int xclip_simreg_diff(const void* A, int64_t lda, const void* C, int64_t ldc, vo
     else
         hipLaunchKernelGGL((simreg_diff_kernel<float>), grid, block, 16, (hipStream_t)stream, (const float*)A, (long)lda, (const float*)C,
                            (long)ldc, (float*)D, (long)ldd, (int)rows, (int)cols, (int)diag_off, sumsq_accum);
+    return check_launch(__func__);
+}
+
+namespace {
+constexpr int BN_MAX_SLICES = 256;
+inline ColNormGeom colnorm_geom(int64_t rows, int64_t cols, int dtype) {
+    const int nch = (int)(cols / vec_of(dtype));
+    ColNormGeom g;
+    g.cw = 64;
+    if (nch < 64) { g.cw = 1; while (g.cw < nch) g.cw *= 2; }
+    g.slabs = (nch + g.cw - 1) / g.cw;
+    const int64_t rows_per_wg = 4 * (64 / g.cw);
+    int64_t slices = 2048 / g.slabs;
+    const int64_t useful = (rows + rows_per_wg - 1) / rows_per_wg;
+    if (slices > useful) slices = useful;
+    if (slices > BN_MAX_SLICES) slices = BN_MAX_SLICES;
+    if (slices < 1) slices = 1;
+    g.slices = (int)slices;
+    return g;
+}
+}  // namespace
+
+int64_t xclip_batchnorm_workspace_bytes(int64_t rows, int64_t cols) {
+    (void)rows;
+    return (int64_t)(2 * BN_MAX_SLICES + 2) * cols * (int64_t)sizeof(float);
+}
+
+int xclip_batchnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean,
+                        float* running_var, float momentum, float eps, int training, int relu, int64_t rows, int64_t cols,
+                        void* workspace, int64_t workspace_bytes, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(rows > 0 && cols > 0 && cols % vec_of(dtype) == 0 && rows < (1LL << 31) && cols < (1LL << 24), "cols must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(x && y && mean && rstd && aligned16(x) && aligned16(y), "null or misaligned pointer");
+    XC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var come together");
+    XC_REQUIRE(training || running_mean, "evaluation mode needs the running statistics");
+    XC_REQUIRE(!training || rows > 1, "Expected more than 1 value per channel when training");
+    XC_REQUIRE(!training || (workspace && workspace_bytes >= xclip_batchnorm_workspace_bytes(rows, cols)), "workspace too small");
+    const ColNormGeom g = colnorm_geom(rows, cols, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)g.slabs, (unsigned)g.slices), block(256);
+    const int R = (int)rows, C = (int)cols;
+    const int fin_blocks = (C + 255) / 256;
+    float* part = (float*)workspace;
+    if (training) {
+        const int lds = 256 * 2 * vec_of(dtype) * (int)sizeof(float);
+        if (dtype == XCLIP_BF16) {
+            hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), grid, block, lds, st, (const bf16_t*)x, part, R, C, g.cw);
+            hipLaunchKernelGGL((bn_finalize_kernel<bf16_t>), dim3(fin_blocks), block, 0, st, (const bf16_t*)x, part, g.slices, R, C, eps, momentum,
+                               mean, rstd, running_mean, running_var);
+        } else {
+            hipLaunchKernelGGL((bn_stats_kernel<float>), grid, block, lds, st, (const float*)x, part, R, C, g.cw);
+            hipLaunchKernelGGL((bn_finalize_kernel<float>), dim3(fin_blocks), block, 0, st, (const float*)x, part, g.slices, R, C, eps, momentum,
+                               mean, rstd, running_mean, running_var);
+        }
+    } else {
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(fin_blocks), block, 0, st, running_mean, running_var, eps, mean, rstd, C);
+    }
+#define BN_APPLY(T, RELU) hipLaunchKernelGGL((bn_apply_kernel<T, RELU>), grid, block, 0, st, (const T*)x, mean, rstd, gamma, beta, (T*)y, R, C, g.cw)
+    if (dtype == XCLIP_BF16) { if (relu) BN_APPLY(bf16_t, true); else BN_APPLY(bf16_t, false); }
+    else                     { if (relu) BN_APPLY(float, true); else BN_APPLY(float, false); }
+#undef BN_APPLY
+    return check_launch(__func__);
+}
+
+int xclip_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        void* dx, float* dgamma, float* dbeta, int training, int relu, int64_t rows, int64_t cols, void* workspace,
+                        int64_t workspace_bytes, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(rows > 0 && cols > 0 && cols % vec_of(dtype) == 0 && rows < (1LL << 31) && cols < (1LL << 24), "cols must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(x && dy && dx && mean && rstd && aligned16(x) && aligned16(dy) && aligned16(dx), "null or misaligned pointer");
+    XC_REQUIRE(workspace && workspace_bytes >= xclip_batchnorm_workspace_bytes(rows, cols), "workspace too small");
+    const ColNormGeom g = colnorm_geom(rows, cols, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)g.slabs, (unsigned)g.slices), block(256);
+    const int R = (int)rows, C = (int)cols;
+    float* part = (float*)workspace;
+    float* coef = part + (int64_t)2 * BN_MAX_SLICES * cols;
+    const BnCols cols_p{mean, rstd, gamma, beta};
+    const int lds = 256 * 2 * vec_of(dtype) * (int)sizeof(float);
+#define BN_BWD(T, RELU)                                                                                                              \
+    do {                                                                                                                             \
+        hipLaunchKernelGGL((bn_bwd_sums_kernel<T, RELU>), grid, block, lds, st, (const T*)x, (const T*)dy, cols_p, part, R, C, g.cw); \
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), block, 0, st, part, g.slices, R, C, training, dgamma, dbeta, coef); \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RELU>), grid, block, 0, st, (const T*)x, (const T*)dy, cols_p, coef, (T*)dx, R, C, g.cw); \
+    } while (0)
+    if (dtype == XCLIP_BF16) { if (relu) BN_BWD(bf16_t, true); else BN_BWD(bf16_t, false); }
+    else                     { if (relu) BN_BWD(float, true); else BN_BWD(float, false); }
+#undef BN_BWD
+    return check_launch(__func__);
+}
+
+int xclip_neg_cosine_fwd(const void* p, const void* z, int64_t rows, int64_t dim, float coef, float* cosv, float* rp, float* rz,
+                         float* loss_accum, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec_of(dtype) == 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(p && z && cosv && rp && rz && loss_accum && aligned16(p) && aligned16(z), "null or misaligned pointer");
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((neg_cosine_fwd_kernel<bf16_t>), grid, block, 16, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)z, (int)rows, (int)dim, coef, cosv, rp, rz, loss_accum);
+    else
+        hipLaunchKernelGGL((neg_cosine_fwd_kernel<float>), grid, block, 16, (hipStream_t)stream, (const float*)p, (const float*)z, (int)rows, (int)dim, coef, cosv, rp, rz, loss_accum);
+    return check_launch(__func__);
+}
+
+int xclip_neg_cosine_bwd(const void* p, const void* z, const float* cosv, const float* rp, const float* rz, const float* gmul, float coef,
+                         void* dp, int64_t rows, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec_of(dtype) == 0, "dim must be a multiple of the 16-byte chunk");
+    XC_REQUIRE(p && z && cosv && rp && rz && gmul && dp && aligned16(p) && aligned16(z) && aligned16(dp), "null or misaligned pointer");
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((neg_cosine_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)z, cosv, rp, rz, gmul, coef, (bf16_t*)dp, (int)rows, (int)dim);
+    else
+        hipLaunchKernelGGL((neg_cosine_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)p, (const float*)z, cosv, rp, rz, gmul, coef, (float*)dp, (int)rows, (int)dim);
     return check_launch(__func__);
 }
 

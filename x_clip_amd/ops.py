@@ -601,3 +601,70 @@ def layernorm_chain_bwd(dh2: Tensor, x1: Tensor, g2: Tensor, mean2: Tensor, rstd
                                            rstd1.data_ptr(), dp.data_ptr(), dg2.data_ptr(), dg1.data_ptr(), ws.data_ptr(), wbytes, rows, dim,
                                            dtype_code(x1), _stream(x1)), "xclip_layernorm_chain_bwd")
     return dx1, dp
+
+
+# ---- visual self-supervision head ---------------------------------------------------------------------------------------
+
+
+def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
+    return None if t is None else _c(t.detach().float())
+
+
+def batchnorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                  momentum: float, eps: float, training: bool, relu: bool):
+    """BatchNorm1d (+ ReLU) over the rows of x [rows, cols] -> (y, mean, rstd); running_mean / running_var (fp32, contiguous) are
+    updated in place in training mode (visual_ssl.py:112-136)"""
+    _dev_check(x, gamma, beta, running_mean, running_var)
+    assert x.dim() == 2 and x.is_contiguous()
+    for r in (running_mean, running_var):
+        assert r is None or (r.dtype == torch.float32 and r.is_contiguous())
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(cols, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(cols, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    wbytes = L.xclip_batchnorm_workspace_bytes(rows, cols)
+    ws = workspace(x.device, wbytes)
+    _lib.check(L.xclip_batchnorm_fwd(x.data_ptr(), _ptr(gamma), _ptr(beta), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean),
+                                     _ptr(running_var), momentum, eps, int(training), int(relu), rows, cols, _ptr(ws), wbytes, dtype_code(x),
+                                     _stream(x)), "xclip_batchnorm_fwd")
+    return y, mean, rstd
+
+
+def batchnorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], mean: Tensor, rstd: Tensor, training: bool, relu: bool,
+                  need_affine_grads: bool):
+    """-> (dx, dgamma, dbeta); the last two fp32 [cols] or None"""
+    _dev_check(x, dy, gamma, beta, mean, rstd)
+    dy = _c(dy)
+    assert x.dim() == 2 and x.is_contiguous() and dy.shape == x.shape and dy.dtype == x.dtype
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(cols, dtype=torch.float32, device=x.device) if need_affine_grads else None
+    db = torch.empty(cols, dtype=torch.float32, device=x.device) if need_affine_grads else None
+    L = _lib.lib()
+    wbytes = L.xclip_batchnorm_workspace_bytes(rows, cols)
+    ws = workspace(x.device, wbytes)
+    _lib.check(L.xclip_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), _ptr(gamma), _ptr(beta), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                     _ptr(dg), _ptr(db), int(training), int(relu), rows, cols, _ptr(ws), wbytes, dtype_code(x), _stream(x)),
+               "xclip_batchnorm_bwd")
+    return dx, dg, db
+
+
+def neg_cosine_fwd(p: Tensor, z: Tensor, coef: float, loss_accum: Tensor):
+    """*loss_accum += coef sum_r (2 - 2 cos(p_r, z_r)) -> (cos, 1/|p|, 1/|z|) per row (visual_ssl.py:104-107)"""
+    _dev_check(p, z, loss_accum)
+    assert p.dim() == 2 and p.is_contiguous() and z.is_contiguous() and z.shape == p.shape and z.dtype == p.dtype
+    rows, dim = p.shape
+    st = [torch.empty(rows, dtype=torch.float32, device=p.device) for _ in range(3)]
+    _lib.check(_lib.lib().xclip_neg_cosine_fwd(p.data_ptr(), z.data_ptr(), rows, dim, coef, st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
+                                               loss_accum.data_ptr(), dtype_code(p), _stream(p)), "xclip_neg_cosine_fwd")
+    return st
+
+
+def neg_cosine_bwd(p: Tensor, z: Tensor, st, gmul: Tensor, coef: float) -> Tensor:
+    _dev_check(p, z, gmul)
+    assert gmul.dtype == torch.float32 and gmul.numel() == 1
+    dp = torch.empty_like(p)
+    _lib.check(_lib.lib().xclip_neg_cosine_bwd(p.data_ptr(), z.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), gmul.data_ptr(),
+                                               coef, dp.data_ptr(), p.shape[0], p.shape[1], dtype_code(p), _stream(p)), "xclip_neg_cosine_bwd")
+    return dp
