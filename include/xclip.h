@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 10
+#define XCLIP_ABI_VERSION 11
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -117,12 +117,14 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
 
 /* ---- fused attention (reference Attention.forward x_clip.py:213-245; dim_head = 64) -------------------------------
  * qkv [batch, n, 3, heads, 64] = output of the to_qkv Linear; mask [batch, n] bytes (1 = attend) or NULL;
- * out [batch, n, heads*64]; lse [batch, heads, n] fp32 saved for the backward.  scale = dim_head^-0.5. */
+ * out [batch, n, heads*64]; lse [batch, heads, n] fp32 saved for the backward.  scale = dim_head^-0.5.
+ * causal != 0: key j is hidden from query i when j > i (the causal text encoder, x_clip.py:231-234), on top of the key mask.
+ * A query with no visible key gets output 0 (the reference's softmax over all -max scores gives the uniform average there). */
 int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n,
-                        int64_t heads, float scale, int dtype, void* stream);
+                        int64_t heads, float scale, int causal, int dtype, void* stream);
 /* delta_ws: [batch, heads, n] fp32 scratch; dqkv [batch, n, 3, heads, 64] fully overwritten */
 int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
-                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int dtype,
+                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int causal, int dtype,
                         void* stream);
 
 /* ---- contrastive head (similarity + InfoNCE / DCL, x_clip.py:813-847) ---------------------------------------------

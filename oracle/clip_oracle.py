@@ -44,6 +44,8 @@ class ClipConfig:
     text_has_cls_token: bool = True
     text_pad_id: int = 0
     text_rotary_pos_emb: bool = False
+    text_causal_mask: bool = False              # autoregressive text encoder: no CLS token, causal attention, EOS pooling
+    text_eos_id: Optional[int] = None
     visual_enc_depth: int = 6
     visual_heads: int = 8
     visual_dim_head: int = 64
@@ -129,10 +131,10 @@ def apply_rotary(freqs: Tensor, t: Tensor) -> Tensor:
 
 
 def attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: int,
-              key_mask: Optional[Tensor], rotary: Optional[Tensor] = None) -> Tensor:
+              key_mask: Optional[Tensor], rotary: Optional[Tensor] = None, causal: bool = False) -> Tensor:
     """Attention.forward (x_clip.py:213-245): bias-free fused qkv projection, q scaled by
-    dim_head**-0.5, key padding mask, softmax in fp32 (or wider), bias-free out projection followed by a
-    LayerNorm."""
+    dim_head**-0.5, key padding mask, optional causal mask (:231-234), softmax in fp32 (or wider), bias-free out
+    projection followed by a LayerNorm."""
     b, n, _ = x.shape
     qkv = x @ sd[pfx + "to_qkv.weight"].t()                     # [b, n, 3*h*d]
     qkv = qkv.view(b, n, 3, heads, dim_head).permute(2, 0, 3, 1, 4)   # [3, b, h, n, d]
@@ -142,6 +144,8 @@ def attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: 
     scores = q @ k.transpose(-1, -2)                            # [b, h, n, n]
     if key_mask is not None:
         scores = scores.masked_fill(~key_mask[:, None, None, :], -torch.finfo(scores.dtype).max)
+    if causal:
+        scores = scores.masked_fill(torch.ones(n, n, dtype=torch.bool).triu(1), -torch.finfo(scores.dtype).max)
     sm_dtype = torch.float32 if scores.dtype != torch.float64 else torch.float64
     probs = torch.softmax(scores.to(sm_dtype), dim=-1).to(scores.dtype)
     o = (probs @ v).permute(0, 2, 1, 3).reshape(b, n, heads * dim_head)
@@ -158,14 +162,14 @@ def feed_forward(x: Tensor, sd: Dict[str, Tensor], pfx: str) -> Tensor:
 
 
 def transformer(x: Tensor, sd: Dict[str, Tensor], pfx: str, depth: int, heads: int, dim_head: int,
-                key_mask: Optional[Tensor], rotary: Optional[Tensor] = None) -> Tensor:
+                key_mask: Optional[Tensor], rotary: Optional[Tensor] = None, causal: bool = False) -> Tensor:
     """Transformer.forward (x_clip.py:274-291): norm_in, pre-norm residual attention + feed-forward
     blocks, norm_out."""
     x = layer_norm(x, sd[pfx + "norm_in.g"])
     for l in range(depth):
         a = f"{pfx}layers.{l}.0."
         f = f"{pfx}layers.{l}.1."
-        x = attention(layer_norm(x, sd[a + "norm.g"]), sd, a + "fn.", heads, dim_head, key_mask, rotary) + x
+        x = attention(layer_norm(x, sd[a + "norm.g"]), sd, a + "fn.", heads, dim_head, key_mask, rotary, causal) + x
         x = feed_forward(layer_norm(x, sd[f + "norm.g"]), sd, f + "fn.") + x
     return layer_norm(x, sd[pfx + "norm_out.g"])
 
@@ -184,12 +188,25 @@ def encode_text(sd: Dict[str, Tensor], cfg: ClipConfig, tokens: Tensor, mask: Op
         rotary = rotary_freqs(n + 1, cfg.text_dim_head)
     else:
         x = x + sd[pfx + "abs_pos_emb.weight"][:n][None]
-    cls = sd[pfx + "cls_token"].expand(b, 1, -1)
-    x = torch.cat([cls, x], dim=1)
-    if mask is not None:
-        mask = torch.cat([torch.ones(b, 1, dtype=torch.bool), mask], dim=1)
+    if not cfg.text_causal_mask:                                # the causal encoder has no CLS token (x_clip.py:314,332-337)
+        cls = sd[pfx + "cls_token"].expand(b, 1, -1)
+        x = torch.cat([cls, x], dim=1)
+        if mask is not None:
+            mask = torch.cat([torch.ones(b, 1, dtype=torch.bool), mask], dim=1)
     return transformer(x, sd, pfx + "transformer.", cfg.text_enc_depth, cfg.text_heads,
-                       cfg.text_dim_head, mask, rotary)
+                       cfg.text_dim_head, mask, rotary, cfg.text_causal_mask)
+
+
+def eos_to_front(enc: Tensor, tokens: Tensor, eos_id: int) -> Tensor:
+    """CLIP.forward's post-processing of the causal encoder (x_clip.py:670-685; the `b` those lines use is the batch size): the
+    encoding at each row's FIRST eos token moves to position 0, the remaining positions keep their order."""
+    b, n, _ = enc.shape
+    first = (tokens == eos_id).float().argmax(dim=-1)
+    rows = []
+    for i in range(b):
+        e = int(first[i])
+        rows.append(torch.cat([enc[i, e: e + 1], enc[i, :e], enc[i, e + 1:]], dim=0))
+    return torch.stack(rows)
 
 
 def patchify(image: Tensor, p: int) -> Tensor:
@@ -396,6 +413,8 @@ def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Te
     image = torch.cat([image, *aug_image], dim=0)
     text_mask = text != cfg.text_pad_id                                   # x_clip.py:614
     enc_t = encode_text(sd, cfg, text, text_mask)
+    if cfg.text_causal_mask:
+        enc_t = eos_to_front(enc_t, text, cfg.text_eos_id)
     enc_i = encode_image(sd, cfg, image, keep_idx)
     if cfg.use_all_token_embeds:                                          # x_clip.py:702-709
         et = enc_t[:, 1:] if cfg.text_has_cls_token else enc_t
@@ -489,7 +508,8 @@ def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
         shapes[pfx + "norm_out.g"] = (dim,)
 
     t = "text_transformer."
-    shapes[t + "cls_token"] = (cfg.dim_text,)
+    if not cfg.text_causal_mask:
+        shapes[t + "cls_token"] = (cfg.dim_text,)
     shapes[t + "token_emb.weight"] = (cfg.num_text_tokens + (1 if cfg.use_mlm else 0), cfg.dim_text)     # x_clip.py:487
     if cfg.text_rotary_pos_emb:                                 # buffer of RotaryEmbedding (x_clip.py:158-159)
         shapes[t + "rotary_pos_emb.inv_freq"] = (min(cfg.text_dim_head, 32) // 2,)
@@ -602,6 +622,10 @@ def make_inputs(cfg: ClipConfig, batch: int, seed: int, n_aug_text: int = 0, n_a
             k = (r * 7 + 1) % (pad_tail + 1)
             if k:
                 t[r, -k:] = cfg.text_pad_id
+            if cfg.text_causal_mask:                            # every row ends in the eos id (before its padding); row 1 has an
+                t[r, t.shape[1] - k - 1] = cfg.text_eos_id      # earlier one as well: the FIRST eos is the pooled position
+                if r == 1:
+                    t[r, 5] = cfg.text_eos_id
         return torch.tensor(t, dtype=torch.int64)
 
     def img():

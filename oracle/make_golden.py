@@ -17,7 +17,9 @@ The reference needs two work-arounds that do not touch the hot path (SURVEY.md s
   * `torchvision` (only used by visual_ssl.py's default augmentation pipeline) is stubbed in sys.modules; the SimSiam cases
     pass the oracle's two deterministic augmentation callables instead;
   * x_clip/distributed.py references `F` and `exists` without defining them; for the 2-rank case they
-    are injected into that module's namespace before use.
+    are injected into that module's namespace before use;
+  * the causal text encoder's EOS pooling (x_clip.py:683-684) reads an undefined name `b`; the batch size is injected into the
+    module namespace for the causal cases.
 """
 from __future__ import annotations
 
@@ -72,6 +74,8 @@ CASES = {
     "cfg1_simsiam": (dict(use_visual_ssl=True, ssl_projection_size=32, ssl_projection_hidden_size=64), 4, 0, 0, 0.0),
     "cfg1_simsiam_mlm_dcl": (dict(use_visual_ssl=True, image_ssl_loss_weight=0.3, ssl_projection_size=24, ssl_projection_hidden_size=48,
                                   use_mlm=True, decoupled_contrastive_learning=True), 5, 0, 0, 0.0),
+    "cfg1_causal": (dict(text_causal_mask=True, text_eos_id=999), 4, 0, 0, 0.0),
+    "cfg1_causal_dcl_multiview": (dict(text_causal_mask=True, text_eos_id=7, decoupled_contrastive_learning=True, extra_latent_projection=True), 4, 1, 1, 0.0),
     "cfg1_rotary": (dict(text_rotary_pos_emb=True), 4, 0, 0, 0.0),
     "cfg1_rotary_dcl_multiview": (dict(text_rotary_pos_emb=True, decoupled_contrastive_learning=True), 4, 1, 0, 0.0),
     "cfg1_simreg_extra": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.1), 4, 0, 0, 0.0),
@@ -131,6 +135,11 @@ def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropou
         masked_seq = text.clone().masked_fill(msk * replace, m.mask_token_id)
         mlm_rec = (masked_seq, labels)
         torch.manual_seed(drop_seed)
+    if cfg.text_causal_mask:
+        # CLIP.forward's EOS pooling (x_clip.py:683-684) reads a name `b` that the method never defines (its batch variable is called
+        # `batch`): the lookup falls through to the module globals, so the intended value -- the number of text rows -- is put there
+        import x_clip.x_clip as xx
+        xx.b = batch * (1 + n_aug_t)
     kw = {}
     if aug_t:
         kw["aug_text"] = tuple(aug_t)

@@ -136,7 +136,10 @@ def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_ima
     after = model.state_dict()
     for k, want in running.items():                             # SimSiam: BatchNorm running statistics after the step
         got = after[k].double().cpu()
-        assert float((got - want).norm() / want.norm()) < (2e-5 if fp32 else 2e-2), k
+        # (bf16: the statistics are stored in bf16 after each of the four passes, and a column MEAN is small against the spread of
+        #  the activations whose 1-2 % bf16 deviation it inherits: measure its error against sqrt(running_var))
+        scale = want.norm() if (fp32 or k.endswith("running_var")) else running[k[:-len("running_mean")] + "running_var"].sqrt().norm()
+        assert float((got - want).norm() / scale) < (2e-5 if fp32 else 2e-2), k
     assert abs(float(loss.detach()) - float(ref_loss)) < (1e-5 if fp32 else 2e-2) * max(1.0, abs(float(ref_loss))), (float(loss.detach()), float(ref_loss))
     for k, p in model.named_parameters():
         rg = ref_grads[k]
@@ -145,6 +148,9 @@ def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_ima
             continue
         g = p.grad.double().cpu()
         assert torch.isfinite(g).all(), k
+        if float(rg.norm()) < 1e-12:                            # mathematically zero (a Linear bias feeding a BatchNorm): round-off only
+            assert float(g.norm()) < (1e-5 if fp32 else 1e-2), (k, float(g.norm()))
+            continue
         rel = float((g - rg).norm() / rg.norm())
         cos = float((g * rg).sum() / (g.norm() * rg.norm()))
         if fp32:

@@ -162,17 +162,19 @@ def case_gemm(dev, dtype, M, N, K, layout, epilogue=False, alpha=1.0):
     close(c, r, dtype, f"gemm {layout} {M}x{N}x{K}", scale=max(scale, float(r.abs().max())))
 
 
-def _attention_ref(qkv64, mask, heads, scale):
+def _attention_ref(qkv64, mask, heads, scale, causal=False):
     b, n, _ = qkv64.shape
     q, k, v = qkv64.view(b, n, 3, heads, 64).permute(2, 0, 3, 1, 4)
     s = (q * scale) @ k.transpose(-1, -2)
     if mask is not None:
         s = s.masked_fill(~mask[:, None, None, :], -torch.finfo(s.dtype).max)
+    if causal:                                                  # x_clip.py:231-234
+        s = s.masked_fill(torch.ones(n, n, dtype=torch.bool).triu(1), -torch.finfo(s.dtype).max)
     p = torch.softmax(s, dim=-1)
     return (p @ v).permute(0, 2, 1, 3).reshape(b, n, heads * 64)
 
 
-def case_attention(dev, dtype, batch, n, heads, masked):
+def case_attention(dev, dtype, batch, n, heads, masked, causal=False):
     qkv = rnd((batch, n, 3 * heads * 64), dtype, 22)
     dout = rnd((batch, n, heads * 64), dtype, 23)
     mask = None
@@ -185,12 +187,12 @@ def case_attention(dev, dtype, batch, n, heads, masked):
             if n > 3:
                 mask[bi, 2] = bi % 2 == 0           # a hole in the middle as well
     scale = 64 ** -0.5
-    out, lse = ops.attention_fwd(qkv.to(dev), None if mask is None else mask.to(dev), heads, scale)
+    out, lse = ops.attention_fwd(qkv.to(dev), None if mask is None else mask.to(dev), heads, scale, causal)
     q64 = ref64(qkv).requires_grad_(True)
-    r = _attention_ref(q64, mask, heads, scale)
+    r = _attention_ref(q64, mask, heads, scale, causal)
     r.backward(ref64(dout))
     close(out, r, dtype, "attn out")
-    dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale)
+    dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale, causal)
     close(dqkv, q64.grad, dtype, "attn dqkv", mult=3.0)
 
 
@@ -502,7 +504,11 @@ def case_batchnorm(dev, dtype, rows, cols, relu, affine, training, offset=0.0):
     b64 = None if beta is None else ref64(beta).requires_grad_(True)
     rm64, rv64 = ref64(rm0).clone(), ref64(rv0).clone()
     z = F.batch_norm(x64, rm64, rv64, g64, b64, training, mom, eps)
-    want = torch.relu(z) if relu else z
+    # a pre-activation within rounding of 0 may take either side of the ReLU (at 70000 x 4096 a handful do, and each moves a column sum
+    # by O(1)): the reference uses the side the kernel took
+    want = z * (y.detach().cpu() > 0).double() if relu else z
+    if relu:
+        assert float((torch.relu(z.detach()) - want.detach()).abs().max()) < (1e-5 if dtype == torch.float32 else 1e-2)
     (want * ref64(dy)).sum().backward()
     close(y, want, dtype, "bn y", mult=2.0)
     if training:
@@ -510,10 +516,7 @@ def case_batchnorm(dev, dtype, rows, cols, relu, affine, training, offset=0.0):
         close(rv, rv64, torch.float32, "bn running_var", mult=5.0)
     else:
         assert torch.equal(rm.cpu(), rm0) and torch.equal(rv.cpu(), rv0)
-    # elements whose pre-activation sits within rounding of 0 may take either side of the ReLU: exclude them from the comparison
-    live = torch.ones_like(want, dtype=torch.bool) if not relu else (z.detach().abs() > 1e-4)
-    gscale = float(x64.grad.abs().max())
-    close(torch.where(live, dx.detach().cpu().double(), x64.grad), x64.grad, dtype, "bn dx", scale=gscale, mult=4.0)
+    close(dx, x64.grad, dtype, "bn dx", mult=4.0)
     if affine:
         close(dg, g64.grad, dtype, "bn dgamma", mult=4.0)
         close(db, b64.grad, dtype, "bn dbeta", mult=4.0)

@@ -73,6 +73,18 @@ def test_attention(dtype, n, masked):
     K.case_attention(DEV, dtype, 2, n, 2, masked)
 
 
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("n,masked", [(65, False), (97, True), (32, True)])
+def test_attention_causal(dtype, n, masked):
+    K.case_attention(DEV, dtype, 2, n, 2, masked, causal=True)
+
+
+@pytest.mark.parametrize("n", [257, 320])
+def test_attention_causal_long_bf16(n):
+    """n = 257: the cooperative-tail path of the head-resident kernels; n = 320: the tiled kernels for long sequences"""
+    K.case_attention(DEV, torch.bfloat16, 1, n, 1, True, causal=True)
+
+
 def test_attention_rescale_spike():
     K.case_attention_spike(DEV, torch.float32)
 

@@ -75,6 +75,12 @@ def test_attention(dtype, n, heads, masked):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("n,heads,masked", [(65, 2, False), (256, 8, True), (257, 4, True), (97, 3, True), (32, 2, True), (288, 2, False), (320, 2, True)])
+def test_attention_causal(dtype, n, heads, masked):
+    K.case_attention(DEV, dtype, 3, n, heads, masked, causal=True)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 def test_attention_rescale_spike(dtype):
     K.case_attention_spike(DEV, dtype)
 

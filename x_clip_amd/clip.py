@@ -7,8 +7,8 @@ draws the same initial weights as the reference) -- but the modules are paramete
 the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is no CPU / ATen fallback; tensors must live
 on an MI355X.
 
-Not on this path (constructor raises NotImplementedError): causal text encoder (broken in the
-reference itself), the SimCLR variant of the visual-SSL side loss.
+Not on this path (constructor raises NotImplementedError): the SimCLR variant of the visual-SSL side
+loss; the causal text encoder together with rotary embeddings, FILIP or MLM (each fails inside the reference's own forward).
 """
 from __future__ import annotations
 
@@ -77,8 +77,6 @@ class Attention(nn.Module):
 
     def __init__(self, dim, dim_head=64, heads=8, causal=False, dropout=0.):
         super().__init__()
-        if causal:
-            raise NotImplementedError("causal attention is not on the accelerated path yet (SURVEY.md 8(f))")
         if dropout != 0.:
             raise NotImplementedError("attn_dropout != 0 is not on the accelerated path (reference default 0)")
         self.heads = heads
@@ -97,7 +95,7 @@ class Transformer(nn.Module):
                  checkpoint_during_training=False):
         super().__init__()
         self.checkpoint_during_training = checkpoint_during_training
-        self.dim, self.depth, self.heads, self.dim_head = dim, depth, heads, dim_head
+        self.dim, self.depth, self.heads, self.dim_head, self.causal = dim, depth, heads, dim_head, causal
         self.layers = nn.ModuleList([])
         for _ in range(depth):
             self.layers.append(nn.ModuleList([
@@ -118,7 +116,7 @@ class Transformer(nn.Module):
 
     def spec(self, rotary: Optional[Tensor] = None) -> XF.StackSpec:
         return XF.StackSpec(depth=self.depth, heads=self.heads, dim_head=self.dim_head,
-                            checkpoint=bool(self.training and self.checkpoint_during_training), rotary=rotary)
+                            checkpoint=bool(self.training and self.checkpoint_during_training), rotary=rotary, causal=self.causal)
 
     def forward(self, x, rotary_pos_emb=None, mask=None):
         if exists(rotary_pos_emb):
@@ -151,17 +149,18 @@ class RotaryEmbedding(nn.Module):
 
 
 class TextTransformer(nn.Module):
-    """reference TextTransformer (x_clip.py:295-338): forward(x int64 [b, n], mask bool [b, n]) -> [b, n+1, dim]"""
+    """reference TextTransformer (x_clip.py:295-338): forward(x int64 [b, n], mask bool [b, n]) -> [b, n+1, dim]; with causal = True
+    there is no CLS token (x_clip.py:314) and the output is [b, n, dim]"""
 
     def __init__(self, dim, *, num_tokens, max_seq_len, dim_head, rotary_pos_emb=None, causal=False, **kwargs):
         super().__init__()
-        if causal:
-            raise NotImplementedError("text_causal_mask is not on the accelerated path yet (SURVEY.md 8(f); the reference "
-                                      "path itself raises NameError, x_clip.py:683-684)")
+        if causal and rotary_pos_emb:
+            raise NotImplementedError("causal + rotary text encoder: the reference builds its angle table for n + 1 positions (x_clip.py:330) "
+                                      "but a causal encoder has n (no CLS token), so its own forward fails with a shape error")
         self.token_emb = nn.Embedding(num_tokens, dim)
         self.abs_pos_emb = nn.Embedding(max_seq_len, dim) if not rotary_pos_emb else None      # x_clip.py:311-312
         self.rotary_pos_emb = RotaryEmbedding(min(dim_head, 32)) if rotary_pos_emb else None
-        self.cls_token = nn.Parameter(torch.randn(dim))
+        self.cls_token = nn.Parameter(torch.randn(dim)) if not causal else None            # x_clip.py:314
         self.transformer = Transformer(dim, dim_head=dim_head, causal=causal, **kwargs)
 
     def forward(self, x, mask=None):
@@ -290,6 +289,11 @@ class CLIP(nn.Module):
         self.text_eos_id = text_eos_id
 
         assert not (text_causal_mask and not exists(text_eos_id)), 'text EOS token id must be given if using causal mask in text transformer'
+        if text_causal_mask and (use_all_token_embeds or use_mlm):
+            # both fail inside the reference's own forward: the causal encoder has no CLS token, so `[:, 1:]` leaves n - 1 tokens against
+            # an n-wide text mask (x_clip.py:705 -> size error in the FILIP einsum) / n-wide MLM labels (mlm.py:100-107)
+            raise NotImplementedError("text_causal_mask together with use_all_token_embeds or use_mlm fails in the reference's own forward "
+                                      "(token count n - 1 against an n-wide mask / label tensor)")
 
         if exists(text_encoder):
             self.text_transformer = text_encoder
@@ -458,6 +462,9 @@ class CLIP(nn.Module):
         else:
             enc_text = model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze_text_encoder)
             enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
+
+        if self.text_causal_mask:                                                          # x_clip.py:670-685 (its `b` is the batch size)
+            enc_text = XF.eos_to_front(enc_text, text, self.text_eos_id)
 
         if return_encodings:                                                               # x_clip.py:697-698
             return enc_text, enc_image

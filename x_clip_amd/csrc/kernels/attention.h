@@ -39,6 +39,7 @@ struct AttnParams {
     int batch, n, heads;
     float scale;
     int chunks;                  // row chunks (of NW*32) per (batch, head)
+    int causal;                  // != 0: key j is visible to query i only if j <= i (reference Attention.forward, x_clip.py:231-234)
 };
 
 template <typename T>
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     const int q0 = (qc * NW + wave) * 32;
     const int qrow = q0 + c31;
     const int qld = qrow < n ? qrow : n - 1;
+    const int qlim = p.causal ? qrow : 0x7fffffff;         // last key this lane's query may attend to
     u32x4 qf[C::DKB];
 #pragma unroll
     for (int kb = 0; kb < C::DKB; ++kb) qf[kb] = ld16(Qb + (long)qld * ldq + kb * C::KB + h * C::VEC);
@@ -171,7 +173,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float sv = Ms[t * 32 + mfma_row(r, lane)] ? s[t][r] * p.scale : ATT_NEG;
+                const int kj = t * 32 + mfma_row(r, lane);
+                    const float sv = (Ms[kj] && kt0 + kj <= qlim) ? s[t][r] * p.scale : ATT_NEG;
                 s[t][r] = sv;
                 mx = fmaxf(mx, sv);
             }
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_kernel(AttnParams p) {
     const int q0 = (qc * NW + wave) * 32;
     const int qrow = q0 + c31;
     const int qld = qrow < n ? qrow : n - 1;
+    const int qlim = p.causal ? qrow : 0x7fffffff;         // last key this lane's query may attend to
     u32x4 qf[C::DKB], dof[C::DKB];
 #pragma unroll
     for (int kb = 0; kb < C::DKB; ++kb) {
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_kernel(AttnParams p) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = Ms[t * 32 + mfma_row(r, lane)] ? fast_exp(s[r] * p.scale - lse_q) : 0.f;
+                const int kj = t * 32 + mfma_row(r, lane);
+                    const float pv = (Ms[kj] && kt0 + kj <= qlim) ? fast_exp(s[r] * p.scale - lse_q) : 0.f;
                 s[r] = pv * (dp[r] - delta_q) * p.scale;                       // dS^T (already times the q scale)
             }
 #pragma unroll
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(AttnParams p) {
     const int krow = k0 + c31;
     const int kld = krow < n ? krow : n - 1;
     const bool kvalid = krow < n && (p.mask == nullptr || p.mask[(long)bi * n + kld] != 0);
+    const int kmin = p.causal ? krow : 0;                  // first query that may attend to this lane's key
     u32x4 kf[C::DKB], vf[C::DKB];
 #pragma unroll
     for (int kb = 0; kb < C::DKB; ++kb) {
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = t * 32 + mfma_row(r, lane);
-                const float pv = (kvalid && qt0 + ql < n) ? fast_exp(s[r] * p.scale - Ls[ql]) : 0.f;
+                const float pv = (kvalid && qt0 + ql < n && qt0 + ql >= kmin) ? fast_exp(s[r] * p.scale - Ls[ql]) : 0.f;
                 s[r] = pv;                                                     // P
                 dp[r] = pv * (dp[r] - Ds[ql]) * p.scale;                       // dS (times the q scale)
             }

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(NW * 64) void attn2_fwd_kernel(AttnParams p) {
     const int q0 = (qc * NW + wave) * 32;
     const int qrow = q0 + c31;
     const int qld = qrow < n ? qrow : n - 1;
+    const int qlim = p.causal ? qrow : 0x7fffffff;         // last key this lane's query may attend to
     u32x4 qf[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) qf[kb] = ld16(Qb + (long)qld * ldq + kb * 16 + h * 8);
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(NW * 64) void attn2_fwd_kernel(AttnParams p) {
                 for (int kb = 0; kb < 4; ++kb) s[t] = mma_kblock(a2_row_frag(Ks, t * 32 + c31, kb, h), qf[kb], s[t], (bf16_t*)nullptr);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float sv = Ms[t * 32 + mfma_row(r, lane)] ? s[t][r] * p.scale : ATT_NEG;
+                    const int kj = t * 32 + mfma_row(r, lane);
+                    const float sv = (Ms[kj] && kt0 + kj <= qlim) ? s[t][r] * p.scale : ATT_NEG;
                     s[t][r] = sv;
                     mx = fmaxf(mx, sv);
                 }
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(NW * 64) void attn2_dq_kernel(AttnParams p) {
     const int q0 = (qc * NW + wave) * 32;
     const int qrow = q0 + c31;
     const int qld = qrow < n ? qrow : n - 1;
+    const int qlim = p.causal ? qrow : 0x7fffffff;         // last key this lane's query may attend to
     u32x4 qf[4], dof[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(NW * 64) void attn2_dq_kernel(AttnParams p) {
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = Ms[t * 32 + mfma_row(r, lane)] ? fast_exp(s[r] * p.scale - lse_q) : 0.f;
+                    const int kj = t * 32 + mfma_row(r, lane);
+                    const float pv = (Ms[kj] && kt0 + kj <= qlim) ? fast_exp(s[r] * p.scale - lse_q) : 0.f;
                     s[r] = pv * (dp[r] - delta_q) * p.scale;                   // dS^T (already times the q scale)
                 }
 #pragma unroll
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(NW * 64) void attn2_dkv_kernel(AttnParams p) {
     const int krow = k0 + c31;
     const int kld = krow < n ? krow : n - 1;
     const bool kvalid = krow < n && (p.mask == nullptr || p.mask[(long)bi * n + kld] != 0);
+    const int kmin = p.causal ? krow : 0;                  // first query that may attend to this lane's key
     u32x4 kf[4], vf[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(NW * 64) void attn2_dkv_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = t * 32 + mfma_row(r, lane);
-                    const float pv = (kvalid && qt0 + ql < n) ? fast_exp(s[r] * p.scale - Ls[ql]) : 0.f;
+                    const float pv = (kvalid && qt0 + ql < n && qt0 + ql >= kmin) ? fast_exp(s[r] * p.scale - Ls[ql]) : 0.f;
                     s[r] = pv;                                                     // P
                     dp[r] = pv * (dp[r] - Ds[ql]) * p.scale;                       // dS (times the q scale)
                 }

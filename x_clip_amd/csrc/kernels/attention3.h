@@ -47,9 +47,11 @@ constexpr int A3_TAIL_REC = 66;                                // floats per (wa
 // over the raw accumulators), p = exp2(fma(s, scale2, -m2)) is one fma + one bare v_exp_f32 per score, and the key-validity
 // selects are only compiled into the MASKED variant -- the caller votes per sub-tile (all keys valid: plain path; none: the
 // sub-tile is skipped, its probabilities are exactly 0).
-template <bool MASKED>
+// CAUSAL (reference Attention.forward, x_clip.py:231-234: key j is hidden from query i when j > i) adds the comparison against
+// the lane's own query index qidx -- compiled only into the sub-tiles that straddle the diagonal.
+template <bool MASKED, bool CAUSAL>
 XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
-                        float scale2, int lane, f32x16 (&o)[2], float& m2, float& l) {
+                        float scale2, int lane, int qidx, f32x16 (&o)[2], float& m2, float& l) {
     const int h = lane >> 5, c31 = lane & 31;
     f32x16 s;
 #pragma unroll
@@ -60,7 +62,7 @@ XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const 
     float mx = ATT_NEG;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        valid[r] = !MASKED || Ms[t * 32 + mfma_row(r, lane)] != 0;
+        valid[r] = (!MASKED || Ms[t * 32 + mfma_row(r, lane)] != 0) && (!CAUSAL || t * 32 + mfma_row(r, lane) <= qidx);
         mx = fmaxf(mx, valid[r] ? s[r] : ATT_NEG);
     }
     mx = fmaxf(mx, shfl_xor(mx, 32));
@@ -70,7 +72,7 @@ XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float pv = fast_exp2(s[r] * scale2 - m_new);
-        if (MASKED) pv = valid[r] ? pv : 0.f;
+        if (MASKED || CAUSAL) pv = valid[r] ? pv : 0.f;
         s[r] = pv;
         rs += pv;
     }
@@ -88,16 +90,24 @@ XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const 
         for (int db = 0; db < 2; ++db) o[db] = mma_kblock(a2_col_frag(Vs, t, blk, db, lane), pf, o[db], (bf16_t*)nullptr);
     }
 }
-// votes on the sub-tile's key validity and runs the matching variant
+// votes on the sub-tile's key validity and runs the matching variant; with CAUSAL the wave's queries are [qlo, qlo + 32): sub-tiles
+// entirely above the diagonal are skipped, the ones straddling it take the per-element comparison
+template <bool CAUSAL>
 XC_DEV void a3_fwd_step_auto(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
-                             float scale2, int lane, f32x16 (&o)[2], float& m2, float& l) {
+                             float scale2, int lane, int qlo, f32x16 (&o)[2], float& m2, float& l) {
+    const int qidx = qlo + (lane & 31);
+    if (CAUSAL) {
+        if (t * 32 > qlo + 31) return;
+        if (t * 32 + 31 > qlo) { a3_fwd_step<true, true>(Ks, Vs, Ms, t, qf, scale2, lane, qidx, o, m2, l); return; }
+    }
     const bool kv = Ms[t * 32 + (lane & 31)] != 0;
-    if (wave_all(kv)) a3_fwd_step<false>(Ks, Vs, Ms, t, qf, scale2, lane, o, m2, l);
-    else if (wave_any(kv)) a3_fwd_step<true>(Ks, Vs, Ms, t, qf, scale2, lane, o, m2, l);
+    if (wave_all(kv)) a3_fwd_step<false, false>(Ks, Vs, Ms, t, qf, scale2, lane, qidx, o, m2, l);
+    else if (wave_any(kv)) a3_fwd_step<true, false>(Ks, Vs, Ms, t, qf, scale2, lane, qidx, o, m2, l);
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------------
 // (at most 128 VGPRs: two 8-wave work-groups of ~78 KB LDS share a CU)
+template <bool CAUSAL>
 __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(AttnParams p) {
     XC_LDS_DYNAMIC(lds);
     const int n = p.n, npad = (n + 31) & ~31;
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
         float m = ATT_NEG, l = 0.f;
-        for (int t = wave; t < nsub; t += nwaves) a3_fwd_step_auto(Ks, Vs, Ms, t, qf, scale2, lane, o, m, l);
+        for (int t = wave; t < nsub; t += nwaves) a3_fwd_step_auto<CAUSAL>(Ks, Vs, Ms, t, qf, scale2, lane, tail0, o, m, l);
         if (c31 < ntail) {
             float* rec = Ts + ((long)wave * A3_TAIL_MAX + c31) * A3_TAIL_REC;
             if (h == 0) { rec[0] = m; rec[1] = l; }
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m = ATT_NEG, l = 0.f;
-    for (int t = 0; t < nsub; ++t) a3_fwd_step_auto(Ks, Vs, Ms, t, qf, scale2, lane, o, m, l);
+    for (int t = 0; t < nsub; ++t) a3_fwd_step_auto<CAUSAL>(Ks, Vs, Ms, t, qf, scale2, lane, q0, o, m, l);
     sync();                                                    // every wave is done with the K / V images (and the tail partials are in)
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     a2_store_rows(lds + wave * 32 * 144, o, inv, out, (long)p.heads * ATT_DH, q0, n, lane);
@@ -180,8 +190,10 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
 // ---- backward (dQ, dK, dV and delta in one kernel) ------------------------------------------------------------------------
 // phase A body: dQ^T[d, query] += K^T dS^T for the 32 queries whose fragments are (qf, dof) against key sub-tile t
 // (lse2_q = lse_q log2(e) and scale2 = scale log2(e): the probability is one fma + a bare v_exp_f32)
+template <bool CAUSAL>
 XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
-                           const u32x4 (&dof)[4], float lse2_q, float delta_q, float scale, float scale2, int lane, f32x16 (&dq)[2]) {
+                           const u32x4 (&dof)[4], float lse2_q, float delta_q, float scale, float scale2, int lane, int qidx,
+                           f32x16 (&dq)[2]) {
     const int h = lane >> 5, c31 = lane & 31;
     f32x16 s, dp;
 #pragma unroll
@@ -193,7 +205,8 @@ XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Vs, con
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float pv = Ms[t * 32 + mfma_row(r, lane)] ? fast_exp2(s[r] * scale2 - lse2_q) : 0.f;
+        const int kj = t * 32 + mfma_row(r, lane);
+        const float pv = (Ms[kj] && (!CAUSAL || kj <= qidx)) ? fast_exp2(s[r] * scale2 - lse2_q) : 0.f;
         s[r] = pv * (dp[r] - delta_q) * scale;                                 // dS^T (already times the q scale)
     }
 #pragma unroll
@@ -204,8 +217,9 @@ XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Vs, con
     }
 }
 // phase B body: dK^T, dV^T for the 32 keys whose fragments are (kf, vf) against query sub-tile t
+template <bool CAUSAL>
 XC_DEV void a3_bwd_dkv_step(const unsigned char* Qs, const unsigned char* dOs, const float* Ls2, const float* Ds, int t, int n,
-                            const u32x4 (&kf)[4], const u32x4 (&vf)[4], bool kvalid, float scale, float scale2, int lane,
+                            const u32x4 (&kf)[4], const u32x4 (&vf)[4], bool kvalid, float scale, float scale2, int lane, int kidx,
                             f32x16 (&dk)[2], f32x16 (&dv)[2]) {
     const int h = lane >> 5, c31 = lane & 31;
     f32x16 s, dp;
@@ -231,7 +245,7 @@ XC_DEV void a3_bwd_dkv_step(const unsigned char* Qs, const unsigned char* dOs, c
     for (int r = 0; r < 16; ++r) {
         const int ql = t * 32 + mfma_row(r, lane);
         float pv = fast_exp2(s[r] * scale2 - l2[r]);
-        pv = (kvalid && (full || ql < n)) ? pv : 0.f;
+        pv = (kvalid && (full || ql < n) && (!CAUSAL || ql >= kidx)) ? pv : 0.f;
         s[r] = pv;                                                             // P
         dp[r] = pv * (dp[r] - dl[r]) * scale;                                  // dS (times the q scale)
     }
@@ -291,6 +305,7 @@ XC_DEV void a3_row_frags(const bf16_t* X, long ldx, int r, int lane, u32x4 (&f)[
 // of 160: TWO work-groups of four waves per CU (each wave takes every fourth 32-row block), one computing while the other
 // waits for HBM.  (The one-work-group-per-CU version measured load + store skeleton 405 us, phase A 225, phase B 395, total
 // 1060 = their sum at n = 256.)  p.chunks is a measurement switch here (XCLIP_ATTN_ABL: 1 = skip phase A, 2 = skip phase B).
+template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
     XC_LDS_DYNAMIC(lds);
     const int n = p.n, npad = (n + 31) & ~31;
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g0[db][r] = 0.f;
             const float lq = Ls[tail0 + c31], dl = Ds[tail0 + c31];
-            for (int t = wave; t < nsub; t += nwaves) a3_bwd_dq_step(R0, R1, Ms, t, f0, f1, lq, dl, p.scale, scale2, lane, g0);
+            for (int t = wave; t < nsub; t += nwaves) a3_bwd_dq_step<CAUSAL>(R0, R1, Ms, t, f0, f1, lq, dl, p.scale, scale2, lane, tail0 + c31, g0);
             if (c31 < ntail) a3_put_col(Tp + ((long)wave * A3_TAIL_MAX + c31) * 128, g0, lane);
         }
         for (int rb = wave; rb < nblk; rb += nwaves) {
@@ -370,7 +385,8 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g0[db][r] = 0.f;
             const float lse_q = Ls[row], delta_q = Ds[row];
-            for (int t = 0; t < nsub; ++t) a3_bwd_dq_step(R0, R1, Ms, t, f0, f1, lse_q, delta_q, p.scale, scale2, lane, g0);
+            const int tend = CAUSAL ? (rb + 1 < nsub ? rb + 1 : nsub) : nsub;      // key sub-tiles above the diagonal contribute nothing
+            for (int t = 0; t < tend; ++t) a3_bwd_dq_step<CAUSAL>(R0, R1, Ms, t, f0, f1, lse_q, delta_q, p.scale, scale2, lane, row, g0);
             a3_store_rows_direct(g0, dQ, ldq, rb * 32, n, lane);
         }
     }
@@ -399,7 +415,8 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { g0[db][r] = 0.f; g1[db][r] = 0.f; }
-            for (int t = 0; t < nsub; ++t) a3_bwd_dkv_step(R0, R1, Ls, Ds, t, n, f0, f1, kvalid, p.scale, scale2, lane, g0, g1);
+            for (int t = CAUSAL ? rb : 0; t < nsub; ++t)                           // query sub-tiles below the diagonal see none of these keys
+                a3_bwd_dkv_step<CAUSAL>(R0, R1, Ls, Ds, t, n, f0, f1, kvalid, p.scale, scale2, lane, row, g0, g1);
             a3_store_rows_direct(g0, dK, ldq, rb * 32, n, lane);
             a3_store_rows_direct(g1, dV, ldq, rb * 32, n, lane);
         }
@@ -412,7 +429,8 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { g0[db][r] = 0.f; g1[db][r] = 0.f; }
-            for (int t = wave; t < nsub; t += nwaves) a3_bwd_dkv_step(R0, R1, Ls, Ds, t, n, f0, f1, tvalid, p.scale, scale2, lane, g0, g1);
+            for (int t = wave; t < nsub; t += nwaves)
+                a3_bwd_dkv_step<CAUSAL>(R0, R1, Ls, Ds, t, n, f0, f1, tvalid, p.scale, scale2, lane, tail0 + c31, g0, g1);
             if (c31 < ntail) {
                 float* rec = Tp + ((long)wave * A3_TAIL_MAX + c31) * 128;
                 a3_put_col(rec, g0, lane);

@@ -59,7 +59,7 @@ int attn_waves(int64_t n) {
 extern "C" {
 
 int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n, int64_t heads,
-                        float scale, int dtype, void* stream) {
+                        float scale, int causal, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
     XC_REQUIRE(aligned16(qkv) && aligned16(out), "pointers must be 16-byte aligned");
@@ -67,13 +67,18 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     AttnParams p;
     memset(&p, 0, sizeof(p));
     p.qkv = qkv; p.mask = mask; p.out = out; p.lse = lse;
-    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
+    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale; p.causal = causal != 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // head-resident kernel: one work-group per (batch, head)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
-        XC_ALLOW_LDS(attn3_fwd_kernel, 160 * 1024);
         const int nwq = a3_waves((int)n);
-        hipLaunchKernelGGL(attn3_fwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
+        if (causal) {
+            XC_ALLOW_LDS(attn3_fwd_kernel<true>, 160 * 1024);
+            hipLaunchKernelGGL(attn3_fwd_kernel<true>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
+        } else {
+            XC_ALLOW_LDS(attn3_fwd_kernel<false>, 160 * 1024);
+            hipLaunchKernelGGL(attn3_fwd_kernel<false>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
+        }
         return check_launch(__func__);
     }
     const int nw = attn_waves(n);
@@ -88,7 +93,8 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
 }
 
 int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
-                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int dtype, void* stream) {
+                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int causal, int dtype,
+                        void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
     XC_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "pointers must be 16-byte aligned");
@@ -97,15 +103,20 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     memset(&p, 0, sizeof(p));
     p.qkv = qkv; p.mask = mask; p.out = const_cast<void*>(out); p.lse = const_cast<float*>(lse); p.dout = dout;
     p.delta = delta_ws; p.dqkv = dqkv;
-    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale;
+    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale; p.causal = causal != 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         const int nwq = a3_bwd_waves((int)n);
         static const int abl = [] { const char* e = getenv("XCLIP_ATTN_ABL"); return e ? atoi(e) : 0; }();   // measurement only
         p.chunks = abl;
-        XC_ALLOW_LDS(attn3_bwd_kernel, 160 * 1024);
-        hipLaunchKernelGGL(attn3_bwd_kernel, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
+        if (causal) {
+            XC_ALLOW_LDS(attn3_bwd_kernel<true>, 160 * 1024);
+            hipLaunchKernelGGL(attn3_bwd_kernel<true>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
+        } else {
+            XC_ALLOW_LDS(attn3_bwd_kernel<false>, 160 * 1024);
+            hipLaunchKernelGGL(attn3_bwd_kernel<false>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_bwd_lds_bytes((int)n), st, p);
+        }
         return check_launch(__func__);
     }
     dim3 dgrid((unsigned)((batch * n + 3) / 4)), dblock(256);

@@ -88,6 +88,7 @@ class StackSpec:
     dim_head: int = 64
     checkpoint: bool = False
     rotary: Optional[Tensor] = None         # rotary embedding on q, k, v: the inv_freq buffer (16 fp32), x_clip.py:155-176,221-223
+    causal: bool = False                    # causal attention (the autoregressive text encoder), x_clip.py:231-234
 
     def __post_init__(self):
         if self.dim_head != 64:
@@ -111,7 +112,8 @@ class _GainGrads:
 
 
 # ---- one pre-norm residual block pair (x_clip.py:285-289) --------------------------------------------------------------
-def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor], rotary: Optional[Tensor] = None):
+def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor], rotary: Optional[Tensor] = None,
+                   causal: bool = False):
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     M, D = x.shape
     inner = heads * 64
@@ -119,7 +121,7 @@ def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, m
     qkv = ops.gemm(h, w_qkv, M, 3 * inner, D)                                          # to_qkv            :216
     if rotary is not None:
         ops.rotary_(qkv, n, rotary)                                                            # q, k, v rotated   :221-223
-    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, 64 ** -0.5)     # scale/mask/softmax :217-244
+    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, 64 ** -0.5, causal)   # scale/mask/softmax :217-244
     p = ops.gemm(o.view(M, inner), w_out, M, D, inner)                                 # to_out.0          :245
     x1, m2, r2, h2, m3, r3 = ops.layernorm_chain_fwd(p, g_out, x, g_ff)                # to_out.1 + skip :245,288 and PreNorm :126, one pass
     u = ops.gemm(h2, w_ff1, M, w_ff1.shape[0], D)                                      # net.0             :191
@@ -129,7 +131,8 @@ def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, m
 
 
 def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
-                    gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm", rotary: Optional[Tensor] = None):
+                    gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm", rotary: Optional[Tensor] = None,
+                    causal: bool = False):
     """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2])"""
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     dg_attn, dg_out, dg_ff, dg_inner = gain_acc
@@ -152,7 +155,7 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     do = ops.gemm(dp, w_out, M, inner, D, b_kmajor=True)
     d_out = sg.wgrad(dp, o.view(M, inner), D, inner, M) if need_w[1] else None
     del dp
-    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, 64 ** -0.5)
+    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, 64 ** -0.5, causal)
     del do
     if rotary is not None:
         ops.rotary_(dqkv.view(M, 3 * inner), n, rotary, inverse=True)      # the saved qkv is the rotated one; R^T maps its gradient back
@@ -173,7 +176,7 @@ def stack_forward(x0: Tensor, B: int, n: int, spec: StackSpec, params: Sequence[
     layers = []
     for l in range(spec.depth):
         W = params[1 + LAYER_PARAMS * l: 1 + LAYER_PARAMS * (l + 1)]
-        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary)
+        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary, spec.causal)
         if keep_tape:
             layers.append((saved[0],) if spec.checkpoint else saved)
         x = x_next
@@ -196,9 +199,9 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
         W = params[base: base + LAYER_PARAMS]
         saved = layers[l]
         if spec.checkpoint:                      # re-run the layer forward from its saved input
-            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary)
+            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary, spec.causal)
         need_w = [need[base + 1], need[base + 2], need[base + 5], need[base + 7]]
-        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary)
+        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal)
         layers[l] = None                         # release this layer's activations
         sg.layer_done()
         grads[base + 1], grads[base + 2], grads[base + 5], grads[base + 7] = dws
@@ -494,3 +497,36 @@ class _SelectRowFn(torch.autograd.Function):
 
 def select_row(enc: Tensor, index: int = 0) -> Tensor:
     return _SelectRowFn.apply(enc, index)
+
+
+class _PermuteRowsFn(torch.autograd.Function):
+    """out[r] = x[idx[r]] for a PERMUTATION idx of the rows of x [rows, D]; the backward gathers with the inverse permutation"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, idx: Tensor, inv: Tensor):
+        ctx.save_for_backward(inv)
+        return ops.gather_rows(x, idx)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (inv,) = ctx.saved_tensors
+        return ops.gather_rows(ops._c(dout), inv), None, None
+
+
+def eos_to_front(enc: Tensor, tokens: Tensor, eos_id: int) -> Tensor:
+    """the causal text encoder's pooling (x_clip.py:670-685): per sample, the encoding at the FIRST eos token moves to position 0
+    and the other positions follow in their original order.  The index bookkeeping is integer work on the [b, n] token tensor;
+    the rows move through xclip_gather_rows."""
+    B, n, D = enc.shape
+    is_eos = tokens == eos_id
+    assert torch.all(torch.any(is_eos, dim=-1)), f'some of the text rows does not have the eos id {eos_id}'
+    e = is_eos.float().argmax(dim=-1, keepdim=True)                           # first eos per row                  x_clip.py:675
+    j = torch.arange(n, device=tokens.device)[None]
+    src = torch.where(j == 0, e, torch.where(j <= e, j - 1, j))               # out position j <- source position
+    base = torch.arange(B, device=tokens.device)[:, None] * n
+    idx = (src + base).reshape(-1)
+    inv = torch.empty_like(idx)
+    inv[idx] = torch.arange(B * n, device=tokens.device)
+    out = _PermuteRowsFn.apply(ops._c(enc).view(B * n, D), idx.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous())
+    return out.view(B, n, D)

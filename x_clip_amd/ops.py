@@ -346,8 +346,8 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
 
 
 # ---- attention --------------------------------------------------------------------------------------------------------
-def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float) -> Tuple[Tensor, Tensor]:
-    """qkv [b, n, 3*heads*64]; mask bool [b, n] or None -> out [b, n, heads*64], lse fp32 [b, heads, n]"""
+def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float, causal: bool = False) -> Tuple[Tensor, Tensor]:
+    """qkv [b, n, 3*heads*64]; mask bool [b, n] or None; causal: key j hidden from query i < j -> out [b, n, heads*64], lse fp32 [b, heads, n]"""
     _dev_check(qkv, mask)
     qkv = _c(qkv)
     b, n, w = qkv.shape
@@ -358,18 +358,19 @@ def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float)
         assert mask.dtype == torch.bool and tuple(mask.shape) == (b, n)
         mask = _c(mask)
     _lib.check(_lib.lib().xclip_attention_fwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), lse.data_ptr(), b, n, heads, scale,
-                                              dtype_code(qkv), _stream(qkv)), "xclip_attention_fwd")
+                                              int(causal), dtype_code(qkv), _stream(qkv)), "xclip_attention_fwd")
     return out, lse
 
 
-def attention_bwd(qkv: Tensor, mask: Optional[Tensor], out: Tensor, dout: Tensor, lse: Tensor, heads: int, scale: float) -> Tensor:
+def attention_bwd(qkv: Tensor, mask: Optional[Tensor], out: Tensor, dout: Tensor, lse: Tensor, heads: int, scale: float,
+                  causal: bool = False) -> Tensor:
     _dev_check(qkv, mask, out, dout)
     dout = _c(dout)
     b, n, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(b, heads, n, dtype=torch.float32, device=qkv.device)
     _lib.check(_lib.lib().xclip_attention_bwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                              delta.data_ptr(), dqkv.data_ptr(), b, n, heads, scale, dtype_code(qkv),
+                                              delta.data_ptr(), dqkv.data_ptr(), b, n, heads, scale, int(causal), dtype_code(qkv),
                                               _stream(qkv)), "xclip_attention_bwd")
     return dqkv
 
