@@ -113,7 +113,7 @@ def test_simsiam_default_construction_and_patch_dropout():
         import torchvision  # noqa: F401
     except ImportError:
         with pytest.raises(ImportError, match="torchvision"):
-            CLIP(**MID.ctor_kwargs(), use_visual_ssl=True)
+            CLIP(**{**MID.ctor_kwargs(), "use_visual_ssl": True})
     vit = VisionTransformer(**MID.vit_kwargs(0.5))
     ssl = SimSiam(vit, image_size=MID.visual_image_size, hidden_layer=-1, augment_fn=O.ssl_aug_one, augment_fn2=O.ssl_aug_two)
     kw = {k: v for k, v in MID.ctor_kwargs().items() if k != "use_visual_ssl"}
