@@ -182,19 +182,19 @@ def case_short_and_padded_text(dev, dtype=torch.float32):
         assert rel < 3e-4, (k, rel)
 
 
-def case_freeze_and_early_returns(dev, cfg):
+def case_freeze_and_early_returns(dev, cfg, batch=8):
     """LiT-style frozen tower (x_clip.py:394-408), return_encodings / return_latents / inference similarity (:697-698,728-746)"""
     import math
     import pytest
     m = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0).to(dev).train()
-    text, image, _, _ = O.make_inputs(cfg, 8, 6)
+    text, image, _, _ = O.make_inputs(cfg, batch, 6)
     text, image = text.to(dev), image.float().to(dev)
     m(text, image, return_loss=True, freeze_text_encoder=True).backward()
     assert all(p.grad is None for p in m.text_transformer.parameters())
     assert all(p.grad is not None for p in m.visual_transformer.parameters())
     assert m.to_text_latent.weight.grad is not None
     et, ei = m(text, image, return_encodings=True)
-    assert et.shape == (8, cfg.text_seq_len + 1, cfg.dim_text) and ei.shape == (8, 1 + cfg.num_patches, cfg.dim_image)
+    assert et.shape == (batch, cfg.text_seq_len + 1, cfg.dim_text) and ei.shape == (batch, 1 + cfg.num_patches, cfg.dim_image)
     tl, il = m(text, image, return_latents=True)
     m.eval()
     sim = m(text, image)

@@ -25,8 +25,9 @@ def emulator_library():
 
 
 # the emulator runs every fixture in 15-20 s; the plain variants whose code paths are a subset of a combined fixture below
-# (cfg1_dcl, cfg1_multiview, cfg1_filip, cfg1_simreg_extra, cfg1_rotary, cfg1_filip_downsample) are exercised on the GPU only
-@pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_extra_dcl", "cfg1_multiview_m3n1", "cfg1_patchdrop", "cfg1_filip_dcl",
+# (cfg1_dcl, cfg1_extra_dcl, cfg1_multiview, cfg1_multiview_m3n1, cfg1_filip, cfg1_simreg_extra, cfg1_rotary, cfg1_filip_downsample, cfg1_mlm,
+# cfg1_simsiam, cfg1_causal) are exercised on the GPU only
+@pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_patchdrop", "cfg1_filip_dcl",
                                   "cfg1_simreg_extra_dcl", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm_dcl_multiview", "cfg1_simsiam_mlm_dcl", "cfg1_causal_dcl_multiview"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
@@ -62,7 +63,7 @@ def test_short_and_fully_padded_text():
 
 
 def test_freeze_and_early_returns():
-    C.case_freeze_and_early_returns(DEV, O.CFG1)
+    C.case_freeze_and_early_returns(DEV, O.CFG1, batch=4)
 
 
 def test_pluggable_encoders_head_only():
