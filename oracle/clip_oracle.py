@@ -63,6 +63,8 @@ class ClipConfig:
     text_ssl_loss_weight: float = 0.05
     use_visual_ssl: bool = False                # SimSiam side loss (visual_ssl.py:207-259) through CLIP(visual_ssl = module)
     image_ssl_loss_weight: float = 0.05
+    visual_ssl_type: str = "simsiam"            # "simclr": NT-Xent between two views (visual_ssl.py:263-299), projector hidden width 4096
+    simclr_temperature: float = 0.1
     ssl_projection_size: int = 256              # SimSiam(projection_size, projection_hidden_size): not CLIP keywords (the CLIP
     ssl_projection_hidden_size: int = 4096      # constructors swallow them in **kwargs)
 
@@ -343,6 +345,68 @@ def ssl_aug_two(x: Tensor) -> Tensor:
 
 SSL_PROJECTOR = "visual_ssl.online_encoder.projector."
 SSL_PREDICTOR = "visual_ssl.online_predictor."
+SIMCLR_PROJECTOR = "visual_ssl.net.projector."
+
+
+class SslAugPair:
+    """SimCLR takes ONE augmentation callable and calls it once per view (visual_ssl.py:291-295): this one alternates between the two
+    deterministic stand-ins (odd calls: ssl_aug_one, even calls: ssl_aug_two)"""
+
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, x):
+        self.calls += 1
+        return ssl_aug_one(x) if self.calls % 2 == 1 else ssl_aug_two(x)
+
+
+def ssl_projector(sd: Dict[str, Tensor], cfg: ClipConfig, P: str, img: Tensor, stats: Dict[str, list]) -> Tensor:
+    """NetWrapper.forward with hidden_layer = -1 (visual_ssl.py:197-203): every token row of the encoder output through SimSiamMLP
+    (:122-135: Linear - BN - ReLU - Linear - BN - ReLU - Linear - BN(affine = False), no biases)"""
+    rep = encode_image(sd, cfg, img)
+    x = rep.reshape(-1, rep.shape[-1])
+    z1 = batch_norm_rows(x @ sd[P + "0.weight"].t(), sd[P + "1.weight"], sd[P + "1.bias"], stats[P + "1"])
+    z2 = batch_norm_rows(torch.relu(z1) @ sd[P + "3.weight"].t(), sd[P + "4.weight"], sd[P + "4.bias"], stats[P + "4"])
+    if "relu_margin" in stats:                                  # smallest |pre-activation|: how close any unit sits to the ReLU kink
+        stats["relu_margin"].append(min(float(z1.detach().abs().min()), float(z2.detach().abs().min())))
+    return batch_norm_rows(torch.relu(z2) @ sd[P + "6.weight"].t(), None, None, stats[P + "7"])
+
+
+def _running_after(sd, stats, running):
+    for k, seq in stats.items():
+        rm, rv = sd[k + ".running_mean"].detach().clone(), sd[k + ".running_var"].detach().clone()
+        for mean, var in seq:
+            rm = 0.9 * rm + 0.1 * mean
+            rv = 0.9 * rv + 0.1 * var
+        running[k + ".running_mean"], running[k + ".running_var"] = rm, rv
+
+
+def nt_xent(queries: Tensor, keys: Tensor, temperature: float) -> Tensor:
+    """nt_xent_loss (visual_ssl.py:90-102): P = [queries; keys] (n = 2b rows), logits P P^T with the diagonal REMOVED, divided by the
+    temperature; row i's label is its partner (i + b, shifted by the removed diagonal entry; i - b for the second half); summed
+    cross-entropy / n.  The projections are not normalised."""
+    b = queries.shape[0]
+    n = 2 * b
+    projs = torch.cat((queries, keys))
+    logits = projs @ projs.t()
+    logits = logits[~torch.eye(n, dtype=torch.bool)].reshape(n, n - 1) / temperature
+    labels = torch.cat((torch.arange(b) + b - 1, torch.arange(b)))
+    return torch.nn.functional.cross_entropy(logits, labels, reduction="sum") / n
+
+
+def simclr_loss(sd: Dict[str, Tensor], cfg: ClipConfig, image: Tensor, running: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """SimCLR.forward (visual_ssl.py:289-299) with hidden_layer = -1: both views through the same NetWrapper, NT-Xent over the
+    flattened projections (every token row is a sample)"""
+    P = SIMCLR_PROJECTOR
+    stats: Dict[str, list] = {P + "1": [], P + "4": [], P + "7": []}
+    if running is not None:
+        stats["relu_margin"] = []
+    queries = ssl_projector(sd, cfg, P, ssl_aug_one(image), stats)
+    keys = ssl_projector(sd, cfg, P, ssl_aug_two(image), stats)
+    if running is not None:
+        running["relu_margin"] = min(stats.pop("relu_margin"))
+        _running_after(sd, stats, running)
+    return nt_xent(queries, keys, cfg.simclr_temperature)
 
 
 def batch_norm_rows(x: Tensor, g: Optional[Tensor], b: Optional[Tensor], stats: Optional[list] = None) -> Tensor:
@@ -370,11 +434,7 @@ def simsiam_loss(sd: Dict[str, Tensor], cfg: ClipConfig, image: Tensor, running:
     stats: Dict[str, list] = {P + "1": [], P + "4": [], P + "7": [], Q + "1": []}
 
     def project(img):
-        rep = encode_image(sd, cfg, img)
-        x = rep.reshape(-1, rep.shape[-1])
-        x = torch.relu(batch_norm_rows(x @ sd[P + "0.weight"].t(), sd[P + "1.weight"], sd[P + "1.bias"], stats[P + "1"]))
-        x = torch.relu(batch_norm_rows(x @ sd[P + "3.weight"].t(), sd[P + "4.weight"], sd[P + "4.bias"], stats[P + "4"]))
-        return batch_norm_rows(x @ sd[P + "6.weight"].t(), None, None, stats[P + "7"])
+        return ssl_projector(sd, cfg, P, img, stats)
 
     def predict(x):
         x = torch.relu(batch_norm_rows(x @ sd[Q + "0.weight"].t() + sd[Q + "0.bias"], sd[Q + "1.weight"], sd[Q + "1.bias"], stats[Q + "1"]))
@@ -388,12 +448,7 @@ def simsiam_loss(sd: Dict[str, Tensor], cfg: ClipConfig, image: Tensor, running:
     cos = torch.nn.functional.cosine_similarity
     loss = (2 - 2 * cos(pred_one, proj_two.detach(), dim=-1, eps=1e-12)) + (2 - 2 * cos(pred_two, proj_one.detach(), dim=-1, eps=1e-12))
     if running is not None:
-        for k, seq in stats.items():
-            rm, rv = sd[k + ".running_mean"].detach().clone(), sd[k + ".running_var"].detach().clone()
-            for mean, var in seq:
-                rm = 0.9 * rm + 0.1 * mean
-                rv = 0.9 * rv + 0.1 * var
-            running[k + ".running_mean"], running[k + ".running_var"] = rm, rv
+        _running_after(sd, stats, running)
     return loss.mean()
 
 
@@ -407,7 +462,7 @@ def clip_forward(sd: Dict[str, Tensor], cfg: ClipConfig, text: Tensor, image: Te
     if cfg.use_mlm and not return_latents:
         text_ssl = mlm_loss(sd, cfg, mlm_masked[0], mlm_masked[1], text != cfg.text_pad_id)
     if cfg.use_visual_ssl and not return_latents:
-        image_ssl = simsiam_loss(sd, cfg, image, ssl_running)
+        image_ssl = (simclr_loss if cfg.visual_ssl_type == "simclr" else simsiam_loss)(sd, cfg, image, ssl_running)
     m, n = 1 + len(aug_text), 1 + len(aug_image)
     text = torch.cat([text, *aug_text], dim=0)
     image = torch.cat([image, *aug_image], dim=0)
@@ -488,6 +543,11 @@ def simloss_closed_form(T: np.ndarray, I: np.ndarray, tau: float, dcl: bool,
 # deterministic, platform independent parameter / input generation shared by the fixture generator
 # and the tests (numpy legacy RandomState streams are frozen across numpy versions)
 # --------------------------------------------------------------------------------------------------
+def _ssl_aliases(cfg: ClipConfig):
+    """state_dict prefixes under which the SSL module lists the (shared) vision tower again"""
+    return ("visual_ssl.net.net.",) if cfg.visual_ssl_type == "simclr" else ("visual_ssl.net.", "visual_ssl.online_encoder.net.")
+
+
 def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
     """Key -> shape map of the default-built reference model."""
     shapes: Dict[str, Tuple[int, ...]] = {"temperature": ()}
@@ -540,20 +600,24 @@ def state_dict_shapes(cfg: ClipConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[pfx + ".running_var"] = (width,)
             shapes[pfx + ".num_batches_tracked"] = ()
 
+        simclr = cfg.visual_ssl_type == "simclr"
+        if simclr:                                              # SimCLR(net, project_dim): NetWrapper's default hidden width (visual_ssl.py:142,280)
+            P, H = SIMCLR_PROJECTOR, 4096
         shapes[P + "0.weight"] = (H, cfg.dim_image)
         bn(P + "1", H)
         shapes[P + "3.weight"] = (H, H)
         bn(P + "4", H)
         shapes[P + "6.weight"] = (ps, H)
         bn(P + "7", ps, affine=False)
-        shapes[Q + "0.weight"] = (H, ps)
-        shapes[Q + "0.bias"] = (H,)
-        bn(Q + "1", H)
-        shapes[Q + "3.weight"] = (ps, H)
-        shapes[Q + "3.bias"] = (ps,)
+        if not simclr:
+            shapes[Q + "0.weight"] = (H, ps)
+            shapes[Q + "0.bias"] = (H,)
+            bn(Q + "1", H)
+            shapes[Q + "3.weight"] = (ps, H)
+            shapes[Q + "3.bias"] = (ps,)
         for k in [k for k in shapes if k.startswith(v)]:
-            shapes["visual_ssl.net." + k[len(v):]] = shapes[k]
-            shapes["visual_ssl.online_encoder.net." + k[len(v):]] = shapes[k]
+            for alias in _ssl_aliases(cfg):
+                shapes[alias + k[len(v):]] = shapes[k]
     for k, d in (("to_text_latent", cfg.dim_text), ("to_visual_latent", cfg.dim_image)):
         for sfx in ("", "_extra"):
             if k == "to_visual_latent" and cfg.downsample_image_embeds:   # Sequential(RearrangeImage, Conv2d dw, Conv2d 1x1, Rearrange)
@@ -572,7 +636,7 @@ def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str
     rs = np.random.RandomState(seed)
     sd: Dict[str, Tensor] = {}
     for key, shape in sorted(state_dict_shapes(cfg).items()):
-        if key.startswith("mlm.transformer.") or key.startswith("visual_ssl.net.") or key.startswith("visual_ssl.online_encoder.net."):
+        if key.startswith("mlm.transformer.") or (cfg.use_visual_ssl and key.startswith(_ssl_aliases(cfg))):
             continue                                            # aliases of text_transformer.* / visual_transformer.*, filled in below
         if key.endswith("num_batches_tracked"):
             sd[key] = torch.tensor(0, dtype=torch.long)
@@ -605,8 +669,8 @@ def make_state_dict(cfg: ClipConfig, seed: int, dtype=torch.float32) -> Dict[str
             sd["mlm.transformer." + k[len("text_transformer."):]] = sd[k]
     if cfg.use_visual_ssl:
         for k in [k for k in sd if k.startswith("visual_transformer.")]:
-            sd["visual_ssl.net." + k[len("visual_transformer."):]] = sd[k]
-            sd["visual_ssl.online_encoder.net." + k[len("visual_transformer."):]] = sd[k]
+            for alias in _ssl_aliases(cfg):
+                sd[alias + k[len("visual_transformer."):]] = sd[k]
     return sd
 
 

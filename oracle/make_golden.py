@@ -37,7 +37,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFERENCE = "/root/reference"
 
 sys.path.insert(0, ROOT)
-from oracle.clip_oracle import CFG1, ClipConfig, make_inputs, make_state_dict, ssl_aug_one, ssl_aug_two  # noqa: E402
+from oracle.clip_oracle import CFG1, ClipConfig, SslAugPair, make_inputs, make_state_dict, ssl_aug_one, ssl_aug_two  # noqa: E402
 
 
 def import_reference():
@@ -76,6 +76,7 @@ CASES = {
                                   use_mlm=True, decoupled_contrastive_learning=True), 5, 0, 0, 0.0),
     "cfg1_causal": (dict(text_causal_mask=True, text_eos_id=999), 4, 0, 0, 0.0),
     "cfg1_causal_dcl_multiview": (dict(text_causal_mask=True, text_eos_id=7, decoupled_contrastive_learning=True, extra_latent_projection=True), 4, 1, 1, 0.0),
+    "cfg1_simclr": (dict(use_visual_ssl=True, visual_ssl_type="simclr", image_ssl_loss_weight=0.2, ssl_projection_size=32, simclr_temperature=0.5), 4, 0, 0, 0.0),
     "cfg1_rotary": (dict(text_rotary_pos_emb=True), 4, 0, 0, 0.0),
     "cfg1_rotary_dcl_multiview": (dict(text_rotary_pos_emb=True, decoupled_contrastive_learning=True), 4, 1, 0, 0.0),
     "cfg1_simreg_extra": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.1), 4, 0, 0, 0.0),
@@ -89,7 +90,8 @@ PARAM_SEED = 20240901
 INPUT_SEED = 1234
 
 
-def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropout, want_latents=True):
+def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropout, want_latents=True, input_seed=None):
+    input_seed = INPUT_SEED if input_seed is None else input_seed
     torch.manual_seed(0)
     if cfg.use_visual_ssl:
         # SimSiam around the vision tower, handed to CLIP through its `visual_ssl` / `image_encoder` keywords (README "custom vision
@@ -97,18 +99,23 @@ def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropou
         # is torchvision's, which this container does not have -- and the projector sizes are kept small
         assert patch_dropout == 0, "the recorded SimSiam cases use a deterministic encoder"
         from x_clip.x_clip import VisionTransformer
-        from x_clip.visual_ssl import SimSiam
+        from x_clip.visual_ssl import SimCLR, SimSiam
         vit = VisionTransformer(**cfg.vit_kwargs(patch_dropout))
-        ssl = SimSiam(vit, image_size=cfg.visual_image_size, channels=cfg.channels, hidden_layer=-1,
-                      projection_size=cfg.ssl_projection_size, projection_hidden_size=cfg.ssl_projection_hidden_size,
-                      augment_fn=ssl_aug_one, augment_fn2=ssl_aug_two)
+        if cfg.visual_ssl_type == "simclr":
+            # (its constructor's mock forward calls the augmentation twice, which leaves the alternating callable in phase)
+            ssl = SimCLR(vit, image_size=cfg.visual_image_size, channels=cfg.channels, hidden_layer=-1, project_dim=cfg.ssl_projection_size,
+                         augment_fn=SslAugPair(), temperature=cfg.simclr_temperature)
+        else:
+            ssl = SimSiam(vit, image_size=cfg.visual_image_size, channels=cfg.channels, hidden_layer=-1,
+                          projection_size=cfg.ssl_projection_size, projection_hidden_size=cfg.ssl_projection_hidden_size,
+                          augment_fn=ssl_aug_one, augment_fn2=ssl_aug_two)
         ref = x_clip.CLIP(**cfg.ctor_kwargs(), image_encoder=vit, visual_ssl=ssl)
     else:
         ref = x_clip.CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=patch_dropout)
     sd = make_state_dict(cfg, PARAM_SEED)
     ref.load_state_dict(sd, strict=True)          # strict: pins the key/shape map of Appendix A
     ref.train()
-    text, image, aug_t, aug_i = make_inputs(cfg, batch, INPUT_SEED, n_aug_t, n_aug_i)
+    text, image, aug_t, aug_i = make_inputs(cfg, batch, input_seed, n_aug_t, n_aug_i)
     image = image.float()
     aug_i = [a.float() for a in aug_i]
     keep_idx = None
@@ -164,8 +171,9 @@ def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropou
         # BatchNorm running statistics after the step (SimSiam runs every projector BatchNorm four times, the predictor's twice)
         after = ref.state_dict()
         out["ssl_running"] = {k: dict(norm=float(v.double().norm()), head=v.flatten()[:4].double().tolist())
-                              for k, v in after.items() if k.startswith("visual_ssl.online") and ("running_" in k)}
-        out["ssl_num_batches_tracked"] = {k: int(v) for k, v in after.items() if k.startswith("visual_ssl.online") and k.endswith("num_batches_tracked")}
+                              for k, v in after.items() if (".projector." in k or ".online_predictor." in k) and ("running_" in k)}
+        out["ssl_num_batches_tracked"] = {k: int(v) for k, v in after.items()
+                                          if (".projector." in k or ".online_predictor." in k) and k.endswith("num_batches_tracked")}
     if keep_idx is not None:
         out["keep_idx"] = keep_idx.tolist()
     if mlm_rec is not None:
@@ -233,9 +241,24 @@ def main():
         if only and name not in only:
             continue
         cfg = ClipConfig(**{**CFG1.ctor_kwargs(), **over})
-        out = run_reference(x_clip, cfg, batch, nat, nai, pdrop)
+        input_seed = INPUT_SEED
+        if cfg.use_visual_ssl and cfg.visual_ssl_type == "simclr":
+            # 20 sample rows through two 4096-wide ReLU layers: a pre-activation within fp32 rounding of 0 takes either side of the kink
+            # depending on the accumulation order, and with so few rows ONE flipped unit moves the upstream gradients by 1e-3.  Pick the
+            # first input seed whose smallest |pre-activation| (fp64 oracle) is far above fp32 rounding, so the fixture tests arithmetic
+            from oracle.clip_oracle import clip_forward
+            sd64 = make_state_dict(cfg, PARAM_SEED, torch.float64)
+            while True:
+                t_, i_, _, _ = make_inputs(cfg, batch, input_seed)
+                r_ = {}
+                clip_forward(sd64, cfg, t_, i_.float().double(), ssl_running=r_)
+                if r_["relu_margin"] > 2e-5:
+                    break
+                input_seed += 1
+            print(f"{name}: input seed {input_seed}, smallest |pre-activation| {r_['relu_margin']:.2e}")
+        out = run_reference(x_clip, cfg, batch, nat, nai, pdrop, input_seed=input_seed)
         rec = dict(case=name, config=cfg.ctor_kwargs(), batch=batch, n_aug_text=nat, n_aug_image=nai,
-                   visual_patch_dropout=pdrop, param_seed=PARAM_SEED, input_seed=INPUT_SEED,
+                   visual_patch_dropout=pdrop, param_seed=PARAM_SEED, input_seed=input_seed,
                    reference="lucidrains/x-clip v0.14.4 (x_clip/x_clip.py), fp32, torch %s CPU" % torch.__version__,
                    **out)
         with open(os.path.join(GOLDEN, name + ".json"), "w") as f:

@@ -536,3 +536,21 @@ def case_neg_cosine(dev, dtype, rows, dim):
     gm = torch.full((1,), 0.6, dtype=torch.float32, device=dev)
     dp = ops.neg_cosine_bwd(p_.to(dev), z_.to(dev), st, gm, coef)
     close(dp, p64.grad, dtype, "cosine dp", mult=2.0)
+
+
+def case_nt_xent(dev, dtype, rows, dim, temperature):
+    """NT-Xent between two sets of projections (nt_xent_loss, visual_ssl.py:90-102) built from the contrastive head's kernels, against
+    the oracle's restatement in fp64; both gradients"""
+    from x_clip_amd.visual_ssl import nt_xent_loss
+    scale = 1.0 if dtype == torch.float32 else 0.5
+    q_, k_ = rnd((rows, dim), dtype, 111, scale), rnd((rows, dim), dtype, 112, scale)
+    q, k = q_.to(dev).requires_grad_(True), k_.to(dev).requires_grad_(True)
+    loss = nt_xent_loss(q, k, temperature)
+    (loss * 0.7).backward()
+    q64, k64 = ref64(q_).requires_grad_(True), ref64(k_).requires_grad_(True)
+    want = O.nt_xent(q64, k64, temperature)
+    (want * 0.7).backward()
+    assert abs(float(loss.detach()) - float(want.detach())) < (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, abs(float(want.detach()))), (float(loss.detach()), float(want.detach()))
+    gs = max(float(q64.grad.abs().max()), float(k64.grad.abs().max()))
+    close(q.grad, q64.grad, dtype, "nt-xent dq", scale=gs, mult=4.0)
+    close(k.grad, k64.grad, dtype, "nt-xent dk", scale=gs, mult=4.0)

@@ -26,7 +26,7 @@ def emulator_library():
 
 # the emulator runs every fixture in 15-20 s; the plain variants whose code paths are a subset of a combined fixture below
 # (cfg1_dcl, cfg1_extra_dcl, cfg1_multiview, cfg1_multiview_m3n1, cfg1_filip, cfg1_simreg_extra, cfg1_rotary, cfg1_filip_downsample, cfg1_mlm,
-# cfg1_simsiam, cfg1_causal) are exercised on the GPU only
+# cfg1_simsiam, cfg1_simclr (4096-wide projector: minutes on the emulator), cfg1_causal) are exercised on the GPU only
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_patchdrop", "cfg1_filip_dcl",
                                   "cfg1_simreg_extra_dcl", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm_dcl_multiview", "cfg1_simsiam_mlm_dcl", "cfg1_causal_dcl_multiview"])
 def test_clip_matches_reference_fixture(name):

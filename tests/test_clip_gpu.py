@@ -28,7 +28,7 @@ def hip_library():
 
 
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm", "cfg1_mlm_dcl_multiview", "cfg1_simsiam", "cfg1_simsiam_mlm_dcl", "cfg1_causal", "cfg1_causal_dcl_multiview"])
+                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm", "cfg1_mlm_dcl_multiview", "cfg1_simsiam", "cfg1_simsiam_mlm_dcl", "cfg1_simclr", "cfg1_causal", "cfg1_causal_dcl_multiview"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 
@@ -101,6 +101,24 @@ def test_mid_simsiam_vs_oracle(dtype):
     #  temperature gradient of the contrastive head; the emulator run of this case gives cosine 0.964 / relative error 0.31 for it and
     #  >= 0.984 / <= 0.18 for every other tensor)
     C.case_vs_oracle(DEV, dtype, cfg, 16, bf16_rel=0.4, bf16_cos=0.94)
+
+
+def test_simclr_bf16_patch_dropout_runs():
+    """SimCLR / NT-Xent variant (visual_ssl.py:263-299) in bf16 with the tower's random patch dropout: finite loss, every parameter reached
+    (parity: tests/golden/cfg1_simclr.json above and the NT-Xent kernel cases)"""
+    from x_clip_amd import CLIP, VisionTransformer
+    from x_clip_amd.visual_ssl import SimCLR
+    vit = VisionTransformer(**MID.vit_kwargs(0.5))
+    ssl = SimCLR(vit, image_size=MID.visual_image_size, hidden_layer=-1, augment_fn=O.SslAugPair(), temperature=4.0)
+    kw = {k: v for k, v in MID.ctor_kwargs().items() if k != "use_visual_ssl"}
+    m = CLIP(**kw, image_encoder=vit, visual_ssl=ssl, use_visual_ssl=True).to(torch.bfloat16).to(DEV).train()
+    text, image, _, _ = O.make_inputs(MID, 8, 3)
+    loss = m(text.to(DEV), image.to(torch.bfloat16).to(DEV), return_loss=True)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in m.named_parameters():
+        if "_extra" not in k:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
 def test_simsiam_default_construction_and_patch_dropout():

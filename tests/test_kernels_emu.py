@@ -167,7 +167,7 @@ def test_dwconv(dtype, batch, h, C):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
-@pytest.mark.parametrize("rows,cols,ld", [(5, 24, 24), (9, 1000, 1000), (3, 13, 16)])
+@pytest.mark.parametrize("rows,cols,ld", [(5, 24, 24), (9, 1000, 1000), (3, 13, 16), (4200, 24, 24)])
 def test_cross_entropy(dtype, rows, cols, ld):
     K.case_cross_entropy(DEV, dtype, rows, cols, ld)
 
@@ -187,6 +187,12 @@ def test_batchnorm(dtype, rows, cols, relu, affine, training, offset):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
-@pytest.mark.parametrize("rows,dim", [(130, 256), (3, 64), (17, 1024)])
+@pytest.mark.parametrize("rows,dim", [(130, 256), (3, 64), (17, 1024), (4300, 64)])
 def test_neg_cosine(dtype, rows, dim):
     K.case_neg_cosine(DEV, dtype, rows, dim)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,dim,temperature", [(20, 32, 0.5), (70, 128, 1.0), (5, 12, 0.3)])
+def test_nt_xent(dtype, rows, dim, temperature):
+    K.case_nt_xent(DEV, dtype, rows, dim, temperature)

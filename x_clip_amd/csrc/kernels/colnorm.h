@@ -242,9 +242,8 @@ __global__ __launch_bounds__(256) void neg_cosine_fwd_kernel(const T* __restrict
     XC_LDS_DYNAMIC(lds);
     float* red = reinterpret_cast<float*>(lds);           // [4]
     const int lane = lane_id(), wave = wave_id();
-    const long row = (long)blockIdx.x * 4 + wave;
     float term = 0.f;
-    if (row < rows) {
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {     // capped grid: one atomic per work-group
         float pp = 0.f, zz = 0.f, pz = 0.f;
         for (int c = lane; c < D / VEC; c += 64) {
             float a[VEC], b[VEC];
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(256) void neg_cosine_fwd_kernel(const T* __restrict
         const float ip = 1.0f / fmaxf(sqrtf(pp), 1e-12f), iz = 1.0f / fmaxf(sqrtf(zz), 1e-12f);
         const float cs = pz * ip * iz;
         if (lane == 0) { cosv[row] = cs; rp[row] = ip; rz[row] = iz; }
-        term = 2.f - 2.f * cs;
+        term += 2.f - 2.f * cs;
     }
     if (lane == 0) red[wave] = term;
     sync();

@@ -546,11 +546,13 @@ int xclip_cross_entropy_fwd(const void* logits, int64_t ld, const int64_t* label
     XC_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && ld % vec_of(dtype) == 0, "row stride must cover the columns in whole 16-byte chunks");
     XC_REQUIRE(logits && labels && lse && loss_accum && aligned16(logits), "null or misaligned pointer");
     if (rows == 0) return 0;
-    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > ROWLOSS_MAX_BLOCKS) blocks = ROWLOSS_MAX_BLOCKS;
+    dim3 grid((unsigned)blocks), block(256);
     if (dtype == XCLIP_BF16)
-        hipLaunchKernelGGL((ce_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)logits, (long)ld, (const long long*)labels, (int)rows, (int)cols, lse, loss_accum);
+        hipLaunchKernelGGL((ce_fwd_kernel<bf16_t>), grid, block, 16, (hipStream_t)stream, (const bf16_t*)logits, (long)ld, (const long long*)labels, (int)rows, (int)cols, lse, loss_accum);
     else
-        hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)logits, (long)ld, (const long long*)labels, (int)rows, (int)cols, lse, loss_accum);
+        hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, block, 16, (hipStream_t)stream, (const float*)logits, (long)ld, (const long long*)labels, (int)rows, (int)cols, lse, loss_accum);
     return check_launch(__func__);
 }
 int xclip_cross_entropy_bwd(void* logits, int64_t ld, const int64_t* labels, const float* lse, const float* gmul, int64_t rows, int64_t cols,
@@ -942,7 +944,9 @@ int xclip_neg_cosine_fwd(const void* p, const void* z, int64_t rows, int64_t dim
     XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec_of(dtype) == 0, "dim must be a multiple of the 16-byte chunk");
     XC_REQUIRE(p && z && cosv && rp && rz && loss_accum && aligned16(p) && aligned16(z), "null or misaligned pointer");
     if (rows == 0) return 0;
-    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > ROWLOSS_MAX_BLOCKS) blocks = ROWLOSS_MAX_BLOCKS;
+    dim3 grid((unsigned)blocks), block(256);
     if (dtype == XCLIP_BF16)
         hipLaunchKernelGGL((neg_cosine_fwd_kernel<bf16_t>), grid, block, 16, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)z, (int)rows, (int)dim, coef, cosv, rp, rz, loss_accum);
     else

@@ -669,3 +669,27 @@ def neg_cosine_bwd(p: Tensor, z: Tensor, st, gmul: Tensor, coef: float) -> Tenso
     _lib.check(_lib.lib().xclip_neg_cosine_bwd(p.data_ptr(), z.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), gmul.data_ptr(),
                                                coef, dp.data_ptr(), p.shape[0], p.shape[1], dtype_code(p), _stream(p)), "xclip_neg_cosine_bwd")
     return dp
+
+
+def ntxent_lse(q: Tensor, other: Tensor, scale: float, coef: float, loss_accum: Tensor) -> Tensor:
+    """NT-Xent rows of `q` (nt_xent_loss, visual_ssl.py:90-102): logits scale * [q q^T with its diagonal removed | q other^T], the positive
+    of row i is column i of the second block.  -> lse [nq] fp32;  *loss_accum += coef * sum_i (lse_i - scale <q_i, other_i>).
+    Two xclip_simloss_partial passes into one slot table (the first excludes its diagonal and owns no positive), one combine."""
+    _dev_check(q, other, loss_accum)
+    q, other = _c(q), _c(other)
+    nq, d = q.shape
+    assert other.shape == q.shape and other.dtype == q.dtype
+    L = _lib.lib()
+    half = (nq + 63) // 64
+    slots = 2 * half
+    ws = workspace(q.device, 2 * slots * nq * 4)
+    unused = torch.zeros(nq, dtype=torch.float32, device=q.device)
+    pos = torch.zeros(nq, dtype=torch.float32, device=q.device)
+    lse = torch.empty(nq, dtype=torch.float32, device=q.device)
+    code, st = dtype_code(q), _stream(q)
+    _lib.check(L.xclip_simloss_partial(q.data_ptr(), q.data_ptr(), nq, nq, d, scale, None, 0, 1, ws.data_ptr(), 0, slots, unused.data_ptr(), code, st),
+               "xclip_simloss_partial")
+    _lib.check(L.xclip_simloss_partial(q.data_ptr(), other.data_ptr(), nq, nq, d, scale, None, 0, 0, ws.data_ptr(), half, slots, pos.data_ptr(), code, st),
+               "xclip_simloss_partial")
+    _lib.check(L.xclip_simloss_combine(ws.data_ptr(), nq, slots, pos.data_ptr(), lse.data_ptr(), _ptr(loss_accum), coef, st), "xclip_simloss_combine")
+    return lse

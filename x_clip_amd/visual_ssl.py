@@ -15,8 +15,10 @@ given (the reference has the same dependency at import time).
 Differences from the reference, all at construction time: the lazily built projector (visual_ssl.py:167-171) is created in the
 constructor when the encoder's output width is known (`representation_dim=` or an encoder with a `.dim` attribute) instead of
 by a mock forward on random data (visual_ssl.py:235) -- the kernels need device tensors and a model is usually built on the host
-first; otherwise it is created on the first forward, exactly like the reference's singleton.  SimCLR / NT-Xent
-(visual_ssl.py:81-102,263-299) is not on the accelerated path yet and raises.
+first; otherwise it is created on the first forward, exactly like the reference's singleton.
+
+`SimCLR(net, image_size, ...)` (visual_ssl.py:263-299) is the NT-Xent variant: two views through the same wrapper, loss over the
+2R x 2R projection similarities with the diagonal removed -- computed block-wise by the contrastive head's kernels.
 """
 from __future__ import annotations
 
@@ -302,9 +304,71 @@ class SimSiam(nn.Module):
                 + _NegCosineFn.apply(online_pred_two, target_proj_one, 1.0 / rows))
 
 
-class SimCLR(nn.Module):
-    """reference SimCLR (visual_ssl.py:263-299): not on the accelerated path yet"""
+class _NtXentFn(torch.autograd.Function):
+    """nt_xent_loss (visual_ssl.py:90-102) of queries / keys [R, d]: with P = [queries; keys] and N = 2R, the mean over the N rows of
+    -log softmax over the row's N - 1 off-diagonal logits P P^T / temperature at its partner's column.  The N x N logits are never
+    formed: the four R x R blocks go through the contrastive head's kernels (xclip_simloss_partial / _combine for the row
+    log-sum-exps, xclip_simloss_grad for the gradient factors, whose a / c terms give G + G^T of a symmetric block in one pass)."""
 
-    def __init__(self, *args, **kwargs):
+    @staticmethod
+    def forward(ctx, queries: Tensor, keys: Tensor, temperature: float):
+        Q, K = ops._c(queries), ops._c(keys)
+        R, d = Q.shape
+        v = ops.vec(Q.dtype)
+        if d % v:                                              # the kernels take whole 16-byte chunks: zero columns change no dot product
+            Q = torch.nn.functional.pad(Q, (0, v - d % v))
+            K = torch.nn.functional.pad(K, (0, v - d % v))
+        acc = torch.zeros(1, dtype=torch.float32, device=Q.device)
+        scale, coef = 1.0 / temperature, 1.0 / (2 * R)
+        lse_q = ops.ntxent_lse(Q, K, scale, coef, acc)
+        lse_k = ops.ntxent_lse(K, Q, scale, coef, acc)
+        ctx.save_for_backward(Q, K, lse_q, lse_k)
+        ctx.meta = (scale, coef, d, queries.dtype)
+        return acc.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        Q, K, lse_q, lse_k = ctx.saved_tensors
+        scale, coef, d, dt = ctx.meta
+        R, dp = Q.shape
+        g = dloss.detach().float().reshape(1).contiguous()
+        # self blocks (diagonal excluded, no positive): G + G^T in one pass; cross block: both row softmaxes and the two positives
+        Gq = ops.simloss_grad(Q, Q, scale, 0, True, coef, coef, 0.0, lse_q, lse_q, None, gmul=g, times_scale=True)
+        Gk = ops.simloss_grad(K, K, scale, 0, True, coef, coef, 0.0, lse_k, lse_k, None, gmul=g, times_scale=True)
+        Gx = ops.simloss_grad(Q, K, scale, 0, False, coef, coef, 2 * coef, lse_q, lse_k, None, gmul=g, times_scale=True)
+        dQ = ops.gemm(Gq[:, :R], Q, R, dp, R, b_kmajor=True)
+        dQ = ops.gemm(Gx[:, :R], K, R, dp, R, b_kmajor=True, residual=dQ, out=dQ)
+        dK = ops.gemm(Gk[:, :R], K, R, dp, R, b_kmajor=True)
+        dK = ops.gemm(Gx[:, :R], Q, R, dp, R, a_kmajor=True, b_kmajor=True, residual=dK, out=dK)
+        return dQ[:, :d].to(dt), dK[:, :d].to(dt), None
+
+
+def nt_xent_loss(queries: Tensor, keys: Tensor, temperature: float = 0.1) -> Tensor:
+    return _NtXentFn.apply(queries, keys, temperature)
+
+
+class SimCLR(nn.Module):
+    """reference SimCLR (visual_ssl.py:263-299): forward(image [b, c, H, W]) -> NT-Xent loss between the projections of two augmented
+    views; every token row of the representation is a sample (NetWrapper flattens '... d -> (...) d').  `augment_fn` is called twice
+    per step (once per view).  Note the reference divides the raw, un-normalised projections' dot products by the temperature."""
+
+    def __init__(self, net, image_size, channels=3, hidden_layer=-2, project_hidden=True, project_dim=128, augment_both=True,
+                 use_nt_xent_loss=False, augment_fn=None, temperature=0.1, representation_dim: Optional[int] = None):
         super().__init__()
-        raise NotImplementedError("SimCLR / NT-Xent (x_clip/visual_ssl.py:81-102,263-299) is not on the accelerated path; use visual_ssl_type = 'simsiam'")
+        if representation_dim is None and hidden_layer == -1:
+            representation_dim = getattr(net, 'dim', None)
+        self.net = NetWrapper(net, project_dim, layer=hidden_layer, representation_dim=representation_dim)
+        self.augment = augment_fn if augment_fn is not None else get_default_aug(image_size, channels)
+        self.augment_both = augment_both
+        self.temperature = temperature
+        params = list(net.parameters())
+        if params:
+            self.to(params[0].device)
+
+    def forward(self, x):
+        transform_fn = self.augment if self.augment_both else (lambda t: t)     # (the reference names an undefined `noop` here)
+        queries, _ = self.net(transform_fn(x))
+        keys, _ = self.net(self.augment(x))
+        queries, keys = queries.reshape(queries.shape[0], -1), keys.reshape(keys.shape[0], -1)
+        return nt_xent_loss(queries, keys, temperature=self.temperature)
