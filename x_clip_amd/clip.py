@@ -7,8 +7,8 @@ draws the same initial weights as the reference) -- but the modules are paramete
 the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is no CPU / ATen fallback; tensors must live
 on an MI355X.
 
-Not on this path (constructor raises NotImplementedError): the SimCLR variant of the visual-SSL side
-loss; the causal text encoder together with rotary embeddings, FILIP or MLM (each fails inside the reference's own forward).
+Not on this path (constructor raises NotImplementedError): the causal text encoder together with rotary embeddings, FILIP or
+MLM (each fails inside the reference's own forward); attention / feed-forward dropout; dim_head != 64.
 """
 from __future__ import annotations
 
