@@ -2,7 +2,8 @@
 //   mode 0: global_load_lds_dwordx4, lane-linear sources (8 rows x 128 B per wave-instruction, row stride `ld`)
 //   mode 1: same, 16-byte chunks permuted within each 128-byte row (the gemm2/gemm3 source swizzle)
 //   mode 2: global_load_dwordx4 -> registers -> ds_write_b128 (register staging)
-//   mode 3: global_load_lds, fully contiguous 1 KiB per wave-instruction
+//   mode 3: global_load_lds, fully contiguous 1 KiB per wave-instruction, the SAME 64 KiB every step (L1 / L2 hits)
+//   mode 4: global_load_lds, contiguous 1 KiB per wave-instruction, walking the same 512 KiB window per work-group as mode 0
 // 512 threads per work-group, one work-group per CU, each K step = 64 KiB (two 32 KiB operand tiles), barrier per step.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(512) void k(const unsigned short* __restrict__ A, l
                 if (MODE == 1) chunk ^= (row >> 1) & 7;
                 const unsigned short* src = A + (long)(row_base + op * 256 + row) * ld + k0 + chunk * 8;
                 if (MODE == 3) src = A + (long)(row_base + op * 256) * ld + (long)id * 512 + lane * 8;
+                if (MODE == 4) src = A + (long)row_base * ld + ((long)(s % 7) * 65536 + op * 32768 + id * 1024) / 2 + lane * 8;
                 if (MODE == 2) {
                     u32x4 v = *reinterpret_cast<const u32x4*>(src);
                     *reinterpret_cast<u32x4*>(buf + op * 32768 + id * 1024 + lane * 16) = v;
@@ -51,14 +53,15 @@ int main(int argc, char** argv) {
     printf("ld = %ld elements (%ld B row stride)\n", ld, ld * 2);
     const int steps = 2000, grid = 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             switch (mode) {
                 case 0: hipLaunchKernelGGL(k<0>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
                 case 1: hipLaunchKernelGGL(k<1>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
                 case 2: hipLaunchKernelGGL(k<2>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
-                default: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
+                case 3: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
+                default: hipLaunchKernelGGL(k<4>, dim3(grid), dim3(512), 131072, 0, A, ld, rows, steps, sink); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
