@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--dcl", action="store_true")
     ap.add_argument("--filip", action="store_true", help="BASELINE configs[3] instead of the headline configs[1]: use_all_token_embeds, "
                     "image 224 / patch 16, text length 77 (own measurements; the driver's line is the default configuration)")
+    ap.add_argument("--simsiam", action="store_true", help="own measurement of the README configuration `use_visual_ssl = True`: SimSiam around "
+                    "the vision tower (four more tower passes + the 4096-wide BatchNorm MLPs per step) with two cheap device-side "
+                    "augmentations (flip / shift-blend) standing in for torchvision's host pipeline")
+    ap.add_argument("--causal", action="store_true", help="own measurement: autoregressive text encoder (text_causal_mask, EOS pooling)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -115,6 +119,14 @@ def main():
 
     torch.manual_seed(0)
     extra = dict(use_all_token_embeds=True, visual_image_size=224, visual_patch_size=16, text_seq_len=77) if args.filip else {}
+    if args.causal:
+        extra.update(text_causal_mask=True, text_eos_id=9999)
+    if args.simsiam:
+        from x_clip_amd import VisionTransformer
+        from x_clip_amd.visual_ssl import SimSiam
+        vit = VisionTransformer(512, image_size=256, patch_size=32, channels=3, depth=6, heads=8, dim_head=64, patch_dropout=0.5)
+        ssl = SimSiam(vit, image_size=256, hidden_layer=-1, augment_fn=lambda x: x.flip(-1), augment_fn2=lambda x: 0.8 * x + 0.2 * x.roll(3, dims=-2))
+        extra.update(image_encoder=vit, visual_ssl=ssl, use_visual_ssl=True)
     model = CLIP(decoupled_contrastive_learning=args.dcl, **extra).to(torch.bfloat16).to(dev)
     model.train()
     model.assume_equal_batch = True
@@ -122,7 +134,9 @@ def main():
 
     b = args.batch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    text = torch.randint(0, 10000, (b, model.text_seq_len), generator=g).to(dev)
+    text = torch.randint(0, 9999 if args.causal else 10000, (b, model.text_seq_len), generator=g).to(dev)
+    if args.causal:
+        text[:, -1] = 9999                                      # every row ends in the eos id
     image = torch.randn(b, 3, model.image_size, model.image_size, generator=g).to(torch.bfloat16).to(dev)
 
     def step():
@@ -179,7 +193,8 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (randint tokens, randn images, random-init weights)",
         "config": {"workload": ("BASELINE configs[3] (FILIP): dim 512 depth 6/6 image 224 patch 16 text seq 77, " if args.filip else
                                 "BASELINE configs[1]: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, ") +
-                               "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ", fwd+bwd",
+                               "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ("" if not args.simsiam else " + SimSiam side loss") +
+                               ("" if not args.causal else ", causal text encoder") + ", fwd+bwd",
                    "local_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                    "gflop_per_pair_fwd_bwd": round(3 * fwd_flops / 1e9, 3)},
         "model_mfma_frac": round(value * 3 * fwd_flops / (world * MFMA_PEAK_BF16), 4),

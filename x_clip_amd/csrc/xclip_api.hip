@@ -888,17 +888,17 @@ int xclip_batchnorm_fwd(const void* x, const float* gamma, const float* beta, vo
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)g.slabs, (unsigned)g.slices), block(256);
     const int R = (int)rows, C = (int)cols;
-    const int fin_blocks = (C + 255) / 256;
+    const int fin_blocks = (C + 63) / 64;              // finalize: 64 columns x 4 slice strips per work-group
     float* part = (float*)workspace;
     if (training) {
         const int lds = 256 * 2 * vec_of(dtype) * (int)sizeof(float);
         if (dtype == XCLIP_BF16) {
             hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), grid, block, lds, st, (const bf16_t*)x, part, R, C, g.cw);
-            hipLaunchKernelGGL((bn_finalize_kernel<bf16_t>), dim3(fin_blocks), block, 0, st, (const bf16_t*)x, part, g.slices, R, C, eps, momentum,
+            hipLaunchKernelGGL((bn_finalize_kernel<bf16_t>), dim3(fin_blocks), block, 2048, st, (const bf16_t*)x, part, g.slices, R, C, eps, momentum,
                                mean, rstd, running_mean, running_var);
         } else {
             hipLaunchKernelGGL((bn_stats_kernel<float>), grid, block, lds, st, (const float*)x, part, R, C, g.cw);
-            hipLaunchKernelGGL((bn_finalize_kernel<float>), dim3(fin_blocks), block, 0, st, (const float*)x, part, g.slices, R, C, eps, momentum,
+            hipLaunchKernelGGL((bn_finalize_kernel<float>), dim3(fin_blocks), block, 2048, st, (const float*)x, part, g.slices, R, C, eps, momentum,
                                mean, rstd, running_mean, running_var);
         }
     } else {
@@ -929,7 +929,7 @@ int xclip_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const
 #define BN_BWD(T, RELU)                                                                                                              \
     do {                                                                                                                             \
         hipLaunchKernelGGL((bn_bwd_sums_kernel<T, RELU>), grid, block, lds, st, (const T*)x, (const T*)dy, cols_p, part, R, C, g.cw); \
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), block, 0, st, part, g.slices, R, C, training, dgamma, dbeta, coef); \
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), block, 2048, st, part, g.slices, R, C, training, dgamma, dbeta, coef); \
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, RELU>), grid, block, 0, st, (const T*)x, (const T*)dy, cols_p, coef, (T*)dx, R, C, g.cw); \
     } while (0)
     if (dtype == XCLIP_BF16) { if (relu) BN_BWD(bf16_t, true); else BN_BWD(bf16_t, false); }
