@@ -554,3 +554,15 @@ def case_nt_xent(dev, dtype, rows, dim, temperature):
     gs = max(float(q64.grad.abs().max()), float(k64.grad.abs().max()))
     close(q.grad, q64.grad, dtype, "nt-xent dq", scale=gs, mult=4.0)
     close(k.grad, k64.grad, dtype, "nt-xent dk", scale=gs, mult=4.0)
+
+
+def case_gemm_splitk_uneven(dev, M=1248, N=768, K=6144):
+    """split-K with a slice count that does not divide the K steps (96 steps over 17 slices: rounding the slice up to 6 steps leaves the
+    17th slice empty).  The scratch is poisoned first: a slice that returns without writing its slab would put NaN into every output."""
+    dtype = torch.bfloat16
+    a = rnd((M, K), dtype, 121, 0.1)
+    b = rnd((K, N), dtype, 122, 0.1)
+    ws = ops.workspace(dev, 80 << 20)
+    ws.fill_(0xFF)
+    c = ops.gemm(a.to(dev), b.to(dev), M, N, K, b_kmajor=True)
+    close(c, ref64(a) @ ref64(b), dtype, "gemm split-K uneven")

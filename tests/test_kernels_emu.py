@@ -196,3 +196,7 @@ def test_neg_cosine(dtype, rows, dim):
 @pytest.mark.parametrize("rows,dim,temperature", [(20, 32, 0.5), (70, 128, 1.0), (5, 12, 0.3)])
 def test_nt_xent(dtype, rows, dim, temperature):
     K.case_nt_xent(DEV, dtype, rows, dim, temperature)
+
+
+def test_gemm_splitk_uneven_slices():
+    K.case_gemm_splitk_uneven(DEV, M=256, N=256, K=2880)

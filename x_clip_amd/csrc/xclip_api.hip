@@ -624,6 +624,9 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
         int splits = gemm2_splits(M, N, K);
         if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
         q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);
+        // rounding the slice up can leave the last slices EMPTY (96 K steps over 17 slices -> 6 per slice, 16 slices cover them): a slice
+        // without work returns without touching its slab and the reduction would add whatever the workspace held before
+        splits = (int)((K + q.k_per_split - 1) / q.k_per_split);
         q.partial = splits > 1 ? (float*)workspace : nullptr;
         if (!a_kmajor && !b_kmajor) launch_gemm2<false, false>(q, splits, st);
         else if (!a_kmajor && b_kmajor) launch_gemm2<false, true>(q, splits, st);
@@ -645,6 +648,7 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
     if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
     const int bk = 8 * vec;
     p.k_per_split = (int)((((K + splits - 1) / splits) + bk - 1) / bk * bk);
+    splits = (int)((K + p.k_per_split - 1) / p.k_per_split);      // no empty slices (see above)
     p.partial = splits > 1 ? (float*)workspace : nullptr;
     if (dtype == XCLIP_BF16) {
         if (!a_kmajor && !b_kmajor) launch_gemm<bf16_t, false, false>(p, splits, st);
