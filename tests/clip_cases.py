@@ -24,6 +24,31 @@ from x_clip_amd import CLIP
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
+class poisoned_empty:
+    """NaN-poisons every torch.empty / empty_like allocation made inside the block (0xFF bytes for uint8 scratch = fp32 NaN): a kernel
+    that reads memory it was supposed to write first -- an unwritten split-K slab, a skipped padding row -- then fails a parity check
+    even when the allocator happens to hand out zeroed pages (which is what hid such a bug on the CPU)"""
+
+    def __enter__(self):
+        self.saved = (torch.empty, torch.empty_like)
+        e, el = self.saved
+
+        def poison(t):
+            if t.is_floating_point():
+                t.fill_(float("nan"))
+            elif t.dtype == torch.uint8:
+                t.fill_(0xFF)
+            return t
+
+        torch.empty = lambda *a, **k: poison(e(*a, **k))
+        torch.empty_like = lambda *a, **k: poison(el(*a, **k))
+        return self
+
+    def __exit__(self, *exc):
+        torch.empty, torch.empty_like = self.saved
+        return False
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name + ".json")) as f:
         return json.load(f)

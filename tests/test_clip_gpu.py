@@ -256,3 +256,12 @@ def test_full_size_properties_bf16():
 
 def test_short_and_fully_padded_text():
     C.case_short_and_padded_text(DEV)
+
+
+def test_no_kernel_reads_unwritten_memory():
+    """ViT-L-like widths (the shape whose uneven split-K once reduced an unwritten slab) with every torch.empty the product makes
+    poisoned with NaN"""
+    cfg = O.ClipConfig(dim_text=768, dim_image=1024, dim_latent=768, num_text_tokens=3000, text_enc_depth=1, text_seq_len=77,
+                       text_heads=12, visual_enc_depth=2, visual_image_size=56, visual_patch_size=14, visual_heads=16)
+    with C.poisoned_empty():
+        C.case_vs_oracle(DEV, torch.bfloat16, cfg, 8, n_aug_text=1, n_aug_image=1, patch_keep=8)
