@@ -17,7 +17,15 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 
+def _maybe_poison():
+    """XCLIP_TEST_POISON=1 (diagnostics): NaN-poison every torch.empty in the worker, see clip_cases.poisoned_empty"""
+    if os.environ.get("XCLIP_TEST_POISON") == "1":
+        import clip_cases
+        clip_cases.poisoned_empty().__enter__()
+
+
 def _worker(rank, world, port, name, sizes, tmp):
+    _maybe_poison()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -77,6 +85,7 @@ def test_two_ranks_match_reference_semantics(name, sizes, tmp_path):
 
 
 def _worker_even(rank, world, port, cfg_kwargs, batch, tmp):
+    _maybe_poison()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -132,6 +141,7 @@ def test_two_ranks_even_batches_gradsync_vs_oracle(tmp_path):
 
 
 def _worker_filip(rank, world, port, cfg_kwargs, batch, tmp):
+    _maybe_poison()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
