@@ -38,14 +38,72 @@ def test_clip_bf16_vs_oracle():
     C.case_vs_oracle(DEV, torch.bfloat16, O.CFG1, 4)
 
 
-def test_state_dict_keys_and_shapes():
-    from x_clip_amd import CLIP
-    model = CLIP(**O.CFG1.ctor_kwargs())
-    shapes = O.state_dict_shapes(O.CFG1)
+@pytest.mark.parametrize("over", [dict(), dict(text_causal_mask=True, text_eos_id=7), dict(text_rotary_pos_emb=True), dict(use_mlm=True),
+                                  dict(extra_latent_projection=True), dict(use_all_token_embeds=True, downsample_image_embeds=True, visual_patch_size=16),
+                                  dict(use_visual_ssl=True, ssl_projection_size=32, ssl_projection_hidden_size=64),
+                                  dict(use_visual_ssl=True, visual_ssl_type="simclr", ssl_projection_size=32)],
+                         ids=["default", "causal", "rotary", "mlm", "extra", "downsample", "simsiam", "simclr"])
+def test_state_dict_keys_and_shapes(over):
+    """the product's state_dict (keys, shapes, the aliases under which shared towers are listed again) against the map the reference's
+    strict load_state_dict pinned in oracle/make_golden.py"""
+    import dataclasses
+    cfg = dataclasses.replace(O.CFG1, **over)
+    model = C.build_clip(cfg, O.make_state_dict(cfg, 1, torch.float32), DEV, torch.float32)     # strict load inside
+    shapes = O.state_dict_shapes(cfg)
     sd = model.state_dict()
-    assert set(sd) == set(shapes)
+    assert set(sd) == set(shapes), set(sd) ^ set(shapes)
     for k, v in sd.items():
         assert tuple(v.shape) == tuple(shapes[k]), k
+
+
+def test_batchnorm_module_semantics():
+    """x_clip_amd.visual_ssl.BatchNorm1d against torch.nn.BatchNorm1d: train / eval, running statistics and num_batches_tracked, cumulative
+    average (momentum = None), affine = False, buffers cast to bf16"""
+    from x_clip_amd.visual_ssl import BatchNorm1d
+    g = torch.Generator().manual_seed(3)
+    for kw in (dict(), dict(momentum=None), dict(affine=False), dict(momentum=0.3, eps=1e-3)):
+        ours, ref = BatchNorm1d(64, **kw), torch.nn.BatchNorm1d(64, **kw).double()
+        if kw.get("affine", True):
+            with torch.no_grad():
+                ours.weight.copy_(1 + 0.1 * torch.randn(64, generator=g))
+                ours.bias.copy_(0.1 * torch.randn(64, generator=g))
+                ref.weight.copy_(ours.weight.double())
+                ref.bias.copy_(ours.bias.double())
+        for step in range(3):
+            x = torch.randn(10 + step, 64, generator=g) * (1 + step) + step
+            y, yr = ours(x), ref(x.double())
+            torch.testing.assert_close(y.double(), yr, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(ours.running_mean.double(), ref.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(ours.running_var.double(), ref.running_var, rtol=1e-5, atol=1e-6)
+        assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 3
+        ours.eval(), ref.eval()
+        x = torch.randn(5, 64, generator=g)
+        torch.testing.assert_close(ours(x).double(), ref(x.double()), rtol=1e-5, atol=1e-5)
+        assert int(ours.num_batches_tracked) == 3                      # eval mode leaves the statistics alone
+    b16 = BatchNorm1d(64).to(torch.bfloat16)
+    b16(torch.randn(12, 64, generator=g).to(torch.bfloat16))
+    assert b16.running_mean.dtype == torch.bfloat16 and torch.isfinite(b16.running_var.float()).all() and float(b16.running_mean.float().abs().max()) > 0
+
+
+def test_eos_pooling_indices():
+    """XF.eos_to_front against the oracle's restatement (first eos per row to the front, the rest in order) and its gradient (a row permutation)"""
+    from x_clip_amd import functional as XF
+    g = torch.Generator().manual_seed(5)
+    enc = torch.randn(5, 9, 64, generator=g, requires_grad=True)
+    tokens = torch.randint(1, 50, (5, 9), generator=g)
+    eos = 77
+    for r, pos in enumerate((8, 0, 4, 3, 6)):
+        tokens[r, pos] = eos
+    tokens[2, 7] = eos                                                   # a second eos later in the row is ignored
+    out = XF.eos_to_front(enc, tokens, eos)
+    assert torch.equal(out.detach(), O.eos_to_front(enc.detach(), tokens, eos))
+    w = torch.randn(5, 9, 64, generator=g)
+    (out * w).sum().backward()
+    enc2 = enc.detach().clone().requires_grad_(True)
+    (O.eos_to_front(enc2, tokens, eos) * w).sum().backward()
+    assert torch.equal(enc.grad, enc2.grad)
+    with pytest.raises(AssertionError, match="does not have the eos id"):
+        XF.eos_to_front(enc.detach(), torch.ones(5, 9, dtype=torch.int64), eos)
 
 
 def test_no_cpu_fallback_without_library():
