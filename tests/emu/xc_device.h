@@ -223,7 +223,12 @@ inline hipError_t hipFuncSetAttributeMaxDynLds(const void*, int) { return 0; }
     xcemu::launch([=]() { kernel(__VA_ARGS__); }, grid, block)
 inline void __syncthreads() { xcemu::block_barrier(); }
 
-inline int xc_num_cus() { return 3; }          // small on purpose: persistent kernels wrap around in the tests
+// small on purpose: persistent kernels wrap around in the tests.  XCLIP_EMU_CUS=256 (diagnostics) makes the host-side grid / split
+// heuristics take the decisions they take on an MI355X.
+inline int xc_num_cus() {
+    static const int v = [] { const char* e = getenv("XCLIP_EMU_CUS"); return e != nullptr && atoi(e) > 0 ? atoi(e) : 3; }();
+    return v;
+}
 
 namespace xc {
 
