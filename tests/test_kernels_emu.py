@@ -200,3 +200,33 @@ def test_nt_xent(dtype, rows, dim, temperature):
 
 def test_gemm_splitk_uneven_slices():
     K.case_gemm_splitk_uneven(DEV, M=256, N=256, K=2880)
+
+
+def test_edge_cases_of_the_row_kernels():
+    """zero rows are a no-op (an empty tensor has a null data pointer); NT-Xent with a single pair; a zero prediction row in the SimSiam
+    loss follows F.normalize's clamp; causal attention whose leading keys are padding (the first queries see no key: output 0, finite
+    gradients -- the reference's softmax over all-masked scores returns the uniform average there, include/xclip.h)"""
+    from x_clip_amd import ops
+    from x_clip_amd.visual_ssl import _NegCosineFn, nt_xent_loss
+    F = torch.nn.functional
+    assert tuple(ops.gather_rows(torch.randn(4, 8), torch.zeros(0, dtype=torch.int32)).shape) == (0, 8)
+    acc = torch.zeros(1)
+    assert ops.cross_entropy_fwd(torch.randn(0, 8), 8, torch.zeros(0, dtype=torch.int64), acc).numel() == 0 and float(acc) == 0.0
+    q, k = torch.randn(1, 16, requires_grad=True), torch.randn(1, 16, requires_grad=True)
+    loss = nt_xent_loss(q, k, 0.5)                       # one pair: each row's only candidate is its partner
+    loss.backward()
+    assert float(loss) == 0.0 and float(q.grad.abs().max()) == 0.0
+    p = torch.randn(6, 32)
+    p[2] = 0
+    p.requires_grad_(True)
+    z = torch.randn(6, 32)
+    _NegCosineFn.apply(p, z, 1.0 / 6).backward()
+    p64 = p.detach().double().requires_grad_(True)
+    (2 - 2 * (F.normalize(p64, dim=-1) * F.normalize(z.double(), dim=-1)).sum(-1)).mean().backward()
+    torch.testing.assert_close(p.grad.double(), p64.grad, rtol=1e-5, atol=1e-6)
+    qkv = K.rnd((2, 40, 3 * 64), torch.bfloat16, 5)
+    mask = torch.ones(2, 40, dtype=torch.bool)
+    mask[0, :3] = False
+    out, lse = ops.attention_fwd(qkv, mask, 1, 0.125, True)
+    dq = ops.attention_bwd(qkv, mask, out, torch.ones_like(out), lse, 1, 0.125, True)
+    assert torch.isfinite(out.float()).all() and float(out[0, :3].float().abs().max()) == 0.0 and torch.isfinite(dq.float()).all()

@@ -529,8 +529,8 @@ int xclip_dwconv4s2_bwd(const void* dy, const void* x, const void* w, void* dx, 
 int xclip_gather_rows(const void* src, int64_t lds, const int32_t* idx, void* out, int64_t rows, int64_t dim, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec_of(dtype) == 0 && lds % vec_of(dtype) == 0, "dim / row stride must be whole 16-byte chunks");
+    if (rows == 0) return 0;                                  // (an empty tensor has a null data pointer)
     XC_REQUIRE(src && idx && out && aligned16(src) && aligned16(out), "null or misaligned pointer");
-    if (rows == 0) return 0;
     int64_t blocks = (rows * (dim / vec_of(dtype)) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     dim3 grid((unsigned)blocks), block(256);
@@ -544,8 +544,8 @@ int xclip_cross_entropy_fwd(const void* logits, int64_t ld, const int64_t* label
                             int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && ld % vec_of(dtype) == 0, "row stride must cover the columns in whole 16-byte chunks");
+    if (rows == 0) return 0;                                  // (an empty tensor has a null data pointer)
     XC_REQUIRE(logits && labels && lse && loss_accum && aligned16(logits), "null or misaligned pointer");
-    if (rows == 0) return 0;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > ROWLOSS_MAX_BLOCKS) blocks = ROWLOSS_MAX_BLOCKS;
     dim3 grid((unsigned)blocks), block(256);
@@ -559,8 +559,8 @@ int xclip_cross_entropy_bwd(void* logits, int64_t ld, const int64_t* labels, con
                             int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && ld % vec_of(dtype) == 0, "row stride must cover the columns in whole 16-byte chunks");
+    if (rows == 0) return 0;                                  // (an empty tensor has a null data pointer)
     XC_REQUIRE(logits && labels && lse && gmul && aligned16(logits), "null or misaligned pointer");
-    if (rows == 0) return 0;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (dtype == XCLIP_BF16)
         hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)logits, (long)ld, (const long long*)labels, lse, gmul, (int)rows, (int)cols);
@@ -946,8 +946,8 @@ int xclip_neg_cosine_fwd(const void* p, const void* z, int64_t rows, int64_t dim
                          float* loss_accum, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec_of(dtype) == 0, "dim must be a multiple of the 16-byte chunk");
+    if (rows == 0) return 0;                                  // (an empty tensor has a null data pointer)
     XC_REQUIRE(p && z && cosv && rp && rz && loss_accum && aligned16(p) && aligned16(z), "null or misaligned pointer");
-    if (rows == 0) return 0;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > ROWLOSS_MAX_BLOCKS) blocks = ROWLOSS_MAX_BLOCKS;
     dim3 grid((unsigned)blocks), block(256);
@@ -962,8 +962,8 @@ int xclip_neg_cosine_bwd(const void* p, const void* z, const float* cosv, const 
                          void* dp, int64_t rows, int64_t dim, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(rows >= 0 && dim > 0 && dim % vec_of(dtype) == 0, "dim must be a multiple of the 16-byte chunk");
+    if (rows == 0) return 0;                                  // (an empty tensor has a null data pointer)
     XC_REQUIRE(p && z && cosv && rp && rz && gmul && dp && aligned16(p) && aligned16(z) && aligned16(dp), "null or misaligned pointer");
-    if (rows == 0) return 0;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (dtype == XCLIP_BF16)
         hipLaunchKernelGGL((neg_cosine_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)z, cosv, rp, rz, gmul, coef, (bf16_t*)dp, (int)rows, (int)dim);
