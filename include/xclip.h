@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 11
+#define XCLIP_ABI_VERSION 12
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -58,12 +58,15 @@ int xclip_l2norm_fwd(const void* x, void* y, float* rnorm, int64_t rows, int64_t
 int xclip_l2norm_bwd(const void* dy, const void* y, const float* rnorm, void* dx, int64_t rows, int64_t dim, int dtype, void* stream);
 
 /* ---- text embedding (reference TextTransformer.forward x_clip.py:320-335) ---------------------------------------
- * out[b,0] = cls ; out[b,1+j] = E[tok[b,j]] + P[j].  cls / P may be NULL (no CLS row / no absolute positions). */
+ * out[b,0] = cls ; out[b,1+j] = E[tok[b,j]] + P[j].  cls / P may be NULL (no CLS row / no absolute positions).
+ * E has `vocab` rows.  A token id outside [0, vocab) -- where the reference's nn.Embedding raises IndexError (CPU) or trips a
+ * device assert (x_clip.py:320) -- reads and writes nothing out of bounds: its output row is NaN and *bad_token_flag (device
+ * int32, may be NULL) is set to 1 for the host to report; the backward entry points skip such ids. */
 int xclip_text_embed_fwd(const int64_t* tokens, const void* E, const void* P, const void* cls, void* out,
-                         int64_t batch, int64_t n, int64_t dim, int dtype, void* stream);
+                         int64_t batch, int64_t n, int64_t dim, int64_t vocab, int32_t* bad_token_flag, int dtype, void* stream);
 /* fp32 accumulators: dE [vocab, dim], dP [n, dim] (may be NULL), dcls [dim] (NULL when has_cls = 0) */
 int xclip_text_embed_bwd(const void* dout, const int64_t* tokens, float* dE_accum, float* dP_accum, float* dcls_accum,
-                         int64_t batch, int64_t n, int64_t dim, int has_cls, int dtype, void* stream);
+                         int64_t batch, int64_t n, int64_t dim, int64_t vocab, int has_cls, int dtype, void* stream);
 
 /* ---- patchify 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (x_clip.py:357) with the PatchDropout keep-set
  * (x_clip.py:140-151) folded in: out[(b,i), :] = patch keep[b*nkeep + i] of image b (keep NULL: identity, nkeep =
@@ -97,9 +100,11 @@ int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, flo
  * index entry e had before sorting, row(p) = (p / n_in) * n_out + p % n_in + row_off.  Equal ids are summed in registers and
  * flushed once per run: the token-embedding gradient (nn.Embedding backward of x_clip.py:320) with n_in = n, n_out = n + cls,
  * row_off = cls; the position-table gradient of the kept patches (x_clip.py:382-385) with n_in = n_out = 1, row_off = 0.
- * xclip_text_embed_bwd may be called with dE_accum = NULL when the embedding gradient is produced this way. */
+ * xclip_text_embed_bwd may be called with dE_accum = NULL when the embedding gradient is produced this way.  The table has
+ * `table_rows` rows; entries whose id lies outside [0, table_rows) are dropped. */
 int xclip_scatter_add_sorted(const void* src, int64_t lds, const int64_t* sorted_ids, const int64_t* perm, float* table_accum,
-                             int64_t count, int64_t dim, int64_t n_in, int64_t n_out, int64_t row_off, int dtype, void* stream);
+                             int64_t table_rows, int64_t count, int64_t dim, int64_t n_in, int64_t n_out, int64_t row_off, int dtype,
+                             void* stream);
 
 /* dst[i] = (dtype) (src[i] * scale) : fp32 gradient accumulators -> parameter dtype */
 int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale, int dtype, void* stream);

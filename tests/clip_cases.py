@@ -139,9 +139,15 @@ def oracle_run(cfg, sd64, text, image64, aug_t, aug_i64, keep, mlm=None, ssl_run
     return loss.detach(), {k: v.grad for k, v in sd.items()}
 
 
+# measured end-to-end errors of this session: case label -> {loss_err, worst gradient (relative error, cosine) and its tensor};
+# tests/conftest.py writes the table next to the per-kernel one (gpurun_out/parity_report_*.txt)
+REPORT = {}
+
+
 def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_image=0, patch_keep=None, seed=7, bf16_cos=0.98,
-                   bf16_rel=0.2, **extra):
-    """product vs. the fp64 oracle on the same (dtype-rounded) parameters and inputs; every gradient in full"""
+                   bf16_rel=0.2, bf16_loss=2e-2, label=None, **extra):
+    """product vs. the fp64 oracle on the same (dtype-rounded) parameters and inputs; every gradient in full.  bf16: the oracle runs
+    in fp64 on the bf16-rounded parameters WITH THE bf16 LayerNorm epsilon (1e-3, x_clip.py:118) -- the model the product computes"""
     sd = O.make_state_dict(cfg, seed, torch.float32)
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     text, image, aug_t, aug_i = O.make_inputs(cfg, batch, seed + 1, n_aug_text, n_aug_image)
@@ -160,8 +166,9 @@ def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_ima
     loss = run_product(model, text, image, aug_t, aug_i, dev, dtype, keep, mlm)
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     running = {}
-    ref_loss, ref_grads = oracle_run(cfg, sd64, text, image.double(), aug_t, [a.double() for a in aug_i], keep, mlm, running)
     fp32 = dtype == torch.float32
+    with O.layer_norm_eps(1e-5 if fp32 else 1e-3):
+        ref_loss, ref_grads = oracle_run(cfg, sd64, text, image.double(), aug_t, [a.double() for a in aug_i], keep, mlm, running)
     after = model.state_dict()
     running.pop("relu_margin", None)
     for k, want in running.items():                             # SimSiam: BatchNorm running statistics after the step
@@ -170,7 +177,14 @@ def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_ima
         #  the activations whose 1-2 % bf16 deviation it inherits: measure its error against sqrt(running_var))
         scale = want.norm() if (fp32 or k.endswith("running_var")) else running[k[:-len("running_mean")] + "running_var"].sqrt().norm()
         assert float((got - want).norm() / scale) < (2e-5 if fp32 else 2e-2), k
-    assert abs(float(loss.detach()) - float(ref_loss)) < (1e-5 if fp32 else 2e-2) * max(1.0, abs(float(ref_loss))), (float(loss.detach()), float(ref_loss))
+    loss_err = abs(float(loss.detach()) - float(ref_loss)) / max(1.0, abs(float(ref_loss)))
+    rec = {"loss_err": loss_err, "worst_rel": (0.0, ""), "worst_cos": (1.0, "")}
+    REPORT[label or f"{'fp32' if fp32 else 'bf16'} b={batch} depth={cfg.text_enc_depth}/{cfg.visual_enc_depth} seq={cfg.text_seq_len} "
+           f"aug={n_aug_text}+{n_aug_image} keep={patch_keep} {'dcl ' if cfg.decoupled_contrastive_learning else ''}"
+           f"{'filip ' if cfg.use_all_token_embeds else ''}seed={seed}"] = rec
+    failures = []
+    if not loss_err < (1e-5 if fp32 else bf16_loss):
+        failures.append(("loss", float(loss.detach()), float(ref_loss)))
     for k, p in model.named_parameters():
         rg = ref_grads[k]
         if rg is None or float(rg.abs().max()) == 0.0:
@@ -183,10 +197,16 @@ def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_ima
             continue
         rel = float((g - rg).norm() / rg.norm())
         cos = float((g * rg).sum() / (g.norm() * rg.norm()))
+        if rel > rec["worst_rel"][0]:
+            rec["worst_rel"] = (rel, k)
+        if cos < rec["worst_cos"][0]:
+            rec["worst_cos"] = (cos, k)
         if fp32:
-            assert rel < 2e-4, (k, rel)
-        else:
-            assert cos > bf16_cos and rel < bf16_rel, (k, rel, cos)
+            if not rel < 2e-4:
+                failures.append((k, rel))
+        elif not (cos > bf16_cos and rel < bf16_rel):
+            failures.append((k, rel, cos))
+    assert not failures or os.environ.get("XCLIP_TEST_MEASURE_ONLY") == "1", failures
     return float(loss.detach())
 
 

@@ -1,0 +1,212 @@
+"""Workers of the 2-rank runs of the product, shared by the CPU suite (tests/test_distributed_gloo.py: gloo backend, kernels from the
+wave64 emulator build) and the GPU suite (tests/test_distributed_gpu.py: two processes on cuda:0, libxclip_hip.so, real HIP streams;
+gloo carries the collectives because RCCL does not accept two ranks on one device).  `kind` = "cpu" | "cuda"."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _maybe_poison():
+    """XCLIP_TEST_POISON=1: NaN-poison every torch.empty in the worker, see clip_cases.poisoned_empty"""
+    if os.environ.get("XCLIP_TEST_POISON") == "1":
+        import clip_cases
+        clip_cases.poisoned_empty().__enter__()
+
+
+def setup(rank, world, port, kind, backend="gloo"):
+    """process group + kernel library for this worker -> torch.device"""
+    _maybe_poison()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from x_clip_amd import _lib
+    if kind == "cuda":
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        _lib._use_library_for_tests(None)
+        _lib.lib()                                   # libxclip_hip.so or an exception: no fallback
+        assert not _lib.is_emulator()
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        from emu.build_emu import build
+        _lib._use_library_for_tests(build())
+    return dev
+
+
+def worker_fixture(rank, world, port, name, sizes, tmp, kind="cpu"):
+    dev = setup(rank, world, port, kind)
+    from x_clip_amd import CLIP
+    from x_clip_amd.distributed import all_gather
+    from oracle import clip_oracle as O
+    with open(os.path.join(HERE, "golden", name + ".json")) as f:
+        rec = json.load(f)
+    cfg = O.ClipConfig(**rec["config"])
+    sd = O.make_state_dict(cfg, rec["param_seed"], torch.float32)
+    total = sum(sizes)
+    text, image, _, _ = O.make_inputs(cfg, total, rec["input_seed"])
+    lo = sum(sizes[:rank])
+    text, image = text[lo: lo + sizes[rank]].to(dev), image[lo: lo + sizes[rank]].float().to(dev)
+    model = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)        # AFTER init_process_group (x_clip.py:591)
+    assert model.requires_all_gather
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    loss = model(text, image, return_loss=True)
+    loss.backward()
+    grads = {k: (p.grad.detach().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    # reference-contract all_gather: uneven sizes along dim 1, backward keeps the local slice
+    x = (torch.arange(2 * sizes[rank] * 3, dtype=torch.float32).view(2, sizes[rank], 3) + 100 * rank).to(dev).requires_grad_(True)
+    gathered, szs = all_gather(x, 1, None)
+    assert szs.tolist() == sizes and gathered.shape == (2, total, 3)
+    assert torch.equal(gathered[:, lo: lo + sizes[rank]], x.detach())
+    (gathered * torch.arange(total, dtype=torch.float32, device=dev).view(1, -1, 1)).sum().backward()
+    assert torch.equal(x.grad.cpu(), torch.arange(lo, lo + sizes[rank], dtype=torch.float32).view(1, -1, 1).expand(2, -1, 3))
+    torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def worker_even(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", dtype_name="float32", patch_keep=None):
+    dev = setup(rank, world, port, kind)
+    from x_clip_amd import CLIP
+    from x_clip_amd.distributed import GradSync
+    from oracle import clip_oracle as O
+    dtype = getattr(torch, dtype_name)
+    cfg = O.ClipConfig(**cfg_kwargs)
+    sd = O.make_state_dict(cfg, 5, torch.float32)
+    sd = {k: (v.to(dtype).float() if v.is_floating_point() else v) for k, v in sd.items()}
+    text, image, aug_t, aug_i = O.make_inputs(cfg, batch * world, 6, 1, 0)
+    sl = slice(rank * batch, (rank + 1) * batch)
+    model = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.5 if patch_keep else 0.0)
+    model.load_state_dict(sd)
+    model = model.to(dtype).to(dev).train()
+    model.assume_equal_batch = True
+    if patch_keep:
+        g = torch.Generator().manual_seed(8)
+        keep = torch.randn(batch * world * 2, cfg.num_patches, generator=g).topk(patch_keep, dim=-1).indices
+        # rows of this rank's images: the main view, then the augmented views in the order CLIP.forward concatenates them
+        model.visual_transformer.keep_indices_override = keep[sl].to(torch.int32).to(dev)
+    sync = GradSync(model)
+    loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, aug_text=[aug_t[0][sl].to(dev)])
+    loss.backward()
+    sync.finish()
+    if kind == "cuda":
+        torch.cuda.synchronize()
+    grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def worker_filip(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu"):
+    dev = setup(rank, world, port, kind)
+    from x_clip_amd import CLIP
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig(**cfg_kwargs)
+    sd = O.make_state_dict(cfg, 15, torch.float32)
+    text, image, _, _ = O.make_inputs(cfg, batch * world, 16)
+    sl = slice(rank * batch, (rank + 1) * batch)
+    model = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    loss = model(text[sl].to(dev), image[sl].float().to(dev), return_loss=True)
+    loss.backward()
+    grads = {k: (p.grad.detach().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def worker_nccl_probe(rank, world, port, tmp):
+    """does RCCL accept two ranks on ONE device?  Records the outcome; never raises."""
+    out = {"rank": rank}
+    try:
+        dev = setup(rank, world, port, "cuda", backend="nccl")
+        t = torch.full((4,), float(rank + 1), device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        out["ok"], out["sum"] = True, t.tolist()
+        dist.destroy_process_group()
+    except Exception as e:                                    # noqa: BLE001 -- the point is to record what RCCL says
+        out["ok"], out["error"] = False, f"{type(e).__name__}: {str(e)[:400]}"
+    torch.save(out, os.path.join(tmp, f"nccl_rank{rank}.pt"))
+
+
+# ---- the checks (run in the parent on the workers' files) ------------------------------------------------------------------------
+def check_fixture(tmp, name, world=2):
+    with open(os.path.join(HERE, "golden", name + ".json")) as f:
+        rec = json.load(f)
+    outs = [torch.load(os.path.join(tmp, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    single = rec["single_process"]
+    for o in outs:
+        assert abs(o["loss"] - single["loss"]) < 1e-5, (o["loss"], single["loss"])
+    for k, ref_norm in single["grad_norm"].items():
+        if ref_norm is None:
+            continue
+        g0, g1 = outs[0]["grads"][k], outs[1]["grads"][k]
+        if k == "temperature":
+            for g in (g0, g1):          # downstream of the gather: every rank holds the full gradient
+                assert abs(float(g.norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-7
+            continue
+        tot = (g0 + g1).double().norm()
+        assert abs(float(tot) - ref_norm) <= 5e-4 * ref_norm + 1e-7, (k, float(tot), ref_norm)
+
+
+def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, rel_bar=3e-4, loss_bar=1e-5, cos_bar=None):
+    from oracle import clip_oracle as O
+    outs = [torch.load(os.path.join(tmp, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    sd = O.make_state_dict(cfg, 5, torch.float32)
+    sd = {k: (v.to(dtype).double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    text, image, aug_t, _ = O.make_inputs(cfg, batch * world, 6, 1, 0)
+    keep = None
+    if patch_keep:
+        g = torch.Generator().manual_seed(8)
+        keep = torch.randn(batch * world * 2, cfg.num_patches, generator=g).topk(patch_keep, dim=-1).indices[: batch * world]
+    with O.layer_norm_eps(1e-5 if dtype == torch.float32 else 1e-3):
+        ref = O.clip_forward(sd, cfg, text, image.to(dtype).double(), aug_t, [], keep)
+        ref.backward()
+    for o in outs:
+        assert abs(o["loss"] - float(ref.detach())) < loss_bar * max(1.0, abs(float(ref.detach()))), (o["loss"], float(ref.detach()))
+    worst = (0.0, "")
+    for k, v in sd.items():
+        if not torch.is_tensor(v) or not v.is_floating_point() or v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        # temperature: every rank computes the full d tau (like the reference), so its mean is the full gradient
+        want = v.grad if k == "temperature" else v.grad / world
+        for o in outs:
+            g = o["grads"][k].double()
+            rel = float((g - want).norm() / want.norm().clamp_min(1e-30))
+            worst = max(worst, (rel, k))
+            assert rel < rel_bar, (k, rel)
+            if cos_bar is not None:
+                assert float((g * want).sum() / (g.norm() * want.norm())) > cos_bar, k
+        assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k     # the all-reduced gradients are the same bits on both ranks
+    return worst
+
+
+def check_filip(tmp, cfg, batch, world=2):
+    from oracle import clip_oracle as O
+    outs = [torch.load(os.path.join(tmp, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    sd = {k: v.double().requires_grad_(True) for k, v in O.make_state_dict(cfg, 15, torch.float32).items()}
+    text, image, _, _ = O.make_inputs(cfg, batch * world, 16)
+    ref = O.clip_forward(sd, cfg, text, image.float().double())
+    ref.backward()
+    for o in outs:
+        assert abs(o["loss"] - float(ref.detach())) < 1e-5, (o["loss"], float(ref.detach()))
+    for k, v in sd.items():
+        if v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        g0, g1 = outs[0]["grads"][k], outs[1]["grads"][k]
+        tot = (g0 + g1).double() / (world if k == "temperature" else 1)
+        rel = float((tot - v.grad).norm() / v.grad.norm().clamp_min(1e-30))
+        assert rel < 3e-4, (k, rel)

@@ -8,6 +8,7 @@ one rounding on store) must sit within 1.5 bf16 ulps of the output scale (2^-8 *
 reading of the north-star's "1e-3 bf16 / 1e-5 fp32" given in SURVEY.md section 0.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -31,14 +32,62 @@ def ref64(t):
     return t.detach().cpu().to(torch.float64)
 
 
-def close(got, want, dtype, name="", scale=None, mult=1.0):
+# name -> [largest measured error, the bound it was held to, unit]: written out by tests/conftest.py at session end (the GPU run's
+# table is committed under profiles/ and quoted in DESIGN.md section 7 -- measured errors, not bounds)
+REPORT = {}
+
+
+def _record(name, dtype, measured, bound, unit):
+    key = f"{name} [{'bf16' if dtype == torch.bfloat16 else 'fp32'}]"
+    cur = REPORT.get(key)
+    if cur is None or measured > cur[0]:
+        REPORT[key] = [measured, bound, unit]
+
+
+def bf16_ulp(x):
+    """spacing of bfloat16 (8 significand bits) at |x|, elementwise, fp64 in / out"""
+    ax = x.abs().clamp_min(2.0 ** -126)
+    return torch.exp2(torch.floor(torch.log2(ax)) - 7)
+
+
+def close(got, want, dtype, name="", scale=None, mult=1.0, ulps=1.0, unit="elem"):
+    """fp32 storage: max |got - want| <= 2e-5 * mult of the output scale (`mult` applies to fp32 only).
+    bf16 storage (bound `ulps`), measured against the fp64 reference ROUNDED to bf16, in bf16 ulps, two ways:
+      unit="elem"  (kernels with fp32 arithmetic and ONE rounding on store: every GEMM, LayerNorm forward, embeddings, means,
+                   log-sum-exps ...): ELEMENT-WISE, |got_i - bf16(want_i)| <= `ulps` ulps of max(|want_i|, scale / 256) -- one ulp is
+                   all such a kernel can differ by from the rounded exact value; elements below 1/256 of the output scale are held
+                   to the ulp at scale / 256 = 1.5e-5 of the scale, the fp32 bar (an fp32 sum cancelling to ~0 is not exact to ITS
+                   OWN bf16 ulp);
+      unit="scale" (kernels whose arithmetic itself passes through bf16: attention rounds P and dS to feed the matrix cores, a
+                   backward kernel reads the forward's ROUNDED output, two chained GEMMs round the intermediate): the error of
+                   an output element is set by the magnitude of the terms summed into it, not by its own size, so the check is
+                   max |got - bf16(want)| <= `ulps` ulps OF THE OUTPUT SCALE; each such case states its bound next to the measured
+                   value (tests print both into gpurun_out/parity_report_*.txt)."""
     got = got.detach().cpu().to(torch.float64)
     want = want.detach().cpu().to(torch.float64)
     assert got.shape == want.shape, (name, got.shape, want.shape)
-    s = float(want.abs().max()) if scale is None else scale
-    err = float((got - want).abs().max())
-    assert math.isfinite(err), name
-    assert err <= tol(dtype) * mult * max(s, 1e-6), f"{name}: max err {err:.3e} vs scale {s:.3e} ({dtype})"
+    s = max(float(want.abs().max()) if scale is None else scale, 1e-30)
+    assert bool(torch.isfinite(got).all()), name
+    if dtype == torch.float32:
+        err = float((got - want).abs().max())
+        _record(name, dtype, err / s, tol(dtype) * mult, "of the output scale")
+        assert err <= tol(dtype) * mult * max(s, 1e-6), f"{name}: max err {err:.3e} vs scale {s:.3e} ({dtype})"
+        return
+    want_r = want.to(torch.bfloat16).to(torch.float64)
+    diff = (got - want_r).abs()
+    if unit == "elem":
+        err_ulps = float((diff / bf16_ulp(torch.maximum(want.abs(), torch.full_like(want, s / 256)))).max())
+        label = "bf16 ulp, element-wise"
+    else:
+        assert unit == "scale"
+        err_ulps = float(diff.max() / bf16_ulp(torch.tensor(s, dtype=torch.float64)))
+        label = "bf16 ulp of the output scale"
+    _record(name, dtype, err_ulps, ulps, label)
+    if os.environ.get("XCLIP_TEST_MEASURE_ONLY") == "1":
+        other = float(diff.max() / bf16_ulp(torch.tensor(s, dtype=torch.float64)))
+        _record(name + " {scale-ulp}", dtype, other, 0, "info")
+        return
+    assert err_ulps <= ulps, f"{name}: {err_ulps:.3f} {label} (bound {ulps}) at output scale {s:.3e}"
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -76,7 +125,7 @@ def case_l2norm(dev, dtype, rows, dim):
     yr.backward(ref64(dy))
     close(y, yr, dtype, "l2 y")
     # the backward consumes the (rounded) y the forward stored
-    close(dx, x64.grad, dtype, "l2 dx", mult=3.0)
+    close(dx, x64.grad, dtype, "l2 dx", mult=3.0, ulps=2.0, unit="scale")
 
 
 def case_text_embed(dev, dtype, batch, n, dim, vocab, has_pos=True, has_cls=True):
@@ -103,6 +152,41 @@ def case_text_embed(dev, dtype, batch, n, dim, vocab, has_pos=True, has_cls=True
         close(dP, P64.grad, torch.float32, "dP", mult=4.0)
     if has_cls:
         close(dcls, c64.grad, torch.float32, "dcls", mult=4.0)
+
+
+def case_text_embed_bad_ids(dev, dtype):
+    """token ids outside [0, vocab): the reference's nn.Embedding raises IndexError (x_clip.py:320); here nothing is read or written
+    out of bounds, the offending rows come out NaN, the host raises IndexError (at once on the CPU build, at the next call on the GPU
+    once the flag copy has landed -- no sync in the step), and the backward kernels drop those ids"""
+    import pytest
+    batch, n, dim, vocab = 3, 6, 64, 11
+    g = torch.Generator().manual_seed(70)
+    tok = torch.randint(0, vocab, (batch, n), generator=g)
+    tok[1, 2], tok[2, 5] = vocab, -1
+    E = rnd((vocab, dim), dtype, 71)
+    P = rnd((n, dim), dtype, 72)
+    gpu = torch.device(dev).type == "cuda"
+    if gpu:
+        out = ops.text_embed_fwd(tok.to(dev), E.to(dev), P.to(dev), None)      # launches; the flag copy is in flight
+        torch.cuda.synchronize()
+        assert torch.isnan(out[1, 2].float()).all() and torch.isnan(out[2, 5].float()).all()
+        assert torch.isfinite(out[0].float()).all() and torch.isfinite(out[1, :2].float()).all()
+        with pytest.raises(IndexError, match="index out of range"):
+            ops.text_embed_fwd(tok.clamp(0, vocab - 1).to(dev), E.to(dev), P.to(dev), None)   # the NEXT call reports it
+    else:
+        with pytest.raises(IndexError, match="index out of range"):
+            ops.text_embed_fwd(tok.to(dev), E.to(dev), P.to(dev), None)
+    ok = ops.text_embed_fwd(tok.clamp(0, vocab - 1).to(dev), E.to(dev), P.to(dev), None)       # and the state is clean again
+    assert torch.isfinite(ok.float()).all()
+    dout = rnd((batch, n, dim), dtype, 73)
+    good = (tok >= 0) & (tok < vocab)
+    want = torch.zeros(vocab, dim, dtype=torch.float64)
+    want.index_add_(0, tok[good], ref64(dout)[good])
+    dE, dP, _ = ops.text_embed_bwd(dout.to(dev), tok.to(dev), vocab, True, False)
+    close(dE, want, torch.float32, "dE with bad ids dropped", mult=4.0)
+    st = torch.sort(tok.reshape(-1))
+    dE2, _, _ = ops.text_embed_bwd(dout.to(dev), tok.to(dev), vocab, True, False, sorted_tokens=(st.values.to(dev), st.indices.to(dev)))
+    close(dE2, want, torch.float32, "dE sorted with bad ids dropped", mult=4.0)
 
 
 def case_patchify(dev, dtype, batch, c, size, p, keep_frac):
@@ -191,9 +275,9 @@ def case_attention(dev, dtype, batch, n, heads, masked, causal=False):
     q64 = ref64(qkv).requires_grad_(True)
     r = _attention_ref(q64, mask, heads, scale, causal)
     r.backward(ref64(dout))
-    close(out, r, dtype, "attn out")
+    close(out, r, dtype, "attn out", ulps=2.0, unit="scale")
     dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale, causal)
-    close(dqkv, q64.grad, dtype, "attn dqkv", mult=3.0)
+    close(dqkv, q64.grad, dtype, "attn dqkv", mult=3.0, ulps=2.0, unit="scale")
 
 
 def case_attention_spike(dev, dtype):
@@ -207,7 +291,7 @@ def case_attention_spike(dev, dtype):
     scale = 64 ** -0.5
     out, lse = ops.attention_fwd(qkv.to(dev), None, heads, scale)
     r = _attention_ref(ref64(qkv), None, heads, scale)
-    close(out, r, dtype, "attn spike")
+    close(out, r, dtype, "attn spike", ulps=2.0, unit="scale")
 
 
 def case_simloss(dev, dtype, nq, nk, d, dcl, diag_off=0, tau=1.3):
@@ -263,8 +347,8 @@ def case_simloss_closed_form(dev, dtype, B, d, dcl):
     close(loss.reshape(1), torch.tensor([want["loss"]]), dtype, "loss", mult=2.0)
     close(dtau.reshape(1), torch.tensor([want["dtau"]]), dtype, "dtau", scale=1.0, mult=2.0)
     sc = float(np.abs(want["dT"]).max())
-    close(dT, torch.tensor(want["dT"]), dtype, "dT", scale=sc, mult=4.0)
-    close(dI, torch.tensor(want["dI"]), dtype, "dI", scale=sc, mult=4.0)
+    close(dT, torch.tensor(want["dT"]), dtype, "dT", scale=sc, mult=4.0, ulps=2.0, unit="scale")
+    close(dI, torch.tensor(want["dI"]), dtype, "dI", scale=sc, mult=4.0, ulps=2.0, unit="scale")
 
 
 def case_layernorm_residual_paths(dev, dtype, rows, dim, grp):
@@ -409,7 +493,7 @@ def case_rotary(dev, dtype, batch, n, heads):
     ref = O.apply_rotary(fr[None, :, None, :], x64).reshape(batch * n, slots * 64)
     close(y, ref, dtype, "rotary fwd")
     z = ops.rotary_(y.clone(), n, inv_freq, inverse=True)                      # R^T R = identity
-    close(z, ref64(x), dtype, "rotary inverse", mult=2.0)
+    close(z, ref64(x), dtype, "rotary inverse", mult=2.0, ulps=2.0, unit="scale")
 
 
 def case_dwconv(dev, dtype, batch, h, C):
@@ -473,15 +557,15 @@ def case_layernorm_chain(dev, dtype, rows, dim):
     h2r = ln(x1r, g264)
     (h2r * ref64(dh2)).sum().backward(retain_graph=True)
     close(x1, x1r, dtype, "chain x1")
-    close(h2, h2r, dtype, "chain h2", mult=3.0)                    # (h2 is computed from the ROUNDED x1, like two separate calls)
+    close(h2, h2r, dtype, "chain h2", mult=3.0, ulps=2.0, unit="scale")                    # (h2 is computed from the ROUNDED x1, like two separate calls)
     # total gradient of x1 = through LN2 + the skip path; dp = through LN1
     want_dx1 = x1r.grad + ref64(dres)
-    close(dx1, want_dx1, dtype, "chain dx1", mult=3.0)
+    close(dx1, want_dx1, dtype, "chain dx1", mult=3.0, ulps=2.0, unit="scale")
     gp, = torch.autograd.grad((ln(p64, g164) * want_dx1.detach()).sum(), p64)
-    close(dp, gp, dtype, "chain dp", mult=4.0)
-    close(dg2, g264.grad, torch.float32 if dtype == torch.float32 else dtype, "chain dg2", mult=4.0)
+    close(dp, gp, dtype, "chain dp", mult=4.0, ulps=2.0, unit="scale")
+    close(dg2, g264.grad, torch.float32 if dtype == torch.float32 else dtype, "chain dg2", mult=4.0, ulps=2.0, unit="scale")
     xh1 = ((p64 - p64.mean(-1, keepdim=True)) * torch.rsqrt(p64.var(-1, unbiased=False, keepdim=True) + eps)).detach()
-    close(dg1, (want_dx1.detach() * xh1).sum(0), torch.float32 if dtype == torch.float32 else dtype, "chain dg1", mult=4.0)
+    close(dg1, (want_dx1.detach() * xh1).sum(0), torch.float32 if dtype == torch.float32 else dtype, "chain dg1", mult=4.0, ulps=2.0, unit="scale")
 
 
 def case_batchnorm(dev, dtype, rows, cols, relu, affine, training, offset=0.0):
@@ -552,8 +636,8 @@ def case_nt_xent(dev, dtype, rows, dim, temperature):
     (want * 0.7).backward()
     assert abs(float(loss.detach()) - float(want.detach())) < (2e-5 if dtype == torch.float32 else 2e-2) * max(1.0, abs(float(want.detach()))), (float(loss.detach()), float(want.detach()))
     gs = max(float(q64.grad.abs().max()), float(k64.grad.abs().max()))
-    close(q.grad, q64.grad, dtype, "nt-xent dq", scale=gs, mult=4.0)
-    close(k.grad, k64.grad, dtype, "nt-xent dk", scale=gs, mult=4.0)
+    close(q.grad, q64.grad, dtype, "nt-xent dq", scale=gs, mult=4.0, ulps=2.0, unit="scale")
+    close(k.grad, k64.grad, dtype, "nt-xent dk", scale=gs, mult=4.0, ulps=2.0, unit="scale")
 
 
 def case_gemm_splitk_uneven(dev, M=1248, N=768, K=6144):

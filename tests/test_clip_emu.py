@@ -129,6 +129,57 @@ def test_pluggable_encoders_head_only():
     C.case_pluggable_encoders_head_only(DEV)
 
 
+def test_filip_odd_batch_and_token_counts():
+    """fine-grained head where (images x image tokens) is not a whole 16-byte chunk of similarity columns: 5 images x 9 patches = 45
+    (fp32 chunk 4, bf16 chunk 8) -- the reference runs these shapes, the token-similarity GEMM needs its N / K padded"""
+    import dataclasses
+    cfg = dataclasses.replace(O.CFG1, use_all_token_embeds=True, visual_image_size=96)
+    C.case_vs_oracle(DEV, torch.float32, cfg, 5)
+    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 5, bf16_cos=0.9, bf16_rel=0.5)
+
+
+def test_backward_twice_and_inplace_edits_fail_loudly():
+    """the activation tape is released while the backward walks it: a second backward says so; parameters are registered with
+    autograd, so an in-place edit between forward and backward trips its version check instead of giving silently wrong gradients"""
+    from x_clip_amd import CLIP
+    m = CLIP(**O.CFG1.ctor_kwargs(), visual_patch_dropout=0.0).train()
+    text, image, _, _ = O.make_inputs(O.CFG1, 4, 3)
+    loss = m(text, image.float(), return_loss=True)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already back-propagated"):
+        loss.backward()
+    m.zero_grad()
+    loss = m(text, image.float(), return_loss=True)
+    with torch.no_grad():
+        m.text_transformer.transformer.layers[0][0].fn.to_qkv.weight.mul_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+
+
+def test_no_grad_pass_keeps_no_tape():
+    """inference / frozen-tower passes must not hold the training tape (needs_input_grad is True for parameters even under no_grad)"""
+    from x_clip_amd import functional as XF
+    kept = []
+    orig = XF.stack_forward
+
+    def spy(*a, **k):
+        kept.append(k.get("keep_tape", True))
+        return orig(*a, **k)
+    XF.stack_forward = spy
+    try:
+        from x_clip_amd import CLIP
+        m = CLIP(**O.CFG1.ctor_kwargs(), visual_patch_dropout=0.0).train()
+        text, image, _, _ = O.make_inputs(O.CFG1, 4, 3)
+        with torch.no_grad():
+            m(text, image.float(), return_latents=True)
+        assert kept == [False, False], kept
+        kept.clear()
+        m(text, image.float(), return_loss=True, freeze_image_encoder=True)
+        assert sorted(kept) == [False, True], kept
+    finally:
+        XF.stack_forward = orig
+
+
 def test_no_kernel_reads_unwritten_memory():
     """reference fixtures again (FILIP head; SimSiam + MLM side losses) with every torch.empty the product makes poisoned with NaN"""
     with C.poisoned_empty():

@@ -43,6 +43,25 @@ def test_mid_vs_oracle(dtype):
     C.case_vs_oracle(DEV, dtype, MID, 24)
 
 
+# ---- the HEADLINE architecture (what bench.py times: O.ClipConfig() defaults = depth 6 / 6, text length 256 -> 257 positions, 64
+# patches of which 32 are kept) against the fp64 oracle, every parameter gradient in full ---------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_default_arch_vs_oracle(dtype):
+    """BASELINE configs[1] model at batch 12 (not a whole 16-byte chunk of rows in bf16), InfoNCE, patch dropout 0.5 with a fixed
+    draw.  fp32: loss 1e-5, every gradient 2e-4 relative (the north star's fp32 bar); bf16: see clip_cases.case_vs_oracle"""
+    C.case_vs_oracle(DEV, dtype, O.ClipConfig(), 12, patch_keep=32, seed=31, label=f"default arch InfoNCE b=12 keep=32 [{'fp32' if dtype == torch.float32 else 'bf16'}]")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_default_arch_dcl_multiview_vs_oracle(dtype):
+    """BASELINE configs[2] / [4] head on the default towers: decoupled contrastive loss, one augmented text + one augmented image
+    (four view pairs), patch dropout with a fixed draw for both image views"""
+    import dataclasses
+    cfg = dataclasses.replace(O.ClipConfig(), decoupled_contrastive_learning=True)
+    C.case_vs_oracle(DEV, dtype, cfg, 8, n_aug_text=1, n_aug_image=1, patch_keep=32, seed=41,
+                     label=f"default arch DCL multiview b=8 keep=32 [{'fp32' if dtype == torch.float32 else 'bf16'}]")
+
+
 def test_mid_patch_dropout_multiview_dcl_fp32():
     import dataclasses
     cfg = dataclasses.replace(MID, decoupled_contrastive_learning=True, extra_latent_projection=True)
@@ -168,6 +187,17 @@ def test_filip_chunked_workspace_matches_single_chunk(monkeypatch):
     l2 = m(text, image, return_loss=True); l2.backward()
     assert abs(float(l1.detach()) - float(l2.detach())) < 1e-6
     torch.testing.assert_close(g1, m.to_visual_latent.weight.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_filip_odd_chunks_vs_oracle(monkeypatch):
+    """fine-grained head with 9 image tokens and 22 images: no chunk of images gives a whole 16-byte chunk of similarity columns, and
+    the workspace bound is lowered so that several partial chunks are walked (N / K padding of the token GEMMs)"""
+    import dataclasses
+    from x_clip_amd import losses
+    cfg = dataclasses.replace(MID, use_all_token_embeds=True, visual_image_size=96)
+    monkeypatch.setattr(losses, "_FILIP_CHUNK_BYTES", 22 * cfg.text_seq_len * 9 * 4 * 5)       # ~5 images per chunk
+    C.case_vs_oracle(DEV, torch.float32, cfg, 22)
+    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 22, bf16_cos=0.9, bf16_rel=0.5)
 
 
 def test_vit_l_like_shapes_vs_oracle():

@@ -1,0 +1,81 @@
+"""The multi-rank path on a real MI355X: two processes share cuda:0, every kernel is libxclip_hip.so, the gathers / side streams /
+gradient hooks run on real HIP streams (what the CPU emulator run cannot see: ordering of the collective against the vision side
+stream, the weight-gradient side stream and workspace reuse).  gloo carries the collectives (it stages device tensors through the
+host), because RCCL refuses two ranks on one device -- `test_rccl_two_ranks_one_device_probe` records what it says.  Same workers and
+same checks as tests/test_distributed_gloo.py; every worker additionally runs with NaN-poisoned torch.empty."""
+import dataclasses
+import json
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import dist_cases as D  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def poisoned_workers(monkeypatch):
+    monkeypatch.setenv("XCLIP_TEST_POISON", "1")
+
+
+@pytest.mark.parametrize("name,sizes", [("dist2_infonce", [5, 3]), ("dist2_dcl", [5, 3]), ("dist2_simreg_extra", [5, 3])])
+def test_two_ranks_on_gpu_match_reference_semantics(name, sizes, tmp_path):
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(D.worker_fixture, args=(2, port, name, sizes, str(tmp_path), "cuda"), nprocs=2, join=True)
+    D.check_fixture(str(tmp_path), name)
+
+
+def test_two_ranks_on_gpu_even_batches_gradsync_vs_oracle(tmp_path):
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True, extra_latent_projection=True)
+    port = 31700 + (os.getpid() % 2000)
+    mp.spawn(D.worker_even, args=(2, port, dataclasses.asdict(cfg), 8, str(tmp_path), "cuda"), nprocs=2, join=True)
+    D.check_even(str(tmp_path), cfg, 8, 2)
+
+
+def test_two_ranks_on_gpu_mid_bf16_overlap_streams(tmp_path):
+    """a model large enough for the fast kernels and the side streams to matter (dim 512, 2 layers, 71 text positions, patch dropout),
+    bf16, DCL + an augmented text view, GradSync hooks firing under the wgrad side stream: vs the fp64 oracle of the global batch"""
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig(dim_text=512, dim_image=512, dim_latent=512, num_text_tokens=2000, text_enc_depth=2, text_seq_len=70,
+                       text_heads=8, visual_enc_depth=2, visual_image_size=128, visual_patch_size=32, visual_heads=8,
+                       decoupled_contrastive_learning=True)
+    port = 32700 + (os.getpid() % 2000)
+    mp.spawn(D.worker_even, args=(2, port, dataclasses.asdict(cfg), 16, str(tmp_path), "cuda", "bfloat16", 8), nprocs=2, join=True)
+    worst = D.check_even(str(tmp_path), cfg, 16, 2, dtype=torch.bfloat16, patch_keep=8, rel_bar=0.2, loss_bar=2e-2, cos_bar=0.98)
+    print("worst gradient relative error (2 ranks, bf16):", worst)
+
+
+@pytest.mark.parametrize("dcl", [False, True])
+def test_two_ranks_on_gpu_filip_vs_oracle(tmp_path, dcl):
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(O.CFG1, use_all_token_embeds=True, decoupled_contrastive_learning=dcl)
+    port = 33700 + (os.getpid() % 2000) + (1 if dcl else 0)
+    mp.spawn(D.worker_filip, args=(2, port, dataclasses.asdict(cfg), 4, str(tmp_path), "cuda"), nprocs=2, join=True)
+    D.check_filip(str(tmp_path), cfg, 4, 2)
+
+
+def test_rccl_two_ranks_one_device_probe(tmp_path):
+    """RCCL (`nccl` backend) with both ranks on cuda:0: recorded, not required -- the single-GPU box cannot give each rank its own
+    device; the driver's multi-GPU scaling run is where RCCL itself executes"""
+    port = 34700 + (os.getpid() % 2000)
+    try:
+        mp.spawn(D.worker_nccl_probe, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    except Exception as e:                                   # noqa: BLE001
+        outcome = {"spawn_error": str(e)[:400]}
+    else:
+        outcome = {f"rank{r}": torch.load(os.path.join(tmp_path, f"nccl_rank{r}.pt"), weights_only=False) for r in range(2)
+                   if os.path.exists(os.path.join(tmp_path, f"nccl_rank{r}.pt"))}
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "rccl_one_device_probe.json"), "w") as f:
+        json.dump(outcome, f, indent=1, default=str)
+    print("RCCL two ranks on one device:", outcome)

@@ -44,6 +44,11 @@ def test_text_embed(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_text_embed_out_of_range_ids(dtype):
+    K.case_text_embed_bad_ids(DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
 def test_patchify(dtype):
     K.case_patchify(DEV, dtype, 2, 3, 64, 32, 1.0)
     K.case_patchify(DEV, dtype, 3, 3, 32, 8, 0.5)

@@ -43,6 +43,11 @@ def test_text_embed(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_text_embed_out_of_range_ids(dtype):
+    K.case_text_embed_bad_ids(DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 def test_patchify(dtype):
     K.case_patchify(DEV, dtype, 5, 3, 256, 32, 0.5)
     K.case_patchify(DEV, dtype, 3, 3, 224, 16, 1.0)

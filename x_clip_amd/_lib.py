@@ -30,8 +30,8 @@ _SIGNATURES = {
     "xclip_layernorm_bwd": (c_int, [P, P, L, P, P, P, P, P, L, P, P, L, L, L, I, I, P]),
     "xclip_l2norm_fwd": (c_int, [P, P, P, L, L, I, P]),
     "xclip_l2norm_bwd": (c_int, [P, P, P, P, L, L, I, P]),
-    "xclip_text_embed_fwd": (c_int, [P, P, P, P, P, L, L, L, I, P]),
-    "xclip_text_embed_bwd": (c_int, [P, P, P, P, P, L, L, L, I, I, P]),
+    "xclip_text_embed_fwd": (c_int, [P, P, P, P, P, L, L, L, L, P, I, P]),
+    "xclip_text_embed_bwd": (c_int, [P, P, P, P, P, L, L, L, L, I, I, P]),
     "xclip_patchify": (c_int, [P, P, P, L, L, L, L, L, L, L, I, P]),
     "xclip_token_mean_fwd": (c_int, [P, L, P, L, L, L, I, P]),
     "xclip_token_mean_bwd": (c_int, [P, P, L, P, L, L, L, I, P]),
@@ -39,7 +39,7 @@ _SIGNATURES = {
     "xclip_add": (c_int, [P, P, P, L, I, P]),
     "xclip_rows_scatter_add_workspace_bytes": (c_int64, [L, L]),
     "xclip_rows_scatter_add": (c_int, [P, L, P, P, P, L, L, P, L, I, P]),
-    "xclip_scatter_add_sorted": (c_int, [P, L, P, P, P, L, L, L, L, L, I, P]),
+    "xclip_scatter_add_sorted": (c_int, [P, L, P, P, P, L, L, L, L, L, L, I, P]),
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),
@@ -72,7 +72,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def _bind(path: str):

@@ -7,10 +7,13 @@ namespace xc {
 
 // ---- text embedding (reference TextTransformer.forward, x_clip.py:320-335) ----------------------------------
 // out[b, 0] = cls ; out[b, 1+j] = E[tok[b, j]] + P[j]   (cls == nullptr: no CLS row; P == nullptr: no abs-pos)
+// A token id outside [0, vocab) (nn.Embedding raises IndexError / a device assert there) never touches memory: its output row is
+// NaN -- the loss of that step is loudly not a number -- and *bad_flag (may be null) is set for the host to turn into the IndexError.
 template <typename T>
 __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const long long* __restrict__ tok, const T* __restrict__ E,
                                                              const T* __restrict__ P, const T* __restrict__ cls,
-                                                             T* __restrict__ out, int batch, int n, int D) {
+                                                             T* __restrict__ out, int batch, int n, int D, long long vocab,
+                                                             int* __restrict__ bad_flag) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = lane_id();
     const int npos = n + (cls != nullptr ? 1 : 0);
@@ -19,10 +22,20 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const long long* __
     const int bi = (int)(row / npos), pos = (int)(row % npos);
     const int j = pos - (cls != nullptr ? 1 : 0);
     const int nch = D / VEC;
-    const T* src = (j < 0) ? cls : E + (long)tok[(long)bi * n + j] * D;
+    long long id = (j < 0) ? 0 : tok[(long)bi * n + j];
+    const bool bad = id < 0 || id >= vocab;                   // (wave-uniform)
+    if (bad) {
+        id = 0;
+        if (lane == 0 && bad_flag != nullptr) *bad_flag = 1;
+    }
+    const T* src = (j < 0) ? cls : E + (long)id * D;
     for (int c = lane; c < nch; c += 64) {
         float v[VEC];
         load_vec<T>(src + c * VEC, v);
+        if (bad) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[k] = __builtin_nanf("");
+        }
         if (j >= 0 && P != nullptr) {
             float pv[VEC];
             load_vec<T>(P + (long)j * D + c * VEC, pv);
@@ -39,7 +52,8 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const long long* __
 template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict__ dout, const long long* __restrict__ tok,
                                                              float* __restrict__ dE, float* __restrict__ dP,
-                                                             float* __restrict__ dcls, int batch, int n, int D, int has_cls) {
+                                                             float* __restrict__ dcls, int batch, int n, int D, int has_cls,
+                                                             long long vocab) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = lane_id();
     const int npos = n + has_cls;
@@ -53,7 +67,11 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const T* __restrict
         for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
     for (int bi = blockIdx.y * 4 + wave_id(); bi < batch; bi += gridDim.y * 4) {
         const T* src = dout + ((long)bi * npos + pos) * D;
-        float* erow = (j >= 0 && dE != nullptr) ? dE + (long)tok[(long)bi * n + j] * D : nullptr;
+        float* erow = nullptr;
+        if (j >= 0 && dE != nullptr) {
+            const long long id = tok[(long)bi * n + j];
+            if (id >= 0 && id < vocab) erow = dE + (long)id * D;   // out-of-range ids (flagged by the forward) own no row
+        }
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
@@ -271,7 +289,8 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const T* __restri
 template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void scatter_add_sorted_kernel(const T* __restrict__ src, long lds_, const long long* __restrict__ ids,
                                                                  const long long* __restrict__ perm, float* __restrict__ table,
-                                                                 long count, int D, int n_in, int n_out, int row_off, int chunk) {
+                                                                 long count, int D, int n_in, int n_out, int row_off, int chunk,
+                                                                 long long table_rows) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = lane_id();
     const int nch = D / VEC;
@@ -288,13 +307,14 @@ __global__ __launch_bounds__(256) void scatter_add_sorted_kernel(const T* __rest
         const long long id = e < e1 ? ids[e] : -1;
         if (id != cur) {                                   // wave-uniform: flush the finished run
             float* trow = table + (long)cur * D;
+            const bool in_table = cur >= 0 && cur < table_rows;  // an id without a row is dropped, never written out of bounds
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int c = lane + 64 * i;
                 if (c < nch)
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        atomic_add(trow + c * VEC + k, acc[i][k]);
+                        if (in_table) atomic_add(trow + c * VEC + k, acc[i][k]);
                         acc[i][k] = 0.f;
                     }
             }

@@ -302,8 +302,9 @@ int xclip_l2norm_bwd(const void* dy, const void* y, const float* rnorm, void* dx
 }
 
 int xclip_text_embed_fwd(const int64_t* tokens, const void* E, const void* P, const void* cls, void* out, int64_t batch,
-                         int64_t n, int64_t dim, int dtype, void* stream) {
+                         int64_t n, int64_t dim, int64_t vocab, int32_t* bad_token_flag, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(vocab > 0, "vocab (rows of the embedding table) must be positive");
     XC_REQUIRE(dim > 0 && dim % vec_of(dtype) == 0, "dim must be a multiple of the 16-byte chunk");
     XC_REQUIRE(aligned16(E) && aligned16(P) && aligned16(cls) && aligned16(out), "pointers must be 16-byte aligned");
     const int64_t rows = batch * (n + (cls ? 1 : 0));
@@ -311,15 +312,17 @@ int xclip_text_embed_fwd(const int64_t* tokens, const void* E, const void* P, co
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (dtype == XCLIP_BF16)
         hipLaunchKernelGGL((text_embed_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const long long*)tokens,
-                           (const bf16_t*)E, (const bf16_t*)P, (const bf16_t*)cls, (bf16_t*)out, (int)batch, (int)n, (int)dim);
+                           (const bf16_t*)E, (const bf16_t*)P, (const bf16_t*)cls, (bf16_t*)out, (int)batch, (int)n, (int)dim,
+                           (long long)vocab, bad_token_flag);
     else
         hipLaunchKernelGGL((text_embed_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const long long*)tokens,
-                           (const float*)E, (const float*)P, (const float*)cls, (float*)out, (int)batch, (int)n, (int)dim);
+                           (const float*)E, (const float*)P, (const float*)cls, (float*)out, (int)batch, (int)n, (int)dim,
+                           (long long)vocab, bad_token_flag);
     return check_launch(__func__);
 }
 
 int xclip_text_embed_bwd(const void* dout, const int64_t* tokens, float* dE_accum, float* dP_accum, float* dcls_accum,
-                         int64_t batch, int64_t n, int64_t dim, int has_cls, int dtype, void* stream) {
+                         int64_t batch, int64_t n, int64_t dim, int64_t vocab, int has_cls, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     const int vec = vec_of(dtype);
     XC_REQUIRE(dim > 0 && dim % vec == 0, "dim must be a multiple of the 16-byte chunk");
@@ -331,7 +334,7 @@ int xclip_text_embed_bwd(const void* dout, const int64_t* tokens, float* dE_accu
     if (ysplit > 16) ysplit = 16;
     dim3 grid((unsigned)(n + (has_cls ? 1 : 0)), ysplit), block(256);
     const size_t red_bytes = (size_t)3 * dim * sizeof(float);
-#define F(T, C) hipLaunchKernelGGL((text_embed_bwd_kernel<T, C>), grid, block, red_bytes, (hipStream_t)stream, (const T*)dout, (const long long*)tokens, dE_accum, dP_accum, dcls_accum, (int)batch, (int)n, (int)dim, has_cls ? 1 : 0)
+#define F(T, C) hipLaunchKernelGGL((text_embed_bwd_kernel<T, C>), grid, block, red_bytes, (hipStream_t)stream, (const T*)dout, (const long long*)tokens, dE_accum, dP_accum, dcls_accum, (int)batch, (int)n, (int)dim, has_cls ? 1 : 0, (long long)vocab)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
     return check_launch(__func__);
@@ -451,19 +454,20 @@ int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, flo
 }
 
 int xclip_scatter_add_sorted(const void* src, int64_t lds, const int64_t* sorted_ids, const int64_t* perm, float* table_accum,
-                             int64_t count, int64_t dim, int64_t n_in, int64_t n_out, int64_t row_off, int dtype, void* stream) {
+                             int64_t table_rows, int64_t count, int64_t dim, int64_t n_in, int64_t n_out, int64_t row_off, int dtype,
+                             void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     const int vec = vec_of(dtype);
     XC_REQUIRE(dim > 0 && dim % vec == 0 && lds % vec == 0 && lds >= dim, "dim / lds must be chunk multiples covering a row");
     XC_REQUIRE(aligned16(src) && sorted_ids != nullptr && perm != nullptr && table_accum != nullptr, "bad pointers");
-    XC_REQUIRE(n_in > 0 && n_out > 0, "bad row map");
+    XC_REQUIRE(n_in > 0 && n_out > 0 && table_rows > 0, "bad row map");
     if (count == 0) return 0;
     const int cpl = chunks_per_lane(dim, vec);
     int64_t chunk = (count + 16383) / 16384;               // ~16k waves; at least 16 entries per wave
     if (chunk < 16) chunk = 16;
     const int64_t waves = (count + chunk - 1) / chunk;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-#define F(T, C) hipLaunchKernelGGL((scatter_add_sorted_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)src, (long)lds, (const long long*)sorted_ids, (const long long*)perm, table_accum, (long)count, (int)dim, (int)n_in, (int)n_out, (int)row_off, (int)chunk)
+#define F(T, C) hipLaunchKernelGGL((scatter_add_sorted_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)src, (long)lds, (const long long*)sorted_ids, (const long long*)perm, table_accum, (long)count, (int)dim, (int)n_in, (int)n_out, (int)row_off, (int)chunk, (long long)table_rows)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
     return check_launch(__func__);

@@ -147,9 +147,17 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group)
         self.buckets = []
-        rest = [p for p in module.parameters(recurse=False) if p.requires_grad]
+        seen = set()                                         # a tower shared with a side-loss wrapper (mlm.transformer, visual_ssl.net)
+                                                             # is listed under both children: reduce every parameter once
+
+        def fresh(ps):
+            out = [p for p in ps if p.requires_grad and id(p) not in seen]
+            seen.update(id(p) for p in out)
+            return out
+
+        rest = fresh(module.parameters(recurse=False))
         for _, child in module.named_children():
-            ps = [p for p in child.parameters() if p.requires_grad]
+            ps = fresh(child.parameters())
             if sum(p.numel() for p in ps) >= (1 << 20):
                 self.buckets.append(ps)                      # a tower: its own bucket, reduced while the other tower runs
             else:

@@ -222,41 +222,56 @@ def _contig_grad(d: Optional[Tensor], like_shape, dtype, device) -> Tensor:
     return d if d.is_contiguous() else d.contiguous()
 
 
+def _take_tape(ctx):
+    """the activation tape of a node, exactly once: it is released while the backward walks it (gigabytes per layer), so a second
+    backward through the same graph (retain_graph=True, two losses sharing a tower) cannot be served -- say so instead of failing
+    on a None deep inside"""
+    tape = ctx.tape
+    if tape is None:
+        raise RuntimeError("x_clip_amd: this encoder pass was already back-propagated and its activations were released during that "
+                           "backward; run the forward again (or sum the losses before calling backward once) -- retain_graph is not supported")
+    ctx.tape = None
+    return tape
+
+
 class _TransformerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, spec: StackSpec, mask: Optional[Tensor], x: Tensor, *params: Tensor):
+    def forward(ctx, spec: StackSpec, mask: Optional[Tensor], grad_mode: bool, x: Tensor, *params: Tensor):
         B, n, D = x.shape
-        keep = any(ctx.needs_input_grad)
+        # (ctx.needs_input_grad reflects the parameters' requires_grad even under torch.no_grad(): without the caller's grad mode
+        #  an inference pass or a frozen tower would build and hold the whole training tape until forward returned)
+        keep = grad_mode and any(ctx.needs_input_grad)
         x2 = ops._c(x).view(B * n, D)
         y, tape = stack_forward(x2, B, n, spec, params, mask, keep_tape=keep)
-        ctx.spec, ctx.mask, ctx.tape, ctx.params, ctx.shape = spec, mask, tape, params, (B, n, D)
+        ctx.save_for_backward(*params)                       # autograd's version counters then catch in-place edits before backward
+        ctx.spec, ctx.mask, ctx.tape, ctx.shape = spec, mask, tape, (B, n, D)
         return y.view(B, n, D)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         B, n, D = ctx.shape
-        need = ctx.needs_input_grad[3:]
-        dy = _contig_grad(dy, (B, n, D), ctx.params[0].dtype, ctx.params[0].device).view(B * n, D)
-        dx, grads = stack_backward(dy, ctx.tape, B, n, ctx.spec, ctx.params, ctx.mask, need)
-        ctx.tape = None
-        return (None, None, dx.view(B, n, D) if ctx.needs_input_grad[2] else None, *grads)
+        params = ctx.saved_tensors
+        need = ctx.needs_input_grad[4:]
+        dy = _contig_grad(dy, (B, n, D), params[0].dtype, params[0].device).view(B * n, D)
+        dx, grads = stack_backward(dy, _take_tape(ctx), B, n, ctx.spec, params, ctx.mask, need)
+        return (None, None, None, dx.view(B, n, D) if ctx.needs_input_grad[3] else None, *grads)
 
 
 def transformer(x: Tensor, params: Sequence[Tensor], spec: StackSpec, mask: Optional[Tensor] = None) -> Tensor:
     """Transformer.forward (x_clip.py:274-291) on [b, n, D]; mask: bool [b, n] key-padding mask or None."""
-    return _TransformerFn.apply(spec, mask, x, *params)
+    return _TransformerFn.apply(spec, mask, torch.is_grad_enabled(), x, *params)
 
 
 # ---- text encoder ---------------------------------------------------------------------------------------------------------
 class _TextEncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, spec: StackSpec, tokens: Tensor, mask: Optional[Tensor], E: Tensor, P: Optional[Tensor],
+    def forward(ctx, spec: StackSpec, tokens: Tensor, mask: Optional[Tensor], grad_mode: bool, E: Tensor, P: Optional[Tensor],
                 cls: Optional[Tensor], *stack: Tensor):
         B, n = tokens.shape
         npos = n + (1 if cls is not None else 0)
         D = E.shape[1]
-        keep = any(ctx.needs_input_grad)
+        keep = grad_mode and any(ctx.needs_input_grad)
         ctx_pos_rows = P.shape[0] if P is not None else 0              # rows of the full table (its gradient keeps that shape)
         if P is not None and P.shape[0] != n:
             P = P[:n]                                                   # abs_pos_emb(arange(n))      x_clip.py:323
@@ -266,7 +281,8 @@ class _TextEncodeFn(torch.autograd.Function):
             kmask = mask if cls is None else torch.cat([mask.new_ones(B, 1), mask], dim=1)
             kmask = kmask.contiguous()
         y, tape = stack_forward(x0.view(B * npos, D), B, npos, spec, stack, kmask, keep_tape=keep)
-        ctx.spec, ctx.kmask, ctx.tape, ctx.stack = spec, kmask, tape, stack
+        ctx.save_for_backward(*stack)
+        ctx.spec, ctx.kmask, ctx.tape = spec, kmask, tape
         ctx.tokens, ctx.meta = tokens, (B, n, npos, D, E.shape[0], P is not None, cls is not None, E.dtype)
         ctx.pos_rows = ctx_pos_rows
         return y.view(B, npos, D)
@@ -275,10 +291,9 @@ class _TextEncodeFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy):
         B, n, npos, D, vocab, has_pos, has_cls, dtype = ctx.meta
-        need = ctx.needs_input_grad
+        need = ctx.needs_input_grad[1:]                                  # (indices below: without the grad_mode slot)
         dy = _contig_grad(dy, (B, npos, D), dtype, ctx.tokens.device).view(B * npos, D)
-        dx0, sgrads = stack_backward(dy, ctx.tape, B, npos, ctx.spec, ctx.stack, ctx.kmask, need[6:])
-        ctx.tape = None
+        dx0, sgrads = stack_backward(dy, _take_tape(ctx), B, npos, ctx.spec, ctx.saved_tensors, ctx.kmask, need[6:])
         dE = dP = dcls = None
         if need[3] or need[4] or need[5]:
             st = torch.sort(ctx.tokens.reshape(-1))                      # index plumbing: ids ascending + their positions
@@ -291,7 +306,7 @@ class _TextEncodeFn(torch.autograd.Function):
                 full[:dP.shape[0]].copy_(dP)
                 dP = full
             dcls = ops.cast_from_f32(acls, dtype) if (need[5] and has_cls) else None
-        return (None, None, None, dE, dP, dcls, *sgrads)
+        return (None, None, None, None, dE, dP, dcls, *sgrads)
 
 
 def text_encode(tokens: Tensor, mask: Optional[Tensor], E: Tensor, P: Optional[Tensor], cls: Optional[Tensor],
@@ -303,18 +318,18 @@ def text_encode(tokens: Tensor, mask: Optional[Tensor], E: Tensor, P: Optional[T
         raise IndexError(f"text length {tokens.shape[1]} exceeds max_seq_len {P.shape[0]}")
     if mask is not None and mask.dtype != torch.bool:
         mask = mask.bool()
-    return _TextEncodeFn.apply(spec, tokens, mask, E, P, cls, *stack)
+    return _TextEncodeFn.apply(spec, tokens, mask, torch.is_grad_enabled(), E, P, cls, *stack)
 
 
 # ---- vision encoder -----------------------------------------------------------------------------------------------------------
 class _VisionEncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, spec: StackSpec, patch: int, image: Tensor, keep_idx: Optional[Tensor], w_tok: Tensor, b_tok: Tensor,
-                pos: Tensor, w_cls: Tensor, *stack: Tensor):
+    def forward(ctx, spec: StackSpec, patch: int, image: Tensor, keep_idx: Optional[Tensor], grad_mode: bool, w_tok: Tensor,
+                b_tok: Tensor, pos: Tensor, w_cls: Tensor, *stack: Tensor):
         B, C, H, Wd = image.shape
         D = w_tok.shape[0]
         npatch = (H // patch) * (Wd // patch)
-        keep = any(ctx.needs_input_grad)
+        keep = grad_mode and any(ctx.needs_input_grad)
         if keep_idx is not None:                                        # PatchDropout keep-set        x_clip.py:140-151
             nk = keep_idx.shape[1]
             rowidx = keep_idx.reshape(-1)
@@ -335,8 +350,9 @@ class _VisionEncodeFn(torch.autograd.Function):
         y, tape = stack_forward(tok, B, nk, spec, stack, None, out=enc.view(B * (1 + nk), D), out_group=nk, keep_tape=keep)
         pooled = ops.token_mean_fwd(enc[:, 1:])                         # Reduce('b n d -> b d', 'mean') :367
         ops.gemm(pooled, w_cls, B, D, D, out=enc[:, 0])                 # to_cls_tokens Linear + concat  :368,389-390
-        ctx.spec, ctx.tape, ctx.stack = spec, tape, stack
-        ctx.saved = (patches if keep else None, rowidx, pooled, w_pad, w_cls)
+        ctx.save_for_backward(w_cls, *stack)
+        ctx.spec, ctx.tape = spec, tape
+        ctx.saved = (patches if keep else None, rowidx, pooled, w_pad)
         ctx.meta = (B, nk, D, npatch, Kp, w_tok.shape[1], w_tok.dtype)
         return enc
 
@@ -344,15 +360,15 @@ class _VisionEncodeFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, denc):
         B, nk, D, npatch, Kp, Kw, dtype = ctx.meta
-        patches, rowidx, pooled, w_pad, w_cls = ctx.saved
-        need = ctx.needs_input_grad
+        patches, rowidx, pooled, w_pad = ctx.saved
+        w_cls, *stack = ctx.saved_tensors
+        need = ctx.needs_input_grad[1:]                                  # (indices below: without the grad_mode slot)
         denc = _contig_grad(denc, (B, 1 + nk, D), dtype, pooled.device)
         dcls = denc[:, 0]                                               # [B, D], row stride (1+nk) D
         dpooled = ops.gemm(dcls, w_cls, B, D, D, b_kmajor=True)
         dw_cls = ops.gemm(dcls, pooled, D, D, B, a_kmajor=True, b_kmajor=True) if need[7] else None
         dy = ops.token_mean_bwd(dpooled, nk, add=denc[:, 1:])           # mean-pool backward + direct token gradients
-        dtok, sgrads = stack_backward(dy.view(B * nk, D), ctx.tape, B, nk, ctx.spec, ctx.stack, None, need[8:])
-        ctx.tape = None
+        dtok, sgrads = stack_backward(dy.view(B * nk, D), _take_tape(ctx), B, nk, ctx.spec, stack, None, need[8:])
         dw_tok = db = dpos = None
         if need[4]:
             dw_tok = ops.gemm(dtok, patches, D, Kp, B * nk, a_kmajor=True, b_kmajor=True)
@@ -368,7 +384,7 @@ class _VisionEncodeFn(torch.autograd.Function):
                 ops.scatter_add_sorted(dtok, st.values, st.indices, acc_p)
             db = ops.cast_from_f32(acc_b, dtype) if need[5] else None
             dpos = ops.cast_from_f32(acc_p, dtype) if need[6] else None
-        return (None, None, None, None, dw_tok, db, dpos, dw_cls, *sgrads)
+        return (None, None, None, None, None, dw_tok, db, dpos, dw_cls, *sgrads)
 
 
 def vision_encode(image: Tensor, keep_idx: Optional[Tensor], patch: int, w_tok: Tensor, b_tok: Tensor, pos: Tensor,
@@ -380,8 +396,8 @@ def vision_encode(image: Tensor, keep_idx: Optional[Tensor], patch: int, w_tok: 
         raise TypeError(f"image dtype {image.dtype} must match the model dtype {w_tok.dtype}")
     if keep_idx is not None and keep_idx.dtype != torch.int32:
         keep_idx = keep_idx.to(torch.int32)
-    return _VisionEncodeFn.apply(spec, patch, image, None if keep_idx is None else keep_idx.contiguous(), w_tok, b_tok, pos,
-                                 w_cls, *stack)
+    return _VisionEncodeFn.apply(spec, patch, image, None if keep_idx is None else keep_idx.contiguous(), torch.is_grad_enabled(),
+                                 w_tok, b_tok, pos, w_cls, *stack)
 
 
 # ---- small differentiable pieces of the head -------------------------------------------------------------------------------

@@ -36,6 +36,10 @@ class ContrastiveSpec:
     assume_equal_batch: bool = False      # skip the per-step size exchange (distributed.py:17-21)
 
 
+_TWICE = ("x_clip_amd: this loss was already back-propagated and the state of its head (latent views, log-sum-exps, arg-max maps) was "
+          "released during that backward; run the forward again -- retain_graph is not supported")
+
+
 def _acc_gemm(acc: Optional[Tensor], a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool) -> Tensor:
     """acc (+)= op(a) b with b k-major ([K, N]); the first product allocates acc"""
     if acc is None:
@@ -119,6 +123,8 @@ class _ContrastiveFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dloss):
+        if ctx.mats is None:
+            raise RuntimeError(_TWICE)
         spec, plan, groups = ctx.spec, ctx.plan, ctx.groups
         mats, gathered, lse_local, lse_all, tau32 = ctx.mats, ctx.gathered, ctx.lse_local, ctx.lse_all, ctx.tau32
         m, n, b, d, B, off, sizes, rank, extra, tau_dtype = ctx.geom
@@ -317,13 +323,28 @@ class _FilipBlock:
             self._ws = torch.empty(self.bx * self.nt, self.ld, dtype=self.X.dtype, device=self.X.device)
         return self._ws
 
+    def _image_rows(self, y0: int, yc: int):
+        """token rows of images [y0, y0 + yc) as a [cols, d] matrix whose row count is a whole number of 16-byte chunks of the
+        similarity rows it produces (GEMM N / K granularity): zero rows are appended when yc * ni is not (odd batch x odd token count,
+        e.g. 5 images x 9 patches, or the last partial chunk); they give zero similarity columns, which filip_reduce never reads and
+        filip_route leaves zero"""
+        n = yc * self.ni
+        v = ops.vec(self.X.dtype)
+        cols = (n + v - 1) // v * v
+        Yc = self.Y[y0: y0 + yc].reshape(n, self.d)
+        if cols == n:
+            return Yc, n
+        Yp = torch.zeros(cols, self.d, dtype=self.Y.dtype, device=self.Y.device)
+        ops.copy_rows(Yc, Yp[:n])
+        return Yp, cols
+
     def forward(self):
         X2 = self.X.reshape(self.bx * self.nt, self.d)
         for y0 in range(0, self.by, self.yc):
             yc = min(self.yc, self.by - y0)
             S = self._workspace()
-            Yc = self.Y[y0: y0 + yc].reshape(yc * self.ni, self.d)
-            ops.gemm(X2, Yc, self.bx * self.nt, yc * self.ni, self.d, out=S[:, : yc * self.ni])
+            Yc, cols = self._image_rows(y0, yc)
+            ops.gemm(X2, Yc, self.bx * self.nt, cols, self.d, out=S[:, :cols])
             ops.filip_reduce(S, self.mask, self.tau32, self.t2i, self.i2t, self.kmax, self.tmax, self.cnt, self.nt, self.ni, yc, y0)
         self._ws = None
         return self
@@ -337,12 +358,11 @@ class _FilipBlock:
             yc = min(self.yc, self.by - y0)
             P = self._workspace()
             ops.filip_route(P, self.mask, self.tau32, g1, g2, self.kmax, self.tmax, self.cnt, self.nt, self.ni, yc, y0)
-            Pc = P[:, : yc * self.ni]
-            Yc = self.Y[y0: y0 + yc].reshape(yc * self.ni, self.d)
+            Yc, cols = self._image_rows(y0, yc)           # (padding: zero columns of P against zero rows of Yc)
             if want_dx:                                   # dX += P Yc           (contraction over the chunk's image tokens)
-                dX = _acc_gemm(dX, Pc, Yc, self.bx * self.nt, self.d, yc * self.ni, a_kmajor=False)
+                dX = _acc_gemm(dX, P[:, :cols], Yc, self.bx * self.nt, self.d, cols, a_kmajor=False)
             if want_dy:                                   # dYc = P^T X          (contraction over all text tokens)
-                ops.gemm(Pc, X2, yc * self.ni, self.d, self.bx * self.nt, a_kmajor=True, b_kmajor=True,
+                ops.gemm(P[:, : yc * self.ni], X2, yc * self.ni, self.d, self.bx * self.nt, a_kmajor=True, b_kmajor=True,
                          out=dY[y0 * self.ni: (y0 + yc) * self.ni])
         self._ws = None
         return (None if dX is None else dX.view(self.bx, self.nt, self.d)), (None if dY is None else dY.view(self.by, self.ni, self.d))
@@ -410,6 +430,8 @@ class _FilipFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dloss):
+        if ctx.blocks is None:
+            raise RuntimeError(_TWICE)
         spec, blocks = ctx.spec, ctx.blocks
         m, n, b, nt, ni, d, extra, tau_dtype, sizes, off, B, tau32 = ctx.geom
         Ts, Txs, Is_loc, Ixs_loc, mask_u8 = ctx.local

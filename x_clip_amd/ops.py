@@ -150,16 +150,66 @@ def l2norm_bwd(dy: Tensor, y: Tensor, rn: Tensor) -> Tensor:
 
 
 # ---- embeddings / patches ---------------------------------------------------------------------------------------------
+class _TokenFlag:
+    """Out-of-range token ids, reported without a host sync: the embedding kernel sets a device flag (and writes NaN rows, so the
+    step's loss is already loudly wrong); after each launch the flag is copied to pinned host memory behind an event, and the NEXT
+    call that finds that event completed raises the IndexError the reference's nn.Embedding raises (x_clip.py:320).  CPU tensors
+    (the emulator build) are checked on the spot.  `XCLIP_CHECK_TOKENS=1` checks synchronously on the GPU too (debugging)."""
+    _per_device = {}
+
+    def __init__(self, device):
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory() if device.type == "cuda" else None
+        self.event = None
+
+    @classmethod
+    def get(cls, device) -> "_TokenFlag":
+        f = cls._per_device.get(device)
+        if f is None:
+            f = cls._per_device[device] = cls(device)
+        return f
+
+    def _raise(self, vocab):
+        self.flag.zero_()
+        if self.host is not None:
+            self.host.zero_()
+        self.event = None
+        raise IndexError(f"index out of range in self: a text token id lies outside [0, {vocab}) (num_text_tokens)")
+
+    def poll(self, vocab):
+        """before a launch: report what an EARLIER launch found, if its flag copy has already landed"""
+        if self.event is not None and self.event.query():
+            self.event = None
+            if int(self.host[0]) != 0:
+                self._raise(vocab)
+
+    def after_launch(self, vocab):
+        import os
+        if self.host is None:
+            if int(self.flag[0]) != 0:
+                self._raise(vocab)
+            return
+        self.host.copy_(self.flag, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(self.flag.device))
+        if os.environ.get("XCLIP_CHECK_TOKENS") == "1":
+            self.event.synchronize()
+            self.poll(vocab)
+
+
 def text_embed_fwd(tokens: Tensor, E: Tensor, P: Optional[Tensor], cls: Optional[Tensor]) -> Tensor:
     _dev_check(tokens, E, P, cls)
     assert tokens.dtype == torch.int64
     tokens = _c(tokens)
     b, n = tokens.shape
-    dim = E.shape[1]
+    vocab, dim = E.shape
     out = torch.empty(b, n + (1 if cls is not None else 0), dim, dtype=E.dtype, device=E.device)
+    tf = _TokenFlag.get(E.device)
+    tf.poll(vocab)
     _lib.check(_lib.lib().xclip_text_embed_fwd(tokens.data_ptr(), _c(E).data_ptr(), _ptr(None if P is None else _c(P)),
-                                               _ptr(None if cls is None else _c(cls)), out.data_ptr(), b, n, dim,
-                                               dtype_code(E), _stream(E)), "xclip_text_embed_fwd")
+                                               _ptr(None if cls is None else _c(cls)), out.data_ptr(), b, n, dim, vocab,
+                                               tf.flag.data_ptr(), dtype_code(E), _stream(E)), "xclip_text_embed_fwd")
+    tf.after_launch(vocab)
     return out
 
 
@@ -177,7 +227,7 @@ def text_embed_bwd(dout: Tensor, tokens: Tensor, vocab: int, has_pos: bool, has_
     L = _lib.lib()
     if has_pos or has_cls or sorted_tokens is None:
         _lib.check(L.xclip_text_embed_bwd(dout.data_ptr(), tokens.data_ptr(), 0 if sorted_tokens is not None else dE.data_ptr(),
-                                          _ptr(dP), _ptr(dcls), b, n, dim, int(has_cls), dtype_code(dout), _stream(dout)),
+                                          _ptr(dP), _ptr(dcls), b, n, dim, vocab, int(has_cls), dtype_code(dout), _stream(dout)),
                    "xclip_text_embed_bwd")
     if sorted_tokens is not None:
         ids, perm = sorted_tokens
@@ -193,7 +243,7 @@ def scatter_add_sorted(src: Tensor, sorted_ids: Tensor, perm: Tensor, table: Ten
     assert sorted_ids.dtype == torch.int64 and perm.dtype == torch.int64 and sorted_ids.is_contiguous() and perm.is_contiguous()
     assert sorted_ids.numel() == perm.numel() and table.shape[1] == src.shape[1]
     _lib.check(_lib.lib().xclip_scatter_add_sorted(src.data_ptr(), src.stride(0), sorted_ids.data_ptr(), perm.data_ptr(),
-                                                   table.data_ptr(), sorted_ids.numel(), src.shape[1], n_in, n_out, row_off,
+                                                   table.data_ptr(), table.shape[0], sorted_ids.numel(), src.shape[1], n_in, n_out, row_off,
                                                    dtype_code(src), _stream(src)), "xclip_scatter_add_sorted")
 
 
