@@ -43,35 +43,55 @@ def model_flops_per_pair(model, n_text_tokens, n_img_tokens, n_patches_embedded)
     return f
 
 
-def cpu_baseline(budget_s=20.0):
-    """the CPU oracle (oracle/clip_oracle.py = torch-CPU restatement of the reference, pinned to reference golden vectors)
-    timed on a bounded sample of the same workload: default architecture, fp32, batch 8, forward + backward."""
+def cpu_baseline(budget_s=30.0):
+    """the CPU oracle (oracle/clip_oracle.py = torch-CPU restatement of the reference, pinned to reference golden vectors) timed on
+    a bounded sample of the same workload -- default architecture, patch dropout 0.5, forward + backward -- at the settings that
+    are BEST for the CPU: the thread count is swept at batch 8 (oversubscribing a small batch with every hardware thread is slower
+    than a few cores), then batch 32 in fp32 and in bf16 (the GPU run's dtype; AMX / AVX512-BF16 hosts are ~3x faster there) run
+    at the best thread count.  `value` = the best pairs/s of all of them."""
     from oracle import clip_oracle as O
     cfg = O.ClipConfig()
-    sd = {k: v.requires_grad_(True) for k, v in O.make_state_dict(cfg, 0, torch.float32).items()}
-    b = 8
-    text, image, _, _ = O.make_inputs(cfg, b, 1)
-    image = image.float()
-    g = torch.Generator().manual_seed(2)
-    keep = torch.randn(b, cfg.num_patches, generator=g).topk(cfg.num_patches // 2, dim=-1).indices
+    ncpu = os.cpu_count() or 1
+    t_start = time.perf_counter()
 
-    def step():
-        for v in sd.values():
-            v.grad = None
-        loss = O.clip_forward(sd, cfg, text, image, keep_idx=keep)
-        loss.backward()
-    step()
-    t0 = time.perf_counter()
-    iters = 0
-    while True:
-        step()
-        iters += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or iters >= 20:
+    def bench(dtype, b, threads, steps):
+        torch.set_num_threads(threads)
+        sd = {k: v.requires_grad_(True) for k, v in O.make_state_dict(cfg, 0, dtype).items()}
+        text, image, _, _ = O.make_inputs(cfg, b, 1)
+        image = image.to(dtype)
+        g = torch.Generator().manual_seed(2)
+        keep = torch.randn(b, cfg.num_patches, generator=g).topk(cfg.num_patches // 2, dim=-1).indices
+
+        def step():
+            for v in sd.values():
+                v.grad = None
+            loss = O.clip_forward(sd, cfg, text, image, keep_idx=keep)
+            loss.backward()
+        step()                                                       # warm-up (allocator, oneDNN primitive caches)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        return b * steps / (time.perf_counter() - t0)
+
+    before = torch.get_num_threads()
+    runs = []
+    for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+        runs.append(("fp32", 8, th, bench(torch.float32, 8, th, 1)))
+        if time.perf_counter() - t_start > 0.5 * budget_s:
             break
-    return {"value": round(b * iters / el, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/clip_oracle.py clip_forward+backward, default CLIP fp32, batch {b}, patch dropout 0.5, "
-                      f"{iters} steps in {el:.1f} s on {torch.get_num_threads()} threads"}
+    best_th = max(runs, key=lambda r: r[3])[2]
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        if time.perf_counter() - t_start < 1.5 * budget_s:
+            runs.append((name, 32, best_th, bench(dt, 32, best_th, 1)))
+    torch.set_num_threads(before)
+    best = max(runs, key=lambda r: r[3])
+    return {"value": round(best[3], 3), "unit": "pairs/s", "cores": best[2], "kind": "port", "dtype": best[0], "batch": best[1],
+            "host_cpus": ncpu,
+            "sweep": [{"dtype": d, "batch": b, "threads": t, "pairs_per_s": round(v, 3)} for d, b, t, v in runs],
+            "sample": f"oracle/clip_oracle.py clip_forward+backward, default CLIP, patch dropout 0.5, 1 timed step per setting after a warm-up; "
+                      f"best = {best[0]} batch {best[1]} on {best[2]} of {ncpu} host threads ({time.perf_counter() - t_start:.0f} s of CPU work in all). "
+                      f"The reference itself, measured in the build container on 8 vCPUs (BASELINE.md section 2): 6.9 pairs/s fp32 b=8, "
+                      f"5.7 fp32 b=32, 18.2 bf16 b=32"}
 
 
 def main():
@@ -92,6 +112,9 @@ def main():
                     "the vision tower (four more tower passes + the 4096-wide BatchNorm MLPs per step) with two cheap device-side "
                     "augmentations (flip / shift-blend) standing in for torchvision's host pipeline")
     ap.add_argument("--causal", action="store_true", help="own measurement: autoregressive text encoder (text_causal_mask, EOS pooling)")
+    ap.add_argument("--config", default="default", choices=["default", "vitl"], help="vitl = BASELINE configs[4] per GPU (own measurement): "
+                    "ViT-L/14 at image 336 (dim 1024, depth 24, 16 heads, 576 patches of which 288 are kept) + text dim 768 depth 12, latent 768, "
+                    "vocab 49408, text length 77, one augmented text + one augmented image (multiview), DCL, activation checkpointing")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -127,6 +150,10 @@ def main():
         vit = VisionTransformer(512, image_size=256, patch_size=32, channels=3, depth=6, heads=8, dim_head=64, patch_dropout=0.5)
         ssl = SimSiam(vit, image_size=256, hidden_layer=-1, augment_fn=lambda x: x.flip(-1), augment_fn2=lambda x: 0.8 * x + 0.2 * x.roll(3, dims=-2))
         extra.update(image_encoder=vit, visual_ssl=ssl, use_visual_ssl=True)
+    if args.config == "vitl":
+        extra.update(dim_text=768, dim_image=1024, dim_latent=768, num_text_tokens=49408, text_enc_depth=12, text_seq_len=77, text_heads=12,
+                     visual_enc_depth=24, visual_heads=16, visual_image_size=336, visual_patch_size=14, checkpoint_during_training=True)
+        args.dcl = True
     model = CLIP(decoupled_contrastive_learning=args.dcl, **extra).to(torch.bfloat16).to(dev)
     model.train()
     model.assume_equal_batch = True
@@ -134,14 +161,20 @@ def main():
 
     b = args.batch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    text = torch.randint(0, 9999 if args.causal else 10000, (b, model.text_seq_len), generator=g).to(dev)
+    vocab = model.text_transformer.token_emb.weight.shape[0]
+    text = torch.randint(0, 9999 if args.causal else vocab, (b, model.text_seq_len), generator=g).to(dev)
     if args.causal:
         text[:, -1] = 9999                                      # every row ends in the eos id
     image = torch.randn(b, 3, model.image_size, model.image_size, generator=g).to(torch.bfloat16).to(dev)
 
+    aug = {}
+    if args.config == "vitl":                                   # one augmented view of each modality (BASELINE configs[4]: multiview on)
+        aug = dict(aug_text=[torch.randint(0, vocab, (b, model.text_seq_len), generator=g).to(dev)],
+                   aug_image=[torch.randn(b, 3, model.image_size, model.image_size, generator=g).to(torch.bfloat16).to(dev)])
+
     def step():
         model.zero_grad(set_to_none=True)
-        loss = model(text, image, return_loss=True)
+        loss = model(text, image, return_loss=True, **aug)
         loss.backward()
         if sync is not None:
             sync.finish()
@@ -183,7 +216,8 @@ def main():
 
     vt = model.visual_transformer
     n_keep = max(1, int(vt.num_patches * (1 - vt.patch_dropout.prob)))
-    fwd_flops = model_flops_per_pair(model, model.text_seq_len + 1, n_keep, n_keep)
+    views = 2 if args.config == "vitl" else 1                # a pair with one augmented text + image = two passes of each tower
+    fwd_flops = views * model_flops_per_pair(model, model.text_seq_len + 1, n_keep, n_keep)
     pairs = b * world * args.steps
     value = pairs / elapsed
     out = {
@@ -191,7 +225,9 @@ def main():
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (randint tokens, randn images, random-init weights)",
-        "config": {"workload": ("BASELINE configs[3] (FILIP): dim 512 depth 6/6 image 224 patch 16 text seq 77, " if args.filip else
+        "config": {"workload": ("BASELINE configs[4] per GPU: ViT-L/14 image 336 (dim 1024 depth 24) + text dim 768 depth 12 seq 77, latent 768, multiview "
+                                "(1 aug text + 1 aug image), activation checkpointing (1/3 more forward work than the algorithmic count), " if args.config == "vitl" else
+                                "BASELINE configs[3] (FILIP): dim 512 depth 6/6 image 224 patch 16 text seq 77, " if args.filip else
                                 "BASELINE configs[1]: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, ") +
                                "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ("" if not args.simsiam else " + SimSiam side loss") +
                                ("" if not args.causal else ", causal text encoder") + ", fwd+bwd",
@@ -218,16 +254,21 @@ def main():
         fence()
         launches, flops, secs = probe.summary()
         ach = flops / secs / 1e12 if secs > 0 else 0.0
-        traffic = None                                        # HBM-side bytes per launch from the committed PMC passes of this command
+        # HBM-side bytes per launch: PMC counters cannot be read from inside the process, so this is the figure of the committed
+        # rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py -> profiles/gemm_traffic.json, which names the commit and
+        # the summary file it came from); null when that file is absent or was measured for another kernel generation
+        traffic, traffic_src = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as f:
-                traffic = round(json.load(f)["bytes_per_launch"])
+                tj = json.load(f)
+            if tj.get("kernel_generation") == ops.GEMM_GENERATION:
+                traffic, traffic_src = round(tj["bytes_per_launch"]), tj.get("source")
         except Exception:
             pass
         out["roofline"] = {"kernel": "xclip_gemm (gemm3_kernel<bf16> NT/NN/TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": traffic,
-                           "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command (profiles/r01_step10_hbm_traffic_pmc.txt)",
+                           "traffic_note": f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command ({traffic_src})",
                            "algorithmic_bytes_per_launch": round(probe.algorithmic_bytes / max(launches, 1)),
                            "launches_per_step": launches // max(args.steps, 1),
                            "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),

@@ -33,3 +33,18 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_reference_import_name_resolves_to_the_product():
+    """`from x_clip import CLIP, TextTransformer` (x_clip/__init__.py:1 of the reference) works unchanged: the alias package at the
+    repository root re-exports x_clip_amd and its distributed / mlm / visual_ssl sub-modules under the reference's names"""
+    import importlib
+    import sys
+    sys.modules.pop("x_clip", None)
+    x = importlib.import_module("x_clip")
+    import x_clip_amd
+    assert os.path.dirname(os.path.abspath(x.__file__)) == os.path.join(ROOT, "x_clip")
+    assert x.CLIP is x_clip_amd.CLIP and x.TextTransformer is x_clip_amd.TextTransformer
+    from x_clip.distributed import all_gather
+    from x_clip_amd.distributed import all_gather as ours
+    assert all_gather is ours

@@ -2,7 +2,7 @@
 """HBM-side traffic per kernel family from two rocprofv3 PMC passes of the same command (CSV output):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d F -o p -- <cmd>
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d W -o p -- <cmd>
-    python tools/pmc_traffic.py F/p_counter_collection.csv W/p_counter_collection.csv [gemm_traffic.json]
+    python tools/pmc_traffic.py F/p_counter_collection.csv W/p_counter_collection.csv [gemm_traffic.json [kernel family, default gemm3]]
 FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts the 128-byte requests of wide coalesced reads as 64 B -> x2
 (MI355X_MICROARCH.md, HBM section).  Infinity-Cache hits are part of FETCH_SIZE (fabric traffic: an upper bound on HBM reads)."""
 import csv
@@ -41,13 +41,14 @@ def main():
     print(f"{'kernel':60s} {'launches':>8s} {'FETCH KiB/launch':>18s} {'reads x2 (MB)':>14s} {'writes (MB)':>12s} {'total (MB)':>11s}")
     for r in rows[:24]:
         print(f"{r[0]:60s} {r[1]:8d} {r[2]:18.0f} {r[3]:14.1f} {r[4]:12.1f} {r[5]:11.1f}")
-    g = [r for r in rows if r[0].startswith("gemm3_kernel")]
+    fam = sys.argv[4] if len(sys.argv) > 4 else "gemm3"
+    g = [r for r in rows if r[0].startswith(fam + "_kernel")]
     n = sum(r[1] for r in g)
     per = sum(r[5] * r[1] for r in g) / max(n, 1)
-    print(f"# gemm3 family: {n} launches, {per:.1f} MB per launch (reads x2 + writes)")
+    print(f"# {fam} family: {n} launches, {per:.1f} MB per launch (reads x2 + writes)")
     if len(sys.argv) > 3:
         with open(sys.argv[3], "w") as f:
-            json.dump({"kernel_family": "gemm3_kernel", "bytes_per_launch": per * 1e6, "launches": n,
+            json.dump({"kernel_family": fam + "_kernel", "kernel_generation": fam, "bytes_per_launch": per * 1e6, "launches": n,
                        "source": "tools/pmc_traffic.py over rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (FETCH_SIZE x2 gfx950 correction)"}, f, indent=1)
 
 
