@@ -336,6 +336,19 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * lane_id(), gsrc, 16);
 }
 inline void glds4(const void* gsrc, void* lds_wave_base) { memcpy((unsigned char*)lds_wave_base + 4 * lane_id(), gsrc, 4); }
+// buffer resources (csrc/hw/xc_device.h): base + byte count; out-of-range accesses read zero / are dropped
+struct BufRsrc { const unsigned char* base; uint32_t bytes; };
+inline BufRsrc make_rsrc(const void* base, uint32_t bytes) { return BufRsrc{static_cast<const unsigned char*>(base), bytes}; }
+inline void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    const uint64_t off = (uint64_t)voff + soff;
+    unsigned char* dst = (unsigned char*)lds_wave_base + 16 * lane_id();
+    if (off + 16 <= r.bytes) memcpy(dst, r.base + off, 16); else memset(dst, 0, 16);
+}
+template <int IMM>
+inline void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
+    const uint64_t off = (uint64_t)voff + soff + IMM;
+    if (off + 16 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + off, &v, 16);
+}
 inline void wait_vmem() {}
 // transpose read: lane c of a 16-lane group, slot j <- element (c & 3) at the address supplied by lane 4j + (c >> 2)
 inline s16x4 lds_read_tr16(const void* p) {

@@ -27,8 +27,11 @@ def gemm_case(name, M, N, K, a_k, b_k):
     b = torch.randn((K, N) if b_k else (N, K), device=dev, dtype=bf)
     out = torch.empty(M, N, device=dev, dtype=bf)
     t = timeit(lambda: ops.gemm(a, b, M, N, K, a_k, b_k, out=out))
-    tr = timeit(lambda: torch.matmul(a.t() if a_k else a, b if b_k else b.t()))
-    print(f"{name:28s} M={M:7d} N={N:5d} K={K:7d}  {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s   (hipBLASLt {tr*1e3:8.3f} ms {2*M*N*K/tr/1e12:7.1f} TF/s)", flush=True)
+    ref = ""
+    if os.environ.get("XCLIP_PROBE_NO_REF") != "1":
+        tr = timeit(lambda: torch.matmul(a.t() if a_k else a, b if b_k else b.t()))
+        ref = f"   (hipBLASLt {tr*1e3:8.3f} ms {2*M*N*K/tr/1e12:7.1f} TF/s)"
+    print(f"{name:28s} M={M:7d} N={N:5d} K={K:7d}  {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s{ref}", flush=True)
 
 
 Mt = 1024 * 257
@@ -42,6 +45,11 @@ gemm_case("ff1 wgrad (TN)", 4096, 512, Mt, True, True)
 gemm_case("ff2 wgrad (TN)", 512, 2048, Mt, True, True)
 gemm_case("qkv wgrad (TN)", 1536, 512, Mt, True, True)
 gemm_case("patch embed (NT)", 1024 * 32, 512, 3072, False, False)
+gemm_case("out dgrad (NN)", Mt, 512, 512, False, True)
+gemm_case("qkv dgrad (NN)", Mt, 512, 1536, False, True)
+gemm_case("out wgrad (TN)", 512, 512, Mt, True, True)
+if os.environ.get("XCLIP_PROBE_GEMM_ONLY") == "1":
+    sys.exit(0)
 
 b, n, h = 1024, 257, 8
 qkv = torch.randn(b, n, 3 * h * 64, device=dev, dtype=bf)

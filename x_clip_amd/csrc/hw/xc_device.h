@@ -108,6 +108,24 @@ XC_DEV void glds4(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
+// ---- buffer resources: wave-uniform base + 32-bit byte offsets, hardware bounds check ---------------------------------------
+// A raw buffer descriptor (128 bits in SGPRs) built from wave-uniform values (cdna_hip_programming.md T8 / T20): memory instructions
+// through it take a per-lane 32-bit byte offset in ONE VGPR plus a scalar byte offset in an SGPR -- no 64-bit per-lane address
+// arithmetic -- and an access that reaches past `bytes` reads zero / is dropped (ragged tile edges need no clamps or masks).
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+XC_DEV BufRsrc make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// LDS DMA through a descriptor (buffer_load_dwordx4 ... offen lds): lane copies 16 bytes from base + voff + soff to
+// lds_wave_base + 16 * lane; tracked by vmcnt like glds16
+XC_DEV void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+// 16-byte store at base + voff + soff + IMM (IMM: the instruction's 12-bit immediate offset)
+template <int IMM>
+XC_DEV void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff + IMM, (int)soff, 0);
+}
 // wait until every outstanding vector-memory operation of this wave (LDS DMA included) has completed
 XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // lds_read_tr16 (ds_read_b64_tr_b16): within each 16-lane group, lane c (slot j) receives the 16-bit element

@@ -1,0 +1,285 @@
+// gemm4.h -- the production bf16 GEMM: gemm3.h's tile, LDS images and K-step schedule (256 x 256 output tile, 8 waves of 128 x 64,
+// K step 64, two 64 KiB stages filled by LDS DMA, fragment reads pipelined under the MFMAs, barrier before the last k-block,
+// persistent work-groups), with the instruction overhead AROUND the matrix work removed.  What the ISA of gemm3.h showed
+// (hipcc -S, the K-step loop of gemm3_kernel<false, false>):
+//   * every one of the 8 DMA pieces a wave issues per K step rebuilt its 64-bit source address from the tile origin -- 11 VALU
+//     instructions each, two v_mul_lo_u32 and a v_mad_u64_u32 among them -- behind a vector-compare branch on "is the DMA
+//     iterator still valid": ~90 VALU instructions and 8 branches per K step wedged between the MFMA pairs of an in-order wave;
+//   * the epilogue tested "interior tile or column in range" per store with exec-mask branches and evaluated the optional bias /
+//     row-gather / residual / split-K pointers at run time for each of the 8 accumulator blocks.
+// Here the DMA goes through buffer descriptors (xc_device.h: BufRsrc): the descriptor base carries the tile origin and the K
+// position and is advanced with scalar instructions once per K step; a lane's byte offset inside the tile is ONE loop-invariant VGPR
+// per piece parity; ragged edges need no clamps (a row or byte past the descriptor's extent reads as zero).  The DMA iterator never
+// becomes invalid -- past the last tile it re-fetches its last position into an LDS stage nobody reads again -- so the K loop has no
+// branches but its own back-edge.  The epilogue is compiled per MODE (what the caller's optional terms are) with a straight-line
+// interior-tile path: 64 conversions, 32 v_permlane32_swap, 16 descriptor stores with immediate offsets.
+#pragma once
+#include "gemm3.h"
+
+namespace xc {
+
+// what the epilogue of a launch has to do, fixed at compile time (the host picks the instantiation)
+enum : int {
+    G4_PLAIN = 0,        // C = alpha * acc                         (bf16)
+    G4_SLAB = 1,         // fp32 split-K slab, no alpha
+    G4_TERMS = 2         // + bias / gathered rows / residual, any subset (the general form of gemm3.h)
+};
+
+// per-lane byte offset of DMA piece q (0..3) of this wave inside an operand tile whose descriptor base is the tile's first element
+// at the current K position; pieces q and q + 2 differ by 16 rows (normal) / 16 k-rows (k-major): that part travels in soffset
+template <bool KMAJOR>
+XC_DEV uint32_t g4_voff(long ld, int wave, int lane, int q) {
+    const int id = wave * 4 + q;
+    if (!KMAJOR) {
+        const int row = id * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        return ((uint32_t)row * (uint32_t)ld + (uint32_t)chunk * 8u) * 2u;
+    } else {
+        const int panel = id >> 3;
+        const int row = (id & 7) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        return ((uint32_t)row * (uint32_t)ld + (uint32_t)(panel * 64 + chunk * 8)) * 2u;
+    }
+}
+// One operand of the DMA iterator: the (wave-uniform) address of the tile's first element at the iterator's K position and the
+// extent of the descriptor that covers one K step from there.  Reads past the tile's last valid row (normal operand) or past the
+// operand's last valid column in the tile's last k-row (k-major: earlier rows run on into the next row -- valid memory whose values
+// only reach output columns that are never stored) return zero instead of faulting.  The address moves by a constant per K step
+// (two scalar adds); only a tile change recomputes it.
+template <bool KMAJOR>
+struct G4Operand {
+    const bf16_t* pos;
+    uint32_t bytes;
+    XC_DEV void tile(const bf16_t* X, long ld, int outer0, int nouter, int k0) {
+        int valid = nouter - outer0;
+        valid = valid < 256 ? valid : 256;
+        if (!KMAJOR) {
+            pos = X + (long)outer0 * ld + k0;
+            bytes = (uint32_t)(valid - 1) * (uint32_t)ld * 2u + 128u;
+        } else {
+            pos = X + (long)k0 * ld + outer0;
+            bytes = 63u * (uint32_t)ld * 2u + (uint32_t)valid * 2u;
+        }
+    }
+    XC_DEV void advance(long ld) { pos += KMAJOR ? (long)G2_BK * ld : (long)G2_BK; }
+    XC_DEV BufRsrc rsrc() const { return make_rsrc(pos, bytes); }
+};
+
+struct G4Dma {
+    BufRsrc a, b;
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR, class Epilogue>
+XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = uniform(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+    const int nt = (kend - kbeg) / G2_BK;
+    const int stride = gridDim.x;
+    if ((int)blockIdx.x >= ntiles || nt <= 0) return;            // (uniform over the work-group)
+
+    auto tile_origin = [&](int id, int& m0, int& n0) {
+        const int tile = xcd_remap(id, ntiles);
+        m0 = (tile / p.tiles_n) * G2_BM;
+        n0 = (tile % p.tiles_n) * G2_BN;
+    };
+    // loop-invariant per-lane offsets of the DMA pieces (parity of the piece index) and the scalar step between pieces q, q + 2
+    const uint32_t va[2] = {g4_voff<A_KMAJOR>(p.lda, wave, lane, 0), g4_voff<A_KMAJOR>(p.lda, wave, lane, 1)};
+    const uint32_t vb[2] = {g4_voff<B_KMAJOR>(p.ldb, wave, lane, 0), g4_voff<B_KMAJOR>(p.ldb, wave, lane, 1)};
+    const uint32_t sa = (uint32_t)p.lda * 32u, sb = (uint32_t)p.ldb * 32u;     // 16 rows * ld * 2 bytes
+    unsigned char* const my0 = lds + wave * 4096;                               // this wave's first piece inside an operand image
+
+    // the DMA iterator: tile `did`, K step `dt`; runs up to two steps ahead of the MFMAs, across tile boundaries
+    int did = blockIdx.x, dt = 0, dm = 0, dn = 0;
+    tile_origin(did, dm, dn);
+    G4Operand<A_KMAJOR> oa;
+    G4Operand<B_KMAJOR> ob;
+    oa.tile(p.A, p.lda, dm, p.M, kbeg);
+    ob.tile(p.B, p.ldb, dn, p.N, kbeg);
+    G4Dma d;
+    auto dma_next = [&]() {
+        if (++dt == nt) {
+            if (did + stride < ntiles) {
+                dt = 0;
+                did += stride;
+                tile_origin(did, dm, dn);
+                oa.tile(p.A, p.lda, dm, p.M, kbeg);
+                ob.tile(p.B, p.ldb, dn, p.N, kbeg);
+            } else {
+                dt = nt - 1;                                  // past the end: the same position again, into a stage nobody reads
+            }
+        } else {
+            oa.advance(p.lda);
+            ob.advance(p.ldb);
+        }
+        d.a = oa.rsrc();
+        d.b = ob.rsrc();
+    };
+    d.a = oa.rsrc();
+    d.b = ob.rsrc();
+    auto piece_a = [&](int q, unsigned char* stage) { buf_glds16(d.a, va[q & 1], (q >> 1) ? sa : 0u, stage + (my0 - lds) + q * 1024); };
+    auto piece_b = [&](int q, unsigned char* stage) { buf_glds16(d.b, vb[q & 1], (q >> 1) ? sb : 0u, stage + G2_OPER_BYTES + (my0 - lds) + q * 1024); };
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(q, lds);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_b(q, lds);
+    dma_next();
+    XC_WAIT_VMEM_LE(0);
+    barrier_nodrain();                                        // step 0 has landed for every wave
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(q, lds + G2_STAGE_BYTES);    // what "C3 of step -1" would have issued: A of step 1
+
+    u32x4 a[2][4], b[2][2];
+    g3_read_frags<A_KMAJOR, B_KMAJOR>(lds, lds + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[0], b[0]);
+    lds_wait<0>(a[0], b[0]);
+
+    int step = 0;                                             // running K-step counter: LDS stage = step & 1
+    for (int id = blockIdx.x; id < ntiles; id += stride) {
+        int m0, n0;
+        tile_origin(id, m0, n0);
+        // acc[i][j] holds the TRANSPOSED 32 x 32 block (MFMA operands swapped): register r of lane l is
+        // C[m = i-block row (l & 31)][n = j-block column (r & 3) + 8 (r >> 2) + 4 (l >> 5)]
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int t = 0; t < nt; ++t, ++step) {
+            unsigned char* cur_stage = lds + (step & 1) * G2_STAGE_BYTES;
+            unsigned char* nxt_stage = lds + ((step + 1) & 1) * G2_STAGE_BYTES;
+            const unsigned char* As = cur_stage;
+            const unsigned char* Bs = cur_stage + G2_OPER_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk < 3) {
+                    g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
+                } else {
+                    XC_WAIT_VMEM_LE(0);                          // this wave's share of DMA(step + 1) (and any epilogue stores)
+                    barrier_nodrain();                           // ... everybody's; and nobody reads stage step & 1 any more
+                    // (after the work-group's very last step these fragments are never used: reading them keeps the loop branch-free)
+                    g3_read_frags<A_KMAJOR, B_KMAJOR>(nxt_stage, nxt_stage + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[nxt], b[nxt]);
+                }
+                sched_fence();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mma_kblock(b[cur][j], a[cur][i], acc[i][j], (bf16_t*)nullptr);   // D^T
+                    // DMA issue schedule of gemm3.h: B0-3 behind the MFMA pairs of C0 (into the next stage), A0-3 behind those of C3
+                    // (into the stage the barrier above has just freed, for the step after next)
+                    if (kk == 0) { sched_fence(); piece_b(i, nxt_stage); sched_fence(); }
+                    if (kk == 3) { sched_fence(); piece_a(i, cur_stage); sched_fence(); }
+                }
+                if (kk == 0) dma_next();                         // this wave's share of that stage is on its way: next position
+                sched_fence();
+                lds_wait<0>(a[nxt], b[nxt]);
+                sched_fence();
+            }
+        }
+        epi(acc, m0, n0);
+    }
+    XC_WAIT_VMEM_LE(0);                                       // the trailing (redundant) DMA pieces must land before the LDS is released
+    epi.finish();
+}
+
+// ---- epilogue: registers -> global, one output row per lane ----------------------------------------------------------------
+template <int MODE>
+struct G4GemmEpilogue {
+    const Gemm2Params& p;
+    XC_DEV void finish() const {}
+
+    // interior tile, bf16 output: straight-line
+    XC_DEV void store_full_bf16(f32x16 (&acc)[4][2], int m0, int n0) const {
+        const int lane = threadIdx.x & 63, h = lane >> 5;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane & 31)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * h)) * 2u;
+        const uint32_t si = (uint32_t)p.ldc * 64u;                                  // 32 rows * ldc * 2 bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t pk[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pk[q][0] = (uint32_t)f2bf(acc[i][j][4 * q] * p.alpha) | ((uint32_t)f2bf(acc[i][j][4 * q + 1] * p.alpha) << 16);
+                    pk[q][1] = (uint32_t)f2bf(acc[i][j][4 * q + 2] * p.alpha) | ((uint32_t)f2bf(acc[i][j][4 * q + 3] * p.alpha) << 16);
+                }
+                // quads (0,1) and (2,3): lower lanes end up with columns [0,8) / [16,24), upper lanes with [8,16) / [24,32)
+                permlane32_swap(pk[0][0], pk[1][0]);
+                permlane32_swap(pk[0][1], pk[1][1]);
+                permlane32_swap(pk[2][0], pk[3][0]);
+                permlane32_swap(pk[2][1], pk[3][1]);
+                const u32x4 o0 = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                const u32x4 o1 = {pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
+                if (j == 0) {
+                    buf_st16<0>(rc, vc, si * i, o0);
+                    buf_st16<32>(rc, vc, si * i, o1);
+                } else {
+                    buf_st16<64>(rc, vc, si * i, o0);
+                    buf_st16<96>(rc, vc, si * i, o1);
+                }
+            }
+        }
+    }
+    // interior tile, fp32 split-K slab: 32 stores of 4 floats per lane
+    XC_DEV void store_full_slab(f32x16 (&acc)[4][2], int m0, int n0) const {
+        const int lane = threadIdx.x & 63, h = lane >> 5;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const float* slab = p.partial + ((long)blockIdx.y * p.M + m0) * p.N + n0;
+        const BufRsrc rc = make_rsrc(slab, 255u * (uint32_t)p.N * 4u + 1024u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane & 31)) * (uint32_t)p.N + (uint32_t)(wn * 64 + 4 * h)) * 4u;
+        const uint32_t si = (uint32_t)p.N * 128u;                                   // 32 rows * N * 4 bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 v0 = {f2u(acc[i][j][0]), f2u(acc[i][j][1]), f2u(acc[i][j][2]), f2u(acc[i][j][3])};
+                const u32x4 v1 = {f2u(acc[i][j][4]), f2u(acc[i][j][5]), f2u(acc[i][j][6]), f2u(acc[i][j][7])};
+                const u32x4 v2 = {f2u(acc[i][j][8]), f2u(acc[i][j][9]), f2u(acc[i][j][10]), f2u(acc[i][j][11])};
+                const u32x4 v3 = {f2u(acc[i][j][12]), f2u(acc[i][j][13]), f2u(acc[i][j][14]), f2u(acc[i][j][15])};
+                if (j == 0) {
+                    buf_st16<0>(rc, vc, si * i, v0);
+                    buf_st16<32>(rc, vc, si * i, v1);
+                    buf_st16<64>(rc, vc, si * i, v2);
+                    buf_st16<96>(rc, vc, si * i, v3);
+                } else {
+                    buf_st16<128>(rc, vc, si * i, v0);
+                    buf_st16<160>(rc, vc, si * i, v1);
+                    buf_st16<192>(rc, vc, si * i, v2);
+                    buf_st16<224>(rc, vc, si * i, v3);
+                }
+            }
+        }
+    }
+
+    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
+        const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);       // interior tile (uniform)
+        if (MODE == G4_PLAIN && full) {
+            store_full_bf16(acc, m0, n0);
+            return 16;
+        }
+        if (MODE == G4_SLAB && full) {
+            store_full_slab(acc, m0, n0);
+            return 32;
+        }
+        // ragged tiles and the optional epilogue terms: the general form (per-element range checks, clamped reads)
+        return G3GemmEpilogue<0>{p}(acc, m0, n0);
+    }
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm4_kernel(Gemm2Params p) {
+    XC_LDS_DYNAMIC(lds);
+    g4_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE>{p});
+}
+
+}  // namespace xc

@@ -8,6 +8,7 @@
 #include "kernels/gemm.h"
 #include "kernels/gemm2.h"
 #include "kernels/gemm3.h"
+#include "kernels/gemm4.h"
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
 #include "kernels/simloss3.h"
@@ -124,32 +125,48 @@ void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, block, GemmCfg<T>::LDS_BYTES, st, p);
 }
 
-// XCLIP_GEMM=2 selects the two-phase kernel (gemm2.h) for A/B measurements; default is the ring-pipelined gemm3.h
-inline bool gemm_two_phase() {
-    static const bool v = [] { const char* e = getenv("XCLIP_GEMM"); return e != nullptr && e[0] == '2'; }();
+// XCLIP_GEMM=2 / 3 select the two-phase kernel (gemm2.h) / the first scheduled kernel (gemm3.h) for A/B measurements; the default is
+// gemm4.h (descriptor-addressed DMA, branch-free K loop, per-mode epilogue)
+inline int gemm_generation() {
+    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 4; }();
     return v;
+}
+template <bool AK, bool BK_, int MODE>
+void launch_gemm4(const Gemm2Params& p, dim3 pgrid, hipStream_t st) {
+    XC_ALLOW_LDS((gemm4_kernel<AK, BK_, MODE>), G3_LDS_BYTES);
+    hipLaunchKernelGGL((gemm4_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G3_LDS_BYTES, st, p);
 }
 template <bool AK, bool BK_>
 void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, splits), block(G2_THREADS);
-    if (gemm_two_phase()) {
+    const int gen = gemm_generation();
+    if (gen == 2) {
         XC_ALLOW_LDS((gemm2_kernel<AK, BK_>), G2_LDS_BYTES);
         hipLaunchKernelGGL((gemm2_kernel<AK, BK_>), grid, block, G2_LDS_BYTES, st, p);
-    } else {
-        // persistent: one work-group per CU walks the tiles (split-K problems are sized to ~one tile per work-group already)
-        int gx = p.tiles_m * p.tiles_n;
-        const int cus = xc_num_cus();
-        if (gx * splits > cus && splits == 1) gx = gx < cus ? gx : cus;
-        dim3 pgrid(gx, splits);
-        static const int abl = [] { const char* e = getenv("XCLIP_GEMM_ABL"); return e ? atoi(e) : 0; }();
-        if (abl != 0 && !AK && !BK_) {                      // measurement-only variants of the NT kernel
-#define XC_ABL(N) case N: XC_ALLOW_LDS((gemm3_kernel<false, false, N>), G3_LDS_BYTES); hipLaunchKernelGGL((gemm3_kernel<false, false, N>), pgrid, block, G3_LDS_BYTES, st, p); return;
-            switch (abl) { XC_ABL(1) XC_ABL(2) XC_ABL(4) XC_ABL(8) XC_ABL(3) XC_ABL(9) XC_ABL(10) XC_ABL(11) XC_ABL(14) XC_ABL(15) XC_ABL(25) XC_ABL(41) XC_ABL(64) XC_ABL(73) XC_ABL(105) default: break; }
-#undef XC_ABL
-        }
-        XC_ALLOW_LDS((gemm3_kernel<AK, BK_>), G3_LDS_BYTES);
-        hipLaunchKernelGGL((gemm3_kernel<AK, BK_>), pgrid, block, G3_LDS_BYTES, st, p);
+        return;
     }
+    // persistent: one work-group per CU walks the tiles (split-K problems are sized to ~one tile per work-group already)
+    int gx = p.tiles_m * p.tiles_n;
+    const int cus = xc_num_cus();
+    if (gx * splits > cus && splits == 1) gx = gx < cus ? gx : cus;
+    dim3 pgrid(gx, splits);
+    // gemm4's 32-bit in-tile byte offsets: leading dimensions below 2^22 elements (anything else is not a Linear of this model)
+    const bool small_ld = p.lda < (1L << 22) && p.ldb < (1L << 22) && p.ldc < (1L << 22) && (long)p.N < (1L << 21);
+    if (gen == 4 && small_ld) {
+        const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
+        if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(p, pgrid, st);
+        else if (terms) launch_gemm4<AK, BK_, G4_TERMS>(p, pgrid, st);
+        else launch_gemm4<AK, BK_, G4_PLAIN>(p, pgrid, st);
+        return;
+    }
+    static const int abl = [] { const char* e = getenv("XCLIP_GEMM_ABL"); return e ? atoi(e) : 0; }();
+    if (abl != 0 && !AK && !BK_) {                      // measurement-only variants of the NT kernel
+#define XC_ABL(N) case N: XC_ALLOW_LDS((gemm3_kernel<false, false, N>), G3_LDS_BYTES); hipLaunchKernelGGL((gemm3_kernel<false, false, N>), pgrid, block, G3_LDS_BYTES, st, p); return;
+        switch (abl) { XC_ABL(1) XC_ABL(2) XC_ABL(4) XC_ABL(8) XC_ABL(3) XC_ABL(9) XC_ABL(10) XC_ABL(11) XC_ABL(14) XC_ABL(15) XC_ABL(25) XC_ABL(41) XC_ABL(64) XC_ABL(73) XC_ABL(105) default: break; }
+#undef XC_ABL
+    }
+    XC_ALLOW_LDS((gemm3_kernel<AK, BK_>), G3_LDS_BYTES);
+    hipLaunchKernelGGL((gemm3_kernel<AK, BK_>), pgrid, block, G3_LDS_BYTES, st, p);
 }
 
 // the 256x256 DMA-staged kernel (gemm2.h) takes every bf16 problem whose contraction is a multiple of its K step and
