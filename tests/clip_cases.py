@@ -8,7 +8,7 @@ libxclip_hip.so on an MI355X).  Two kinds of checks:
 
 Tolerances: fp32 storage -> the north star's 1e-5 (loss) and a few 1e-5 relative on gradients (fp32 accumulation order
 differs from ATen's); bf16 storage -> oracle evaluated in fp64 on the bf16-rounded parameters; the network compounds
-one bf16 rounding per stored activation, so loss 2e-2 and gradient direction (cosine) are checked -- the per-kernel
+one bf16 rounding per stored activation: loss 2e-3 (measured 1e-4 at depth 6), gradients 15 % relative / cosine 0.99 -- the per-kernel
 1e-3-class bound lives in tests/kernel_cases.py (the reference's own bf16 run is 1.3e-2 off its
 fp32 run).
 """
@@ -144,8 +144,8 @@ def oracle_run(cfg, sd64, text, image64, aug_t, aug_i64, keep, mlm=None, ssl_run
 REPORT = {}
 
 
-def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_image=0, patch_keep=None, seed=7, bf16_cos=0.98,
-                   bf16_rel=0.2, bf16_loss=2e-2, label=None, **extra):
+def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_image=0, patch_keep=None, seed=7, bf16_cos=0.99,
+                   bf16_rel=0.15, bf16_loss=2e-3, label=None, **extra):
     """product vs. the fp64 oracle on the same (dtype-rounded) parameters and inputs; every gradient in full.  bf16: the oracle runs
     in fp64 on the bf16-rounded parameters WITH THE bf16 LayerNorm epsilon (1e-3, x_clip.py:118) -- the model the product computes"""
     sd = O.make_state_dict(cfg, seed, torch.float32)
@@ -179,9 +179,12 @@ def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_ima
         assert float((got - want).norm() / scale) < (2e-5 if fp32 else 2e-2), k
     loss_err = abs(float(loss.detach()) - float(ref_loss)) / max(1.0, abs(float(ref_loss)))
     rec = {"loss_err": loss_err, "worst_rel": (0.0, ""), "worst_cos": (1.0, "")}
-    REPORT[label or f"{'fp32' if fp32 else 'bf16'} b={batch} depth={cfg.text_enc_depth}/{cfg.visual_enc_depth} seq={cfg.text_seq_len} "
-           f"aug={n_aug_text}+{n_aug_image} keep={patch_keep} {'dcl ' if cfg.decoupled_contrastive_learning else ''}"
-           f"{'filip ' if cfg.use_all_token_embeds else ''}seed={seed}"] = rec
+    import dataclasses
+    base = O.ClipConfig()
+    flags = " ".join(f"{f.name}={getattr(cfg, f.name)}" for f in dataclasses.fields(cfg)
+                     if isinstance(getattr(cfg, f.name), bool) and getattr(cfg, f.name) != getattr(base, f.name))
+    REPORT[label or f"{'fp32' if fp32 else 'bf16'} b={batch} dim={cfg.dim_text}/{cfg.dim_image} depth={cfg.text_enc_depth}/{cfg.visual_enc_depth} "
+           f"seq={cfg.text_seq_len} aug={n_aug_text}+{n_aug_image} keep={patch_keep} {flags}"] = rec
     failures = []
     if not loss_err < (1e-5 if fp32 else bf16_loss):
         failures.append(("loss", float(loss.detach()), float(ref_loss)))

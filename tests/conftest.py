@@ -51,5 +51,5 @@ def pytest_sessionfinish(session, exitstatus):
         return
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, f"parity_report_{where}.txt"), "a") as f:
+    with open(os.path.join(out, f"parity_report_{where}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")

@@ -135,7 +135,7 @@ def test_filip_odd_batch_and_token_counts():
     import dataclasses
     cfg = dataclasses.replace(O.CFG1, use_all_token_embeds=True, visual_image_size=96)
     C.case_vs_oracle(DEV, torch.float32, cfg, 5)
-    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 5, bf16_cos=0.9, bf16_rel=0.5)
+    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 5, bf16_cos=0.98, bf16_rel=0.25)       # measured: rel 0.141, cosine 0.990 (arg-max ties under bf16 scores)
 
 
 def test_backward_twice_and_inplace_edits_fail_loudly():

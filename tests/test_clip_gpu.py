@@ -75,7 +75,7 @@ def test_filip_mid_vs_oracle(dtype):
     cfg = dataclasses.replace(MID, use_all_token_embeds=True)
     # bf16: the token scores are rounded to bf16 before the max, so near-ties can route through a different token than the fp64
     # oracle (as the reference's own bf16 run would); the small, attention-only gradients (cls_token) show it most
-    C.case_vs_oracle(DEV, dtype, cfg, 24, bf16_cos=0.9, bf16_rel=0.5)
+    C.case_vs_oracle(DEV, dtype, cfg, 24, bf16_cos=0.98, bf16_rel=0.25)      # measured on the MI355X: rel 0.123, cosine 0.9924
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
@@ -85,7 +85,7 @@ def test_mid_sim_reg_extra_vs_oracle(dtype):
     cfg = dataclasses.replace(MID, extra_latent_projection=True, sim_reg_loss_weight=0.5)
     # bf16: D is a difference of two bf16-rounded similarity matrices (the reference's einsum outputs are rounded the same way), so
     # its relative error is larger than that of the other heads; the direction of every gradient still has to match
-    C.case_vs_oracle(DEV, dtype, cfg, 20, bf16_rel=0.35)
+    C.case_vs_oracle(DEV, dtype, cfg, 20)                                      # measured: rel 0.016
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
@@ -197,7 +197,7 @@ def test_filip_odd_chunks_vs_oracle(monkeypatch):
     cfg = dataclasses.replace(MID, use_all_token_embeds=True, visual_image_size=96)
     monkeypatch.setattr(losses, "_FILIP_CHUNK_BYTES", 22 * cfg.text_seq_len * 9 * 4 * 5)       # ~5 images per chunk
     C.case_vs_oracle(DEV, torch.float32, cfg, 22)
-    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 22, bf16_cos=0.9, bf16_rel=0.5)
+    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 22, bf16_cos=0.98, bf16_rel=0.25)    # measured: rel 0.080, cosine 0.9968
 
 
 def test_vit_l_like_shapes_vs_oracle():
