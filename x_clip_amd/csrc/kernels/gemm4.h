@@ -81,6 +81,7 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int nt = (kend - kbeg) / G2_BK;
     const int stride = gridDim.x;
     if ((int)blockIdx.x >= ntiles || nt <= 0) return;            // (uniform over the work-group)
+    if ((p.flags & 1) && wave >= 4) mfma_prio(1);                // (measurement: MI355X_MICROARCH.md "static priority for the younger half")
 
     auto tile_origin = [&](int id, int& m0, int& n0) {
         const int tile = xcd_remap(id, ntiles);
@@ -138,6 +139,14 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     g3_read_frags<A_KMAJOR, B_KMAJOR>(lds, lds + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[0], b[0]);
     lds_wait<0>(a[0], b[0]);
 
+    // Deferred half of the previous tile's epilogue (Epilogue::HELD stores of 16 bytes per lane): the write path of a CU accepts
+    // ~16 bytes per clock, so the 128 KiB a tile stores occupy it for ~4.5 us however the stores are shaped (MI355X: K = 512 tiles
+    // 21 us, of which the store burst with every wave stalled behind it was a fifth).  Half of the packed tile stays in registers
+    // and leaves one store at a time behind the MFMA pairs of the NEXT tile's first K step (k-blocks 1 and 2, which carry no DMA
+    // pieces), where the matrix cores keep running; that step's DMA wait then leaves exactly those stores in flight.
+    u32x4 held[Epilogue::HELD > 0 ? Epilogue::HELD : 1];
+    int pending = 0;                                          // (uniform) the previous tile left stores in `held`
+
     int step = 0;                                             // running K-step counter: LDS stage = step & 1
     for (int id = blockIdx.x; id < ntiles; id += stride) {
         int m0, n0;
@@ -153,6 +162,7 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         for (int t = 0; t < nt; ++t, ++step) {
+            const bool trickle = Epilogue::HELD > 0 && t == 0 && pending != 0;
             unsigned char* cur_stage = lds + (step & 1) * G2_STAGE_BYTES;
             unsigned char* nxt_stage = lds + ((step + 1) & 1) * G2_STAGE_BYTES;
             const unsigned char* As = cur_stage;
@@ -163,7 +173,8 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 if (kk < 3) {
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
                 } else {
-                    XC_WAIT_VMEM_LE(0);                          // this wave's share of DMA(step + 1) (and any epilogue stores)
+                    // this wave's share of DMA(step + 1) (and any epilogue stores issued before it; the 8 trickled ones are younger)
+                    if (Epilogue::HELD == 8 && trickle) XC_WAIT_VMEM_LE(8); else XC_WAIT_VMEM_LE(0);
                     barrier_nodrain();                           // ... everybody's; and nobody reads stage step & 1 any more
                     // (after the work-group's very last step these fragments are never used: reading them keeps the loop branch-free)
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(nxt_stage, nxt_stage + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[nxt], b[nxt]);
@@ -177,6 +188,14 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     // (into the stage the barrier above has just freed, for the step after next)
                     if (kk == 0) { sched_fence(); piece_b(i, nxt_stage); sched_fence(); }
                     if (kk == 3) { sched_fence(); piece_a(i, cur_stage); sched_fence(); }
+                    if (Epilogue::HELD == 8 && (kk == 1 || kk == 2)) {
+                        if (trickle) {
+                            sched_fence();
+                            if (kk == 1) { if (i == 0) epi.template held_store<0>(held); else if (i == 1) epi.template held_store<1>(held); else if (i == 2) epi.template held_store<2>(held); else epi.template held_store<3>(held); }
+                            else { if (i == 0) epi.template held_store<4>(held); else if (i == 1) epi.template held_store<5>(held); else if (i == 2) epi.template held_store<6>(held); else epi.template held_store<7>(held); }
+                            sched_fence();
+                        }
+                    }
                 }
                 if (kk == 0) dma_next();                         // this wave's share of that stage is on its way: next position
                 sched_fence();
@@ -184,25 +203,48 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 sched_fence();
             }
         }
-        epi(acc, m0, n0);
+        pending = epi(acc, m0, n0, held);
+    }
+    if (Epilogue::HELD == 8 && pending != 0) {                   // the last tile's deferred stores
+        epi.template held_store<0>(held); epi.template held_store<1>(held); epi.template held_store<2>(held); epi.template held_store<3>(held);
+        epi.template held_store<4>(held); epi.template held_store<5>(held); epi.template held_store<6>(held); epi.template held_store<7>(held);
     }
     XC_WAIT_VMEM_LE(0);                                       // the trailing (redundant) DMA pieces must land before the LDS is released
     epi.finish();
 }
 
 // ---- epilogue: registers -> global, one output row per lane ----------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool DEFER>
 struct G4GemmEpilogue {
+    static constexpr int HELD = (MODE == G4_PLAIN && DEFER) ? 8 : 0;
     const Gemm2Params& p;
+    BufRsrc rc_held;                                          // descriptor of the tile whose second half waits in registers
     XC_DEV void finish() const {}
 
-    // interior tile, bf16 output: straight-line
-    XC_DEV void store_full_bf16(f32x16 (&acc)[4][2], int m0, int n0) const {
+    XC_DEV uint32_t lane_off_bf16() const {
         const int lane = threadIdx.x & 63, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
-        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
-        const uint32_t vc = ((uint32_t)(wm * 128 + (lane & 31)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * h)) * 2u;
+        return ((uint32_t)(wm * 128 + (lane & 31)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * h)) * 2u;
+    }
+    // store S (0..7) of the deferred half: row block i = 2 + S / 4, column block j = (S / 2) & 1, 16-column half S & 1
+    template <int S>
+    XC_DEV void held_store(const u32x4 (&held)[HELD > 0 ? HELD : 1]) const {
+        constexpr int I = 2 + S / 4, IMM = ((S / 2) & 1) * 64 + (S & 1) * 32;
+        buf_st16<IMM>(rc_held, lane_off_bf16(), (uint32_t)p.ldc * 64u * I, held[HELD > 0 ? S : 0]);
+    }
+
+    // bf16 output, straight-line; row blocks [0, NOW) are stored at once, the rest go to `held` (interior tiles only).  FULL = interior
+    // tile; otherwise rows past M fall outside the descriptor (dropped by the hardware) and each store tests its 8 columns against N
+    template <int NOW, bool FULL>
+    XC_DEV void store_bf16(f32x16 (&acc)[4][2], int m0, int n0, u32x4 (&held)[HELD > 0 ? HELD : 1]) {
+        int rows = p.M - m0, cols = p.N - n0;
+        rows = (FULL || rows > 256) ? 256 : rows;
+        cols = (FULL || cols > 256) ? 256 : cols;
+        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, (uint32_t)(rows - 1) * (uint32_t)p.ldc * 2u + (uint32_t)cols * 2u);
+        const uint32_t vc = lane_off_bf16();
         const uint32_t si = (uint32_t)p.ldc * 64u;                                  // 32 rows * ldc * 2 bytes
+        const int col0 = (uniform(threadIdx.x >> 6) & 3) * 64 + 8 * ((threadIdx.x & 63) >> 5);   // this lane's first column in the tile
+        if (NOW < 4) rc_held = rc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -220,12 +262,15 @@ struct G4GemmEpilogue {
                 permlane32_swap(pk[2][1], pk[3][1]);
                 const u32x4 o0 = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 const u32x4 o1 = {pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
-                if (j == 0) {
-                    buf_st16<0>(rc, vc, si * i, o0);
-                    buf_st16<32>(rc, vc, si * i, o1);
+                if (i >= NOW) {
+                    held[HELD > 0 ? (i - 2) * 4 + j * 2 : 0] = o0;
+                    held[HELD > 0 ? (i - 2) * 4 + j * 2 + 1 : 0] = o1;
+                } else if (j == 0) {
+                    if (FULL || col0 < cols) buf_st16<0>(rc, vc, si * i, o0);
+                    if (FULL || col0 + 16 < cols) buf_st16<32>(rc, vc, si * i, o1);
                 } else {
-                    buf_st16<64>(rc, vc, si * i, o0);
-                    buf_st16<96>(rc, vc, si * i, o1);
+                    if (FULL || col0 + 32 < cols) buf_st16<64>(rc, vc, si * i, o0);
+                    if (FULL || col0 + 48 < cols) buf_st16<96>(rc, vc, si * i, o1);
                 }
             }
         }
@@ -261,25 +306,29 @@ struct G4GemmEpilogue {
         }
     }
 
-    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
+    // -> 1 when the tile left HELD stores in `held` for the K loop to issue, else 0
+    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0, u32x4 (&held)[HELD > 0 ? HELD : 1]) {
         const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);       // interior tile (uniform)
-        if (MODE == G4_PLAIN && full) {
-            store_full_bf16(acc, m0, n0);
-            return 16;
+        if (MODE == G4_PLAIN) {                                  // (never looks at the optional-term pointers: fewer live scalars)
+            if (full && HELD > 0) { store_bf16<2, true>(acc, m0, n0, held); return 1; }
+            if (full) store_bf16<4, true>(acc, m0, n0, held);
+            else store_bf16<4, false>(acc, m0, n0, held);
+            return 0;
         }
         if (MODE == G4_SLAB && full) {
             store_full_slab(acc, m0, n0);
-            return 32;
+            return 0;
         }
         // ragged tiles and the optional epilogue terms: the general form (per-element range checks, clamped reads)
-        return G3GemmEpilogue<0>{p}(acc, m0, n0);
+        (void)G3GemmEpilogue<0>{p}(acc, m0, n0);
+        return 0;
     }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
+template <bool A_KMAJOR, bool B_KMAJOR, int MODE, bool DEFER>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm4_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
-    g4_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE>{p});
+    g4_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE, DEFER>{p});
 }
 
 }  // namespace xc

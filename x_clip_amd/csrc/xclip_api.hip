@@ -131,10 +131,15 @@ inline int gemm_generation() {
     static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 4; }();
     return v;
 }
-template <bool AK, bool BK_, int MODE>
+template <bool AK, bool BK_, int MODE, bool DEFER>
 void launch_gemm4(const Gemm2Params& p, dim3 pgrid, hipStream_t st) {
-    XC_ALLOW_LDS((gemm4_kernel<AK, BK_, MODE>), G3_LDS_BYTES);
-    hipLaunchKernelGGL((gemm4_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G3_LDS_BYTES, st, p);
+    XC_ALLOW_LDS((gemm4_kernel<AK, BK_, MODE, DEFER>), G3_LDS_BYTES);
+    hipLaunchKernelGGL((gemm4_kernel<AK, BK_, MODE, DEFER>), pgrid, dim3(G2_THREADS), G3_LDS_BYTES, st, p);
+}
+// XCLIP_GEMM_DEFER=0 (measurement): the whole epilogue as one burst at the tile boundary
+inline bool gemm_defer() {
+    static const bool v = [] { const char* e = getenv("XCLIP_GEMM_DEFER"); return !(e != nullptr && e[0] == '0'); }();
+    return v;
 }
 template <bool AK, bool BK_>
 void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
@@ -154,9 +159,10 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     const bool small_ld = p.lda < (1L << 22) && p.ldb < (1L << 22) && p.ldc < (1L << 22) && (long)p.N < (1L << 21);
     if (gen == 4 && small_ld) {
         const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
-        if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(p, pgrid, st);
-        else if (terms) launch_gemm4<AK, BK_, G4_TERMS>(p, pgrid, st);
-        else launch_gemm4<AK, BK_, G4_PLAIN>(p, pgrid, st);
+        if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB, false>(p, pgrid, st);
+        else if (terms) launch_gemm4<AK, BK_, G4_TERMS, false>(p, pgrid, st);
+        else if (gemm_defer()) launch_gemm4<AK, BK_, G4_PLAIN, true>(p, pgrid, st);
+        else launch_gemm4<AK, BK_, G4_PLAIN, false>(p, pgrid, st);
         return;
     }
     static const int abl = [] { const char* e = getenv("XCLIP_GEMM_ABL"); return e ? atoi(e) : 0; }();
@@ -642,6 +648,8 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
         q.bias = (const bf16_t*)bias; q.residual = (const bf16_t*)residual; q.ldr = ldr;
         q.addrows = (const bf16_t*)addrows; q.rowidx = rowidx; q.ld_add = ld_add;
         q.tiles_m = (int)((M + G2_BM - 1) / G2_BM); q.tiles_n = (int)((N + G2_BN - 1) / G2_BN);
+        static const int gflags = [] { const char* e = getenv("XCLIP_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
+        q.flags = gflags;
         int splits = gemm2_splits(M, N, K);
         if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
         q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);
