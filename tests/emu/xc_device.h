@@ -256,6 +256,8 @@ inline bf16_t f2bf(float f) {           // round to nearest even, NaN preserved
     return (bf16_t)(u >> 16);
 }
 
+inline uint32_t f2bf_pk(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
 inline int lane_id() { return threadIdx.x & 63; }
 inline int wave_id() { return threadIdx.x >> 6; }
 inline void sync() { xcemu::block_barrier(); }
@@ -311,6 +313,11 @@ inline f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
     }
     return d;
 }
+inline f32x16 mfma_32x32x16_bf16_zero(s16x8 a, s16x8 b) {
+    f32x16 z;
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return mfma_32x32x16_bf16(a, b, z);
+}
 inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
     struct Dep { float a, b; } mine{a, b};
     auto tab = xcemu::wave_exchange(&mine, sizeof(Dep));
@@ -344,7 +351,7 @@ inline void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_b
     unsigned char* dst = (unsigned char*)lds_wave_base + 16 * lane_id();
     if (off + 16 <= r.bytes) memcpy(dst, r.base + off, 16); else memset(dst, 0, 16);
 }
-template <int IMM>
+template <int IMM, int AUX = 0>
 inline void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
     const uint64_t off = (uint64_t)voff + soff + IMM;
     if (off + 16 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + off, &v, 16);

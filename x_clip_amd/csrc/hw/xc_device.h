@@ -56,6 +56,14 @@ XC_DEV bf16_t f2bf(float f) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+// two floats -> one dword of two bf16 (lo in bits 0-15), round-to-nearest-even: ONE v_cvt_pk_bf16_f32
+XC_DEV uint32_t f2bf_pk(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 XC_DEV int lane_id() { return threadIdx.x & 63; }
 XC_DEV int wave_id() { return threadIdx.x >> 6; }
 XC_DEV void sync() { __syncthreads(); }
@@ -88,6 +96,12 @@ XC_DEV float wave_max(float v) {
 XC_DEV f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the same with C = 0 (the first k-block of a tile: no accumulator initialisation pass; the zero is an inline constant)
+XC_DEV f32x16 mfma_32x32x16_bf16_zero(s16x8 a, s16x8 b) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), z, 0, 0, 0);
 }
 // 32x32x2 f32 (exact fp32 fma chain): lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31].
 XC_DEV f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
@@ -122,9 +136,11 @@ XC_DEV void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_b
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
 // 16-byte store at base + voff + soff + IMM (IMM: the instruction's 12-bit immediate offset)
-template <int IMM>
+// AUX: cache policy bits of the store (0 = default write-back; 1 = sc0, 2 = nt, 16 = sc1: write-through that does not keep the line
+// in the XCD's L2 -- MI355X_MICROARCH.md "stores of each flavour")
+template <int IMM, int AUX = 0>
 XC_DEV void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff + IMM, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff + IMM, (int)soff, AUX);
 }
 // wait until every outstanding vector-memory operation of this wave (LDS DMA included) has completed
 XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

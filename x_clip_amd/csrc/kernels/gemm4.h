@@ -153,13 +153,8 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
         tile_origin(id, m0, n0);
         // acc[i][j] holds the TRANSPOSED 32 x 32 block (MFMA operands swapped): register r of lane l is
         // C[m = i-block row (l & 31)][n = j-block column (r & 3) + 8 (r >> 2) + 4 (l >> 5)]
+        // (not initialised: the first k-block of the tile runs its MFMAs with C = 0 instead of 128 register moves per wave)
         f32x16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         for (int t = 0; t < nt; ++t, ++step) {
             const bool trickle = Epilogue::HELD > 0 && t == 0 && pending != 0;
@@ -180,6 +175,15 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(nxt_stage, nxt_stage + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[nxt], b[nxt]);
                 }
                 sched_fence();
+                if (kk == 0 && t == 0) {                         // first k-block of the tile: C = 0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = mfma_32x32x16_bf16_zero(__builtin_bit_cast(s16x8, b[cur][j]), __builtin_bit_cast(s16x8, a[cur][i]));
+                        sched_fence(); piece_b(i, nxt_stage); sched_fence();
+                    }
+                } else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -214,7 +218,7 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 }
 
 // ---- epilogue: registers -> global, one output row per lane ----------------------------------------------------------------
-template <int MODE, bool DEFER>
+template <int MODE, bool DEFER, int AUX = 0>
 struct G4GemmEpilogue {
     static constexpr int HELD = (MODE == G4_PLAIN && DEFER) ? 8 : 0;
     const Gemm2Params& p;
@@ -230,7 +234,7 @@ struct G4GemmEpilogue {
     template <int S>
     XC_DEV void held_store(const u32x4 (&held)[HELD > 0 ? HELD : 1]) const {
         constexpr int I = 2 + S / 4, IMM = ((S / 2) & 1) * 64 + (S & 1) * 32;
-        buf_st16<IMM>(rc_held, lane_off_bf16(), (uint32_t)p.ldc * 64u * I, held[HELD > 0 ? S : 0]);
+        buf_st16<IMM, AUX>(rc_held, lane_off_bf16(), (uint32_t)p.ldc * 64u * I, held[HELD > 0 ? S : 0]);
     }
 
     // bf16 output, straight-line; row blocks [0, NOW) are stored at once, the rest go to `held` (interior tiles only).  FULL = interior
@@ -245,6 +249,7 @@ struct G4GemmEpilogue {
         const uint32_t si = (uint32_t)p.ldc * 64u;                                  // 32 rows * ldc * 2 bytes
         const int col0 = (uniform(threadIdx.x >> 6) & 3) * 64 + 8 * ((threadIdx.x & 63) >> 5);   // this lane's first column in the tile
         if (NOW < 4) rc_held = rc;
+
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -252,8 +257,8 @@ struct G4GemmEpilogue {
                 uint32_t pk[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    pk[q][0] = (uint32_t)f2bf(acc[i][j][4 * q] * p.alpha) | ((uint32_t)f2bf(acc[i][j][4 * q + 1] * p.alpha) << 16);
-                    pk[q][1] = (uint32_t)f2bf(acc[i][j][4 * q + 2] * p.alpha) | ((uint32_t)f2bf(acc[i][j][4 * q + 3] * p.alpha) << 16);
+                    pk[q][0] = f2bf_pk(acc[i][j][4 * q] * p.alpha, acc[i][j][4 * q + 1] * p.alpha);
+                    pk[q][1] = f2bf_pk(acc[i][j][4 * q + 2] * p.alpha, acc[i][j][4 * q + 3] * p.alpha);
                 }
                 // quads (0,1) and (2,3): lower lanes end up with columns [0,8) / [16,24), upper lanes with [8,16) / [24,32)
                 permlane32_swap(pk[0][0], pk[1][0]);
@@ -266,11 +271,11 @@ struct G4GemmEpilogue {
                     held[HELD > 0 ? (i - 2) * 4 + j * 2 : 0] = o0;
                     held[HELD > 0 ? (i - 2) * 4 + j * 2 + 1 : 0] = o1;
                 } else if (j == 0) {
-                    if (FULL || col0 < cols) buf_st16<0>(rc, vc, si * i, o0);
-                    if (FULL || col0 + 16 < cols) buf_st16<32>(rc, vc, si * i, o1);
+                    if (FULL || col0 < cols) buf_st16<0, AUX>(rc, vc, si * i, o0);
+                    if (FULL || col0 + 16 < cols) buf_st16<32, AUX>(rc, vc, si * i, o1);
                 } else {
-                    if (FULL || col0 + 32 < cols) buf_st16<64>(rc, vc, si * i, o0);
-                    if (FULL || col0 + 48 < cols) buf_st16<96>(rc, vc, si * i, o1);
+                    if (FULL || col0 + 32 < cols) buf_st16<64, AUX>(rc, vc, si * i, o0);
+                    if (FULL || col0 + 48 < cols) buf_st16<96, AUX>(rc, vc, si * i, o1);
                 }
             }
         }
@@ -325,10 +330,10 @@ struct G4GemmEpilogue {
     }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, int MODE, bool DEFER>
+template <bool A_KMAJOR, bool B_KMAJOR, int MODE, bool DEFER, int AUX = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm4_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
-    g4_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE, DEFER>{p});
+    g4_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE, DEFER, AUX>{p});
 }
 
 }  // namespace xc

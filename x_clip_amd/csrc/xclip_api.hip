@@ -162,7 +162,16 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
         if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB, false>(p, pgrid, st);
         else if (terms) launch_gemm4<AK, BK_, G4_TERMS, false>(p, pgrid, st);
         else if (gemm_defer()) launch_gemm4<AK, BK_, G4_PLAIN, true>(p, pgrid, st);
-        else launch_gemm4<AK, BK_, G4_PLAIN, false>(p, pgrid, st);
+        else {
+            // XCLIP_GEMM_ST (measurement, forward layout only): cache policy of the epilogue stores -- 16 = sc1, 17 = sc0 sc1, 2 = nt
+            static const int stp = [] { const char* e = getenv("XCLIP_GEMM_ST"); return e ? atoi(e) : 0; }();
+            if (!AK && !BK_ && stp != 0) {
+#define XC_ST(A) case A: XC_ALLOW_LDS((gemm4_kernel<false, false, G4_PLAIN, false, A>), G3_LDS_BYTES); hipLaunchKernelGGL((gemm4_kernel<false, false, G4_PLAIN, false, A>), pgrid, dim3(G2_THREADS), G3_LDS_BYTES, st, p); return;
+                switch (stp) { XC_ST(16) XC_ST(17) XC_ST(2) default: break; }
+#undef XC_ST
+            }
+            launch_gemm4<AK, BK_, G4_PLAIN, false>(p, pgrid, st);
+        }
         return;
     }
     static const int abl = [] { const char* e = getenv("XCLIP_GEMM_ABL"); return e ? atoi(e) : 0; }();
