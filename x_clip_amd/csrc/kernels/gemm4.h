@@ -217,6 +217,174 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     epi.finish();
 }
 
+// ---- the same K step with the HBM-streamed operand three stages deep -------------------------------------------------------------
+// SQ counters of the loop above on the text-tower shapes (profiles/r02_run4_gemm4_sq_pmc.txt): the MFMA pipe is busy 45 % (K = 512)
+// to 65 % (K = 2048) of the time and the waves spend 35-38 % of their cycles PARKED -- at the one s_waitcnt vmcnt(0) + barrier per K
+// step, i.e. waiting for the stage that was requested one step (~1.8 us) earlier: with every CU streaming, an LDS-DMA piece that has
+// to come from HBM is not back within one K step.  More lookahead needs a third stage, and 3 x 64 KiB do not fit the 160 KiB of LDS;
+// but only A (the activations) streams from HBM -- B (a weight panel) is re-read from L2 by every tile of its column.  So: A in a
+// ring of THREE 32 KiB stages, B in two (3 x 32 + 2 x 32 = 160 KiB, all of the CU's LDS).  Per step s:
+//     k-block 0:  issue A(s + 2) into A stage (s + 2) % 3   (free since the barrier of step s - 1)
+//     k-block 3:  s_waitcnt vmcnt(4) -- everything but the four A pieces just issued, i.e. A(s + 1) and B(s + 1) have landed --,
+//                 barrier, fragments of step s + 1, then issue B(s + 2) into B stage s & 1 (free from that barrier on)
+// A piece is requested 1.75 K steps before the wait that needs it (was 1.0), B 1.0 (was 0.75).  The counted wait is safe because LDS-DMA
+// loads retire in issue order and the only younger operations are the four A pieces (the epilogue's stores of a finished tile are
+// older than the next step's A pieces, so they are drained by that step's wait exactly as before).
+constexpr int G5_LDS_BYTES = 5 * G2_OPER_BYTES;              // 160 KiB
+
+template <bool KMAJOR>
+struct G5Iter {                                               // one operand's DMA iterator (tile, K step) with its descriptor
+    int did, dt, outer0;
+    G4Operand<KMAJOR> op;
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR, class Epilogue>
+XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = uniform(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+    const int nt = (kend - kbeg) / G2_BK;
+    const int stride = gridDim.x;
+    if ((int)blockIdx.x >= ntiles || nt <= 0) return;            // (uniform over the work-group)
+
+    auto tile_origin = [&](int id, int& m0, int& n0) {
+        const int tile = xcd_remap(id, ntiles);
+        m0 = (tile / p.tiles_n) * G2_BM;
+        n0 = (tile % p.tiles_n) * G2_BN;
+    };
+    const uint32_t va[2] = {g4_voff<A_KMAJOR>(p.lda, wave, lane, 0), g4_voff<A_KMAJOR>(p.lda, wave, lane, 1)};
+    const uint32_t vb[2] = {g4_voff<B_KMAJOR>(p.ldb, wave, lane, 0), g4_voff<B_KMAJOR>(p.ldb, wave, lane, 1)};
+    const uint32_t sa = (uint32_t)p.lda * 32u, sb = (uint32_t)p.ldb * 32u;
+    unsigned char* const ldsA = lds;                          // three A stages
+    unsigned char* const ldsB = lds + 3 * G2_OPER_BYTES;      // two B stages
+    const int mine = wave * 4096;                             // this wave's four 1 KiB pieces inside an operand image
+
+    // both iterators walk the same sequence of (tile, K step) positions; past the last one they repeat it (dead stage, no branch)
+    int a_id = blockIdx.x, a_t = 0, b_id = blockIdx.x, b_t = 0;
+    G4Operand<A_KMAJOR> oa;
+    G4Operand<B_KMAJOR> ob;
+    {
+        int m0, n0;
+        tile_origin(a_id, m0, n0);
+        oa.tile(p.A, p.lda, m0, p.M, kbeg);
+        ob.tile(p.B, p.ldb, n0, p.N, kbeg);
+    }
+    BufRsrc ra = oa.rsrc(), rb = ob.rsrc();
+    auto next_a = [&]() {
+        if (++a_t == nt) {
+            if (a_id + stride < ntiles) {
+                a_t = 0;
+                a_id += stride;
+                int m0, n0;
+                tile_origin(a_id, m0, n0);
+                oa.tile(p.A, p.lda, m0, p.M, kbeg);
+            } else {
+                a_t = nt - 1;
+            }
+        } else {
+            oa.advance(p.lda);
+        }
+        ra = oa.rsrc();
+    };
+    auto next_b = [&]() {
+        if (++b_t == nt) {
+            if (b_id + stride < ntiles) {
+                b_t = 0;
+                b_id += stride;
+                int m0, n0;
+                tile_origin(b_id, m0, n0);
+                ob.tile(p.B, p.ldb, n0, p.N, kbeg);
+            } else {
+                b_t = nt - 1;
+            }
+        } else {
+            ob.advance(p.ldb);
+        }
+        rb = ob.rsrc();
+    };
+    auto piece_a = [&](int q, unsigned char* stage) { buf_glds16(ra, va[q & 1], (q >> 1) ? sa : 0u, stage + mine + q * 1024); };
+    auto piece_b = [&](int q, unsigned char* stage) { buf_glds16(rb, vb[q & 1], (q >> 1) ? sb : 0u, stage + mine + q * 1024); };
+
+    // prologue: A(0), B(0), A(1), B(1) in this order; the first two must have landed before step 0
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(q, ldsA);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_b(q, ldsB);
+    next_a();
+    next_b();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_a(q, ldsA + G2_OPER_BYTES);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece_b(q, ldsB + G2_OPER_BYTES);
+    next_a();
+    next_b();
+    XC_WAIT_VMEM_LE(8);
+    barrier_nodrain();
+
+    u32x4 a[2][4], b[2][2];
+    g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA, ldsB, wm * 128, wn * 64, 0, lane, a[0], b[0]);
+    lds_wait<0>(a[0], b[0]);
+
+    int step = 0, sa3 = 0;                                    // running K-step counter (B stage = step & 1) and A stage = step % 3
+    for (int id = blockIdx.x; id < ntiles; id += stride) {
+        int m0, n0;
+        tile_origin(id, m0, n0);
+        f32x16 acc[4][2];                                     // (first k-block of the tile runs with C = 0)
+
+        for (int t = 0; t < nt; ++t, ++step) {
+            const int sa_next = sa3 == 2 ? 0 : sa3 + 1;       // A stage of step s + 1
+            const int sa_free = sa3 == 0 ? 2 : sa3 - 1;       // A stage of step s + 2 == the one step s - 1 used
+            const unsigned char* As = ldsA + sa3 * G2_OPER_BYTES;
+            const unsigned char* Bs = ldsB + (step & 1) * G2_OPER_BYTES;
+            unsigned char* const a_dst = ldsA + sa_free * G2_OPER_BYTES;
+            unsigned char* const b_dst = ldsB + (step & 1) * G2_OPER_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk < 3) {
+                    g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
+                } else {
+                    XC_WAIT_VMEM_LE(4);                          // all but this step's four A pieces: A(s + 1), B(s + 1) are in LDS
+                    barrier_nodrain();                           // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more
+                    g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA + sa_next * G2_OPER_BYTES, ldsB + ((step + 1) & 1) * G2_OPER_BYTES, wm * 128, wn * 64,
+                                                      0, lane, a[nxt], b[nxt]);
+                }
+                sched_fence();
+                if (kk == 0 && t == 0) {                         // first k-block of the tile: C = 0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = mfma_32x32x16_bf16_zero(__builtin_bit_cast(s16x8, b[cur][j]), __builtin_bit_cast(s16x8, a[cur][i]));
+                        sched_fence(); piece_a(i, a_dst); sched_fence();
+                    }
+                } else
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mma_kblock(b[cur][j], a[cur][i], acc[i][j], (bf16_t*)nullptr);   // D^T
+                    if (kk == 0) { sched_fence(); piece_a(i, a_dst); sched_fence(); }
+                    if (kk == 3) { sched_fence(); piece_b(i, b_dst); sched_fence(); }
+                }
+                if (kk == 0) next_a();
+                if (kk == 3) next_b();
+                sched_fence();
+                lds_wait<0>(a[nxt], b[nxt]);
+                sched_fence();
+            }
+            sa3 = sa_next;
+        }
+        u32x4 nothing[1];
+        (void)epi(acc, m0, n0, nothing);
+    }
+    XC_WAIT_VMEM_LE(0);                                       // trailing (redundant) pieces must land before the LDS is released
+    epi.finish();
+}
+
 // ---- epilogue: registers -> global, one output row per lane ----------------------------------------------------------------
 template <int MODE, bool DEFER, int AUX = 0>
 struct G4GemmEpilogue {
@@ -329,6 +497,13 @@ struct G4GemmEpilogue {
         return 0;
     }
 };
+
+// the three-deep A ring (g5_run); epilogues as above, no deferral
+template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm5_kernel(Gemm2Params p) {
+    XC_LDS_DYNAMIC(lds);
+    g5_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE, false, 0>{p});
+}
 
 template <bool A_KMAJOR, bool B_KMAJOR, int MODE, bool DEFER, int AUX = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm4_kernel(Gemm2Params p) {

@@ -128,7 +128,7 @@ void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
 // XCLIP_GEMM=2 / 3 select the two-phase kernel (gemm2.h) / the first scheduled kernel (gemm3.h) for A/B measurements; the default is
 // gemm4.h (descriptor-addressed DMA, branch-free K loop, per-mode epilogue)
 inline int gemm_generation() {
-    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 4; }();
+    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 4; }();   // ('5': below)
     return v;
 }
 template <bool AK, bool BK_, int MODE, bool DEFER>
@@ -157,6 +157,17 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     dim3 pgrid(gx, splits);
     // gemm4's 32-bit in-tile byte offsets: leading dimensions below 2^22 elements (anything else is not a Linear of this model)
     const bool small_ld = p.lda < (1L << 22) && p.ldb < (1L << 22) && p.ldc < (1L << 22) && (long)p.N < (1L << 21);
+    // XCLIP_GEMM=5: the three-deep A ring (gemm4.h: g5_run), all of the CU's 160 KiB of LDS
+    static const bool ring3 = [] { const char* e = getenv("XCLIP_GEMM"); return e != nullptr && e[0] == '5'; }();
+    if (ring3 && small_ld) {
+        const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
+#define XC_G5(MODE) do { XC_ALLOW_LDS((gemm5_kernel<AK, BK_, MODE>), G5_LDS_BYTES); hipLaunchKernelGGL((gemm5_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p); } while (0)
+        if (p.partial != nullptr) XC_G5(G4_SLAB);
+        else if (terms) XC_G5(G4_TERMS);
+        else XC_G5(G4_PLAIN);
+#undef XC_G5
+        return;
+    }
     if (gen == 4 && small_ld) {
         const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
         if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB, false>(p, pgrid, st);
