@@ -136,10 +136,9 @@ def test_gemm3_persistent_wraparound(layout):
 
 
 @pytest.mark.parametrize("layout,M,N,K_,alpha", [("nt", 1024, 512, 128, 1.0), ("nn", 768, 512, 64, 0.5), ("nt", 776, 512, 64, 1.0)])
-def test_gemm4_deferred_epilogue_across_tiles(layout, M, N, K_, alpha):
-    """interior tiles in a row on one work-group (3 emulated CUs, 6-8 tiles): half of each tile's packed output waits in registers and
-    is stored from inside the next tile's first K step (gemm4.h); a single K step per tile, a ragged last row of tiles after deferred
-    ones, and the flush after the last tile are all on this path"""
+def test_gemm4_interior_tiles_in_a_row(layout, M, N, K_, alpha):
+    """interior tiles in a row on one work-group (3 emulated CUs, 6-8 tiles): the straight-line descriptor epilogue, the C = 0 first
+    k-block of every tile, a single K step per tile (the three-stage A ring wraps inside the prologue), a ragged last row of tiles"""
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha)
 
 

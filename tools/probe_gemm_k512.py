@@ -1,4 +1,4 @@
-"""K = 512 forward shapes of the text tower under the measurement switches of gemm4 (XCLIP_GEMM_DEFER, XCLIP_GEMM_ST ...):
+"""K = 512 forward shapes of the text tower under the kernel-selection switch XCLIP_GEMM (3 = gemm3.h, 4 = g4_run, 5 = g5_run; see xclip_api.hip):
     python tools/probe_gemm_k512.py      (one process per setting: the switches are read once per process)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -81,7 +81,6 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int nt = (kend - kbeg) / G2_BK;
     const int stride = gridDim.x;
     if ((int)blockIdx.x >= ntiles || nt <= 0) return;            // (uniform over the work-group)
-    if ((p.flags & 1) && wave >= 4) mfma_prio(1);                // (measurement: MI355X_MICROARCH.md "static priority for the younger half")
 
     auto tile_origin = [&](int id, int& m0, int& n0) {
         const int tile = xcd_remap(id, ntiles);
@@ -139,14 +138,6 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     g3_read_frags<A_KMAJOR, B_KMAJOR>(lds, lds + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[0], b[0]);
     lds_wait<0>(a[0], b[0]);
 
-    // Deferred half of the previous tile's epilogue (Epilogue::HELD stores of 16 bytes per lane): the write path of a CU accepts
-    // ~16 bytes per clock, so the 128 KiB a tile stores occupy it for ~4.5 us however the stores are shaped (MI355X: K = 512 tiles
-    // 21 us, of which the store burst with every wave stalled behind it was a fifth).  Half of the packed tile stays in registers
-    // and leaves one store at a time behind the MFMA pairs of the NEXT tile's first K step (k-blocks 1 and 2, which carry no DMA
-    // pieces), where the matrix cores keep running; that step's DMA wait then leaves exactly those stores in flight.
-    u32x4 held[Epilogue::HELD > 0 ? Epilogue::HELD : 1];
-    int pending = 0;                                          // (uniform) the previous tile left stores in `held`
-
     int step = 0;                                             // running K-step counter: LDS stage = step & 1
     for (int id = blockIdx.x; id < ntiles; id += stride) {
         int m0, n0;
@@ -157,7 +148,6 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
         f32x16 acc[4][2];
 
         for (int t = 0; t < nt; ++t, ++step) {
-            const bool trickle = Epilogue::HELD > 0 && t == 0 && pending != 0;
             unsigned char* cur_stage = lds + (step & 1) * G2_STAGE_BYTES;
             unsigned char* nxt_stage = lds + ((step + 1) & 1) * G2_STAGE_BYTES;
             const unsigned char* As = cur_stage;
@@ -168,8 +158,7 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 if (kk < 3) {
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
                 } else {
-                    // this wave's share of DMA(step + 1) (and any epilogue stores issued before it; the 8 trickled ones are younger)
-                    if (Epilogue::HELD == 8 && trickle) XC_WAIT_VMEM_LE(8); else XC_WAIT_VMEM_LE(0);
+                    XC_WAIT_VMEM_LE(0);                          // this wave's share of DMA(step + 1) (and any epilogue stores)
                     barrier_nodrain();                           // ... everybody's; and nobody reads stage step & 1 any more
                     // (after the work-group's very last step these fragments are never used: reading them keeps the loop branch-free)
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(nxt_stage, nxt_stage + G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[nxt], b[nxt]);
@@ -192,14 +181,6 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     // (into the stage the barrier above has just freed, for the step after next)
                     if (kk == 0) { sched_fence(); piece_b(i, nxt_stage); sched_fence(); }
                     if (kk == 3) { sched_fence(); piece_a(i, cur_stage); sched_fence(); }
-                    if (Epilogue::HELD == 8 && (kk == 1 || kk == 2)) {
-                        if (trickle) {
-                            sched_fence();
-                            if (kk == 1) { if (i == 0) epi.template held_store<0>(held); else if (i == 1) epi.template held_store<1>(held); else if (i == 2) epi.template held_store<2>(held); else epi.template held_store<3>(held); }
-                            else { if (i == 0) epi.template held_store<4>(held); else if (i == 1) epi.template held_store<5>(held); else if (i == 2) epi.template held_store<6>(held); else epi.template held_store<7>(held); }
-                            sched_fence();
-                        }
-                    }
                 }
                 if (kk == 0) dma_next();                         // this wave's share of that stage is on its way: next position
                 sched_fence();
@@ -207,11 +188,7 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 sched_fence();
             }
         }
-        pending = epi(acc, m0, n0, held);
-    }
-    if (Epilogue::HELD == 8 && pending != 0) {                   // the last tile's deferred stores
-        epi.template held_store<0>(held); epi.template held_store<1>(held); epi.template held_store<2>(held); epi.template held_store<3>(held);
-        epi.template held_store<4>(held); epi.template held_store<5>(held); epi.template held_store<6>(held); epi.template held_store<7>(held);
+        epi(acc, m0, n0);
     }
     XC_WAIT_VMEM_LE(0);                                       // the trailing (redundant) DMA pieces must land before the LDS is released
     epi.finish();
@@ -378,19 +355,23 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             }
             sa3 = sa_next;
         }
-        u32x4 nothing[1];
-        (void)epi(acc, m0, n0, nothing);
+        epi(acc, m0, n0);
     }
     XC_WAIT_VMEM_LE(0);                                       // trailing (redundant) pieces must land before the LDS is released
     epi.finish();
 }
 
 // ---- epilogue: registers -> global, one output row per lane ----------------------------------------------------------------
-template <int MODE, bool DEFER, int AUX = 0>
+// Measured and NOT kept (MI355X, K = 512 shapes, where a tile is 8 K steps and its boundary costs ~6.5 us -- the fit of tile time
+// against K steps over K = 512 ... 4096 is 6.5 us + 1.80 us per step): holding half of the packed tile in 32 registers and issuing
+// its 8 stores one at a time behind MFMA pairs of the next tile's first K step (789 vs 801 TF/s on the QKV forward: nothing); static
+// s_setprio 1 for waves 4-7 (nothing); sc1 / sc0 sc1 write-through stores that do not stay in L2 (543 vs 801 TF/s: every wait then
+// sits on an HBM acknowledgement); nt stores (786 vs 801).  Cutting the epilogue's VALU work from ~550 to ~230 instructions per wave
+// (packed conversions, C = 0 first k-block, alpha applied with packed multiplies) moved nothing either: the boundary cost is not
+// instruction issue (profiles/r02_run2_gemm4_defer_prio_probe.log, r02_run3_gemm4_store_policy_probe.log).
+template <int MODE>
 struct G4GemmEpilogue {
-    static constexpr int HELD = (MODE == G4_PLAIN && DEFER) ? 8 : 0;
     const Gemm2Params& p;
-    BufRsrc rc_held;                                          // descriptor of the tile whose second half waits in registers
     XC_DEV void finish() const {}
 
     XC_DEV uint32_t lane_off_bf16() const {
@@ -398,17 +379,11 @@ struct G4GemmEpilogue {
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
         return ((uint32_t)(wm * 128 + (lane & 31)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * h)) * 2u;
     }
-    // store S (0..7) of the deferred half: row block i = 2 + S / 4, column block j = (S / 2) & 1, 16-column half S & 1
-    template <int S>
-    XC_DEV void held_store(const u32x4 (&held)[HELD > 0 ? HELD : 1]) const {
-        constexpr int I = 2 + S / 4, IMM = ((S / 2) & 1) * 64 + (S & 1) * 32;
-        buf_st16<IMM, AUX>(rc_held, lane_off_bf16(), (uint32_t)p.ldc * 64u * I, held[HELD > 0 ? S : 0]);
-    }
 
-    // bf16 output, straight-line; row blocks [0, NOW) are stored at once, the rest go to `held` (interior tiles only).  FULL = interior
-    // tile; otherwise rows past M fall outside the descriptor (dropped by the hardware) and each store tests its 8 columns against N
-    template <int NOW, bool FULL>
-    XC_DEV void store_bf16(f32x16 (&acc)[4][2], int m0, int n0, u32x4 (&held)[HELD > 0 ? HELD : 1]) {
+    // bf16 output, straight-line.  FULL = interior tile; otherwise rows past M fall outside the descriptor (dropped by the hardware)
+    // and each store tests its 8 columns against N
+    template <bool FULL>
+    XC_DEV void store_bf16(f32x16 (&acc)[4][2], int m0, int n0) const {
         int rows = p.M - m0, cols = p.N - n0;
         rows = (FULL || rows > 256) ? 256 : rows;
         cols = (FULL || cols > 256) ? 256 : cols;
@@ -416,8 +391,6 @@ struct G4GemmEpilogue {
         const uint32_t vc = lane_off_bf16();
         const uint32_t si = (uint32_t)p.ldc * 64u;                                  // 32 rows * ldc * 2 bytes
         const int col0 = (uniform(threadIdx.x >> 6) & 3) * 64 + 8 * ((threadIdx.x & 63) >> 5);   // this lane's first column in the tile
-        if (NOW < 4) rc_held = rc;
-
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -435,15 +408,12 @@ struct G4GemmEpilogue {
                 permlane32_swap(pk[2][1], pk[3][1]);
                 const u32x4 o0 = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 const u32x4 o1 = {pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
-                if (i >= NOW) {
-                    held[HELD > 0 ? (i - 2) * 4 + j * 2 : 0] = o0;
-                    held[HELD > 0 ? (i - 2) * 4 + j * 2 + 1 : 0] = o1;
-                } else if (j == 0) {
-                    if (FULL || col0 < cols) buf_st16<0, AUX>(rc, vc, si * i, o0);
-                    if (FULL || col0 + 16 < cols) buf_st16<32, AUX>(rc, vc, si * i, o1);
+                if (j == 0) {
+                    if (FULL || col0 < cols) buf_st16<0>(rc, vc, si * i, o0);
+                    if (FULL || col0 + 16 < cols) buf_st16<32>(rc, vc, si * i, o1);
                 } else {
-                    if (FULL || col0 + 32 < cols) buf_st16<64, AUX>(rc, vc, si * i, o0);
-                    if (FULL || col0 + 48 < cols) buf_st16<96, AUX>(rc, vc, si * i, o1);
+                    if (FULL || col0 + 32 < cols) buf_st16<64>(rc, vc, si * i, o0);
+                    if (FULL || col0 + 48 < cols) buf_st16<96>(rc, vc, si * i, o1);
                 }
             }
         }
@@ -479,22 +449,17 @@ struct G4GemmEpilogue {
         }
     }
 
-    // -> 1 when the tile left HELD stores in `held` for the K loop to issue, else 0
-    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0, u32x4 (&held)[HELD > 0 ? HELD : 1]) {
+    XC_DEV void operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
         const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);       // interior tile (uniform)
         if (MODE == G4_PLAIN) {                                  // (never looks at the optional-term pointers: fewer live scalars)
-            if (full && HELD > 0) { store_bf16<2, true>(acc, m0, n0, held); return 1; }
-            if (full) store_bf16<4, true>(acc, m0, n0, held);
-            else store_bf16<4, false>(acc, m0, n0, held);
-            return 0;
-        }
-        if (MODE == G4_SLAB && full) {
+            if (full) store_bf16<true>(acc, m0, n0);
+            else store_bf16<false>(acc, m0, n0);
+        } else if (MODE == G4_SLAB && full) {
             store_full_slab(acc, m0, n0);
-            return 0;
+        } else {
+            // ragged slab tiles and the optional epilogue terms: the general form (per-element range checks, clamped reads)
+            (void)G3GemmEpilogue<0>{p}(acc, m0, n0);
         }
-        // ragged tiles and the optional epilogue terms: the general form (per-element range checks, clamped reads)
-        (void)G3GemmEpilogue<0>{p}(acc, m0, n0);
-        return 0;
     }
 };
 
@@ -502,13 +467,13 @@ struct G4GemmEpilogue {
 template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm5_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
-    g5_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE, false, 0>{p});
+    g5_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE>{p});
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int MODE, bool DEFER, int AUX = 0>
+template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm4_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
-    g4_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE, DEFER, AUX>{p});
+    g4_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE>{p});
 }
 
 }  // namespace xc

@@ -125,21 +125,23 @@ void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, block, GemmCfg<T>::LDS_BYTES, st, p);
 }
 
-// XCLIP_GEMM=2 / 3 select the two-phase kernel (gemm2.h) / the first scheduled kernel (gemm3.h) for A/B measurements; the default is
-// gemm4.h (descriptor-addressed DMA, branch-free K loop, per-mode epilogue)
+// Which bf16 GEMM runs (XCLIP_GEMM, read once; A/B measurements): 2 = gemm2.h (two-phase), 3 = gemm3.h (first scheduled kernel), 4 = gemm4.h
+// g4_run everywhere, 5 = g5_run everywhere.  Default: g5_run (A in a ring of three LDS stages) for the layouts whose B operand is
+// a weight panel that lives in L2 -- forward (NT) and dgrad (NN): +2 ... +6 % there -- and g4_run for wgrad (TN), where BOTH operands
+// stream from HBM and the deeper A ring measured 3-11 % SLOWER (profiles/r02_run5_gemm5_ring_probe.log).
 inline int gemm_generation() {
-    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 4; }();   // ('5': below)
+    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && e[0] >= '2' && e[0] <= '5') ? e[0] - '0' : 0; }();
     return v;
 }
-template <bool AK, bool BK_, int MODE, bool DEFER>
-void launch_gemm4(const Gemm2Params& p, dim3 pgrid, hipStream_t st) {
-    XC_ALLOW_LDS((gemm4_kernel<AK, BK_, MODE, DEFER>), G3_LDS_BYTES);
-    hipLaunchKernelGGL((gemm4_kernel<AK, BK_, MODE, DEFER>), pgrid, dim3(G2_THREADS), G3_LDS_BYTES, st, p);
-}
-// XCLIP_GEMM_DEFER=0 (measurement): the whole epilogue as one burst at the tile boundary
-inline bool gemm_defer() {
-    static const bool v = [] { const char* e = getenv("XCLIP_GEMM_DEFER"); return !(e != nullptr && e[0] == '0'); }();
-    return v;
+template <bool AK, bool BK_, int MODE>
+void launch_gemm4(const Gemm2Params& p, dim3 pgrid, bool ring3, hipStream_t st) {
+    if (ring3) {
+        XC_ALLOW_LDS((gemm5_kernel<AK, BK_, MODE>), G5_LDS_BYTES);
+        hipLaunchKernelGGL((gemm5_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+    } else {
+        XC_ALLOW_LDS((gemm4_kernel<AK, BK_, MODE>), G3_LDS_BYTES);
+        hipLaunchKernelGGL((gemm4_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G3_LDS_BYTES, st, p);
+    }
 }
 template <bool AK, bool BK_>
 void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
@@ -155,34 +157,14 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     const int cus = xc_num_cus();
     if (gx * splits > cus && splits == 1) gx = gx < cus ? gx : cus;
     dim3 pgrid(gx, splits);
-    // gemm4's 32-bit in-tile byte offsets: leading dimensions below 2^22 elements (anything else is not a Linear of this model)
+    // 32-bit in-tile byte offsets: leading dimensions below 2^22 elements (anything else is not a Linear of this model)
     const bool small_ld = p.lda < (1L << 22) && p.ldb < (1L << 22) && p.ldc < (1L << 22) && (long)p.N < (1L << 21);
-    // XCLIP_GEMM=5: the three-deep A ring (gemm4.h: g5_run), all of the CU's 160 KiB of LDS
-    static const bool ring3 = [] { const char* e = getenv("XCLIP_GEMM"); return e != nullptr && e[0] == '5'; }();
-    if (ring3 && small_ld) {
+    if (gen != 3 && small_ld) {
+        const bool ring3 = gen == 5 || (gen == 0 && !AK);
         const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
-#define XC_G5(MODE) do { XC_ALLOW_LDS((gemm5_kernel<AK, BK_, MODE>), G5_LDS_BYTES); hipLaunchKernelGGL((gemm5_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p); } while (0)
-        if (p.partial != nullptr) XC_G5(G4_SLAB);
-        else if (terms) XC_G5(G4_TERMS);
-        else XC_G5(G4_PLAIN);
-#undef XC_G5
-        return;
-    }
-    if (gen == 4 && small_ld) {
-        const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
-        if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB, false>(p, pgrid, st);
-        else if (terms) launch_gemm4<AK, BK_, G4_TERMS, false>(p, pgrid, st);
-        else if (gemm_defer()) launch_gemm4<AK, BK_, G4_PLAIN, true>(p, pgrid, st);
-        else {
-            // XCLIP_GEMM_ST (measurement, forward layout only): cache policy of the epilogue stores -- 16 = sc1, 17 = sc0 sc1, 2 = nt
-            static const int stp = [] { const char* e = getenv("XCLIP_GEMM_ST"); return e ? atoi(e) : 0; }();
-            if (!AK && !BK_ && stp != 0) {
-#define XC_ST(A) case A: XC_ALLOW_LDS((gemm4_kernel<false, false, G4_PLAIN, false, A>), G3_LDS_BYTES); hipLaunchKernelGGL((gemm4_kernel<false, false, G4_PLAIN, false, A>), pgrid, dim3(G2_THREADS), G3_LDS_BYTES, st, p); return;
-                switch (stp) { XC_ST(16) XC_ST(17) XC_ST(2) default: break; }
-#undef XC_ST
-            }
-            launch_gemm4<AK, BK_, G4_PLAIN, false>(p, pgrid, st);
-        }
+        if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(p, pgrid, ring3, st);
+        else if (terms) launch_gemm4<AK, BK_, G4_TERMS>(p, pgrid, ring3, st);
+        else launch_gemm4<AK, BK_, G4_PLAIN>(p, pgrid, ring3, st);
         return;
     }
     static const int abl = [] { const char* e = getenv("XCLIP_GEMM_ABL"); return e ? atoi(e) : 0; }();
@@ -668,8 +650,7 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
         q.bias = (const bf16_t*)bias; q.residual = (const bf16_t*)residual; q.ldr = ldr;
         q.addrows = (const bf16_t*)addrows; q.rowidx = rowidx; q.ld_add = ld_add;
         q.tiles_m = (int)((M + G2_BM - 1) / G2_BM); q.tiles_n = (int)((N + G2_BN - 1) / G2_BN);
-        static const int gflags = [] { const char* e = getenv("XCLIP_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
-        q.flags = gflags;
+        q.flags = 0;
         int splits = gemm2_splits(M, N, K);
         if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
         q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);
