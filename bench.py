@@ -271,7 +271,7 @@ def main():
                 traffic, traffic_src = round(tj["bytes_per_launch"]), tj.get("source")
         except Exception:
             pass
-        out["roofline"] = {"kernel": "xclip_gemm (gemm3_kernel<bf16> NT/NN/TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
+        out["roofline"] = {"kernel": "xclip_gemm (gemm5_kernel<bf16> NT/NN + gemm4_kernel<bf16> TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": traffic,
                            "traffic_note": f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command ({traffic_src})",

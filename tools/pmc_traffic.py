@@ -42,13 +42,16 @@ def main():
     for r in rows[:24]:
         print(f"{r[0]:60s} {r[1]:8d} {r[2]:18.0f} {r[3]:14.1f} {r[4]:12.1f} {r[5]:11.1f}")
     fam = sys.argv[4] if len(sys.argv) > 4 else "gemm3"
-    g = [r for r in rows if r[0].startswith(fam + "_kernel")]
+    g = [r for r in rows if r[0].startswith(fam) and "_kernel" in r[0]]          # "gemm" = gemm4_kernel + gemm5_kernel + ...
     n = sum(r[1] for r in g)
     per = sum(r[5] * r[1] for r in g) / max(n, 1)
     print(f"# {fam} family: {n} launches, {per:.1f} MB per launch (reads x2 + writes)")
     if len(sys.argv) > 3:
         with open(sys.argv[3], "w") as f:
-            json.dump({"kernel_family": fam + "_kernel", "kernel_generation": fam, "bytes_per_launch": per * 1e6, "launches": n,
+            import os
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from x_clip_amd.ops import GEMM_GENERATION
+            json.dump({"kernel_family": fam + "*_kernel", "kernel_generation": GEMM_GENERATION, "bytes_per_launch": per * 1e6, "launches": n,
                        "source": "tools/pmc_traffic.py over rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (FETCH_SIZE x2 gfx950 correction)"}, f, indent=1)
 
 
