@@ -66,6 +66,34 @@ def test_gemm_layouts(dtype, layout, M, N, K_):
     K.case_gemm(DEV, dtype, M, N, K_, layout)
 
 
+@pytest.mark.parametrize("layout,M,N,K_", [("nt", 263168, 1536, 512), ("nn", 263168, 512, 1536), ("nt", 131584, 512, 512), ("tn", 1536, 512, 263168)])
+def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_):
+    """text-tower shapes at full size, every CU streaming (the regime the counted DMA waits and the stores left in flight across the
+    tile boundary have to be right in -- the emulator lands every DMA piece at once and cannot see an early read): every output
+    element against an fp32-accumulated reference product of the same bf16 operands, and ten launches bit-identical"""
+    from x_clip_amd import ops
+    a_k, b_k = layout == "tn", layout in ("nn", "tn")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = torch.randn((K_, M) if a_k else (M, K_), generator=g).to(torch.bfloat16).to(DEV)
+    b = torch.randn((K_, N) if b_k else (N, K_), generator=g).to(torch.bfloat16).to(DEV)
+    outs = [ops.gemm(a, b, M, N, K_, a_k, b_k) for _ in range(10)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "the same launch must give the same bits"
+    A = a.t() if a_k else a
+    B = b if b_k else b.t()
+    rows = 16384                                                 # reference in row blocks (fp32 accumulate on the device, checked on the fly)
+    worst = 0.0
+    for r0 in range(0, M, rows):
+        ref = A[r0: r0 + rows].float() @ B.float()
+        got = outs[0][r0: r0 + rows].float()
+        scale = float(ref.abs().max())
+        worst = max(worst, float((got - ref.to(torch.bfloat16).float()).abs().max()) / (scale * 2.0 ** -8))
+    # element-wise 1 bf16 ulp holds per element (kernel_cases.close); here: no element off by more than 2 ulps OF THE SCALE -- a tile
+    # computed from a stale LDS stage is off by the size of the output itself
+    assert worst <= 2.0, worst
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 def test_gemm_epilogue_and_splitk(dtype):
     K.case_gemm(DEV, dtype, 1030, 520, 3072, "nt", epilogue=True, alpha=0.5)

@@ -188,8 +188,7 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 sched_fence();
             }
         }
-        u32x4 none[Epilogue::HELD > 0 ? Epilogue::HELD : 1];
-        (void)epi(acc, m0, n0, none);
+        (void)epi(acc, m0, n0);
     }
     XC_WAIT_VMEM_LE(0);                                       // the trailing (redundant) DMA pieces must land before the LDS is released
     epi.finish();
@@ -205,9 +204,15 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 //     k-block 0:  issue A(s + 2) into A stage (s + 2) % 3   (free since the barrier of step s - 1)
 //     k-block 3:  s_waitcnt vmcnt(4) -- everything but the four A pieces just issued, i.e. A(s + 1) and B(s + 1) have landed --,
 //                 barrier, fragments of step s + 1, then issue B(s + 2) into B stage s & 1 (free from that barrier on)
-// A piece is requested 1.75 K steps before the wait that needs it (was 1.0), B 1.0 (was 0.75).  The counted wait is safe because LDS-DMA
-// loads retire in issue order and the only younger operations are the four A pieces (the epilogue's stores of a finished tile are
-// older than the next step's A pieces, so they are drained by that step's wait exactly as before).
+// A piece is requested 1.75 K steps before the wait that needs it (was 1.0), B 1.0 (was 0.75).  The counted wait is safe because a
+// wave's vector-memory operations -- LDS-DMA loads and stores alike -- retire in issue order on gfx9-class hardware (one vmcnt; the
+// compiler's own counted waits after mixed loads and stores rely on it).
+// The tile boundary: the pieces the first step of the NEXT tile waits for (A(s + 1), B(s + 1)) were both requested BEFORE the
+// epilogue's stores, so that step's wait leaves the stores in flight as well -- vmcnt(4 + 16) after a bf16 interior tile, 4 + 32
+// after an fp32 slab.  A store is acknowledged when L2 has taken it, which with every CU writing 128 KiB at about the same moment
+// (32 MiB, the size of all L2s together) takes several microseconds; gemm3.h / g4_run wait for those acknowledgements at the first
+// K step of every tile (their B(s + 1) is requested after the stores), which is most of the ~6.5 us a tile boundary costs there.
+// Here the stores get one more K step before anything younger than them is needed.
 constexpr int G5_LDS_BYTES = 5 * G2_OPER_BYTES;              // 160 KiB
 
 template <bool KMAJOR>
@@ -307,16 +312,8 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA, ldsB, wm * 128, wn * 64, 0, lane, a[0], b[0]);
     lds_wait<0>(a[0], b[0]);
 
-    // Second half of the PREVIOUS tile's output (Epilogue::HELD stores of 16 bytes per lane, already packed): issued from inside this
-    // tile's K loop, `per_step` per K step (one at K = 512), so that a CU's 128 KiB per tile reach the memory system as a 64 KiB burst
-    // at the tile boundary plus a trickle instead of one burst from all 256 CUs at once.  Every wait in the loop stays what it was:
-    // vmcnt(4) leaves this step's four A pieces -- loads retire in issue order, so whatever else is still outstanding, the pieces
-    // older than those four have landed.
-    u32x4 held[Epilogue::HELD > 0 ? Epilogue::HELD : 1];
-    int next_held = Epilogue::HELD;                           // (uniform) index of the next held store to issue; HELD = none waiting
-    const int per_step = Epilogue::HELD > 0 ? (Epilogue::HELD + nt - 1) / nt : 0;
-
     int step = 0, sa3 = 0;                                    // running K-step counter (B stage = step & 1) and A stage = step % 3
+    int stores_behind = 0;                                    // (uniform) stores per lane the previous tile's epilogue issued, if fixed
     for (int id = blockIdx.x; id < ntiles; id += stride) {
         int m0, n0;
         tile_origin(id, m0, n0);
@@ -335,7 +332,11 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 if (kk < 3) {
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
                 } else {
-                    XC_WAIT_VMEM_LE(4);                          // all but this step's four A pieces: A(s + 1), B(s + 1) are in LDS
+                    // all but this step's four A pieces (and, in the first step after an interior tile, that tile's stores, which are
+                    // younger than the pieces needed here): A(s + 1), B(s + 1) are in LDS
+                    if (t == 0 && stores_behind == 16) XC_WAIT_VMEM_LE(20);
+                    else if (t == 0 && stores_behind == 32) XC_WAIT_VMEM_LE(36);
+                    else XC_WAIT_VMEM_LE(4);
                     barrier_nodrain();                           // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA + sa_next * G2_OPER_BYTES, ldsB + ((step + 1) & 1) * G2_OPER_BYTES, wm * 128, wn * 64,
                                                       0, lane, a[nxt], b[nxt]);
@@ -356,13 +357,6 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     for (int j = 0; j < 2; ++j) acc[i][j] = mma_kblock(b[cur][j], a[cur][i], acc[i][j], (bf16_t*)nullptr);   // D^T
                     if (kk == 0) { sched_fence(); piece_a(i, a_dst); sched_fence(); }
                     if (kk == 3) { sched_fence(); piece_b(i, b_dst); sched_fence(); }
-                    if (Epilogue::HELD > 0 && kk == 1 && i == 0) {
-                        for (int k = 0; k < per_step && next_held < Epilogue::HELD; ++k) {
-                            sched_fence();
-                            epi.held_store_rt(next_held++, held);
-                            sched_fence();
-                        }
-                    }
                 }
                 if (kk == 0) next_a();
                 if (kk == 3) next_b();
@@ -372,10 +366,8 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             }
             sa3 = sa_next;
         }
-        if (epi(acc, m0, n0, held)) next_held = 0;
+        stores_behind = epi(acc, m0, n0);
     }
-    if (Epilogue::HELD > 0)
-        while (next_held < Epilogue::HELD) epi.held_store_rt(next_held++, held);      // the last tile's second half
     XC_WAIT_VMEM_LE(0);                                       // trailing (redundant) pieces must land before the LDS is released
     epi.finish();
 }
@@ -388,33 +380,10 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 // sits on an HBM acknowledgement); nt stores (786 vs 801).  Cutting the epilogue's VALU work from ~550 to ~230 instructions per wave
 // (packed conversions, C = 0 first k-block, alpha applied with packed multiplies) moved nothing either: the boundary cost is not
 // instruction issue (profiles/r02_run2_gemm4_defer_prio_probe.log, r02_run3_gemm4_store_policy_probe.log).
-template <int MODE, bool HOLD = false>
+template <int MODE>
 struct G4GemmEpilogue {
-    // HELD 16-byte stores of an interior tile (its row blocks 2 and 3) are not issued by the epilogue but handed back in registers;
-    // the K loop of g5_run issues them one per K step of the NEXT tile (see there)
-    static constexpr int HELD = (MODE == G4_PLAIN && HOLD) ? 8 : 0;
     const Gemm2Params& p;
-    BufRsrc rc_held;                                          // descriptor of the tile whose second half waits in registers
     XC_DEV void finish() const {}
-
-    // store S (0..7) of the held half: row block 2 + S / 4, column block (S / 2) & 1, 16-column half S & 1
-    template <int S>
-    XC_DEV void held_store(const u32x4 (&held)[HELD > 0 ? HELD : 1]) const {
-        constexpr int I = 2 + S / 4, IMM = ((S / 2) & 1) * 64 + (S & 1) * 32;
-        buf_st16<IMM>(rc_held, lane_off_bf16(), (uint32_t)p.ldc * 64u * I, held[HELD > 0 ? S : 0]);
-    }
-    XC_DEV void held_store_rt(int idx, const u32x4 (&held)[HELD > 0 ? HELD : 1]) const {     // idx wave-uniform
-        switch (idx) {
-            case 0: held_store<0>(held); break;
-            case 1: held_store<1>(held); break;
-            case 2: held_store<2>(held); break;
-            case 3: held_store<3>(held); break;
-            case 4: held_store<4>(held); break;
-            case 5: held_store<5>(held); break;
-            case 6: held_store<6>(held); break;
-            default: held_store<7>(held); break;
-        }
-    }
 
     XC_DEV uint32_t lane_off_bf16() const {
         const int lane = threadIdx.x & 63, h = lane >> 5;
@@ -424,8 +393,8 @@ struct G4GemmEpilogue {
 
     // bf16 output, straight-line.  FULL = interior tile; otherwise rows past M fall outside the descriptor (dropped by the hardware)
     // and each store tests its 8 columns against N
-    template <bool FULL, int NOW = 4>
-    XC_DEV void store_bf16(f32x16 (&acc)[4][2], int m0, int n0, u32x4 (&held)[HELD > 0 ? HELD : 1]) {
+    template <bool FULL>
+    XC_DEV void store_bf16(f32x16 (&acc)[4][2], int m0, int n0) const {
         int rows = p.M - m0, cols = p.N - n0;
         rows = (FULL || rows > 256) ? 256 : rows;
         cols = (FULL || cols > 256) ? 256 : cols;
@@ -433,7 +402,6 @@ struct G4GemmEpilogue {
         const uint32_t vc = lane_off_bf16();
         const uint32_t si = (uint32_t)p.ldc * 64u;                                  // 32 rows * ldc * 2 bytes
         const int col0 = (uniform(threadIdx.x >> 6) & 3) * 64 + 8 * ((threadIdx.x & 63) >> 5);   // this lane's first column in the tile
-        if (NOW < 4) rc_held = rc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -451,10 +419,7 @@ struct G4GemmEpilogue {
                 permlane32_swap(pk[2][1], pk[3][1]);
                 const u32x4 o0 = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 const u32x4 o1 = {pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
-                if (i >= NOW) {
-                    held[HELD > 0 ? (i - 2) * 4 + j * 2 : 0] = o0;
-                    held[HELD > 0 ? (i - 2) * 4 + j * 2 + 1 : 0] = o1;
-                } else if (j == 0) {
+                if (j == 0) {
                     if (FULL || col0 < cols) buf_st16<0>(rc, vc, si * i, o0);
                     if (FULL || col0 + 16 < cols) buf_st16<32>(rc, vc, si * i, o1);
                 } else {
@@ -495,28 +460,30 @@ struct G4GemmEpilogue {
         }
     }
 
-    // -> true when the tile left HELD stores in `held`
-    XC_DEV bool operator()(f32x16 (&acc)[4][2], int m0, int n0, u32x4 (&held)[HELD > 0 ? HELD : 1]) {
+    // -> how many vector-memory operations per lane the epilogue issued when that number is fixed (interior tiles: 16 / 32 stores),
+    //    0 when it is not (ragged tiles, optional terms with their loads): the caller then drains everything at its next wait
+    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
         const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);       // interior tile (uniform)
         if (MODE == G4_PLAIN) {                                  // (never looks at the optional-term pointers: fewer live scalars)
-            if (full && HELD > 0) { store_bf16<true, 2>(acc, m0, n0, held); return true; }
-            if (full) store_bf16<true>(acc, m0, n0, held);
-            else store_bf16<false>(acc, m0, n0, held);
-        } else if (MODE == G4_SLAB && full) {
-            store_full_slab(acc, m0, n0);
-        } else {
-            // ragged slab tiles and the optional epilogue terms: the general form (per-element range checks, clamped reads)
-            (void)G3GemmEpilogue<0>{p}(acc, m0, n0);
+            if (full) { store_bf16<true>(acc, m0, n0); return 16; }
+            store_bf16<false>(acc, m0, n0);
+            return 0;
         }
-        return false;
+        if (MODE == G4_SLAB && full) {
+            store_full_slab(acc, m0, n0);
+            return 32;
+        }
+        // ragged slab tiles and the optional epilogue terms: the general form (per-element range checks, clamped reads)
+        (void)G3GemmEpilogue<0>{p}(acc, m0, n0);
+        return 0;
     }
 };
 
 // the three-deep A ring (g5_run); epilogues as above, no deferral
-template <bool A_KMAJOR, bool B_KMAJOR, int MODE, bool HOLD = false>
+template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm5_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
-    g5_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE, HOLD>{p});
+    g5_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE>{p});
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR, int MODE>

@@ -133,17 +133,9 @@ inline int gemm_generation() {
     static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && e[0] >= '2' && e[0] <= '5') ? e[0] - '0' : 0; }();
     return v;
 }
-// XCLIP_GEMM_HOLD=0 (measurement): the whole epilogue at the tile boundary instead of half of it trickling into the next tile
-inline bool gemm_hold() {
-    static const bool v = [] { const char* e = getenv("XCLIP_GEMM_HOLD"); return !(e != nullptr && e[0] == '0'); }();
-    return v;
-}
 template <bool AK, bool BK_, int MODE>
 void launch_gemm4(const Gemm2Params& p, dim3 pgrid, bool ring3, hipStream_t st) {
-    if (ring3 && MODE == G4_PLAIN && gemm_hold()) {
-        XC_ALLOW_LDS((gemm5_kernel<AK, BK_, G4_PLAIN, true>), G5_LDS_BYTES);
-        hipLaunchKernelGGL((gemm5_kernel<AK, BK_, G4_PLAIN, true>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
-    } else if (ring3) {
+    if (ring3) {
         XC_ALLOW_LDS((gemm5_kernel<AK, BK_, MODE>), G5_LDS_BYTES);
         hipLaunchKernelGGL((gemm5_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
     } else {
