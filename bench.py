@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side streams for the vision tower / weight gradients "
                     "(use this for rocprofv3 kernel-trace runs whose per-kernel averages should be of kernels running alone)")
     ap.add_argument("--dcl", action="store_true")
+    ap.add_argument("--text-slices", type=int, default=1, help="CLIP.text_micro_batches: slices of the text batch on separate streams")
     ap.add_argument("--filip", action="store_true", help="BASELINE configs[3] instead of the headline configs[1]: use_all_token_embeds, "
                     "image 224 / patch 16, text length 77 (own measurements; the driver's line is the default configuration)")
     ap.add_argument("--simsiam", action="store_true", help="own measurement of the README configuration `use_visual_ssl = True`: SimSiam around "
@@ -189,6 +190,8 @@ def main():
     def set_overlap(on, which="both"):
         functional.OVERLAP_WGRAD = on and which in ("both", "wgrad")
         model.overlap_towers = on and which in ("both", "towers")
+        model.text_micro_batches = args.text_slices if on else 1
+    model.text_micro_batches = args.text_slices
 
     if args.no_overlap:
         set_overlap(False)

@@ -180,6 +180,29 @@ def test_no_grad_pass_keeps_no_tape():
         XF.stack_forward = orig
 
 
+def test_text_micro_batches_same_result():
+    """CLIP.text_micro_batches = 2: the text batch goes through the tower in two slices (on the GPU: on two streams); same latents
+    bit for bit (encoders are row independent), same loss, gradients equal up to the order of the weight-gradient sums"""
+    from x_clip_amd import CLIP
+    torch.manual_seed(4)
+    a = CLIP(**O.CFG1.ctor_kwargs(), visual_patch_dropout=0.0).train()
+    b = CLIP(**O.CFG1.ctor_kwargs(), visual_patch_dropout=0.0).train()
+    b.load_state_dict(a.state_dict())
+    b.text_micro_batches, b._micro_batch_min_rows = 2, 1
+    text, image, _, _ = O.make_inputs(O.CFG1, 6, 9)
+    with torch.no_grad():
+        for x, y in zip(a(text, image.float(), return_latents=True), b(text, image.float(), return_latents=True)):
+            assert torch.equal(x, y)
+    la, lb = a(text, image.float(), return_loss=True), b(text, image.float(), return_loss=True)
+    la.backward(), lb.backward()
+    assert abs(float(la.detach()) - float(lb.detach())) < 1e-6
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None, k
+        else:
+            torch.testing.assert_close(pa.grad, pb.grad, rtol=2e-4, atol=1e-6, msg=k)
+
+
 def test_no_kernel_reads_unwritten_memory():
     """reference fixtures again (FILIP head; SimSiam + MLM side losses) with every torch.empty the product makes poisoned with NaN"""
     with C.poisoned_empty():

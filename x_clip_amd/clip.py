@@ -377,6 +377,12 @@ class CLIP(nn.Module):
         self.assume_equal_batch = False           # set True to skip the per-step batch-size exchange between ranks
 
         self.overlap_towers = True                 # issue the vision tower on a side stream next to the text tower (GPU only)
+        # >1: the text batch runs through the text tower in that many slices, each on its own HIP stream.  The tower alternates
+        # MFMA-bound GEMMs with HBM-bound row kernels; with two slices in flight one slice's LayerNorm / GEGLU kernels (no LDS, few
+        # registers: they fit on a CU beside a persistent GEMM work-group) run under the other slice's GEMMs.  Encoders are row
+        # independent, so the result is the same; weight gradients are summed over the slices by autograd.
+        self.text_micro_batches = 1
+        self._micro_batch_min_rows = 64            # smaller slices than this are not worth a stream
         self._streams = {}
 
         self.sim_reg_loss_weight = sim_reg_loss_weight
@@ -388,14 +394,37 @@ class CLIP(nn.Module):
         if self.has_sim_reg_loss and use_all_token_embeds:
             raise NotImplementedError("sim_reg_loss_weight > 0 with use_all_token_embeds: only the CLS-latent form is on the accelerated path")
 
-    def _side_stream(self, device):
+    def _side_stream(self, device, which=0):
         if device.type != "cuda":
             return None
-        st = self._streams.get(device)
+        st = self._streams.get((device, which))
         if st is None:
             st = torch.cuda.Stream(device=device)
-            self._streams[device] = st
+            self._streams[(device, which)] = st
         return st
+
+    def _encode_text(self, text_args, freeze):
+        """-> list of encodings, one per slice of the batch (a single entry unless text_micro_batches > 1 applies)"""
+        k, dev, b = int(self.text_micro_batches), text_args[0].device, text_args[0].shape[0]
+        if k <= 1 or b % k != 0 or b // k < self._micro_batch_min_rows:
+            return [model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze)]
+        bs = b // k
+        on_gpu = dev.type == "cuda"                              # (CPU = the test build: the slices simply run one after the other)
+        main = torch.cuda.current_stream(dev) if on_gpu else None
+        outs = []
+        for i in range(k):
+            args_i = tuple(a[i * bs: (i + 1) * bs] for a in text_args)
+            if i == 0 or not on_gpu:
+                outs.append(model_forward_with_context(fn=self.text_transformer, args=args_i, freeze=freeze))
+                continue
+            st = self._side_stream(dev, which=i)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(model_forward_with_context(fn=self.text_transformer, args=args_i, freeze=freeze))
+        for i in range(1, k if on_gpu else 1):
+            main.wait_stream(self._side_stream(dev, which=i))
+            outs[i].record_stream(main)
+        return outs
 
     def forward(
         self,
@@ -456,12 +485,16 @@ class CLIP(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
-            enc_text = model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze_text_encoder)
+            enc_text_parts = self._encode_text(text_args, freeze_text_encoder)
             main.wait_stream(side)
             enc_image.record_stream(main)
         else:
-            enc_text = model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze_text_encoder)
+            enc_text_parts = self._encode_text(text_args, freeze_text_encoder)
             enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
+        # (the CLS path below only needs row 0 of every sample: the slices are joined after that selection, not before)
+        cls_only = (len(enc_text_parts) > 1 and not self.text_causal_mask and not return_encodings and not self.use_all_token_embeds
+                    and enc_text_parts[0].ndim == 3)
+        enc_text = enc_text_parts[0] if (len(enc_text_parts) == 1 or cls_only) else torch.cat(enc_text_parts, dim=0)
 
         if self.text_causal_mask:                                                          # x_clip.py:670-685 (its `b` is the batch size)
             enc_text = XF.eos_to_front(enc_text, text, self.text_eos_id)
@@ -475,7 +508,10 @@ class CLIP(nn.Module):
             text_embeds = enc_text[:, 1:] if self.text_has_cls_token else enc_text
             image_embeds = enc_image[:, 1:] if self.visual_has_cls_token else enc_image
         else:                                                                              # x_clip.py:708-709
-            text_embeds = XF.select_row(enc_text, 0) if enc_text.ndim == 3 else enc_text
+            if cls_only:
+                text_embeds = torch.cat([XF.select_row(e, 0) for e in enc_text_parts], dim=0)
+            else:
+                text_embeds = XF.select_row(enc_text, 0) if enc_text.ndim == 3 else enc_text
             image_embeds = XF.select_row(enc_image, 0) if enc_image.ndim == 3 else enc_image
 
         text_latents = XF.l2norm(XF.linear(text_embeds, self.to_text_latent.weight))       # x_clip.py:713-715
