@@ -113,7 +113,6 @@ struct Gemm2Params {
     float* partial;            // split-K slabs [splits][M][N] fp32, or null
     int k_per_split;
     int tiles_m, tiles_n;
-    int flags;                 // measurement switches (gemm4.h): 1 = static s_setprio 1 for the younger half of the waves
 };
 
 template <bool A_KMAJOR, bool B_KMAJOR>

@@ -650,7 +650,6 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
         q.bias = (const bf16_t*)bias; q.residual = (const bf16_t*)residual; q.ldr = ldr;
         q.addrows = (const bf16_t*)addrows; q.rowidx = rowidx; q.ld_add = ld_add;
         q.tiles_m = (int)((M + G2_BM - 1) / G2_BM); q.tiles_n = (int)((N + G2_BN - 1) / G2_BN);
-        q.flags = 0;
         int splits = gemm2_splits(M, N, K);
         if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
         q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);
