@@ -351,6 +351,13 @@ inline void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_b
     unsigned char* dst = (unsigned char*)lds_wave_base + 16 * lane_id();
     if (off + 16 <= r.bytes) memcpy(dst, r.base + off, 16); else memset(dst, 0, 16);
 }
+template <int IMM>
+inline u32x4 buf_ld16(BufRsrc r, uint32_t voff, uint32_t soff) {
+    const uint64_t off = (uint64_t)voff + soff + IMM;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (off + 16 <= r.bytes) memcpy(&v, r.base + off, 16);
+    return v;
+}
 template <int IMM, int AUX = 0>
 inline void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
     const uint64_t off = (uint64_t)voff + soff + IMM;

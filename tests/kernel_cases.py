@@ -221,28 +221,34 @@ def case_token_mean(dev, dtype, batch, n, dim):
     close(acc, ref64(full)[:, 1:] + (ref64(d) / n)[:, None], dtype, "mean bwd + source")
 
 
-def case_gemm(dev, dtype, M, N, K, layout, epilogue=False, alpha=1.0):
-    """layout: 'nt' forward, 'nn' dgrad, 'tn' wgrad"""
+def case_gemm(dev, dtype, M, N, K, layout, epilogue=False, alpha=1.0, residual_only=False, in_place=False):
+    """layout: 'nt' forward, 'nn' dgrad, 'tn' wgrad; residual_only: C = alpha A B + R (the skip connection of the FF2 forward; in_place:
+    R is the output buffer itself, as the accumulating GEMMs of the loss heads call it)"""
     a_k = layout == "tn"
     b_k = layout in ("nn", "tn")
     # asymmetric operands: a transposed / mirrored output cannot pass
     a = rnd((K, M) if a_k else (M, K), dtype, 17)
     b = rnd((K, N) if b_k else (N, K), dtype, 18)
     bias = res = addrows = rowidx = None
+    if residual_only:
+        res = rnd((M, N), dtype, 20)
     if epilogue:
         bias = rnd((N,), dtype, 19)
         res = rnd((M, N), dtype, 20)
         addrows = rnd((5, N), dtype, 21)
         rowidx = (torch.arange(M) * 3 % 5).to(torch.int32)
+    res_dev = None if res is None else res.to(dev).clone()            # (clone: on the CPU build .to() aliases, and in_place overwrites it)
     c = ops.gemm(a.to(dev), b.to(dev), M, N, K, a_k, b_k, alpha, None if bias is None else bias.to(dev),
-                 None if res is None else res.to(dev), None if addrows is None else addrows.to(dev),
-                 None if rowidx is None else rowidx.to(dev))
+                 res_dev, None if addrows is None else addrows.to(dev),
+                 None if rowidx is None else rowidx.to(dev), out=res_dev if in_place else None)
     A = ref64(a).t() if a_k else ref64(a)
     B = ref64(b) if b_k else ref64(b).t()
     r = alpha * (A @ B)
     scale = float(r.abs().max())
     if epilogue:
         r = r + ref64(bias) + ref64(res) + ref64(addrows)[rowidx.long()]
+    if residual_only:
+        r = r + ref64(res)
     close(c, r, dtype, f"gemm {layout} {M}x{N}x{K}", scale=max(scale, float(r.abs().max())))
 
 

@@ -142,6 +142,12 @@ def test_gemm4_interior_tiles_in_a_row(layout, M, N, K_, alpha):
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha)
 
 
+@pytest.mark.parametrize("layout,M,N,K_,alpha,in_place", [("nt", 776, 512, 128, 1.0, False), ("nn", 512, 264, 64, 0.5, True), ("nt", 264, 136, 64, 1.0, False)])
+def test_gemm4_residual_epilogue(layout, M, N, K_, alpha, in_place):
+    """C = alpha A B + R through the straight-line residual epilogue (interior tiles) and the general one (ragged tiles); in place too"""
+    K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha, residual_only=True, in_place=in_place)
+
+
 def test_gemm2_epilogue_and_splitk():
     K.case_gemm(DEV, torch.bfloat16, 136, 264, 64, "nt", epilogue=True, alpha=0.5)
     K.case_gemm(DEV, torch.bfloat16, 776, 264, 64, "nt", epilogue=True, alpha=0.5)      # persistent + epilogue terms

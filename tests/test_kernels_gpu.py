@@ -94,6 +94,11 @@ def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_):
     assert worst <= 2.0, worst
 
 
+@pytest.mark.parametrize("layout,M,N,K_,alpha,in_place", [("nt", 4104, 512, 2048, 1.0, False), ("nn", 1024, 520, 256, 0.5, True), ("nt", 65792, 512, 2048, 1.0, False)])
+def test_gemm_residual_epilogue(layout, M, N, K_, alpha, in_place):
+    K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha, residual_only=True, in_place=in_place)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 def test_gemm_epilogue_and_splitk(dtype):
     K.case_gemm(DEV, dtype, 1030, 520, 3072, "nt", epilogue=True, alpha=0.5)

@@ -22,11 +22,12 @@ def timeit(fn, iters=20, warm=10):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def gemm_case(name, M, N, K, a_k, b_k):
+def gemm_case(name, M, N, K, a_k, b_k, residual=False):
     a = torch.randn((K, M) if a_k else (M, K), device=dev, dtype=bf)
     b = torch.randn((K, N) if b_k else (N, K), device=dev, dtype=bf)
     out = torch.empty(M, N, device=dev, dtype=bf)
-    t = timeit(lambda: ops.gemm(a, b, M, N, K, a_k, b_k, out=out))
+    res = torch.randn(M, N, device=dev, dtype=bf) if residual else None
+    t = timeit(lambda: ops.gemm(a, b, M, N, K, a_k, b_k, residual=res, out=out))
     ref = ""
     if os.environ.get("XCLIP_PROBE_NO_REF") != "1":
         tr = timeit(lambda: torch.matmul(a.t() if a_k else a, b if b_k else b.t()))
@@ -38,6 +39,7 @@ Mt = 1024 * 257
 gemm_case("qkv fwd (NT)", Mt, 1536, 512, False, False)
 gemm_case("ff1 fwd (NT)", Mt, 4096, 512, False, False)
 gemm_case("ff2 fwd (NT)", Mt, 512, 2048, False, False)
+gemm_case("ff2 fwd + skip (NT)", Mt, 512, 2048, False, False, residual=True)
 gemm_case("out fwd (NT)", Mt, 512, 512, False, False)
 gemm_case("ff1 dgrad (NN)", Mt, 512, 4096, False, True)
 gemm_case("ff2 dgrad (NN)", Mt, 2048, 512, False, True)

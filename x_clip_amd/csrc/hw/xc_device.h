@@ -136,6 +136,11 @@ XC_DEV void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_b
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
 // 16-byte store at base + voff + soff + IMM (IMM: the instruction's 12-bit immediate offset)
+// 16-byte load from base + voff + soff + IMM (zero past the descriptor's extent); counted by the compiler's own vmcnt bookkeeping
+template <int IMM>
+XC_DEV u32x4 buf_ld16(BufRsrc r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff + IMM, (int)soff, 0));
+}
 // AUX: cache policy bits of the store (0 = default write-back; 1 = sc0, 2 = nt, 16 = sc1: write-through that does not keep the line
 // in the XCD's L2 -- MI355X_MICROARCH.md "stores of each flavour")
 template <int IMM, int AUX = 0>

@@ -162,7 +162,9 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     if (gen != 3 && small_ld) {
         const bool ring3 = gen == 5 || (gen == 0 && !AK);
         const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
+        const bool res_only = p.residual != nullptr && p.bias == nullptr && p.addrows == nullptr && p.ldr < (1L << 22);
         if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(p, pgrid, ring3, st);
+        else if (res_only) launch_gemm4<AK, BK_, G4_RES>(p, pgrid, ring3, st);
         else if (terms) launch_gemm4<AK, BK_, G4_TERMS>(p, pgrid, ring3, st);
         else launch_gemm4<AK, BK_, G4_PLAIN>(p, pgrid, ring3, st);
         return;
