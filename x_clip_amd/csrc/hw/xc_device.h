@@ -141,11 +141,16 @@ template <int IMM>
 XC_DEV u32x4 buf_ld16(BufRsrc r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff + IMM, (int)soff, 0));
 }
-// AUX: cache policy bits of the store (0 = default write-back; 1 = sc0, 2 = nt, 16 = sc1: write-through that does not keep the line
-// in the XCD's L2 -- MI355X_MICROARCH.md "stores of each flavour")
+// 16-byte store at base + voff + soff + IMM (IMM: the instruction's 12-bit immediate offset); AUX: cache policy bits (0 = default).
+// The two wait states behind it are load-bearing: a 128-bit buffer store reads its four data VGPRs a little after it issues, and a
+// VALU write to the first of them in the very next instruction reached memory instead of the store's value -- rarely, in 4-lane
+// groups, only with a REGISTER soffset (for which hipcc / ROCm 7.2 inserts no wait state: its hazard table covers the immediate-soffset
+// form only), first seen as garbage in one dword of a few rows of the residual epilogue (tools/debug/res_epilogue_check.py).
 template <int IMM, int AUX = 0>
 XC_DEV void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff + IMM, (int)soff, AUX);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 // wait until every outstanding vector-memory operation of this wave (LDS DMA included) has completed
 XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -208,12 +208,10 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 // A piece is requested 1.75 K steps before the wait that needs it (was 1.0), B 1.0 (was 0.75).  The counted wait is safe because a
 // wave's vector-memory operations -- LDS-DMA loads and stores alike -- retire in issue order on gfx9-class hardware (one vmcnt; the
 // compiler's own counted waits after mixed loads and stores rely on it).
-// The tile boundary: the pieces the first step of the NEXT tile waits for (A(s + 1), B(s + 1)) were both requested BEFORE the
-// epilogue's stores, so that step's wait leaves the stores in flight as well -- vmcnt(4 + 16) after a bf16 interior tile, 4 + 32
-// after an fp32 slab.  A store is acknowledged when L2 has taken it, which with every CU writing 128 KiB at about the same moment
-// (32 MiB, the size of all L2s together) takes several microseconds; gemm3.h / g4_run wait for those acknowledgements at the first
-// K step of every tile (their B(s + 1) is requested after the stores), which is most of the ~6.5 us a tile boundary costs there.
-// Here the stores get one more K step before anything younger than them is needed.
+// (Measured and not kept: letting the first wait of a tile leave the previous tile's 16 / 32 stores in flight as well -- vmcnt(4 + 16)
+// -- did not change the K = 512 shapes (814 vs 810 TFLOP/s, profiles/r02_run8_gemm5_counted_boundary_wait_probe.log), and a counted
+// wait across STORES is only safe if stores and LDS-DMA loads retire in order with respect to each other, which the residual
+// epilogue below showed they need not.  Every counted wait here therefore only ever leaves LDS-DMA LOADS outstanding.)
 constexpr int G5_LDS_BYTES = 5 * G2_OPER_BYTES;              // 160 KiB
 
 template <bool KMAJOR>
@@ -314,7 +312,6 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     lds_wait<0>(a[0], b[0]);
 
     int step = 0, sa3 = 0;                                    // running K-step counter (B stage = step & 1) and A stage = step % 3
-    int stores_behind = 0;                                    // (uniform) stores per lane the previous tile's epilogue issued, if fixed
     for (int id = blockIdx.x; id < ntiles; id += stride) {
         int m0, n0;
         tile_origin(id, m0, n0);
@@ -333,11 +330,8 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 if (kk < 3) {
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
                 } else {
-                    // all but this step's four A pieces (and, in the first step after an interior tile, that tile's stores, which are
-                    // younger than the pieces needed here): A(s + 1), B(s + 1) are in LDS
-                    if (t == 0 && stores_behind == 16) XC_WAIT_VMEM_LE(20);
-                    else if (t == 0 && stores_behind == 32) XC_WAIT_VMEM_LE(36);
-                    else XC_WAIT_VMEM_LE(4);
+                    // all but this step's four A pieces: A(s + 1), B(s + 1) are in LDS (and a finished tile's stores have been taken)
+                    XC_WAIT_VMEM_LE(4);
                     barrier_nodrain();                           // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA + sa_next * G2_OPER_BYTES, ldsB + ((step + 1) & 1) * G2_OPER_BYTES, wm * 128, wn * 64,
                                                       0, lane, a[nxt], b[nxt]);
@@ -367,7 +361,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             }
             sa3 = sa_next;
         }
-        stores_behind = epi(acc, m0, n0);
+        (void)epi(acc, m0, n0);
     }
     XC_WAIT_VMEM_LE(0);                                       // trailing (redundant) pieces must land before the LDS is released
     epi.finish();
