@@ -358,7 +358,7 @@ inline u32x4 buf_ld16(BufRsrc r, uint32_t voff, uint32_t soff) {
     if (off + 16 <= r.bytes) memcpy(&v, r.base + off, 16);
     return v;
 }
-template <int IMM, int AUX = 0>
+template <int IMM>
 inline void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
     const uint64_t off = (uint64_t)voff + soff + IMM;
     if (off + 16 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + off, &v, 16);

@@ -141,16 +141,15 @@ template <int IMM>
 XC_DEV u32x4 buf_ld16(BufRsrc r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff + IMM, (int)soff, 0));
 }
-// 16-byte store at base + voff + soff + IMM (IMM: the instruction's 12-bit immediate offset); AUX: cache policy bits (0 = default).
-// The two wait states behind it are load-bearing: a 128-bit buffer store reads its four data VGPRs a little after it issues, and a
+// 16-byte store at base + voff + soff + IMM (IMM: the instruction's 12-bit immediate offset), as one asm unit WITH two wait states
+// behind it (so the store is not part of the compiler's vmcnt bookkeeping: every wait around it is explicit or only ever too long).
+// The wait states are load-bearing: a 128-bit buffer store reads its four data VGPRs a little after it issues, and a
 // VALU write to the first of them in the very next instruction reached memory instead of the store's value -- rarely, in 4-lane
 // groups, only with a REGISTER soffset (for which hipcc / ROCm 7.2 inserts no wait state: its hazard table covers the immediate-soffset
 // form only), first seen as garbage in one dword of a few rows of the residual epilogue (tools/debug/res_epilogue_check.py).
-template <int IMM, int AUX = 0>
+template <int IMM>
 XC_DEV void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff + IMM, (int)soff, AUX);
-    asm volatile("s_nop 1" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
 }
 // wait until every outstanding vector-memory operation of this wave (LDS DMA included) has completed
 XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

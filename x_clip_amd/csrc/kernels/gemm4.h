@@ -380,7 +380,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 // SLOWER (772 vs 810: profiles/r02_run7_gemm5_paced_stores_probe.log).  What the counters say instead: the forward GEMMs fetch 2-4 x
 // their algorithmic A bytes from the fabric (profiles/r02_run6_hbm_traffic_pmc.txt) -- the output stream of a tile round is as large
 // as all L2s together and evicts the A panels the sibling N tiles share.
-template <int MODE, int AUX = 0>
+template <int MODE>
 struct G4GemmEpilogue {
     const Gemm2Params& p;
     XC_DEV void finish() const {}
@@ -420,11 +420,11 @@ struct G4GemmEpilogue {
                 const u32x4 o0 = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 const u32x4 o1 = {pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
                 if (j == 0) {
-                    if (FULL || col0 < cols) buf_st16<0, AUX>(rc, vc, si * i, o0);
-                    if (FULL || col0 + 16 < cols) buf_st16<32, AUX>(rc, vc, si * i, o1);
+                    if (FULL || col0 < cols) buf_st16<0>(rc, vc, si * i, o0);
+                    if (FULL || col0 + 16 < cols) buf_st16<32>(rc, vc, si * i, o1);
                 } else {
-                    if (FULL || col0 + 32 < cols) buf_st16<64, AUX>(rc, vc, si * i, o0);
-                    if (FULL || col0 + 48 < cols) buf_st16<96, AUX>(rc, vc, si * i, o1);
+                    if (FULL || col0 + 32 < cols) buf_st16<64>(rc, vc, si * i, o0);
+                    if (FULL || col0 + 48 < cols) buf_st16<96>(rc, vc, si * i, o1);
                 }
             }
         }
@@ -538,10 +538,10 @@ struct G4GemmEpilogue {
 };
 
 // the three-deep A ring (g5_run); epilogues as above, no deferral
-template <bool A_KMAJOR, bool B_KMAJOR, int MODE, int AUX = 0>
+template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm5_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
-    g5_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE, AUX>{p});
+    g5_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE>{p});
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
