@@ -106,8 +106,8 @@ def test_mid_causal_vs_oracle(dtype):
 def test_mid_mlm_vs_oracle(dtype):
     """masked-language-model side loss through the shared text tower (mlm.py:96-109; x_clip.py:620-622, 857-860)"""
     import dataclasses
-    # (bf16: the scalar temperature gradient -- a difference of O(1) sums over 16 x 16 bf16-rounded logits -- sits at 20 % of its fp64 value)
-    C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, use_mlm=True, text_ssl_loss_weight=0.3), 16, bf16_rel=0.3)
+    # (with the oracle on the bf16 LayerNorm epsilon the temperature gradient -- a difference of O(1) sums over 16 x 16 logits -- is 3 % off)
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, use_mlm=True, text_ssl_loss_weight=0.3), 16)      # measured (bf16): rel 0.022
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
@@ -116,10 +116,8 @@ def test_mid_simsiam_vs_oracle(dtype):
     negative-cosine loss, running statistics"""
     import dataclasses
     cfg = dataclasses.replace(MID, use_visual_ssl=True, image_ssl_loss_weight=0.3, ssl_projection_size=256, ssl_projection_hidden_size=1024)
-    # (bf16: the last predictor bias gradient is a sum over rows of vectors tangent to the unit sphere -- heavy cancellation, like the
-    #  temperature gradient of the contrastive head; the emulator run of this case gives cosine 0.964 / relative error 0.31 for it and
-    #  >= 0.984 / <= 0.18 for every other tensor)
-    C.case_vs_oracle(DEV, dtype, cfg, 16, bf16_rel=0.4, bf16_cos=0.94)
+    # (bf16: the worst tensor is the last predictor bias, a sum over rows of vectors tangent to the unit sphere -- heavy cancellation)
+    C.case_vs_oracle(DEV, dtype, cfg, 16)                                     # measured (bf16): rel 0.088, cosine 0.9961 (the last predictor bias)
 
 
 def test_simclr_bf16_patch_dropout_runs():
