@@ -209,9 +209,8 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 // wave's vector-memory operations -- LDS-DMA loads and stores alike -- retire in issue order on gfx9-class hardware (one vmcnt; the
 // compiler's own counted waits after mixed loads and stores rely on it).
 // (Measured and not kept: letting the first wait of a tile leave the previous tile's 16 / 32 stores in flight as well -- vmcnt(4 + 16)
-// -- did not change the K = 512 shapes (814 vs 810 TFLOP/s, profiles/r02_run8_gemm5_counted_boundary_wait_probe.log), and a counted
-// wait across STORES is only safe if stores and LDS-DMA loads retire in order with respect to each other, which the residual
-// epilogue below showed they need not.  Every counted wait here therefore only ever leaves LDS-DMA LOADS outstanding.)
+// -- did not change the K = 512 shapes (814 vs 810 TFLOP/s, profiles/r02_run8_gemm5_counted_boundary_wait_probe.log).  Every counted
+// wait here only ever leaves LDS-DMA LOADS outstanding.)
 constexpr int G5_LDS_BYTES = 5 * G2_OPER_BYTES;              // 160 KiB
 
 template <bool KMAJOR>
