@@ -378,6 +378,11 @@ inline s16x4 lds_read_tr16(const void* p) {
 }
 inline int uniform(int v) { return v; }
 inline void wave_sync() { int z = 0; (void)xcemu::wave_exchange(&z, sizeof(z)); }      // lanes are fibres: rendezvous
+inline void lds_fence() { wave_sync(); }
+inline uint64_t realtime_10ns() { static uint64_t t = 0; return t += 1000; }
+inline uint64_t shader_cycles() { return 0; }
+inline void nap() {}
+template <class T> inline void reg_keep(T&) {}
 
 template <int OFF>
 inline u32x4 lds_read16_async(const void* p) { return *reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(p) + OFF); }

@@ -1,3 +1,5 @@
+"""per-K-step cost of the NT GEMM with parts of the kernel switched off: XCLIP_GEMM5_ABL=<mask> python tools/probe_gemm_abl.py
+(masks: gemm4.h g5_run)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,4 +17,8 @@ for (M, N, K) in [(263168, 1536, 512), (263168, 512, 2048)]:
     a = torch.randn(M, K, device=dev, dtype=torch.bfloat16); b = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     t = timeit(lambda: ops.gemm(a, b, M, N, K, out=out))
-    print(f"ABL={os.environ.get('XCLIP_GEMM_ABL','0'):>2s}  M={M} N={N} K={K}: {t*1e3:8.1f} us  ({t*1e3*256/((M//256)*(N//256)*(K//64)):6.3f} us per K step per CU)", flush=True)
+    if int(os.environ.get('XCLIP_GEMM5_ABL', '0')) & 512:
+        torch.cuda.synchronize()
+        c = out.view(-1)[:8].view(torch.int64).tolist()
+        print(f"    work-group 0: {c[0]} shader cycles in {c[1] * 10} ns -> {c[0] / (c[1] * 10):.3f} GHz")
+    print(f"ABL={os.environ.get('XCLIP_GEMM5_ABL','0'):>2s}  M={M} N={N} K={K}: {t*1e3:8.1f} us  ({t*1e3*256/((M//256)*(N//256)*(K//64)):6.3f} us per K step per CU)", flush=True)

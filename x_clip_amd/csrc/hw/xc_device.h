@@ -187,6 +187,15 @@ XC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // orders this wave's LDS traffic around a wave-private hand-off (lanes exchange data through LDS without a work-group
 // barrier): the hardware executes a wave's LDS instructions in order; this only stops the compiler from reordering.
 XC_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// between a wave's LDS stores and its loads of what OTHER lanes stored (the LDS serves a wave's operations in order: nothing to wait
+// for, the compiler must only keep the order)
+// measurement builds: keep a register value alive / opaque to the optimiser
+template <class T> XC_DEV void reg_keep(T& v) { asm volatile("" : "+v"(v)); }
+// constant-rate (100 MHz) timestamp
+XC_DEV uint64_t realtime_10ns() { return __builtin_amdgcn_s_memrealtime(); }
+XC_DEV uint64_t shader_cycles() { return __builtin_amdgcn_s_memtime(); }
+XC_DEV void nap() { __builtin_amdgcn_s_sleep(8); }
+XC_DEV void lds_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 
 // counted wait: returns when at most N of this wave's vector-memory operations (LDS DMA included) are still outstanding
 #define XC_WAIT_VMEM_LE(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")

@@ -219,7 +219,10 @@ struct G5Iter {                                               // one operand's D
     G4Operand<KMAJOR> op;
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, class Epilogue>
+// ABL (measurement only, XCLIP_GEMM_ABL; results are garbage): 1 no MFMA, 2 no DMA after the prologue, 4 no epilogue, 8 no fragment
+// reads, 16 no barrier, 32 no counted DMA wait, 64 coalesced stores of misplaced values, 128 the row-per-lane epilogue, 256 every other CU half a tile late,
+// 512 C[0..15] <- shader cycles and 10 ns ticks of work-group 0 (the effective clock).
+template <bool A_KMAJOR, bool B_KMAJOR, class Epilogue, int ABL = 0>
 XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -231,6 +234,11 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int nt = (kend - kbeg) / G2_BK;
     const int stride = gridDim.x;
     if ((int)blockIdx.x >= ntiles || nt <= 0) return;            // (uniform over the work-group)
+    const uint64_t clk0 = (ABL & 512) ? shader_cycles() : 0, rt0 = (ABL & 512) ? realtime_10ns() : 0;
+    if ((ABL & 256) && ((blockIdx.x >> 3) & 1)) {                // measurement: every other CU of an XCD starts half a tile late
+        const uint64_t until = realtime_10ns() + (uint64_t)(nt * 90 + 250);
+        while (realtime_10ns() < until) nap();
+    }
 
     auto tile_origin = [&](int id, int& m0, int& n0) {
         const int tile = xcd_remap(id, ntiles);
@@ -287,20 +295,22 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
         }
         rb = ob.rsrc();
     };
-    auto piece_a = [&](int q, unsigned char* stage) { buf_glds16(ra, va[q & 1], (q >> 1) ? sa : 0u, stage + mine + q * 1024); };
-    auto piece_b = [&](int q, unsigned char* stage) { buf_glds16(rb, vb[q & 1], (q >> 1) ? sb : 0u, stage + mine + q * 1024); };
+    auto piece_a0 = [&](int q, unsigned char* stage) { buf_glds16(ra, va[q & 1], (q >> 1) ? sa : 0u, stage + mine + q * 1024); };
+    auto piece_b0 = [&](int q, unsigned char* stage) { buf_glds16(rb, vb[q & 1], (q >> 1) ? sb : 0u, stage + mine + q * 1024); };
+    auto piece_a = [&](int q, unsigned char* stage) { if (!(ABL & 2)) piece_a0(q, stage); };
+    auto piece_b = [&](int q, unsigned char* stage) { if (!(ABL & 2)) piece_b0(q, stage); };
 
     // prologue: A(0), B(0), A(1), B(1) in this order; the first two must have landed before step 0
 #pragma unroll
-    for (int q = 0; q < 4; ++q) piece_a(q, ldsA);
+    for (int q = 0; q < 4; ++q) piece_a0(q, ldsA);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) piece_b(q, ldsB);
+    for (int q = 0; q < 4; ++q) piece_b0(q, ldsB);
     next_a();
     next_b();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) piece_a(q, ldsA + G2_OPER_BYTES);
+    for (int q = 0; q < 4; ++q) piece_a0(q, ldsA + G2_OPER_BYTES);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) piece_b(q, ldsB + G2_OPER_BYTES);
+    for (int q = 0; q < 4; ++q) piece_b0(q, ldsB + G2_OPER_BYTES);
     next_a();
     next_b();
     XC_WAIT_VMEM_LE(8);
@@ -327,15 +337,32 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             for (int kk = 0; kk < 4; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1;
                 if (kk < 3) {
-                    g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
+                    if (!(ABL & 8)) g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
                 } else {
                     // all but this step's four A pieces: A(s + 1), B(s + 1) are in LDS (and a finished tile's stores have been taken)
-                    XC_WAIT_VMEM_LE(4);
-                    barrier_nodrain();                           // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more
+                    if (!(ABL & 32)) XC_WAIT_VMEM_LE(4);
+                    if (!(ABL & 16)) barrier_nodrain();          // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more
+                    if (!(ABL & 8))
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA + sa_next * G2_OPER_BYTES, ldsB + ((step + 1) & 1) * G2_OPER_BYTES, wm * 128, wn * 64,
                                                       0, lane, a[nxt], b[nxt]);
                 }
                 sched_fence();
+                if (ABL & 1) {
+                    if (kk == 0 && t == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_bit_cast(float, a[cur][i][e & 3] ^ b[cur][j][e & 3]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        reg_keep(a[cur][i]);
+                        if (kk == 0) { sched_fence(); piece_a(i, a_dst); sched_fence(); }
+                        if (kk == 3) { sched_fence(); piece_b(i, b_dst); sched_fence(); }
+                    }
+                } else
                 if (kk == 0 && t == 0) {                         // first k-block of the tile: C = 0
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -360,10 +387,24 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             }
             sa3 = sa_next;
         }
-        (void)epi(acc, m0, n0);
+        if (ABL & 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) reg_keep(acc[i][j]);
+        } else if (ABL & 128) {
+            (void)epi(acc, m0, n0);                           // (the row-per-lane stores)
+        } else
+        (void)epi(acc, m0, n0, ldsA + (sa3 == 0 ? 2 : sa3 - 1) * G2_OPER_BYTES + mine);   // the A stage the last step read: free until
+                                                                                          // this wave's own pieces of the next k-block 0
     }
     XC_WAIT_VMEM_LE(0);                                       // trailing (redundant) pieces must land before the LDS is released
     epi.finish();
+    if ((ABL & 512) && blockIdx.x == 0 && threadIdx.x == 0) {   // measurement: shader cycles and 10 ns ticks this work-group lived
+        uint64_t* out = reinterpret_cast<uint64_t*>(p.C);
+        out[0] = shader_cycles() - clk0;
+        out[1] = realtime_10ns() - rt0;
+    }
 }
 
 // ---- epilogue: registers -> global, one output row per lane ----------------------------------------------------------------
@@ -426,6 +467,42 @@ struct G4GemmEpilogue {
                     if (FULL || col0 + 48 < cols) buf_st16<96>(rc, vc, si * i, o1);
                 }
             }
+        }
+    }
+    // interior tile, bf16 output, every store a set of whole 128-byte lines.  A store instruction of the row-per-lane form above
+    // touches 32 different rows (32 bytes in each) and costs the CU's one address path ~80 cycles; 128 of them per tile were the
+    // tile boundary's 5.8 us.  The same 16 stores per lane with 8 lanes side by side on a row (8 rows x 128 bytes per instruction)
+    // take 4.1 us (profiles/r02_run16_gemm5_ablation.log, mask 64).  The exchange between the two lane arrangements goes through
+    // 4 KiB of LDS per wave, 32 rows at a time: `scratch` is this wave's own slice of the A stage the K loop has just finished with
+    // -- the only waves that write there are this one's own DMA pieces, the next of which is issued after this function returns --
+    // so no work-group barrier is involved.  16-byte chunk c of row r sits at chunk position c ^ (r & 7): the 8-byte writes of the
+    // 32 rows of a half-wave then spread over all banks, and so do the 16-byte reads of 8 lanes per row.
+    XC_DEV void store_full_bf16_lds(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
+        const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+        const uint32_t s8 = (uint32_t)p.ldc * 16u;                                  // 8 rows * ldc * 2 bytes
+        unsigned char* const wr = scratch + r * 128 + 8 * h;                        // + chunk position * 16
+        const unsigned char* const rd = scratch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + 1024 per 8 rows
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                                       // columns 32 j + 8 q + 4 h + (0..3) of row r
+                    const u32x2 v = {f2bf_pk(acc[i][j][4 * q] * p.alpha, acc[i][j][4 * q + 1] * p.alpha),
+                                     f2bf_pk(acc[i][j][4 * q + 2] * p.alpha, acc[i][j][4 * q + 3] * p.alpha)};
+                    *reinterpret_cast<u32x2*>(wr + (((4 * j + q) ^ (r & 7)) << 4)) = v;
+                }
+            }
+            lds_fence();
+            u32x4 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = *reinterpret_cast<const u32x4*>(rd + k * 1024);
+            lds_fence();                                                            // (the next 32 rows overwrite the slice)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
         }
     }
     // interior tile, bf16 output with a residual term.  The general epilogue reads the residual 8 bytes at a time right where it is
@@ -515,6 +592,14 @@ struct G4GemmEpilogue {
 
     // -> how many vector-memory operations per lane the epilogue issued when that number is fixed (interior tiles: 16 / 32 stores),
     //    0 when it is not (ragged tiles, optional terms with their loads): the caller then drains everything at its next wait
+    // with `scratch` = 4 KiB of LDS nobody else touches until the caller's next DMA piece
+    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
+        if (MODE == G4_PLAIN && (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N)) {
+            store_full_bf16_lds(acc, m0, n0, scratch);
+            return 16;
+        }
+        return (*this)(acc, m0, n0);
+    }
     XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
         const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);       // interior tile (uniform)
         if (MODE == G4_PLAIN) {                                  // (never looks at the optional-term pointers: fewer live scalars)
@@ -537,10 +622,47 @@ struct G4GemmEpilogue {
 };
 
 // the three-deep A ring (g5_run); epilogues as above, no deferral
-template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
+// measurement only (XCLIP_GEMM5_ABL & 64): the plain epilogue's conversions and its 16 stores per lane, but every store covers
+// 8 rows x 128 contiguous bytes instead of 32 rows x 32 bytes (the VALUES land in the wrong places)
+struct G4ProbeEpilogue {
+    const Gemm2Params& p;
+    XC_DEV void finish() const {}
+    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
+        const int lane = threadIdx.x & 63;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+        const uint32_t s8 = (uint32_t)p.ldc * 16u;                                  // 8 rows * ldc * 2 bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t pk[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pk[q][0] = f2bf_pk(acc[i][j][4 * q] * p.alpha, acc[i][j][4 * q + 1] * p.alpha);
+                    pk[q][1] = f2bf_pk(acc[i][j][4 * q + 2] * p.alpha, acc[i][j][4 * q + 3] * p.alpha);
+                }
+                permlane32_swap(pk[0][0], pk[1][0]);
+                permlane32_swap(pk[0][1], pk[1][1]);
+                permlane32_swap(pk[2][0], pk[3][0]);
+                permlane32_swap(pk[2][1], pk[3][1]);
+                const u32x4 o0 = {pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                const u32x4 o1 = {pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
+                buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + 2 * j), o0);
+                buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + 2 * j + 1), o1);
+            }
+        }
+        return 16;
+    }
+    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return (*this)(acc, m0, n0); }
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR, int MODE, int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm5_kernel(Gemm2Params p) {
     XC_LDS_DYNAMIC(lds);
-    g5_run<A_KMAJOR, B_KMAJOR>(p, lds, G4GemmEpilogue<MODE>{p});
+    if constexpr ((ABL & 64) != 0) g5_run<A_KMAJOR, B_KMAJOR, G4ProbeEpilogue, ABL>(p, lds, G4ProbeEpilogue{p});
+    else g5_run<A_KMAJOR, B_KMAJOR, G4GemmEpilogue<MODE>, ABL>(p, lds, G4GemmEpilogue<MODE>{p});
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR, int MODE>
