@@ -4,6 +4,7 @@
     from x_clip.distributed import all_gather           # x_clip_amd.distributed
     from x_clip.visual_ssl import SimSiam, SimCLR       # x_clip_amd.visual_ssl
     from x_clip.mlm import MLM                          # x_clip_amd.mlm
+    from x_clip.tokenizer import tokenizer              # x_clip_amd.tokenizer (needs a BPE merges file: see that module)
 
 Nothing is implemented here: every name is the object of the same name in `x_clip_amd`, whose constructor keywords, forward
 signature, state_dict keys and assertion messages mirror the reference.  Put the repository root in front
@@ -12,7 +13,7 @@ of a site-packages install of the reference on `sys.path` (or do not install the
 import sys as _sys
 
 import x_clip_amd as _impl
-from x_clip_amd import distributed as _distributed, mlm as _mlm, visual_ssl as _visual_ssl
+from x_clip_amd import distributed as _distributed, mlm as _mlm, tokenizer as _tokenizer, visual_ssl as _visual_ssl
 
 for _name in getattr(_impl, "__all__", [n for n in dir(_impl) if not n.startswith("_")]):
     globals()[_name] = getattr(_impl, _name)
@@ -20,4 +21,5 @@ for _name in getattr(_impl, "__all__", [n for n in dir(_impl) if not n.startswit
 _sys.modules[__name__ + ".distributed"] = _distributed
 _sys.modules[__name__ + ".mlm"] = _mlm
 _sys.modules[__name__ + ".visual_ssl"] = _visual_ssl
-distributed, mlm, visual_ssl = _distributed, _mlm, _visual_ssl
+_sys.modules[__name__ + ".tokenizer"] = _tokenizer
+distributed, mlm, visual_ssl, tokenizer = _distributed, _mlm, _visual_ssl, _tokenizer
