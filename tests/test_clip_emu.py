@@ -38,6 +38,43 @@ def test_clip_bf16_vs_oracle():
     C.case_vs_oracle(DEV, torch.bfloat16, O.CFG1, 4)
 
 
+def test_narrow_heads_vs_oracle():
+    """dim_head below the kernels' 64 (x_clip.py:201-211 accepts any): heads run zero-padded, the scale stays dim_head^-0.5, and the
+    gradients of the real to_qkv / to_out weights come back through the padding; rotary with 32-wide heads rotates the whole head"""
+    import dataclasses
+    C.case_vs_oracle(DEV, torch.float32, dataclasses.replace(O.CFG1, text_dim_head=32, visual_dim_head=24, text_rotary_pos_emb=True), 4)
+    with pytest.raises(NotImplementedError):
+        C.build_clip(dataclasses.replace(O.CFG1, text_dim_head=128), {}, DEV, torch.float32)
+    with pytest.raises(NotImplementedError):
+        C.build_clip(dataclasses.replace(O.CFG1, text_dim_head=16, text_rotary_pos_emb=True), {}, DEV, torch.float32)
+
+
+def test_bare_transformer_with_rotary_table_and_mask():
+    """Transformer.forward(x, rotary_pos_emb = RotaryEmbedding(32)(n), mask) as a user of the reference's building block calls it
+    (x_clip.py:274-291,155-166), forward and input gradient against the oracle's stack; a table that is not position x frequency is
+    refused"""
+    from x_clip_amd.clip import RotaryEmbedding, Transformer
+    torch.manual_seed(3)
+    dim, depth, heads, b, n = 64, 2, 2, 3, 9
+    net = Transformer(dim, depth=depth, heads=heads, dim_head=32)
+    net.train()
+    x = torch.randn(b, n, dim, requires_grad=True)
+    mask = torch.ones(b, n, dtype=torch.bool)
+    mask[1, 6:] = False
+    table = RotaryEmbedding(32)(n, DEV)
+    y = net(x, rotary_pos_emb=table, mask=mask)
+    g = torch.randn_like(y)
+    y.backward(g)
+    sd = {"t." + k: v.detach().double() for k, v in net.state_dict().items()}
+    x64 = x.detach().double().requires_grad_(True)
+    want = O.transformer(x64, sd, "t.", depth, heads, 32, mask, O.rotary_freqs(n, 32, torch.float64), False)
+    want.backward(g.double())
+    assert float((y.detach().double() - want.detach()).abs().max()) < 2e-5
+    assert float((x.grad.double() - x64.grad).abs().max() / x64.grad.abs().max()) < 2e-5
+    with pytest.raises(NotImplementedError):
+        net(x, rotary_pos_emb=table * table, mask=mask)
+
+
 @pytest.mark.parametrize("over", [dict(), dict(text_causal_mask=True, text_eos_id=7), dict(text_rotary_pos_emb=True), dict(use_mlm=True),
                                   dict(extra_latent_projection=True), dict(use_all_token_embeds=True, downsample_image_embeds=True, visual_patch_size=16),
                                   dict(use_visual_ssl=True, ssl_projection_size=32, ssl_projection_hidden_size=64),

@@ -89,6 +89,13 @@ def test_mid_sim_reg_extra_vs_oracle(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_mid_narrow_heads_vs_oracle(dtype):
+    """text_dim_head = 32 (rotary: the whole head is rotated), visual_dim_head = 48: zero-padded to the kernels' 64-wide heads"""
+    import dataclasses
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, text_dim_head=32, visual_dim_head=48, text_rotary_pos_emb=True), 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_mid_rotary_vs_oracle(dtype):
     """rotary text encoder (no absolute position table; q, k and v rotated over n + 1 positions, x_clip.py:155-176,221-223,328-330)"""
     import dataclasses

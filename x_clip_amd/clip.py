@@ -8,7 +8,8 @@ the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is n
 on an MI355X.
 
 Not on this path (constructor raises NotImplementedError): the causal text encoder together with rotary embeddings, FILIP or
-MLM (each fails inside the reference's own forward); attention / feed-forward dropout; dim_head != 64.
+MLM (each fails inside the reference's own forward); attention / feed-forward dropout; dim_head > 64 (narrower heads run
+zero-padded to the kernels' 64: Transformer.stack_params).
 """
 from __future__ import annotations
 
@@ -18,6 +19,7 @@ from typing import Optional
 import torch
 import torch.distributed as distributed
 from torch import nn
+import torch.nn.functional as F
 
 from . import functional as XF
 from . import losses as XL
@@ -96,6 +98,7 @@ class Transformer(nn.Module):
         super().__init__()
         self.checkpoint_during_training = checkpoint_during_training
         self.dim, self.depth, self.heads, self.dim_head, self.causal = dim, depth, heads, dim_head, causal
+        XF.StackSpec(depth=depth, heads=heads, dim_head=dim_head)      # (raises for a head width the kernels do not hold)
         self.layers = nn.ModuleList([])
         for _ in range(depth):
             self.layers.append(nn.ModuleList([
@@ -108,8 +111,13 @@ class Transformer(nn.Module):
     def stack_params(self):
         """flat parameter list in the order x_clip_amd.functional.stack_forward expects"""
         ps = [self.norm_in.g]
+        dh, h = self.dim_head, self.heads
         for attn, ff in self.layers:
-            ps += [attn.norm.g, attn.fn.to_qkv.weight, attn.fn.to_out[0].weight, attn.fn.to_out[1].g,
+            w_qkv, w_out = attn.fn.to_qkv.weight, attn.fn.to_out[0].weight
+            if dh < 64:                                       # heads narrower than the kernels' 64: zero rows / columns (StackSpec)
+                w_qkv = F.pad(w_qkv.view(3, h, dh, -1), (0, 0, 0, 64 - dh)).reshape(3 * h * 64, -1)
+                w_out = F.pad(w_out.view(-1, h, dh), (0, 64 - dh)).reshape(-1, h * 64)
+            ps += [attn.norm.g, w_qkv, w_out, attn.fn.to_out[1].g,
                    ff.norm.g, ff.fn.net[0].weight, ff.fn.net[2].g, ff.fn.net[4].weight]
         ps.append(self.norm_out.g)
         return ps
@@ -119,10 +127,19 @@ class Transformer(nn.Module):
                             checkpoint=bool(self.training and self.checkpoint_during_training), rotary=rotary, causal=self.causal)
 
     def forward(self, x, rotary_pos_emb=None, mask=None):
+        rotary = None
         if exists(rotary_pos_emb):
-            raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): build the TextTransformer with rotary_pos_emb=True "
-                                      "instead -- the kernels take the inv_freq buffer, not the angle table")
-        return XF.transformer(x, self.stack_params(), self.spec(), mask)
+            # the reference takes the [n, 32] angle table RotaryEmbedding.forward returns (x_clip.py:166,274); the kernels regenerate
+            # the angles from 16 frequencies, which are the table's row for position 1 -- provided the table IS position x frequency
+            t = rotary_pos_emb.float()
+            if t.dim() != 2 or t.shape[1] != 32 or t.shape[0] < max(2, x.shape[1]):
+                raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): a [n, 32] angle table covering the sequence")
+            rotary = t[1, :16].contiguous()
+            want = torch.outer(torch.arange(t.shape[0], device=t.device, dtype=torch.float32), rotary).repeat(1, 2)
+            if not torch.allclose(t, want, rtol=1e-5, atol=1e-6):
+                raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): only tables of the form position x frequency "
+                                          "(RotaryEmbedding.forward) are supported by the rotary kernel")
+        return XF.transformer(x, self.stack_params(), self.spec(rotary), mask)
 
 
 class RotaryEmbedding(nn.Module):
@@ -157,6 +174,8 @@ class TextTransformer(nn.Module):
         if causal and rotary_pos_emb:
             raise NotImplementedError("causal + rotary text encoder: the reference builds its angle table for n + 1 positions (x_clip.py:330) "
                                       "but a causal encoder has n (no CLS token), so its own forward fails with a shape error")
+        if rotary_pos_emb and dim_head < 32:
+            raise NotImplementedError("rotary embedding with dim_head < 32 (the kernel rotates the first 32 dimensions of a head)")
         self.token_emb = nn.Embedding(num_tokens, dim)
         self.abs_pos_emb = nn.Embedding(max_seq_len, dim) if not rotary_pos_emb else None      # x_clip.py:311-312
         self.rotary_pos_emb = RotaryEmbedding(min(dim_head, 32)) if rotary_pos_emb else None
