@@ -262,6 +262,10 @@ def main():
                 step()
         fence()
         launches, flops, secs = probe.summary()
+        if os.environ.get("XCLIP_BENCH_GEMM_SHAPES") == "1":      # per-shape table of the probe pass, to stderr
+            for (M, N, K, lay, res), (cnt, ms) in sorted(probe.by_shape().items(), key=lambda kv: -kv[1][1]):
+                print(f"  gemm {lay} M={M:7d} N={N:5d} K={K:7d}{' +res' if res else '     '}  x{cnt // max(args.steps, 1):3d}/step  "
+                      f"{ms / cnt * 1e3:8.1f} us  {2.0 * M * N * K * cnt / ms / 1e9:7.1f} TF/s", file=sys.stderr, flush=True)
         ach = flops / secs / 1e12 if secs > 0 else 0.0
         # HBM-side bytes per launch: PMC counters cannot be read from inside the process, so this is the figure of the committed
         # rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py -> profiles/gemm_traffic.json, which names the commit and

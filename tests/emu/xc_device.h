@@ -363,6 +363,8 @@ inline void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
     const uint64_t off = (uint64_t)voff + soff + IMM;
     if (off + 16 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + off, &v, 16);
 }
+template <int IMM>
+inline void buf_st16_nt(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) { buf_st16<IMM>(r, voff, soff, v); }
 inline void wait_vmem() {}
 // transpose read: lane c of a 16-lane group, slot j <- element (c & 3) at the address supplied by lane 4j + (c >> 2)
 inline s16x4 lds_read_tr16(const void* p) {
@@ -379,6 +381,7 @@ inline s16x4 lds_read_tr16(const void* p) {
 inline int uniform(int v) { return v; }
 inline void wave_sync() { int z = 0; (void)xcemu::wave_exchange(&z, sizeof(z)); }      // lanes are fibres: rendezvous
 inline void lds_fence() { wave_sync(); }
+inline void lds_drain() { wave_sync(); }
 inline uint64_t realtime_10ns() { static uint64_t t = 0; return t += 1000; }
 inline uint64_t shader_cycles() { return 0; }
 inline void nap() {}

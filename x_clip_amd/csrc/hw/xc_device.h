@@ -152,6 +152,11 @@ XC_DEV void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
 }
 // wait until every outstanding vector-memory operation of this wave (LDS DMA included) has completed
+// the same store with the non-temporal hint (streaming: the line is the first to leave the L2)
+template <int IMM>
+XC_DEV void buf_st16_nt(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4 nt\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
+}
 XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // lds_read_tr16 (ds_read_b64_tr_b16): within each 16-lane group, lane c (slot j) receives the 16-bit element
 // at addr[lane 4j + (c >> 2) of the group] + (c & 3): a 4 x 16 block whose rows are addressed by the lanes is
@@ -189,6 +194,8 @@ XC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 XC_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // between a wave's LDS stores and its loads of what OTHER lanes stored (the LDS serves a wave's operations in order: nothing to wait
 // for, the compiler must only keep the order)
+// every LDS operation of this wave has completed (before something else overwrites what it read)
+XC_DEV void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // measurement builds: keep a register value alive / opaque to the optimiser
 template <class T> XC_DEV void reg_keep(T& v) { asm volatile("" : "+v"(v)); }
 // constant-rate (100 MHz) timestamp

@@ -234,7 +234,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int nt = (kend - kbeg) / G2_BK;
     const int stride = gridDim.x;
     if ((int)blockIdx.x >= ntiles || nt <= 0) return;            // (uniform over the work-group)
-    const uint64_t clk0 = (ABL & 512) ? shader_cycles() : 0, rt0 = (ABL & 512) ? realtime_10ns() : 0;
+    const uint64_t clk0 = (ABL & (512 | 2048)) ? shader_cycles() : 0, rt0 = (ABL & 512) ? realtime_10ns() : 0;
     if ((ABL & 256) && ((blockIdx.x >> 3) & 1)) {                // measurement: every other CU of an XCD starts half a tile late
         const uint64_t until = realtime_10ns() + (uint64_t)(nt * 90 + 250);
         while (realtime_10ns() < until) nap();
@@ -320,12 +320,17 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA, ldsB, wm * 128, wn * 64, 0, lane, a[0], b[0]);
     lds_wait<0>(a[0], b[0]);
 
+    uint64_t stamp[12] = {};                                  // (ABL & 2048: this work-group's third tile, shader cycles)
+    int tile_no = 0;
+    bool a_early = false;                                     // the next step's A pieces have been issued at the tile boundary
+    int in_flight = 0;                                        // stores per lane the previous tile's epilogue left behind (16 or 0)
     int step = 0, sa3 = 0;                                    // running K-step counter (B stage = step & 1) and A stage = step % 3
     for (int id = blockIdx.x; id < ntiles; id += stride) {
         int m0, n0;
         tile_origin(id, m0, n0);
         f32x16 acc[4][2];                                     // (first k-block of the tile runs with C = 0)
 
+        if ((ABL & 2048) && (tile_no == 2 || tile_no == 3)) stamp[tile_no == 2 ? 0 : 10] = shader_cycles();
         for (int t = 0; t < nt; ++t, ++step) {
             const int sa_next = sa3 == 2 ? 0 : sa3 + 1;       // A stage of step s + 1
             const int sa_free = sa3 == 0 ? 2 : sa3 - 1;       // A stage of step s + 2 == the one step s - 1 used
@@ -333,6 +338,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             const unsigned char* Bs = ldsB + (step & 1) * G2_OPER_BYTES;
             unsigned char* const a_dst = ldsA + sa_free * G2_OPER_BYTES;
             unsigned char* const b_dst = ldsB + (step & 1) * G2_OPER_BYTES;
+            const bool early = a_early && t == 0;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1;
@@ -340,7 +346,12 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     if (!(ABL & 8)) g3_read_frags<A_KMAJOR, B_KMAJOR>(As, Bs, wm * 128, wn * 64, kk + 1, lane, a[nxt], b[nxt]);
                 } else {
                     // all but this step's four A pieces: A(s + 1), B(s + 1) are in LDS (and a finished tile's stores have been taken)
-                    if (!(ABL & 32)) XC_WAIT_VMEM_LE(4);
+                    // (first step of a tile behind an interior bf16 tile: its 16 whole-line stores are YOUNGER than A(s + 1), B(s + 1)
+                    //  -- the counter retires in issue order -- and may stay in flight for one more K step)
+                    if (!(ABL & 32)) {
+                        if (!(ABL & 1024) && t == 0 && in_flight == 16) XC_WAIT_VMEM_LE(20);
+                        else XC_WAIT_VMEM_LE(4);
+                    }
                     if (!(ABL & 16)) barrier_nodrain();          // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more
                     if (!(ABL & 8))
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA + sa_next * G2_OPER_BYTES, ldsB + ((step + 1) & 1) * G2_OPER_BYTES, wm * 128, wn * 64,
@@ -359,7 +370,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         reg_keep(a[cur][i]);
-                        if (kk == 0) { sched_fence(); piece_a(i, a_dst); sched_fence(); }
+                        if (kk == 0 && !early) { sched_fence(); piece_a(i, a_dst); sched_fence(); }
                         if (kk == 3) { sched_fence(); piece_b(i, b_dst); sched_fence(); }
                     }
                 } else
@@ -369,7 +380,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             acc[i][j] = mfma_32x32x16_bf16_zero(__builtin_bit_cast(s16x8, b[cur][j]), __builtin_bit_cast(s16x8, a[cur][i]));
-                        sched_fence(); piece_a(i, a_dst); sched_fence();
+                        sched_fence(); if (!early) piece_a(i, a_dst); sched_fence();
                     }
                 } else
 #pragma unroll
@@ -379,27 +390,48 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     if (kk == 0) { sched_fence(); piece_a(i, a_dst); sched_fence(); }
                     if (kk == 3) { sched_fence(); piece_b(i, b_dst); sched_fence(); }
                 }
-                if (kk == 0) next_a();
+                if (kk == 0 && !early) next_a();
                 if (kk == 3) next_b();
                 sched_fence();
                 lds_wait<0>(a[nxt], b[nxt]);
                 sched_fence();
             }
             sa3 = sa_next;
+            if ((ABL & 2048) && tile_no == 2 && t < 8) stamp[1 + t] = shader_cycles();
+            if ((ABL & 2048) && tile_no == 3 && t == 0) stamp[11] = shader_cycles();
         }
+        if ((ABL & 2048) && tile_no == 2) reg_keep(acc[3][1]);
+        ++tile_no;
         if (ABL & 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) reg_keep(acc[i][j]);
-        } else if (ABL & 128) {
-            (void)epi(acc, m0, n0);                           // (the row-per-lane stores)
-        } else
-        (void)epi(acc, m0, n0, ldsA + (sa3 == 0 ? 2 : sa3 - 1) * G2_OPER_BYTES + mine);   // the A stage the last step read: free until
-                                                                                          // this wave's own pieces of the next k-block 0
+        } else if (!(ABL & 128) && epi.packs_lines(m0, n0)) {
+            // interior bf16 tile: exchange through the A stage the last step read (free until this wave's own next pieces), then
+            // the four A pieces the next K step would issue in its k-block 0, THEN the stores
+            unsigned char* const freed = ldsA + (sa3 == 0 ? 2 : sa3 - 1) * G2_OPER_BYTES;
+            u32x4 o[4][4];
+            epi.pack_lines(acc, freed + mine, o);
+            lds_drain();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) piece_a(q, freed);
+            next_a();
+            a_early = true;
+            if (p.stream_out) epi.template store_lines<true>(o, m0, n0);
+            else epi.template store_lines<false>(o, m0, n0);
+            in_flight = 16;
+        } else {
+            in_flight = epi(acc, m0, n0);
+            a_early = false;
+        }
     }
     XC_WAIT_VMEM_LE(0);                                       // trailing (redundant) pieces must land before the LDS is released
     epi.finish();
+    if ((ABL & 2048) && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {   // one row of 12 stamps per wave
+        uint64_t* out = reinterpret_cast<uint64_t*>(p.C) + 16 + 12 * (threadIdx.x >> 6);
+        for (int q = 0; q < 12; ++q) out[q] = stamp[q] - clk0;
+    }
     if ((ABL & 512) && blockIdx.x == 0 && threadIdx.x == 0) {   // measurement: shader cycles and 10 ns ticks this work-group lived
         uint64_t* out = reinterpret_cast<uint64_t*>(p.C);
         out[0] = shader_cycles() - clk0;
@@ -474,36 +506,56 @@ struct G4GemmEpilogue {
     // tile boundary's 5.8 us.  The same 16 stores per lane with 8 lanes side by side on a row (8 rows x 128 bytes per instruction)
     // take 4.1 us (profiles/r02_run16_gemm5_ablation.log, mask 64).  The exchange between the two lane arrangements goes through
     // 4 KiB of LDS per wave, 32 rows at a time: `scratch` is this wave's own slice of the A stage the K loop has just finished with
-    // -- the only waves that write there are this one's own DMA pieces, the next of which is issued after this function returns --
+    // -- the only writes there are this wave's own DMA pieces, the next of which the caller issues once pack_lines is through --
     // so no work-group barrier is involved.  16-byte chunk c of row r sits at chunk position c ^ (r & 7): the 8-byte writes of the
     // 32 rows of a half-wave then spread over all banks, and so do the 16-byte reads of 8 lanes per row.
-    XC_DEV void store_full_bf16_lds(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
+    // Two phases, because the caller puts its next four DMA pieces BETWEEN them: the CU's vector-memory path is a queue, and pieces
+    // issued behind 128 KiB of stores reached the L2 ~2000 cycles late -- the second and third K step of every tile then waited for
+    // them (3000-4100 cycles instead of 2440: profiles/r02_run17_gemm5_step_stamps.log).
+    template <bool UNIT_ALPHA>
+    XC_DEV void pack_lines_t(f32x16 (&acc)[4][2], unsigned char* scratch, u32x4 (&o)[4][4]) const {
         const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
-        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
-        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
-        const uint32_t s8 = (uint32_t)p.ldc * 16u;                                  // 8 rows * ldc * 2 bytes
         unsigned char* const wr = scratch + r * 128 + 8 * h;                        // + chunk position * 16
         const unsigned char* const rd = scratch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + 1024 per 8 rows
+        const float al = p.alpha;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                                       // columns 32 j + 8 q + 4 h + (0..3) of row r
-                    const u32x2 v = {f2bf_pk(acc[i][j][4 * q] * p.alpha, acc[i][j][4 * q + 1] * p.alpha),
-                                     f2bf_pk(acc[i][j][4 * q + 2] * p.alpha, acc[i][j][4 * q + 3] * p.alpha)};
+                    const float* a = reinterpret_cast<const float*>(&acc[i][j]) + 4 * q;
+                    const u32x2 v = UNIT_ALPHA ? u32x2{f2bf_pk(a[0], a[1]), f2bf_pk(a[2], a[3])}
+                                               : u32x2{f2bf_pk(a[0] * al, a[1] * al), f2bf_pk(a[2] * al, a[3] * al)};
                     *reinterpret_cast<u32x2*>(wr + (((4 * j + q) ^ (r & 7)) << 4)) = v;
                 }
             }
             lds_fence();
-            u32x4 o[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = *reinterpret_cast<const u32x4*>(rd + k * 1024);
+            for (int k = 0; k < 4; ++k) o[i][k] = *reinterpret_cast<const u32x4*>(rd + k * 1024);
             lds_fence();                                                            // (the next 32 rows overwrite the slice)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
         }
+    }
+    // may this tile go through pack_lines / store_lines?  (uniform)
+    XC_DEV bool packs_lines(int m0, int n0) const { return MODE == G4_PLAIN && (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N); }
+    XC_DEV void pack_lines(f32x16 (&acc)[4][2], unsigned char* scratch, u32x4 (&o)[4][4]) const {
+        if (p.alpha == 1.f) pack_lines_t<true>(acc, scratch, o);                    // (most products: no multiplies)
+        else pack_lines_t<false>(acc, scratch, o);
+    }
+    template <bool NT = false>
+    XC_DEV void store_lines(const u32x4 (&o)[4][4], int m0, int n0) const {
+        const int lane = threadIdx.x & 63;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+        const uint32_t s8 = (uint32_t)p.ldc * 16u;                                  // 8 rows * ldc * 2 bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (NT) buf_st16_nt<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[i][k]);
+                else buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[i][k]);
+            }
     }
     // interior tile, bf16 output with a residual term.  The general epilogue reads the residual 8 bytes at a time right where it is
     // used, and with LDS-DMA pieces in flight every such load is followed by a full vmcnt drain: 32 dependent memory round trips per
@@ -592,14 +644,6 @@ struct G4GemmEpilogue {
 
     // -> how many vector-memory operations per lane the epilogue issued when that number is fixed (interior tiles: 16 / 32 stores),
     //    0 when it is not (ragged tiles, optional terms with their loads): the caller then drains everything at its next wait
-    // with `scratch` = 4 KiB of LDS nobody else touches until the caller's next DMA piece
-    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
-        if (MODE == G4_PLAIN && (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N)) {
-            store_full_bf16_lds(acc, m0, n0, scratch);
-            return 16;
-        }
-        return (*this)(acc, m0, n0);
-    }
     XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
         const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);       // interior tile (uniform)
         if (MODE == G4_PLAIN) {                                  // (never looks at the optional-term pointers: fewer live scalars)
@@ -655,7 +699,9 @@ struct G4ProbeEpilogue {
         }
         return 16;
     }
-    XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return (*this)(acc, m0, n0); }
+    XC_DEV bool packs_lines(int, int) const { return false; }
+    XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4]) const {}
+    template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
 };
 
 template <bool A_KMAJOR, bool B_KMAJOR, int MODE, int ABL = 0>

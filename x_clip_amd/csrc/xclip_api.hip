@@ -139,7 +139,7 @@ void launch_gemm4(const Gemm2Params& p, dim3 pgrid, bool ring3, hipStream_t st) 
         static const int abl = [] { const char* e = getenv("XCLIP_GEMM5_ABL"); return e ? atoi(e) : 0; }();
         if (ring3 && abl) {
 #define XC_ABL5(N) case N: XC_ALLOW_LDS((gemm5_kernel<false, false, G4_PLAIN, N>), G5_LDS_BYTES); hipLaunchKernelGGL((gemm5_kernel<false, false, G4_PLAIN, N>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p); return;
-            switch (abl) { XC_ABL5(1) XC_ABL5(2) XC_ABL5(4) XC_ABL5(8) XC_ABL5(9) XC_ABL5(10) XC_ABL5(11) XC_ABL5(14) XC_ABL5(16) XC_ABL5(32) XC_ABL5(48) XC_ABL5(12) XC_ABL5(6) XC_ABL5(26) XC_ABL5(58) XC_ABL5(64) XC_ABL5(74) XC_ABL5(128) XC_ABL5(256) XC_ABL5(512) XC_ABL5(526) XC_ABL5(522) default: break; }
+            switch (abl) { XC_ABL5(1) XC_ABL5(2) XC_ABL5(4) XC_ABL5(8) XC_ABL5(9) XC_ABL5(10) XC_ABL5(11) XC_ABL5(14) XC_ABL5(16) XC_ABL5(32) XC_ABL5(48) XC_ABL5(12) XC_ABL5(6) XC_ABL5(26) XC_ABL5(58) XC_ABL5(64) XC_ABL5(74) XC_ABL5(128) XC_ABL5(256) XC_ABL5(512) XC_ABL5(1024) XC_ABL5(2560) XC_ABL5(4096) XC_ABL5(526) XC_ABL5(522) default: break; }
 #undef XC_ABL5
         }
     }
@@ -660,6 +660,10 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
         q.bias = (const bf16_t*)bias; q.residual = (const bf16_t*)residual; q.ldr = ldr;
         q.addrows = (const bf16_t*)addrows; q.rowidx = rowidx; q.ld_add = ld_add;
         q.tiles_m = (int)((M + G2_BM - 1) / G2_BM); q.tiles_n = (int)((N + G2_BN - 1) / G2_BN);
+        // an output that cannot stay in the 8 x 4 MiB of L2 anyway is streamed past it: the A / B panels the sibling tiles share then
+        // survive a round's 32 MiB of output (XCLIP_GEMM_NT=0 / 1 forces the policy, for measurement)
+        static const int nt_env = [] { const char* e = getenv("XCLIP_GEMM_NT"); return e ? atoi(e) : -1; }();
+        q.stream_out = nt_env >= 0 ? nt_env : (M * N * 2 > (int64_t)(48 << 20) ? 1 : 0);
         int splits = gemm2_splits(M, N, K);
         if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
         q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);

@@ -361,6 +361,16 @@ class GemmProbe:
         self.algorithmic_bytes = sum(r[3] for r in self.records)
         return len(self.records), flops, secs
 
+    def by_shape(self):
+        """{(M, N, K, layout, has_residual): [launches, milliseconds]} over the recorded launches"""
+        torch.cuda.synchronize()
+        out = {}
+        for r in self.records:
+            e = out.setdefault(r[4], [0, 0.0])
+            e[0] += 1
+            e[1] += r[1].elapsed_time(r[2])
+        return out
+
 
 def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False, alpha: float = 1.0,
          bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, addrows: Optional[Tensor] = None,
@@ -396,7 +406,8 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
     if probe is not None:
         ev1.record(torch.cuda.current_stream(a.device))
         esz = a.element_size()
-        probe.records.append((2.0 * M * N * K, ev0, ev1, (M * K + N * K + M * N) * esz + (M * N * esz if residual is not None else 0)))
+        probe.records.append((2.0 * M * N * K, ev0, ev1, (M * K + N * K + M * N) * esz + (M * N * esz if residual is not None else 0),
+                              (M, N, K, ("T" if a_kmajor else "N") + ("N" if b_kmajor else "T"), residual is not None)))
     return out
 
 
