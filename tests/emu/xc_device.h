@@ -384,6 +384,7 @@ inline void lds_fence() { wave_sync(); }
 inline void lds_drain() { wave_sync(); }
 inline uint64_t realtime_10ns() { static uint64_t t = 0; return t += 1000; }
 inline uint64_t shader_cycles() { return 0; }
+inline uint32_t lds_base_granule() { return 0; }
 inline void nap() {}
 template <class T> inline void reg_keep(T&) {}
 

@@ -201,6 +201,8 @@ template <class T> XC_DEV void reg_keep(T& v) { asm volatile("" : "+v"(v)); }
 // constant-rate (100 MHz) timestamp
 XC_DEV uint64_t realtime_10ns() { return __builtin_amdgcn_s_memrealtime(); }
 XC_DEV uint64_t shader_cycles() { return __builtin_amdgcn_s_memtime(); }
+// first LDS granule of this work-group on its CU (HW_REG_LDS_ALLOC[7:0]): 0 for the work-group that got the CU's LDS first
+XC_DEV uint32_t lds_base_granule() { return __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6); }
 XC_DEV void nap() { __builtin_amdgcn_s_sleep(8); }
 XC_DEV void lds_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 

@@ -40,6 +40,7 @@ struct AttnParams {
     float scale;
     int chunks;                  // row chunks (of NW*32) per (batch, head)
     int causal;                  // != 0: key j is visible to query i only if j <= i (reference Attention.forward, x_clip.py:231-234)
+    int stagger_10ns;            // head-resident kernels: start delay of a CU's second work-group (attention3.h a3_stagger), 0 = none
 };
 
 template <typename T>
@@ -83,7 +84,7 @@ XC_DEV u32x4 frag_from_acc(const f32x16& acc, int blk, bf16_t*) {
     u32x4 f;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-        f[w] = (uint32_t)f2bf(acc[8 * blk + 2 * w]) | ((uint32_t)f2bf(acc[8 * blk + 2 * w + 1]) << 16);
+        f[w] = f2bf_pk(acc[8 * blk + 2 * w], acc[8 * blk + 2 * w + 1]);            // (one v_cvt_pk_bf16_f32 per pair)
     return f;
 }
 XC_DEV u32x4 frag_from_acc(const f32x16& acc, int blk, float*) {

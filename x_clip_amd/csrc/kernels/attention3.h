@@ -41,6 +41,29 @@ XC_HOST_DEV bool a3_coop_tail(int n) { return (n & 31) != 0 && (n & 31) <= A3_TA
 XC_HOST_DEV int a3_waves(int n) { return a3_coop_tail(n) ? n / 32 : (n + 31) / 32; }
 constexpr int A3_TAIL_REC = 66;                                // floats per (wave, tail row): m, l, O[64]
 
+// Operand reads of 32-row sub-tile t of an image (attention2.h layout), written so that everything but `t * 4096` depends on the
+// lane alone: the swizzle of a row only looks at bits 1-3 of the row number, which a sub-tile's base (a multiple of 16) does not
+// touch.  The generic a2_row_frag / a2_col_frag recompute the swizzle from the full row number, and the compiler could not hoist that
+// out of the sub-tile loops: ~50 of the ~115 vector instructions of a backward step were address arithmetic
+// (profiles/r02_run19_attention_pmc.txt: the kernels are VALU-bound, 58 % VALU-busy against 28 % MFMA-busy).
+XC_DEV u32x4 a3_row_frag(const unsigned char* img, int t, int kb, int lane) {
+    const int c31 = lane & 31, h = lane >> 5;
+    return ld16(img + t * 4096 + (c31 * 128 + a2_slot(c31, kb * 2 + h) * 16));
+}
+XC_DEV u32x4 a3_col_frag(const unsigned char* img, int t, int blk, int db, int lane) {
+    const int g = lane >> 4, tt = lane & 15;
+    const int r0 = 4 * (g >> 1) + (tt >> 2);
+    const int col = 32 * db + 16 * (g & 1) + (tt & 3) * 4;
+    const int lo_off = r0 * 128 + a2_slot(r0, col >> 3) * 16 + (col & 7) * 2;
+    const int hi_off = (r0 + 8) * 128 + a2_slot(r0 + 8, col >> 3) * 16 + (col & 7) * 2;
+    const unsigned char* base = img + t * 4096 + blk * 2048;
+    const s16x4 lo = lds_read_tr16(base + lo_off);
+    const s16x4 hi = lds_read_tr16(base + hi_off);
+    const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+    u32x4 f = {a[0], a[1], b[0], b[1]};
+    return f;
+}
+
 // one 32-key sub-tile of the online-softmax forward for the 32 queries whose fragments are qf (shared by both passes).
 // The kernels are VALU-bound (the first version spent ~250 VALU instructions per 8 MFMAs here), so the softmax bookkeeping is
 // kept in the base-2 domain of the SCALED scores: m2 = running max of s * scale2 (scale2 = scale log2 e, the max is taken
@@ -57,7 +80,7 @@ XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) s = mma_kblock(a2_row_frag(Ks, t * 32 + c31, kb, h), qf[kb], s, (bf16_t*)nullptr);
+    for (int kb = 0; kb < 4; ++kb) s = mma_kblock(a3_row_frag(Ks, t, kb, lane), qf[kb], s, (bf16_t*)nullptr);
     bool valid[16];
     float mx = ATT_NEG;
 #pragma unroll
@@ -87,7 +110,7 @@ XC_DEV void a3_fwd_step(const unsigned char* Ks, const unsigned char* Vs, const 
     for (int blk = 0; blk < 2; ++blk) {
         const u32x4 pf = a2_pack_acc(s, blk);
 #pragma unroll
-        for (int db = 0; db < 2; ++db) o[db] = mma_kblock(a2_col_frag(Vs, t, blk, db, lane), pf, o[db], (bf16_t*)nullptr);
+        for (int db = 0; db < 2; ++db) o[db] = mma_kblock(a3_col_frag(Vs, t, blk, db, lane), pf, o[db], (bf16_t*)nullptr);
     }
 }
 // votes on the sub-tile's key validity and runs the matching variant; with CAUSAL the wave's queries are [qlo, qlo + 32): sub-tiles
@@ -105,6 +128,15 @@ XC_DEV void a3_fwd_step_auto(const unsigned char* Ks, const unsigned char* Vs, c
     else if (wave_any(kv)) a3_fwd_step<true, false>(Ks, Vs, Ms, t, qf, scale2, lane, qidx, o, m2, l);
 }
 
+// Two work-groups share a CU and every head takes the same time, so left alone they load together and compute together.  The one
+// that was given the upper part of the CU's LDS in the FIRST round of work-groups waits half a head's time once: from then on one
+// streams its images from HBM while the other is in its MFMA phases.
+XC_DEV void a3_stagger(int ticks_10ns) {
+    if (ticks_10ns > 0 && blockIdx.x < 2u * 256u && lds_base_granule() != 0) {
+        const uint64_t until = realtime_10ns() + (uint64_t)ticks_10ns;
+        while (realtime_10ns() < until) nap();
+    }
+}
 // ---- forward ----------------------------------------------------------------------------------------------------------
 // (at most 128 VGPRs: two 8-wave work-groups of ~78 KB LDS share a CU)
 template <bool CAUSAL>
@@ -117,6 +149,7 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
     float* Ts = reinterpret_cast<float*>(Ms + npad);           // [nwaves][A3_TAIL_MAX][A3_TAIL_REC] tail partials
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c31 = lane & 31;
     const int wave = uniform(tid >> 6), nwaves = blockDim.x >> 6;
+    a3_stagger(p.stagger_10ns);
     const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
     const int hh = bh % p.heads, bi = bh / p.heads;
     const long ldq = 3L * p.heads * ATT_DH;
@@ -189,42 +222,80 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
 
 // ---- backward (dQ, dK, dV and delta in one kernel) ------------------------------------------------------------------------
 // phase A body: dQ^T[d, query] += K^T dS^T for the 32 queries whose fragments are (qf, dof) against key sub-tile t
-// (lse2_q = lse_q log2(e) and scale2 = scale log2(e): the probability is one fma + a bare v_exp_f32)
+// (lse2_q = lse_q log2(e) and scale2 = scale log2(e): the probability is one fma + a bare v_exp_f32).
+// The backward is VALU-bound like the forward, so per score it is kept to fma, exp, mul: the dP accumulator STARTS at -delta
+// (dP - delta comes out of the MFMA chain), the factor `scale` of dS = P (dP - delta) scale is applied once to the finished dQ / dK
+// (a power of two for dim_head 64: the bf16 rounding of dS is unchanged), and the key-validity / causal selects with their LDS mask
+// reads are only compiled into the MASKED variant -- the caller votes per sub-tile, as the forward does.
+// (`masked` is wave-uniform and only switches between the two score loops: one copy of the MFMA chains, so the register allocation
+//  stays that of a single variant -- two inlined instances of the whole step cost 2.7 x the registers and half the occupancy)
+// The step is one dependent chain (fragment reads -> 8 MFMAs -> 16 exp -> pack -> 4 MFMAs) and a SIMD holds two waves, so the row
+// fragments of sub-tile t + 1 are requested by the caller BEFORE the chain of sub-tile t starts (kr / vr = the fragments of t).
+// this lane's row fragments (all four k-blocks) of sub-tile t of an operand image
+XC_DEV void a3_tile_rows(const unsigned char* img, int t, int lane, u32x4 (&f)[4]) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) f[kb] = a3_row_frag(img, t, kb, lane);
+}
 template <bool CAUSAL>
-XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t, const u32x4 (&qf)[4],
-                           const u32x4 (&dof)[4], float lse2_q, float delta_q, float scale, float scale2, int lane, int qidx,
-                           f32x16 (&dq)[2]) {
-    const int h = lane >> 5, c31 = lane & 31;
+XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Ms, int t, const u32x4 (&kr)[4], const u32x4 (&vr)[4],
+                           const u32x4 (&qf)[4], const u32x4 (&dof)[4], float lse2_q, float delta_q, float scale2, int lane, int qidx,
+                           f32x16 (&dq)[2], bool masked) {
     f32x16 s, dp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -delta_q; }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        s = mma_kblock(a2_row_frag(Ks, t * 32 + c31, kb, h), qf[kb], s, (bf16_t*)nullptr);
-        dp = mma_kblock(a2_row_frag(Vs, t * 32 + c31, kb, h), dof[kb], dp, (bf16_t*)nullptr);
+        s = mma_kblock(kr[kb], qf[kb], s, (bf16_t*)nullptr);
+        dp = mma_kblock(vr[kb], dof[kb], dp, (bf16_t*)nullptr);
     }
+    if (masked || CAUSAL) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int kj = t * 32 + mfma_row(r, lane);
-        const float pv = (Ms[kj] && (!CAUSAL || kj <= qidx)) ? fast_exp2(s[r] * scale2 - lse2_q) : 0.f;
-        s[r] = pv * (dp[r] - delta_q) * scale;                                 // dS^T (already times the q scale)
+        for (int r = 0; r < 16; ++r) {
+            const int kj = t * 32 + mfma_row(r, lane);
+            const float pv = (Ms[kj] && (!CAUSAL || kj <= qidx)) ? fast_exp2(s[r] * scale2 - lse2_q) : 0.f;
+            s[r] = pv * dp[r];                                                 // dS^T / scale
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * scale2 - lse2_q) * dp[r];
     }
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
         const u32x4 df = a2_pack_acc(s, blk);
 #pragma unroll
-        for (int db = 0; db < 2; ++db) dq[db] = mma_kblock(a2_col_frag(Ks, t, blk, db, lane), df, dq[db], (bf16_t*)nullptr);
+        for (int db = 0; db < 2; ++db) dq[db] = mma_kblock(a3_col_frag(Ks, t, blk, db, lane), df, dq[db], (bf16_t*)nullptr);
     }
 }
-// phase B body: dK^T, dV^T for the 32 keys whose fragments are (kf, vf) against query sub-tile t
+// sub-tiles t0, t0 + dt, ... < tend of the K / V images against one query block, fragments of the next sub-tile in flight.
+// plain_bits: bit t set = all 32 keys of sub-tile t are valid (voted once per head, not per step)
+template <bool CAUSAL>
+XC_DEV void a3_bwd_dq_sweep(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t0, int tend, int dt,
+                            uint32_t plain_bits, const u32x4 (&qf)[4], const u32x4 (&dof)[4], float lse2_q, float delta_q, float scale2,
+                            int lane, int qidx, f32x16 (&dq)[2]) {
+    if (t0 >= tend) return;
+    u32x4 ka[4], va[4], kb[4], vb[4];
+    a3_tile_rows(Ks, t0, lane, ka);
+    a3_tile_rows(Vs, t0, lane, va);
+    for (int t = t0; t < tend; t += 2 * dt) {
+        const int t1 = t + dt, t2 = t + 2 * dt;
+        a3_tile_rows(Ks, t1 < tend ? t1 : t, lane, kb);
+        a3_tile_rows(Vs, t1 < tend ? t1 : t, lane, vb);
+        a3_bwd_dq_step<CAUSAL>(Ks, Ms, t, ka, va, qf, dof, lse2_q, delta_q, scale2, lane, qidx, dq, !((plain_bits >> t) & 1u));
+        if (t1 < tend) {
+            a3_tile_rows(Ks, t2 < tend ? t2 : t1, lane, ka);
+            a3_tile_rows(Vs, t2 < tend ? t2 : t1, lane, va);
+            a3_bwd_dq_step<CAUSAL>(Ks, Ms, t1, kb, vb, qf, dof, lse2_q, delta_q, scale2, lane, qidx, dq, !((plain_bits >> t1) & 1u));
+        }
+    }
+}
+// phase B body: dK^T, dV^T for the 32 keys whose fragments are (kf, vf) against query sub-tile t.  masked (wave-uniform): some of
+// the wave's keys are padding, or the query sub-tile runs past n
 template <bool CAUSAL>
 XC_DEV void a3_bwd_dkv_step(const unsigned char* Qs, const unsigned char* dOs, const float* Ls2, const float* Ds, int t, int n,
-                            const u32x4 (&kf)[4], const u32x4 (&vf)[4], bool kvalid, float scale, float scale2, int lane, int kidx,
-                            f32x16 (&dk)[2], f32x16 (&dv)[2]) {
-    const int h = lane >> 5, c31 = lane & 31;
+                            const u32x4 (&qr)[4], const u32x4 (&dor)[4], const u32x4 (&kf)[4], const u32x4 (&vf)[4], bool kvalid,
+                            float scale2, int lane, int kidx, f32x16 (&dk)[2], f32x16 (&dv)[2], bool masked) {
+    const int h = lane >> 5;
     f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     // lse log2(e) and delta of the 16 queries this lane's accumulator registers belong to: rows 8 q + 4 h + (0..3) of the
     // sub-tile, i.e. four 16-byte LDS reads each -- issued up front, unconditionally (rows >= n hold 0 and are masked by a
     // select below; a conditional load here compiled to sixteen exec-masked branches with an LDS round trip each)
@@ -236,18 +307,27 @@ XC_DEV void a3_bwd_dkv_step(const unsigned char* Qs, const unsigned char* dOs, c
         for (int e = 0; e < 4; ++e) { l2[4 * q + e] = u2f(a[e]); dl[4 * q + e] = u2f(b[e]); }
     }
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        s = mma_kblock(a2_row_frag(Qs, t * 32 + c31, kb, h), kf[kb], s, (bf16_t*)nullptr);
-        dp = mma_kblock(a2_row_frag(dOs, t * 32 + c31, kb, h), vf[kb], dp, (bf16_t*)nullptr);
-    }
-    const bool full = t * 32 + 32 <= n;
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -dl[r]; }                 // (dP - delta out of the MFMA chain)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ql = t * 32 + mfma_row(r, lane);
-        float pv = fast_exp2(s[r] * scale2 - l2[r]);
-        pv = (kvalid && (full || ql < n) && (!CAUSAL || ql >= kidx)) ? pv : 0.f;
-        s[r] = pv;                                                             // P
-        dp[r] = pv * (dp[r] - dl[r]) * scale;                                  // dS (times the q scale)
+    for (int kb = 0; kb < 4; ++kb) {
+        s = mma_kblock(qr[kb], kf[kb], s, (bf16_t*)nullptr);
+        dp = mma_kblock(dor[kb], vf[kb], dp, (bf16_t*)nullptr);
+    }
+    if (masked || CAUSAL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = t * 32 + mfma_row(r, lane);
+            float pv = fast_exp2(s[r] * scale2 - l2[r]);
+            pv = (kvalid && ql < n && (!CAUSAL || ql >= kidx)) ? pv : 0.f;
+            s[r] = pv;                                                         // P
+            dp[r] = pv * dp[r];                                                // dS / scale
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = fast_exp2(s[r] * scale2 - l2[r]);
+            dp[r] = s[r] * dp[r];
+        }
     }
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -255,9 +335,23 @@ XC_DEV void a3_bwd_dkv_step(const unsigned char* Qs, const unsigned char* dOs, c
         const u32x4 df = a2_pack_acc(dp, blk);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-            dv[db] = mma_kblock(a2_col_frag(dOs, t, blk, db, lane), pf, dv[db], (bf16_t*)nullptr);
-            dk[db] = mma_kblock(a2_col_frag(Qs, t, blk, db, lane), df, dk[db], (bf16_t*)nullptr);
+            dv[db] = mma_kblock(a3_col_frag(dOs, t, blk, db, lane), pf, dv[db], (bf16_t*)nullptr);
+            dk[db] = mma_kblock(a3_col_frag(Qs, t, blk, db, lane), df, dk[db], (bf16_t*)nullptr);
         }
+    }
+}
+// query sub-tiles t0, t0 + dt, ... < tend of the Q / dO images against one key block (as a3_bwd_dq_sweep)
+template <bool CAUSAL>
+XC_DEV void a3_bwd_dkv_sweep(const unsigned char* Qs, const unsigned char* dOs, const float* Ls2, const float* Ds, int t0, int tend, int dt,
+                             int n, bool keys_plain, const u32x4 (&kf)[4], const u32x4 (&vf)[4], bool kvalid, float scale2, int lane,
+                             int kidx, f32x16 (&dk)[2], f32x16 (&dv)[2]) {
+    // (no fragment prefetch here: with dK and dV both live it does not fit in 256 registers -- 254 + 16 measured -- and a third
+    //  wave-slot's worth of registers would halve the occupancy)
+    for (int t = t0; t < tend; t += dt) {
+        u32x4 qa[4], da[4];
+        a3_tile_rows(Qs, t, lane, qa);
+        a3_tile_rows(dOs, t, lane, da);
+        a3_bwd_dkv_step<CAUSAL>(Qs, dOs, Ls2, Ds, t, n, qa, da, kf, vf, kvalid, scale2, lane, kidx, dk, dv, !(keys_plain && t * 32 + 32 <= n));
     }
 }
 // this lane's 32 of the 64 feature values of its column (query / key c31) -> rec[0..63]
@@ -270,7 +364,7 @@ XC_DEV void a3_put_col(float* rec, const f32x16 (&acc)[2], int lane) {
 
 // acc[db] (rows = d = 32 db + mfma_row, column = this lane's row c31) -> dst rows [row0, row0 + 32), straight from the
 // registers: a lane owns a row, v_permlane32_swap pairs the 4-column quads into 16-byte stores (as the GEMM epilogue)
-XC_DEV void a3_store_rows_direct(const f32x16 (&acc)[2], bf16_t* dst, long ldd, int row0, int nrows, int lane) {
+XC_DEV void a3_store_rows_direct(const f32x16 (&acc)[2], bf16_t* dst, long ldd, int row0, int nrows, int lane, float mul = 1.f) {
     const int c31 = lane & 31, h = lane >> 5;
     const int row = row0 + c31;
 #pragma unroll
@@ -278,8 +372,8 @@ XC_DEV void a3_store_rows_direct(const f32x16 (&acc)[2], bf16_t* dst, long ldd, 
         uint32_t pk[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            pk[q][0] = (uint32_t)f2bf(acc[db][4 * q]) | ((uint32_t)f2bf(acc[db][4 * q + 1]) << 16);
-            pk[q][1] = (uint32_t)f2bf(acc[db][4 * q + 2]) | ((uint32_t)f2bf(acc[db][4 * q + 3]) << 16);
+            pk[q][0] = f2bf_pk(acc[db][4 * q] * mul, acc[db][4 * q + 1] * mul);
+            pk[q][1] = f2bf_pk(acc[db][4 * q + 2] * mul, acc[db][4 * q + 3] * mul);
         }
 #pragma unroll
         for (int qq = 0; qq < 4; qq += 2) {
@@ -318,6 +412,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
     float* Tp = Ds + npad;                                     // [nwaves][A3_TAIL_MAX][128] tail partials: dQ (phase A), dK | dV (phase B)
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c31 = lane & 31;
     const int wave = uniform(tid >> 6), nwaves = blockDim.x >> 6;
+    a3_stagger(p.stagger_10ns);
     const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
     const int hh = bh % p.heads, bi = bh / p.heads;
     const long ldq = 3L * p.heads * ATT_DH, ldo = (long)p.heads * ATT_DH;
@@ -358,6 +453,8 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
     }
     wait_vmem();
     sync();
+    uint32_t plain_bits = 0;                                   // bit t: every key of sub-tile t is valid (npad <= 288: 9 sub-tiles)
+    for (int t = 0; t < nsub; ++t) plain_bits |= wave_all(Ms[t * 32 + c31] != 0) ? (1u << t) : 0u;
 
     // ---- phase A: dQ^T[d, query] for the wave's query blocks, streaming the key sub-tiles of the K / V images ----
     u32x4 f0[4], f1[4];                                        // the block's own rows: (Q, dO) in phase A, (K, V) in phase B
@@ -372,7 +469,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g0[db][r] = 0.f;
             const float lq = Ls[tail0 + c31], dl = Ds[tail0 + c31];
-            for (int t = wave; t < nsub; t += nwaves) a3_bwd_dq_step<CAUSAL>(R0, R1, Ms, t, f0, f1, lq, dl, p.scale, scale2, lane, tail0 + c31, g0);
+            a3_bwd_dq_sweep<CAUSAL>(R0, R1, Ms, wave, nsub, nwaves, plain_bits, f0, f1, lq, dl, scale2, lane, tail0 + c31, g0);
             if (c31 < ntail) a3_put_col(Tp + ((long)wave * A3_TAIL_MAX + c31) * 128, g0, lane);
         }
         for (int rb = wave; rb < nblk; rb += nwaves) {
@@ -386,8 +483,8 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
                 for (int r = 0; r < 16; ++r) g0[db][r] = 0.f;
             const float lse_q = Ls[row], delta_q = Ds[row];
             const int tend = CAUSAL ? (rb + 1 < nsub ? rb + 1 : nsub) : nsub;      // key sub-tiles above the diagonal contribute nothing
-            for (int t = 0; t < tend; ++t) a3_bwd_dq_step<CAUSAL>(R0, R1, Ms, t, f0, f1, lse_q, delta_q, p.scale, scale2, lane, row, g0);
-            a3_store_rows_direct(g0, dQ, ldq, rb * 32, n, lane);
+            a3_bwd_dq_sweep<CAUSAL>(R0, R1, Ms, 0, tend, 1, plain_bits, f0, f1, lse_q, delta_q, scale2, lane, row, g0);
+            a3_store_rows_direct(g0, dQ, ldq, rb * 32, n, lane, p.scale);
         }
     }
     sync();                                                    // every wave is done with the K / V images; the tail partials are complete
@@ -397,7 +494,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
         for (int q = 0; q < ntail; ++q) {
             float acc = 0.f;
             for (int w = 0; w < nwaves; ++w) acc += Tp[((long)w * A3_TAIL_MAX + q) * 128 + lane];
-            dQ[(long)(tail0 + q) * ldq + lane] = f2bf(acc);
+            dQ[(long)(tail0 + q) * ldq + lane] = f2bf(acc * p.scale);
         }
     }
     wait_vmem();
@@ -415,9 +512,10 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { g0[db][r] = 0.f; g1[db][r] = 0.f; }
-            for (int t = CAUSAL ? rb : 0; t < nsub; ++t)                           // query sub-tiles below the diagonal see none of these keys
-                a3_bwd_dkv_step<CAUSAL>(R0, R1, Ls, Ds, t, n, f0, f1, kvalid, p.scale, scale2, lane, row, g0, g1);
-            a3_store_rows_direct(g0, dK, ldq, rb * 32, n, lane);
+            const bool keys_plain = wave_all(kvalid);                              // (uniform: no padding among this block's keys)
+            // (query sub-tiles below the diagonal see none of these keys)
+            a3_bwd_dkv_sweep<CAUSAL>(R0, R1, Ls, Ds, CAUSAL ? rb : 0, nsub, 1, n, keys_plain, f0, f1, kvalid, scale2, lane, row, g0, g1);
+            a3_store_rows_direct(g0, dK, ldq, rb * 32, n, lane, p.scale);
             a3_store_rows_direct(g1, dV, ldq, rb * 32, n, lane);
         }
         if (coop) {                                            // tail keys: this wave's share of the query sub-tiles
@@ -429,8 +527,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { g0[db][r] = 0.f; g1[db][r] = 0.f; }
-            for (int t = wave; t < nsub; t += nwaves)
-                a3_bwd_dkv_step<CAUSAL>(R0, R1, Ls, Ds, t, n, f0, f1, tvalid, p.scale, scale2, lane, tail0 + c31, g0, g1);
+            a3_bwd_dkv_sweep<CAUSAL>(R0, R1, Ls, Ds, wave, nsub, nwaves, n, false, f0, f1, tvalid, scale2, lane, tail0 + c31, g0, g1);
             if (c31 < ntail) {
                 float* rec = Tp + ((long)wave * A3_TAIL_MAX + c31) * 128;
                 a3_put_col(rec, g0, lane);
@@ -448,7 +545,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
                     ak += rec[lane];
                     av += rec[64 + lane];
                 }
-                dK[(long)(tail0 + q) * ldq + lane] = f2bf(ak);
+                dK[(long)(tail0 + q) * ldq + lane] = f2bf(ak * p.scale);
                 dV[(long)(tail0 + q) * ldq + lane] = f2bf(av);
             }
         }
