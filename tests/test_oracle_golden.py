@@ -12,7 +12,7 @@ from oracle.clip_oracle import (ClipConfig, clip_forward, make_inputs, make_stat
                                 simloss_closed_form, state_dict_shapes)
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.json")) if not os.path.basename(p).startswith("dist"))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.json")) if not os.path.basename(p).startswith(("dist", "tokenizer")))
 
 
 def load(path):

@@ -236,11 +236,9 @@ XC_DEV void a3_tile_rows(const unsigned char* img, int t, int lane, u32x4 (&f)[4
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) f[kb] = a3_row_frag(img, t, kb, lane);
 }
-template <bool CAUSAL>
-XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Ms, int t, const u32x4 (&kr)[4], const u32x4 (&vr)[4],
-                           const u32x4 (&qf)[4], const u32x4 (&dof)[4], float lse2_q, float delta_q, float scale2, int lane, int qidx,
-                           f32x16 (&dq)[2], bool masked) {
-    f32x16 s, dp;
+// S^T and dP^T - delta of one sub-tile: the two MFMA chains only (the caller issues them one sub-tile AHEAD of the score arithmetic)
+XC_DEV void a3_bwd_dq_scores(const u32x4 (&kr)[4], const u32x4 (&vr)[4], const u32x4 (&qf)[4], const u32x4 (&dof)[4], float delta_q,
+                             f32x16& s, f32x16& dp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -delta_q; }
 #pragma unroll
@@ -248,6 +246,11 @@ XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Ms, int
         s = mma_kblock(kr[kb], qf[kb], s, (bf16_t*)nullptr);
         dp = mma_kblock(vr[kb], dof[kb], dp, (bf16_t*)nullptr);
     }
+}
+// probabilities, dS^T and dQ^T += K^T dS^T of sub-tile t from its finished score accumulators
+template <bool CAUSAL>
+XC_DEV void a3_bwd_dq_finish(const unsigned char* Ks, const unsigned char* Ms, int t, f32x16& s, const f32x16& dp, float lse2_q, float scale2,
+                             int lane, int qidx, f32x16 (&dq)[2], bool masked) {
     if (masked || CAUSAL) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -266,25 +269,34 @@ XC_DEV void a3_bwd_dq_step(const unsigned char* Ks, const unsigned char* Ms, int
         for (int db = 0; db < 2; ++db) dq[db] = mma_kblock(a3_col_frag(Ks, t, blk, db, lane), df, dq[db], (bf16_t*)nullptr);
     }
 }
-// sub-tiles t0, t0 + dt, ... < tend of the K / V images against one query block, fragments of the next sub-tile in flight.
-// plain_bits: bit t set = all 32 keys of sub-tile t are valid (voted once per head, not per step)
+// sub-tiles t0, t0 + dt, ... < tend of the K / V images against one query block, software-pipelined: while the score arithmetic of
+// sub-tile t runs on the VALU, the MFMA chains of t + dt are already in the matrix pipe.  plain_bits: bit t set = all 32 keys of sub-tile t are valid (voted once per head)
 template <bool CAUSAL>
 XC_DEV void a3_bwd_dq_sweep(const unsigned char* Ks, const unsigned char* Vs, const unsigned char* Ms, int t0, int tend, int dt,
                             uint32_t plain_bits, const u32x4 (&qf)[4], const u32x4 (&dof)[4], float lse2_q, float delta_q, float scale2,
                             int lane, int qidx, f32x16 (&dq)[2]) {
     if (t0 >= tend) return;
-    u32x4 ka[4], va[4], kb[4], vb[4];
-    a3_tile_rows(Ks, t0, lane, ka);
-    a3_tile_rows(Vs, t0, lane, va);
+    // (one fragment buffer, two score sets: fragments AND scores two deep need 254 + 24 registers -- one wave per SIMD)
+    u32x4 kr[4], vr[4];
+    f32x16 sa, da, sb, db;
+    a3_tile_rows(Ks, t0, lane, kr);
+    a3_tile_rows(Vs, t0, lane, vr);
+    a3_bwd_dq_scores(kr, vr, qf, dof, delta_q, sa, da);
     for (int t = t0; t < tend; t += 2 * dt) {
         const int t1 = t + dt, t2 = t + 2 * dt;
-        a3_tile_rows(Ks, t1 < tend ? t1 : t, lane, kb);
-        a3_tile_rows(Vs, t1 < tend ? t1 : t, lane, vb);
-        a3_bwd_dq_step<CAUSAL>(Ks, Ms, t, ka, va, qf, dof, lse2_q, delta_q, scale2, lane, qidx, dq, !((plain_bits >> t) & 1u));
         if (t1 < tend) {
-            a3_tile_rows(Ks, t2 < tend ? t2 : t1, lane, ka);
-            a3_tile_rows(Vs, t2 < tend ? t2 : t1, lane, va);
-            a3_bwd_dq_step<CAUSAL>(Ks, Ms, t1, kb, vb, qf, dof, lse2_q, delta_q, scale2, lane, qidx, dq, !((plain_bits >> t1) & 1u));
+            a3_tile_rows(Ks, t1, lane, kr);
+            a3_tile_rows(Vs, t1, lane, vr);
+            a3_bwd_dq_scores(kr, vr, qf, dof, delta_q, sb, db);
+        }
+        a3_bwd_dq_finish<CAUSAL>(Ks, Ms, t, sa, da, lse2_q, scale2, lane, qidx, dq, !((plain_bits >> t) & 1u));
+        if (t1 < tend) {
+            if (t2 < tend) {
+                a3_tile_rows(Ks, t2, lane, kr);
+                a3_tile_rows(Vs, t2, lane, vr);
+                a3_bwd_dq_scores(kr, vr, qf, dof, delta_q, sa, da);
+            }
+            a3_bwd_dq_finish<CAUSAL>(Ks, Ms, t1, sb, db, lse2_q, scale2, lane, qidx, dq, !((plain_bits >> t1) & 1u));
         }
     }
 }

@@ -336,7 +336,7 @@ def cast_from_f32(src: Tensor, dtype, scale: float = 1.0) -> Tensor:
 # ---- GEMM -----------------------------------------------------------------------------------------------------------
 # which production bf16 GEMM kernel the library carries: measurements that cannot be taken inside a run (the PMC traffic figure of
 # profiles/gemm_traffic.json) are tagged with it and ignored by bench.py when they belong to an older kernel
-GEMM_GENERATION = "gemm5"
+GEMM_GENERATION = "gemm5b"   # (b: whole-line epilogue stores through LDS)
 
 
 class GemmProbe:
