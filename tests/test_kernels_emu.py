@@ -148,6 +148,13 @@ def test_gemm4_residual_epilogue(layout, M, N, K_, alpha, in_place):
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha, residual_only=True, in_place=in_place)
 
 
+def test_gemm4_slab_epilogue_interior_tiles():
+    """split-K weight-gradient shape whose tiles are all interior: the fp32 slab leaves through the wave-private LDS transposition
+    (whole-line stores) -- only the LOGIC can be checked here; the store hazard this path once hit exists on the hardware only
+    (tests/test_kernels_gpu.py::test_gemm_layouts[520-512-2048-tn], tools/debug/slab_epilogue_check.py)"""
+    K.case_gemm(DEV, torch.bfloat16, 512, 256, 1024, "tn")
+
+
 def test_gemm2_epilogue_and_splitk():
     K.case_gemm(DEV, torch.bfloat16, 136, 264, 64, "nt", epilogue=True, alpha=0.5)
     K.case_gemm(DEV, torch.bfloat16, 776, 264, 64, "nt", epilogue=True, alpha=0.5)      # persistent + epilogue terms

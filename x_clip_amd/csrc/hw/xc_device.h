@@ -147,15 +147,19 @@ XC_DEV u32x4 buf_ld16(BufRsrc r, uint32_t voff, uint32_t soff) {
 // VALU write to the first of them in the very next instruction reached memory instead of the store's value -- rarely, in 4-lane
 // groups, only with a REGISTER soffset (for which hipcc / ROCm 7.2 inserts no wait state: its hazard table covers the immediate-soffset
 // form only), first seen as garbage in one dword of a few rows of the residual epilogue (tools/debug/res_epilogue_check.py).
+// The five wait states IN FRONT are load-bearing too: the compiler does not look into an asm statement, and when it has spilled the
+// scalar offset (or the descriptor) to a VGPR lane it reloads it with v_readlane right before the statement -- a VALU write of an SGPR
+// that a vector-memory instruction reads needs 5 wait states.  Without them the fp32 slab epilogue stored whole tiles to stale offsets
+// (tools/debug/slab_epilogue_check.py; the emulator cannot see it).
 template <int IMM>
 XC_DEV void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
 }
 // wait until every outstanding vector-memory operation of this wave (LDS DMA included) has completed
 // the same store with the non-temporal hint (streaming: the line is the first to leave the L2)
 template <int IMM>
 XC_DEV void buf_st16_nt(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4 nt\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4 nt\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
 }
 XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // lds_read_tr16 (ds_read_b64_tr_b16): within each 16-lane group, lane c (slot j) receives the 16-bit element

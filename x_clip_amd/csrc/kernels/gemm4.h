@@ -189,7 +189,8 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 sched_fence();
             }
         }
-        (void)epi(acc, m0, n0);
+        // (the 32 KiB above the two stages: 4 KiB per wave for the whole-line form of the fp32 slab epilogue)
+        (void)epi.with_scratch(acc, m0, n0, lds + 2 * G2_STAGE_BYTES + wave * 4096);
     }
     XC_WAIT_VMEM_LE(0);                                       // the trailing (redundant) DMA pieces must land before the LDS is released
     epi.finish();
@@ -640,6 +641,49 @@ struct G4GemmEpilogue {
                 }
             }
         }
+    }
+
+    // interior tile, fp32 split-K slab, every store 8 rows x 128 contiguous bytes (as store_lines; the weight-gradient GEMMs are one
+    // tile per work-group, and 256 row-per-lane store instructions were ~12 us of each launch): eight passes of 32 rows x 32 columns
+    // through the wave's 4 KiB scratch
+    XC_DEV void store_full_slab_lds(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
+        const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const float* slab = p.partial + ((long)blockIdx.y * p.M + m0) * p.N + n0;
+        const BufRsrc rc = make_rsrc(slab, 255u * (uint32_t)p.N * 4u + 1024u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.N + (uint32_t)(wn * 64 + 4 * (lane & 7))) * 4u;
+        const uint32_t s8 = (uint32_t)p.N * 32u;                                    // 8 rows * N * 4 bytes
+        unsigned char* const wr = scratch + r * 128;                                // + chunk position * 16
+        const unsigned char* const rd = scratch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + 1024 per 8 rows
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                                       // columns 32 j + 8 q + 4 h + (0..3) of row r: chunk 2 q + h
+                    const u32x4 v = {f2u(acc[i][j][4 * q]), f2u(acc[i][j][4 * q + 1]), f2u(acc[i][j][4 * q + 2]), f2u(acc[i][j][4 * q + 3])};
+                    *reinterpret_cast<u32x4*>(wr + (((2 * q + h) ^ (r & 7)) << 4)) = v;
+                }
+                lds_fence();
+                u32x4 o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = *reinterpret_cast<const u32x4*>(rd + k * 1024);
+                lds_fence();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j == 0) buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
+                    else buf_st16<128>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
+                }
+            }
+        }
+    }
+    // the caller owns 4 KiB of LDS per wave that nothing else touches while the epilogue runs (g4_run)
+    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
+        if (MODE == G4_SLAB && (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N)) {
+            store_full_slab_lds(acc, m0, n0, scratch);
+            return 32;
+        }
+        return (*this)(acc, m0, n0);
     }
 
     // -> how many vector-memory operations per lane the epilogue issued when that number is fixed (interior tiles: 16 / 32 stores),

@@ -147,8 +147,8 @@ void launch_gemm4(const Gemm2Params& p, dim3 pgrid, bool ring3, hipStream_t st) 
         XC_ALLOW_LDS((gemm5_kernel<AK, BK_, MODE>), G5_LDS_BYTES);
         hipLaunchKernelGGL((gemm5_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
     } else {
-        XC_ALLOW_LDS((gemm4_kernel<AK, BK_, MODE>), G3_LDS_BYTES);
-        hipLaunchKernelGGL((gemm4_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G3_LDS_BYTES, st, p);
+        XC_ALLOW_LDS((gemm4_kernel<AK, BK_, MODE>), G5_LDS_BYTES);   // two stages + 32 KiB of epilogue scratch (gemm4.h g4_run)
+        hipLaunchKernelGGL((gemm4_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
     }
 }
 template <bool AK, bool BK_>
