@@ -423,7 +423,8 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             else epi.template store_lines<false>(o, m0, n0);
             in_flight = 16;
         } else {
-            in_flight = epi(acc, m0, n0);
+            // (residual / slab tiles take the same 4 KiB slice for their whole-line forms; ragged tiles and the general terms ignore it)
+            in_flight = epi.with_scratch(acc, m0, n0, ldsA + (sa3 == 0 ? 2 : sa3 - 1) * G2_OPER_BYTES + mine);
             a_early = false;
         }
     }
@@ -643,6 +644,54 @@ struct G4GemmEpilogue {
         }
     }
 
+    // interior tile, bf16 output with a residual term, residual loads AND stores as whole 128-byte lines.  Per 32-row group: the
+    // residual lines (requested one group ahead) go into the wave's LDS slice in line order and come back in the accumulator layout
+    // (8 bytes per 32 x 32 quad), the sum is formed in fp32 and rounded once, and the packed result takes the way of store_lines.
+    // In place (residual == C) is fine: a group's lines are loaded before they are stored, by the same lanes.
+    XC_DEV void store_full_res_lds(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
+        const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
+        const BufRsrc rr = make_rsrc(p.residual + (long)m0 * p.ldr + n0, 255u * (uint32_t)p.ldr * 2u + 512u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+        const uint32_t vr = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.ldr + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+        const uint32_t c8 = (uint32_t)p.ldc * 16u, r8 = (uint32_t)p.ldr * 16u;      // 8 rows * ld * 2 bytes
+        unsigned char* const quad = scratch + r * 128 + 8 * h;                      // accumulator layout: + chunk position * 16
+        unsigned char* const line = scratch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // line layout: + 1024 per 8 rows
+        const float al = p.alpha;
+        u32x4 res[2][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) res[0][k] = buf_ld16<0>(rr, vr, r8 * (uint32_t)k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) res[(i + 1) & 1][k] = buf_ld16<0>(rr, vr, r8 * (uint32_t)(4 * (i + 1) + k));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(line + k * 1024) = res[i & 1][k];
+            lds_fence();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                                       // columns 32 j + 8 q + 4 h + (0..3) of row r
+                    unsigned char* const at = quad + (((4 * j + q) ^ (r & 7)) << 4);
+                    const u32x2 rv = *reinterpret_cast<const u32x2*>(at);
+                    const float* a = reinterpret_cast<const float*>(&acc[i][j]) + 4 * q;
+                    const u32x2 v = {f2bf_pk(a[0] * al + u2f(rv[0] << 16), a[1] * al + u2f(rv[0] & 0xffff0000u)),
+                                     f2bf_pk(a[2] * al + u2f(rv[1] << 16), a[3] * al + u2f(rv[1] & 0xffff0000u))};
+                    *reinterpret_cast<u32x2*>(at) = v;                              // (this lane's own 8 bytes: read, then overwritten)
+                }
+            }
+            lds_fence();
+            u32x4 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = *reinterpret_cast<const u32x4*>(line + k * 1024);
+            lds_fence();                                                            // (the next group's residual overwrites the slice)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) buf_st16<0>(rc, vc, c8 * (uint32_t)(4 * i + k), o[k]);
+        }
+    }
     // interior tile, fp32 split-K slab, every store 8 rows x 128 contiguous bytes (as store_lines; the weight-gradient GEMMs are one
     // tile per work-group, and 256 row-per-lane store instructions were ~12 us of each launch): eight passes of 32 rows x 32 columns
     // through the wave's 4 KiB scratch
@@ -679,9 +728,14 @@ struct G4GemmEpilogue {
     }
     // the caller owns 4 KiB of LDS per wave that nothing else touches while the epilogue runs (g4_run)
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
-        if (MODE == G4_SLAB && (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N)) {
+        const bool full = (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N);
+        if (MODE == G4_SLAB && full) {
             store_full_slab_lds(acc, m0, n0, scratch);
             return 32;
+        }
+        if (MODE == G4_RES && full) {
+            store_full_res_lds(acc, m0, n0, scratch);
+            return 0;                                            // (loads and stores mixed: the next wait drains them)
         }
         return (*this)(acc, m0, n0);
     }
@@ -744,6 +798,7 @@ struct G4ProbeEpilogue {
         return 16;
     }
     XC_DEV bool packs_lines(int, int) const { return false; }
+    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return (*this)(acc, m0, n0); }
     XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4]) const {}
     template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
 };
