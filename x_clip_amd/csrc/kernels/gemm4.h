@@ -559,92 +559,10 @@ struct G4GemmEpilogue {
                 else buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[i][k]);
             }
     }
-    // interior tile, bf16 output with a residual term.  The general epilogue reads the residual 8 bytes at a time right where it is
-    // used, and with LDS-DMA pieces in flight every such load is followed by a full vmcnt drain: 32 dependent memory round trips per
-    // tile (the FF2 forward ran at 785 TFLOP/s against 1127 for the same product without the skip term).  Here the accumulators are
-    // brought into the STORE layout in fp32 first (v_permlane32_swap on the fp32 quads: a lane then owns 8 consecutive columns), so the
-    // residual arrives as the same 16-byte pieces the stores write, all loads of a half tile are issued together, and there are two
-    // round trips per tile.
-    XC_DEV void store_full_res(f32x16 (&acc)[4][2], int m0, int n0) const {
-        const int lane = threadIdx.x & 63, h = lane >> 5;
-        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
-        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
-        const BufRsrc rr = make_rsrc(p.residual + (long)m0 * p.ldr + n0, 255u * (uint32_t)p.ldr * 2u + 512u);
-        const uint32_t vc = ((uint32_t)(wm * 128 + (lane & 31)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * h)) * 2u;
-        const uint32_t vr = ((uint32_t)(wm * 128 + (lane & 31)) * (uint32_t)p.ldr + (uint32_t)(wn * 64 + 8 * h)) * 2u;
-        const uint32_t sc = (uint32_t)p.ldc * 64u, sr = (uint32_t)p.ldr * 64u;      // 32 rows * ld * 2 bytes
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            u32x4 res[2][2][2];                                                     // [i in the half][j][16-column half]
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = half * 2 + ii;
-                res[ii][0][0] = buf_ld16<0>(rr, vr, sr * i);
-                res[ii][0][1] = buf_ld16<32>(rr, vr, sr * i);
-                res[ii][1][0] = buf_ld16<64>(rr, vr, sr * i);
-                res[ii][1][1] = buf_ld16<96>(rr, vr, sr * i);
-            }
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = half * 2 + ii;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                    for (int qq = 0; qq < 4; qq += 2) {
-                        // quads qq, qq + 1 -> this lane's 8 consecutive columns (lower half-wave: [8 qq, 8 qq + 8), upper: the next 8)
-                        float lo[4], hi[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            uint32_t a = f2u(acc[i][j][4 * qq + e]), b = f2u(acc[i][j][4 * qq + 4 + e]);
-                            permlane32_swap(a, b);
-                            lo[e] = u2f(a) * p.alpha;
-                            hi[e] = u2f(b) * p.alpha;
-                        }
-                        const u32x4 r = res[ii][j][qq >> 1];
-                        lo[0] += u2f(r[0] << 16); lo[1] += u2f(r[0] & 0xffff0000u); lo[2] += u2f(r[1] << 16); lo[3] += u2f(r[1] & 0xffff0000u);
-                        hi[0] += u2f(r[2] << 16); hi[1] += u2f(r[2] & 0xffff0000u); hi[2] += u2f(r[3] << 16); hi[3] += u2f(r[3] & 0xffff0000u);
-                        const u32x4 o = {f2bf_pk(lo[0], lo[1]), f2bf_pk(lo[2], lo[3]), f2bf_pk(hi[0], hi[1]), f2bf_pk(hi[2], hi[3])};
-                        if (j == 0 && qq == 0) buf_st16<0>(rc, vc, sc * i, o);
-                        else if (j == 0) buf_st16<32>(rc, vc, sc * i, o);
-                        else if (qq == 0) buf_st16<64>(rc, vc, sc * i, o);
-                        else buf_st16<96>(rc, vc, sc * i, o);
-                    }
-                }
-            }
-        }
-    }
-    // interior tile, fp32 split-K slab: 32 stores of 4 floats per lane
-    XC_DEV void store_full_slab(f32x16 (&acc)[4][2], int m0, int n0) const {
-        const int lane = threadIdx.x & 63, h = lane >> 5;
-        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
-        const float* slab = p.partial + ((long)blockIdx.y * p.M + m0) * p.N + n0;
-        const BufRsrc rc = make_rsrc(slab, 255u * (uint32_t)p.N * 4u + 1024u);
-        const uint32_t vc = ((uint32_t)(wm * 128 + (lane & 31)) * (uint32_t)p.N + (uint32_t)(wn * 64 + 4 * h)) * 4u;
-        const uint32_t si = (uint32_t)p.N * 128u;                                   // 32 rows * N * 4 bytes
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const u32x4 v0 = {f2u(acc[i][j][0]), f2u(acc[i][j][1]), f2u(acc[i][j][2]), f2u(acc[i][j][3])};
-                const u32x4 v1 = {f2u(acc[i][j][4]), f2u(acc[i][j][5]), f2u(acc[i][j][6]), f2u(acc[i][j][7])};
-                const u32x4 v2 = {f2u(acc[i][j][8]), f2u(acc[i][j][9]), f2u(acc[i][j][10]), f2u(acc[i][j][11])};
-                const u32x4 v3 = {f2u(acc[i][j][12]), f2u(acc[i][j][13]), f2u(acc[i][j][14]), f2u(acc[i][j][15])};
-                if (j == 0) {
-                    buf_st16<0>(rc, vc, si * i, v0);
-                    buf_st16<32>(rc, vc, si * i, v1);
-                    buf_st16<64>(rc, vc, si * i, v2);
-                    buf_st16<96>(rc, vc, si * i, v3);
-                } else {
-                    buf_st16<128>(rc, vc, si * i, v0);
-                    buf_st16<160>(rc, vc, si * i, v1);
-                    buf_st16<192>(rc, vc, si * i, v2);
-                    buf_st16<224>(rc, vc, si * i, v3);
-                }
-            }
-        }
-    }
-
-    // interior tile, bf16 output with a residual term, residual loads AND stores as whole 128-byte lines.  Per 32-row group: the
+    // interior tile, bf16 output with a residual term, residual loads AND stores as whole 128-byte lines.  (History: the general
+    // epilogue reads the residual 8 bytes at a time where it uses it, and with LDS-DMA pieces in flight every such load drained vmcnt --
+    // 32 dependent round trips per tile, the FF2 forward at 785 TFLOP/s against 1127 without the skip term; a first straight-line
+    // version brought the accumulators into the row-per-lane store layout with v_permlane32_swap on fp32 quads: 1029.)  Per 32-row group: the
     // residual lines (requested one group ahead) go into the wave's LDS slice in line order and come back in the accumulator layout
     // (8 bytes per 32 x 32 quad), the sum is formed in fp32 and rounded once, and the packed result takes the way of store_lines.
     // In place (residual == C) is fine: a group's lines are loaded before they are stored, by the same lanes.
@@ -749,14 +667,7 @@ struct G4GemmEpilogue {
             store_bf16<false>(acc, m0, n0);
             return 0;
         }
-        if (MODE == G4_SLAB && full) {
-            store_full_slab(acc, m0, n0);
-            return 32;
-        }
-        if (MODE == G4_RES && full) {
-            store_full_res(acc, m0, n0);
-            return 0;                                            // (loads and stores mixed: the next wait drains them)
-        }
+        // (interior slab / residual tiles leave through with_scratch's whole-line forms)
         // ragged slab tiles and the optional epilogue terms: the general form (per-element range checks, clamped reads)
         (void)G3GemmEpilogue<0>{p}(acc, m0, n0);
         return 0;
