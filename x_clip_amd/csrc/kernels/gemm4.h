@@ -441,19 +441,22 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     }
 }
 
-// ---- epilogue: registers -> global, one output row per lane ----------------------------------------------------------------
-// Measured and NOT kept (MI355X, K = 512 shapes, where a tile is 8 K steps and its boundary costs ~6.5 us -- the fit of tile time
-// against K steps over K = 512 ... 4096 is 6.5 us + 1.80 us per step): holding half of the packed tile in 32 registers and issuing
-// its 8 stores one at a time behind MFMA pairs of the next tile's first K step (789 vs 801 TF/s on the QKV forward: nothing); static
-// s_setprio 1 for waves 4-7 (nothing); sc1 / sc0 sc1 write-through stores that do not stay in L2 (543 vs 801 TF/s: every wait then
-// sits on an HBM acknowledgement); nt stores (786 vs 801).  Cutting the epilogue's VALU work from ~550 to ~230 instructions per wave
-// (packed conversions, C = 0 first k-block, alpha applied with packed multiplies) moved nothing either: the boundary cost is not
-// instruction issue (profiles/r02_run2_gemm4_defer_prio_probe.log, r02_run3_gemm4_store_policy_probe.log).  With g5_run's first wait
-// of a tile leaving the stores in flight (below) the same: sc1 546 vs 834 TF/s, nt +4 % at N = 4096 but -15 % at N = 512
-// (profiles/r02_run9_gemm5_store_policy_probe.log); and the stores of the second half issued one per K step of the next tile were
-// SLOWER (772 vs 810: profiles/r02_run7_gemm5_paced_stores_probe.log).  What the counters say instead: the forward GEMMs fetch 2-4 x
-// their algorithmic A bytes from the fabric (profiles/r02_run6_hbm_traffic_pmc.txt) -- the output stream of a tile round is as large
-// as all L2s together and evicts the A panels the sibling N tiles share.
+// ---- epilogue: registers -> global ------------------------------------------------------------------------------------------------
+// Interior tiles leave as whole 128-byte lines through a wave-private LDS transposition (store_lines / store_full_res_lds /
+// store_full_slab_lds below); ragged tiles keep the row-per-lane form (one output row per lane, store_bf16<false> / the general epilogue).
+//
+// How the tile boundary was understood (MI355X, K = 512 shapes: a tile is 8 K steps and its boundary cost ~6 us of ~20).  First the
+// things that were measured and did NOT pay with the row-per-lane stores (profiles/r02_run2/3/7/8/9): holding half of the packed tile
+// in 32 registers and issuing its 8 stores one at a time behind MFMA pairs of the next tile's first K step (789 vs 801 TF/s on the QKV
+// forward); static s_setprio 1 for waves 4-7; sc1 / sc0 sc1 write-through stores (543 vs 801: every wait then sits on an HBM
+// acknowledgement); nt stores (+4 % at N = 4096, -15 % at N = 512); a counted first wait that leaves the stores in flight; one store
+// per K step of the next tile (772 vs 810); cutting the epilogue's VALU work from ~550 to ~230 instructions per wave.  Then the
+// ablation harness (XCLIP_GEMM5_ABL, profiles/r02_run16): the SAME 16 store instructions per lane cost 4.1 us instead of 5.8 when each
+// covers 8 rows x 128 contiguous bytes instead of 32 rows x 32 bytes -- a store instruction occupies the CU's one address path for
+// about as many cycles as it touches cache lines -- and the cycle stamps (profiles/r02_run17): the K steps after a boundary ran at
+// 3000-4100 cycles instead of 2440 because the next tile's A pieces queued behind 128 KiB of stores.  Hence the whole-line forms, the
+// A pieces issued between pack_lines and store_lines (g5_run), and -- now that a store is cheap to issue -- the non-temporal hint for
+// outputs that cannot stay in the L2s anyway (stream_out).
 template <int MODE>
 struct G4GemmEpilogue {
     const Gemm2Params& p;
