@@ -656,3 +656,31 @@ def case_gemm_splitk_uneven(dev, M=1248, N=768, K=6144):
     ws.fill_(0xFF)
     c = ops.gemm(a.to(dev), b.to(dev), M, N, K, b_kmajor=True)
     close(c, ref64(a) @ ref64(b), dtype, "gemm split-K uneven")
+
+
+def case_gemm_fuzz(dev, cases=150, seed=1):
+    """random shapes / layouts / epilogue terms of xclip_gemm against fp32 torch: interior and ragged tiles, split-K slabs, the residual
+    form, alpha -- the paths whose hardware-only store hazards neither the emulator nor a fixed shape list shows"""
+    g = torch.Generator().manual_seed(seed)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+    for _ in range(cases):
+        lay = ["nt", "nn", "tn"][ri(0, 2)]
+        M = 8 * ri(16, 200) if ri(0, 3) else 256 * ri(1, 6)
+        N = 8 * ri(16, 200) if ri(0, 3) else 256 * ri(1, 6)
+        K = 64 * ri(1, 40) if lay != "tn" else 64 * ri(4, 300)
+        res = lay == "nt" and ri(0, 2) == 0
+        alpha = [1.0, 0.5, 0.125][ri(0, 2)] if not res else 1.0
+        ak, bk = lay[0] == "t", lay[1] == "n"
+        a = torch.randn((K, M) if ak else (M, K), generator=g).to(torch.bfloat16).to(dev)
+        b = torch.randn((K, N) if bk else (N, K), generator=g).to(torch.bfloat16).to(dev)
+        r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev) if res else None
+        got = ops.gemm(a, b, M, N, K, ak, bk, alpha=alpha, residual=r).float()
+        want = alpha * ((a.float().t() if ak else a.float()) @ (b.float() if bk else b.float().t()))
+        if res:
+            want = want + r.float()
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        assert bool(torch.isfinite(got).all()) and err <= scale * 2.0 ** -7, f"gemm {lay} {M}x{N}x{K} res={res} alpha={alpha}: {err:.3e} vs {scale:.3e}"

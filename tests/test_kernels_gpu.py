@@ -231,3 +231,7 @@ def test_nt_xent(dtype, rows, dim, temperature):
 
 def test_gemm_splitk_uneven_slices():
     K.case_gemm_splitk_uneven(DEV)
+
+
+def test_gemm_random_shapes():
+    K.case_gemm_fuzz(DEV, 150, seed=1)
