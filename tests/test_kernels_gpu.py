@@ -235,3 +235,15 @@ def test_gemm_splitk_uneven_slices():
 
 def test_gemm_random_shapes():
     K.case_gemm_fuzz(DEV, 150, seed=1)
+
+
+def test_attention_random_lengths_bf16():
+    """sequence lengths the fixed list does not hit (every residue of n mod 32 changes which sub-tiles are masked, which blocks are
+    cooperative tails and how the software-pipelined sweeps end), with and without key padding / causal masking"""
+    g = torch.Generator().manual_seed(5)
+    for _ in range(14):
+        n = int(torch.randint(33, 289, (1,), generator=g))
+        heads = int(torch.randint(1, 4, (1,), generator=g))
+        masked = bool(torch.randint(0, 2, (1,), generator=g))
+        causal = bool(torch.randint(0, 3, (1,), generator=g) == 0)
+        K.case_attention(DEV, torch.bfloat16, 2, n, heads, masked, causal=causal)
