@@ -148,6 +148,11 @@ def test_gemm4_residual_epilogue(layout, M, N, K_, alpha, in_place):
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha, residual_only=True, in_place=in_place)
 
 
+def test_gemm5_banded_tile_order():
+    """16 N tiles: the ring kernel walks them in two bands of 8 (every tile exactly once, interior + a ragged last row of tiles)"""
+    K.case_gemm(DEV, torch.bfloat16, 264, 4096, 64, "nt")
+
+
 def test_gemm4_slab_epilogue_interior_tiles():
     """split-K weight-gradient shape whose tiles are all interior: the fp32 slab leaves through the wave-private LDS transposition
     (whole-line stores) -- only the LOGIC can be checked here; the store hazard this path once hit exists on the hardware only

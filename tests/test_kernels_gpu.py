@@ -247,3 +247,9 @@ def test_attention_random_lengths_bf16():
         masked = bool(torch.randint(0, 2, (1,), generator=g))
         causal = bool(torch.randint(0, 3, (1,), generator=g) == 0)
         K.case_attention(DEV, torch.bfloat16, 2, n, heads, masked, causal=causal)
+
+
+@pytest.mark.parametrize("layout,M,N,K_", [("nt", 520, 4096, 128), ("nn", 264, 3072, 64), ("nt", 256, 6144, 64)])
+def test_gemm_banded_tile_order(layout, M, N, K_):
+    """more than 8 N tiles: the ring kernel's banded tile order (bands of 8 / 6 / 8 tiles) visits every tile exactly once"""
+    K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout)

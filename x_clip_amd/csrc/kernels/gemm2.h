@@ -113,6 +113,7 @@ struct Gemm2Params {
     float* partial;            // split-K slabs [splits][M][N] fp32, or null
     int k_per_split;
     int tiles_m, tiles_n;
+    int band_n;                // ring kernel: N tiles per band of the tile order (0 = plain n-fastest order; gemm4.h g5_run)
     int stream_out;            // interior bf16 tiles leave with non-temporal stores (an output larger than the L2s: gemm4.h store_lines)
 };
 

@@ -241,10 +241,21 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
         while (realtime_10ns() < until) nap();
     }
 
+    // Tile order inside an XCD's contiguous run: n fastest, so that the N tiles sharing an A panel run together on one L2.  With more
+    // than G4_BAND N tiles (FF1: 16) that makes every round of an XCD touch the whole B operand (4 MiB = its entire L2); the order is
+    // then banded -- all M panels against N tiles [0, G4_BAND), then against the next band -- so that an XCD keeps ONE band of B
+    // resident and reads each A panel once per band instead (p.band_n = 0: plain order).
     auto tile_origin = [&](int id, int& m0, int& n0) {
         const int tile = xcd_remap(id, ntiles);
-        m0 = (tile / p.tiles_n) * G2_BM;
-        n0 = (tile % p.tiles_n) * G2_BN;
+        if (p.band_n > 0) {
+            const int per_band = p.tiles_m * p.band_n;
+            const int band = tile / per_band, rem = tile - band * per_band;
+            m0 = (rem / p.band_n) * G2_BM;
+            n0 = (band * p.band_n + rem % p.band_n) * G2_BN;
+        } else {
+            m0 = (tile / p.tiles_n) * G2_BM;
+            n0 = (tile % p.tiles_n) * G2_BN;
+        }
     };
     const uint32_t va[2] = {g4_voff<A_KMAJOR>(p.lda, wave, lane, 0), g4_voff<A_KMAJOR>(p.lda, wave, lane, 1)};
     const uint32_t vb[2] = {g4_voff<B_KMAJOR>(p.ldb, wave, lane, 0), g4_voff<B_KMAJOR>(p.ldb, wave, lane, 1)};

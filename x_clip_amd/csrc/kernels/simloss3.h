@@ -212,7 +212,7 @@ XC_DEV Gemm2Params sim3_gemm_params(const SimParams& p) {
     g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.addrows = nullptr; g.rowidx = nullptr; g.ld_add = 0;
     g.partial = nullptr; g.k_per_split = p.d;
     g.tiles_m = (p.nq + G2_BM - 1) / G2_BM; g.tiles_n = (p.nk + G2_BN - 1) / G2_BN;
-    g.stream_out = 0;
+    g.stream_out = 0; g.band_n = 0;
     return g;
 }
 

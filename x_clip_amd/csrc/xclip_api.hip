@@ -664,6 +664,14 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
         // survive a round's 32 MiB of output (XCLIP_GEMM_NT=0 / 1 forces the policy, for measurement)
         static const int nt_env = [] { const char* e = getenv("XCLIP_GEMM_NT"); return e ? atoi(e) : -1; }();
         q.stream_out = nt_env >= 0 ? nt_env : (M * N * 2 > (int64_t)(48 << 20) ? 1 : 0);
+        // more than 8 N tiles (FF1: 16): banded tile order for the ring kernel (XCLIP_GEMM_BAND=<tiles per band>, 0 = off, for measurement)
+        static const int band_env = [] { const char* e = getenv("XCLIP_GEMM_BAND"); return e ? atoi(e) : -1; }();
+        // FF1 forward in the step: 1227 -> 1155 us (profiles/r02_run22_gemm_banded_order.log); the widest band of 4..8 tiles that divides
+        // the N tiles, none if there is none (9 tiles) or the operand fits anyway (<= 8 tiles)
+        q.band_n = 0;
+        if (band_env != 0 && q.tiles_n > 8)
+            for (int b = band_env > 0 ? band_env : 8; b >= 4 && q.band_n == 0; --b)
+                if (q.tiles_n % b == 0) q.band_n = b;
         int splits = gemm2_splits(M, N, K);
         if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
         q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);
