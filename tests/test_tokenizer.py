@@ -89,6 +89,22 @@ def test_tokenize_shapes_padding_and_errors():
     assert tok.decode(ids).strip() == "the quick brown fox"
 
 
+def test_edge_cases_against_the_oracle():
+    """specials inside text, a very long word (the heap keeps the merge loop O(n log n)), mixed scripts, entities, truncation"""
+    tok, voc = T.SimpleTokenizer(TOY), TO.load_vocab(TOY)
+    texts = ["<|startoftext|>a photo<|endoftext|> of <|startoftext|> a cat", "x" * 1500 + "photograph" * 40, "ünïcödé 日本語テキスト 🙂🙂🙂 naïve",
+             "&amp;lt;tag&amp;gt; &#233; &quot;q&quot;", "it's they've we'll i'm you'd that's 'tis", "1234567890 3.14 1e-5", "   \t\n  ", ""]
+    for t in texts:
+        assert tok.encode(t) == TO.encode(voc, t), t[:40]
+    assert tok.encode("<|startoftext|>")[0] == tok.sot_id and tok.encode("<|endoftext|>")[0] == tok.eot_id
+    long = "a photo of a cat " * 40
+    ids = tok.encode(long)
+    cut = tok.tokenize([long, "a cat"], context_length=16, truncate_text=True)
+    assert tuple(cut.shape) == (2, 16) and cut[0].tolist() == ids[:16] and cut[1, 2:].eq(0).all()
+    assert tok.decode(ids[:8], pad_tokens={ids[1]}) == tok.decode([i for i in ids[:8] if i != ids[1]])
+    assert tok.decode(torch.tensor([0, 0] + ids[:4] + [0])) == tok.decode(ids[:4])       # pad id 0 dropped (reference tokenizer.py:133)
+
+
 def _corpus(n):
     words = "a photo of the cat dog park sunset mountains running sitting quick brown fox two three".split()
     rng = np.random.RandomState(1)
