@@ -260,3 +260,26 @@ def test_edge_cases_of_the_row_kernels():
     out, lse = ops.attention_fwd(qkv, mask, 1, 0.125, True)
     dq = ops.attention_bwd(qkv, mask, out, torch.ones_like(out), lse, 1, 0.125, True)
     assert torch.isfinite(out.float()).all() and float(out[0, :3].float().abs().max()) == 0.0 and torch.isfinite(dq.float()).all()
+
+
+def test_gemm6_two_workgroups_per_cu_experiment():
+    """gemm6.h (XCLIP_GEMM=6, measured slower than the ring kernel and off by default: DESIGN.md section 6b) still computes the product --
+    the switch is read once per process, so the check runs in its own interpreter"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from x_clip_amd import _lib, ops\n"
+        "from emu.build_emu import build\n"
+        "_lib._use_library_for_tests(build())\n"
+        "for (M, N, K, alpha) in [(512, 256, 128, 1.0), (768, 384, 256, 0.5), (256, 4096, 128, 1.0)]:\n"
+        "    torch.manual_seed(0)\n"
+        "    a = torch.randn(M, K).bfloat16(); b = torch.randn(N, K).bfloat16()\n"
+        "    got = ops.gemm(a, b, M, N, K, alpha=alpha).float()\n"
+        "    want = alpha * (a.float() @ b.float().t())\n"
+        "    assert float((got - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -8, (M, N, K)\n"
+        "print('gemm6 ok')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, XCLIP_GEMM="6")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "gemm6 ok" in out.stdout, out.stderr[-2000:]

@@ -9,6 +9,7 @@
 #include "kernels/gemm2.h"
 #include "kernels/gemm3.h"
 #include "kernels/gemm4.h"
+#include "kernels/gemm6.h"
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
 #include "kernels/simloss3.h"
@@ -130,7 +131,7 @@ void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
 // a weight panel that lives in L2 -- forward (NT) and dgrad (NN): +2 ... +6 % there -- and g4_run for wgrad (TN), where BOTH operands
 // stream from HBM and the deeper A ring measured 3-11 % SLOWER (profiles/r02_run5_gemm5_ring_probe.log).
 inline int gemm_generation() {
-    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && e[0] >= '2' && e[0] <= '5') ? e[0] - '0' : 0; }();
+    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && e[0] >= '2' && e[0] <= '6') ? e[0] - '0' : 0; }();
     return v;
 }
 template <bool AK, bool BK_, int MODE>
@@ -168,8 +169,21 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     // 32-bit in-tile byte offsets: leading dimensions below 2^22 elements (anything else is not a Linear of this model)
     const bool small_ld = p.lda < (1L << 22) && p.ldb < (1L << 22) && p.ldc < (1L << 22) && (long)p.N < (1L << 21);
     if (gen != 3 && small_ld) {
-        const bool ring3 = gen == 5 || (gen == 0 && !AK);
+        const bool ring3 = gen == 5 || ((gen == 0 || gen == 6) && !AK);   // (6: gemm6.h for the shapes it takes, the default otherwise)
         const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
+        // experiment (XCLIP_GEMM=6, XCLIP_GEMM6_MAXK=<K>): two 4-wave work-groups per CU on 256 x 128 tiles for the short-K forward products
+        // whose tiles are all interior (gemm6.h)
+        if (gen == 6 && !AK && !BK_ && !terms && p.partial == nullptr && splits == 1 && p.M % G6_BM == 0 && p.N % G6_BN == 0 &&
+            p.K % G6_BK == 0 && p.K / G6_BK >= 4) {
+            static const int maxk = [] { const char* e = getenv("XCLIP_GEMM6_MAXK"); return e ? atoi(e) : 1024; }();
+            if (p.K <= maxk) {
+                const int tiles6 = (p.M / G6_BM) * (p.N / G6_BN);
+                const int g6 = tiles6 < 2 * cus ? tiles6 : 2 * cus;
+                XC_ALLOW_LDS(gemm6_kernel, G6_LDS_BYTES);
+                hipLaunchKernelGGL(gemm6_kernel, dim3((unsigned)g6), dim3(G6_THREADS), G6_LDS_BYTES, st, p);
+                return;
+            }
+        }
         const bool res_only = p.residual != nullptr && p.bias == nullptr && p.addrows == nullptr && p.ldr < (1L << 22);
         if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(p, pgrid, ring3, st);
         else if (res_only) launch_gemm4<AK, BK_, G4_RES>(p, pgrid, ring3, st);
