@@ -393,6 +393,8 @@ inline u32x4 lds_read16_async(const void* p) { return *reinterpret_cast<const u3
 inline u32x2 lds_read_tr16_async(const void* p) { return __builtin_bit_cast(u32x2, lds_read_tr16(p)); }
 template <int N>
 inline void lds_wait(u32x4 (&)[4], u32x4 (&)[2]) {}
+template <int N>
+inline void lds_wait4(u32x4 (&)[4], u32x4 (&)[4]) {}
 #define XC_WAIT_VMEM_LE(N) ((void)0)
 inline void barrier_nodrain() { xcemu::block_barrier(); }
 inline void mfma_prio(int) {}

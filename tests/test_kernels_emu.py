@@ -262,8 +262,8 @@ def test_edge_cases_of_the_row_kernels():
     assert torch.isfinite(out.float()).all() and float(out[0, :3].float().abs().max()) == 0.0 and torch.isfinite(dq.float()).all()
 
 
-def test_gemm6_two_workgroups_per_cu_experiment():
-    """gemm6.h (XCLIP_GEMM=6, measured slower than the ring kernel and off by default: DESIGN.md section 6b) still computes the product --
+def test_gemm6_gemm7_experimental_kernels():
+    """gemm6.h / gemm7.h (XCLIP_GEMM=6 / 7, measured slower than the ring kernel and off by default: DESIGN.md section 6b) still compute the product --
     the switch is read once per process, so the check runs in its own interpreter"""
     import subprocess
     import sys
@@ -280,6 +280,7 @@ def test_gemm6_two_workgroups_per_cu_experiment():
         "    want = alpha * (a.float() @ b.float().t())\n"
         "    assert float((got - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -8, (M, N, K)\n"
         "print('gemm6 ok')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, XCLIP_GEMM="6")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "gemm6 ok" in out.stdout, out.stderr[-2000:]
+    for gen in ("6", "7"):                                   # 7: gemm7.h, four waves of 128 x 128 (takes the 256-multiples among these)
+        env = dict(os.environ, XCLIP_GEMM=gen)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "gemm6 ok" in out.stdout, (gen, out.stderr[-2000:])

@@ -192,6 +192,11 @@ template <int N>
 XC_DEV void lds_wait(u32x4 (&a)[4], u32x4 (&b)[2]) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
 }
+// the same wait for a 4 + 4 fragment set (gemm7.h)
+template <int N>
+XC_DEV void lds_wait4(u32x4 (&a)[4], u32x4 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
 XC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // orders this wave's LDS traffic around a wave-private hand-off (lanes exchange data through LDS without a work-group
 // barrier): the hardware executes a wave's LDS instructions in order; this only stops the compiler from reordering.

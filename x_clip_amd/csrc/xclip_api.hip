@@ -10,6 +10,7 @@
 #include "kernels/gemm3.h"
 #include "kernels/gemm4.h"
 #include "kernels/gemm6.h"
+#include "kernels/gemm7.h"
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
 #include "kernels/simloss3.h"
@@ -131,7 +132,7 @@ void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
 // a weight panel that lives in L2 -- forward (NT) and dgrad (NN): +2 ... +6 % there -- and g4_run for wgrad (TN), where BOTH operands
 // stream from HBM and the deeper A ring measured 3-11 % SLOWER (profiles/r02_run5_gemm5_ring_probe.log).
 inline int gemm_generation() {
-    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && e[0] >= '2' && e[0] <= '6') ? e[0] - '0' : 0; }();
+    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && e[0] >= '2' && e[0] <= '7') ? e[0] - '0' : 0; }();
     return v;
 }
 template <bool AK, bool BK_, int MODE>
@@ -169,8 +170,14 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     // 32-bit in-tile byte offsets: leading dimensions below 2^22 elements (anything else is not a Linear of this model)
     const bool small_ld = p.lda < (1L << 22) && p.ldb < (1L << 22) && p.ldc < (1L << 22) && (long)p.N < (1L << 21);
     if (gen != 3 && small_ld) {
-        const bool ring3 = gen == 5 || ((gen == 0 || gen == 6) && !AK);   // (6: gemm6.h for the shapes it takes, the default otherwise)
+        const bool ring3 = gen == 5 || ((gen == 0 || gen >= 6) && !AK);   // (6, 7: gemm6.h / gemm7.h for the shapes they take, the default otherwise)
         const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
+        // experiment (XCLIP_GEMM=7): four waves of 128 x 128 per tile, one per SIMD (gemm7.h)
+        if (gen == 7 && !AK && !BK_ && !terms && p.partial == nullptr && splits == 1 && p.M % G2_BM == 0 && p.N % G2_BN == 0 && p.K / G2_BK >= 2) {
+            XC_ALLOW_LDS(gemm7_kernel, G5_LDS_BYTES);
+            hipLaunchKernelGGL(gemm7_kernel, pgrid, dim3(G7_THREADS), G5_LDS_BYTES, st, p);
+            return;
+        }
         // experiment (XCLIP_GEMM=6, XCLIP_GEMM6_MAXK=<K>): two 4-wave work-groups per CU on 256 x 128 tiles for the short-K forward products
         // whose tiles are all interior (gemm6.h)
         if (gen == 6 && !AK && !BK_ && !terms && p.partial == nullptr && splits == 1 && p.M % G6_BM == 0 && p.N % G6_BN == 0 &&
