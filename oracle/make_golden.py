@@ -49,8 +49,15 @@ def import_reference():
     tvt.__getattr__ = lambda name: (lambda *a, **k: torch.nn.Identity())
     sys.modules.setdefault("torchvision", tv)
     sys.modules.setdefault("torchvision.transforms", tvt)
-    if REFERENCE not in sys.path:
-        sys.path.insert(0, REFERENCE)
+    # the repository root carries an `x_clip/` alias package (re-exports x_clip_amd under the reference's import names): the
+    # reference must come FIRST on the path -- also in spawned workers, which inherit a sys.path that already lists it further back --
+    # and an alias imported earlier must not be served from the module cache
+    while REFERENCE in sys.path:
+        sys.path.remove(REFERENCE)
+    sys.path.insert(0, REFERENCE)
+    for name in [m for m in sys.modules if m == "x_clip" or m.startswith("x_clip.")]:
+        if not os.path.realpath(getattr(sys.modules[name], "__file__", None) or REFERENCE).startswith(REFERENCE):
+            del sys.modules[name]
     import x_clip  # the reference package
     assert os.path.realpath(x_clip.__file__).startswith(REFERENCE), x_clip.__file__
     return x_clip
@@ -183,6 +190,15 @@ def run_reference(x_clip, cfg: ClipConfig, batch, n_aug_t, n_aug_i, patch_dropou
 
 
 def _dist_worker(rank, world, port, cfg_kwargs, sizes, q):
+    try:
+        _dist_worker_body(rank, world, port, cfg_kwargs, sizes, q)
+    except BaseException:                          # the parent must hear about it instead of waiting out its queue timeout
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+
+
+def _dist_worker_body(rank, world, port, cfg_kwargs, sizes, q):
     import torch.distributed as dist
     import torch.nn.functional as F
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -215,8 +231,18 @@ def run_reference_distributed(cfg: ClipConfig, sizes):
     procs = [ctx.Process(target=_dist_worker, args=(r, world, port, cfg.ctor_kwargs(), sizes, q))
              for r in range(world)]
     [p.start() for p in procs]
-    res = [q.get(timeout=600) for _ in range(world)]
-    [p.join() for p in procs]
+    res = []
+    try:
+        for _ in range(world):
+            r = q.get(timeout=600)
+            if r[1] is None:
+                raise RuntimeError(f"distributed reference worker {r[0]} failed:\n{r[2]}")
+            res.append(r)
+    except BaseException:
+        [p.kill() for p in procs if p.is_alive()]       # (exact children of this process)
+        raise
+    finally:
+        [p.join(timeout=30) for p in procs]
     res.sort(key=lambda r: r[0])
     losses = [r[1] for r in res]
     summed = {}
