@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "x_clip_amd", "csrc")
 OUT = os.path.join(HERE, "libxclip_emu.so")
+OUT_MEASURE = os.path.join(HERE, "libxclip_emu_measure.so")   # the same with -DXCLIP_MEASURE (experiments + switches, x_clip_amd/build.py)
 UNITS = ["xclip_api.hip", "xclip_attn.hip"]                  # the product's translation units (x_clip_amd/build.py)
 
 
@@ -15,18 +16,21 @@ def sources():
     out = [os.path.join(CSRC, u) for u in UNITS] + [os.path.join(CSRC, "api_common.h"), os.path.join(HERE, "xc_device.h"),
                                                     os.path.join(ROOT, "include", "xclip.h")]
     kdir = os.path.join(CSRC, "kernels")
-    out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir))]
+    out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir)) if f.endswith(".h")]
+    mdir = os.path.join(kdir, "measure")
+    out += [os.path.join(mdir, f) for f in sorted(os.listdir(mdir)) if f.endswith(".h")]
     return out
 
 
-def build(force=False):
+def build(force=False, measure=False):
+    OUT = OUT_MEASURE if measure else globals()["OUT"]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
         return OUT
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = "clang++"
     cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi",
-           "-I", HERE, "-I", CSRC, *[os.path.join(CSRC, u) for u in UNITS], "-o", OUT]
+           *(["-DXCLIP_MEASURE"] if measure else []), "-I", HERE, "-I", CSRC, *[os.path.join(CSRC, u) for u in UNITS], "-o", OUT]
     subprocess.run(cmd, check=True)
     return OUT
 

@@ -26,6 +26,17 @@ def test_header_symbols_are_exported_and_bound():
     assert lib.xclip_abi_version() == _lib.ABI_VERSION
 
 
+def test_product_library_reads_no_environment():
+    """the measurement switches (XCLIP_GEMM, XCLIP_*_ABL, ...: kernel A/B selection, ablation masks that return garbage) live only in
+    the -DXCLIP_MEASURE build; libxclip_hip.so does not import getenv at all, so no environment variable can change what a step computes"""
+    import subprocess
+    from x_clip_amd.build import build
+    path = build()
+    out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert "hipLaunchKernel" in out or "hipModuleLaunchKernel" in out or "__hipPushCallConfiguration" in out, out[:400]
+    assert not re.search(r"\bgetenv\b", out), "libxclip_hip.so imports getenv: a measurement switch leaked into the product build"
+
+
 def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "x_clip_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -263,8 +263,9 @@ def test_edge_cases_of_the_row_kernels():
 
 
 def test_gemm6_gemm7_experimental_kernels():
-    """gemm6.h / gemm7.h (XCLIP_GEMM=6 / 7, measured slower than the ring kernel and off by default: DESIGN.md section 6b) still compute the product --
-    the switch is read once per process, so the check runs in its own interpreter"""
+    """measure/gemm6.h / gemm7.h (MEASUREMENT build only, XCLIP_GEMM=6 / 7; measured slower than the ring kernel: DESIGN.md section 6b) still
+    compute the product -- the switch is read once per process, so the check runs in its own interpreter; and the PRODUCT build ignores the
+    switch altogether"""
     import subprocess
     import sys
     code = (
@@ -272,7 +273,7 @@ def test_gemm6_gemm7_experimental_kernels():
         "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "from x_clip_amd import _lib, ops\n"
         "from emu.build_emu import build\n"
-        "_lib._use_library_for_tests(build())\n"
+        "_lib._use_library_for_tests(build(measure=True))\n"
         "for (M, N, K, alpha) in [(512, 256, 128, 1.0), (768, 384, 256, 0.5), (256, 4096, 128, 1.0)]:\n"
         "    torch.manual_seed(0)\n"
         "    a = torch.randn(M, K).bfloat16(); b = torch.randn(N, K).bfloat16()\n"

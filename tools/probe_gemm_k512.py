@@ -3,7 +3,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from x_clip_amd import ops
+from x_clip_amd import _lib, ops
+_lib.use_measurement_build()       # the XCLIP_* switches below exist only in libxclip_hip_measure.so (python -m x_clip_amd.build --measure)
 dev = torch.device("cuda:0")
 def timeit(fn, iters=20, warm=10):
     for _ in range(warm): fn()

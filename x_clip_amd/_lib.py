@@ -111,6 +111,17 @@ def _use_library_for_tests(path):
         _lib, _is_emulator = _bind(path), True
 
 
+def use_measurement_build():
+    """tools/ only: switch this process to libxclip_hip_measure.so (`python -m x_clip_amd.build --measure`), the build that carries the
+    XCLIP_GEMM / XCLIP_*_ABL / ... environment switches of the A/B and ablation runs.  Never called by the product or the tests' parity
+    cases: several of those switches return garbage by design."""
+    global _lib, _is_emulator
+    path = os.path.join(_HERE, "libxclip_hip_measure.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: python -m x_clip_amd.build --measure")
+    _lib, _is_emulator = _bind(path), False
+
+
 def check(code: int, what: str):
     if code != 0:
         raise RuntimeError(f"{what} failed ({code}): {lib().xclip_last_error().decode()}")

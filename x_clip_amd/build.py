@@ -1,8 +1,12 @@
 """Builds libxclip_hip.so (the gfx950 kernel library) in-tree with hipcc.
 
-    python -m x_clip_amd.build [--force]
+    python -m x_clip_amd.build [--force] [--measure]
 
 hipcc cross-compiles for gfx950 without a GPU; the .so is git-ignored but travels with the working tree.
+
+`--measure` builds libxclip_hip_measure.so instead: the same sources with -DXCLIP_MEASURE, i.e. WITH the environment switches of
+the A/B and ablation runs (kernel generations, ablation masks whose results are garbage, the experiments under
+csrc/kernels/measure/).  Only tools/ load it (x_clip_amd._lib.use_measurement_build()); the product library has none of them.
 """
 import os
 import subprocess
@@ -11,6 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxclip_hip.so")
+LIB_MEASURE = os.path.join(HERE, "libxclip_hip_measure.so")
 
 
 UNITS = [  # (source, extra flags)
@@ -25,11 +30,14 @@ def _sources():
     out = [os.path.join(CSRC, u) for u, _ in UNITS] + [os.path.join(CSRC, "api_common.h"), os.path.join(CSRC, "hw", "xc_device.h"),
                                                         os.path.join(os.path.dirname(HERE), "include", "xclip.h")]
     kdir = os.path.join(CSRC, "kernels")
-    out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir))]
+    out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir)) if f.endswith(".h")]
+    mdir = os.path.join(kdir, "measure")
+    out += [os.path.join(mdir, f) for f in sorted(os.listdir(mdir)) if f.endswith(".h")]
     return out
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, measure: bool = False) -> str:
+    LIB = LIB_MEASURE if measure else globals()["LIB"]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in _sources()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -37,7 +45,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
               "-Wno-unused-value", "-I", os.path.join(CSRC, "hw"), "-I", CSRC]
     if verbose:
         common.insert(0, "-Rpass-analysis=kernel-resource-usage")
-    objdir = os.path.join(HERE, "_obj")
+    if measure:
+        common.append("-DXCLIP_MEASURE")
+    objdir = os.path.join(HERE, "_obj_measure" if measure else "_obj")
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
     for unit, extra in UNITS:                                   # the units compile side by side
@@ -51,4 +61,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, measure="--measure" in sys.argv))

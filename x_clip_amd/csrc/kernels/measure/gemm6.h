@@ -15,7 +15,7 @@
 // (l & 3) ^ ((l >> 4) & 3).  An MFMA operand fragment (lane = row, half h: k = 16 kk + 8 h ...) is the ds_read_b128 of chunk 2 kk + h; the
 // 16 lanes of one LDS cycle (rows r .. r + 15, one chunk) then cover the sixteen 16-byte slots of a 256-byte bank row exactly once.
 #pragma once
-#include "gemm4.h"
+#include "../gemm4.h"
 
 namespace xc {
 

@@ -6,7 +6,7 @@
 // Scope of the experiment: bf16 C = alpha * A[M, K] B[N, K]^T, both operands row-major, M and N multiples of 256, K a multiple of 64 with
 // at least two K steps -- the host (xclip_api.hip) sends everything else to gemm4.h.
 #pragma once
-#include "gemm4.h"
+#include "../gemm4.h"
 
 namespace xc {
 

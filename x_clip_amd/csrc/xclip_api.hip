@@ -9,8 +9,10 @@
 #include "kernels/gemm2.h"
 #include "kernels/gemm3.h"
 #include "kernels/gemm4.h"
-#include "kernels/gemm6.h"
-#include "kernels/gemm7.h"
+#ifdef XCLIP_MEASURE                                             // negative-result experiments, measurement build only
+#include "kernels/measure/gemm6.h"
+#include "kernels/measure/gemm7.h"
+#endif
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
 #include "kernels/simloss3.h"
@@ -127,24 +129,27 @@ void launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, block, GemmCfg<T>::LDS_BYTES, st, p);
 }
 
-// Which bf16 GEMM runs (XCLIP_GEMM, read once; A/B measurements): 2 = gemm2.h (two-phase), 3 = gemm3.h (first scheduled kernel), 4 = gemm4.h
-// g4_run everywhere, 5 = g5_run everywhere.  Default: g5_run (A in a ring of three LDS stages) for the layouts whose B operand is
-// a weight panel that lives in L2 -- forward (NT) and dgrad (NN): +2 ... +6 % there -- and g4_run for wgrad (TN), where BOTH operands
-// stream from HBM and the deeper A ring measured 3-11 % SLOWER (profiles/r02_run5_gemm5_ring_probe.log).
+// Which bf16 GEMM runs.  Product (0): g5_run (A in a ring of three LDS stages) for the layouts whose B operand is a weight panel that
+// lives in L2 -- forward (NT) and dgrad (NN): +2 ... +6 % there -- and g4_run for wgrad (TN), where BOTH operands stream from HBM and
+// the deeper A ring measured 3-11 % SLOWER (profiles/r02_run5_gemm5_ring_probe.log).  Measurement build only (XCLIP_GEMM, read once;
+// A/B runs): 2 = gemm2.h (two-phase), 3 = gemm3.h (first scheduled kernel), 4 = g4_run everywhere, 5 = g5_run everywhere, 6 / 7 = the
+// experiments under kernels/measure/.
 inline int gemm_generation() {
-    static const int v = [] { const char* e = getenv("XCLIP_GEMM"); return (e != nullptr && e[0] >= '2' && e[0] <= '7') ? e[0] - '0' : 0; }();
+    static const int v = [] { const int e = measure_env("XCLIP_GEMM", 0); return (e >= 2 && e <= 7) ? e : 0; }();
     return v;
 }
 template <bool AK, bool BK_, int MODE>
 void launch_gemm4(const Gemm2Params& p, dim3 pgrid, bool ring3, hipStream_t st) {
+#ifdef XCLIP_MEASURE
     if constexpr (!AK && !BK_ && MODE == G4_PLAIN) {             // measurement: XCLIP_GEMM5_ABL=<mask> (gemm4.h g5_run), NT plain only
-        static const int abl = [] { const char* e = getenv("XCLIP_GEMM5_ABL"); return e ? atoi(e) : 0; }();
+        static const int abl = measure_env("XCLIP_GEMM5_ABL", 0);
         if (ring3 && abl) {
 #define XC_ABL5(N) case N: XC_ALLOW_LDS((gemm5_kernel<false, false, G4_PLAIN, N>), G5_LDS_BYTES); hipLaunchKernelGGL((gemm5_kernel<false, false, G4_PLAIN, N>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p); return;
             switch (abl) { XC_ABL5(1) XC_ABL5(2) XC_ABL5(4) XC_ABL5(8) XC_ABL5(9) XC_ABL5(10) XC_ABL5(11) XC_ABL5(14) XC_ABL5(16) XC_ABL5(32) XC_ABL5(48) XC_ABL5(12) XC_ABL5(6) XC_ABL5(26) XC_ABL5(58) XC_ABL5(64) XC_ABL5(74) XC_ABL5(128) XC_ABL5(256) XC_ABL5(512) XC_ABL5(1024) XC_ABL5(2560) XC_ABL5(4096) XC_ABL5(526) XC_ABL5(522) default: break; }
 #undef XC_ABL5
         }
     }
+#endif
     if (ring3) {
         XC_ALLOW_LDS((gemm5_kernel<AK, BK_, MODE>), G5_LDS_BYTES);
         hipLaunchKernelGGL((gemm5_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
@@ -157,11 +162,13 @@ template <bool AK, bool BK_>
 void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, splits), block(G2_THREADS);
     const int gen = gemm_generation();
+#ifdef XCLIP_MEASURE
     if (gen == 2) {
         XC_ALLOW_LDS((gemm2_kernel<AK, BK_>), G2_LDS_BYTES);
         hipLaunchKernelGGL((gemm2_kernel<AK, BK_>), grid, block, G2_LDS_BYTES, st, p);
         return;
     }
+#endif
     // persistent: one work-group per CU walks the tiles (split-K problems are sized to ~one tile per work-group already)
     int gx = p.tiles_m * p.tiles_n;
     const int cus = xc_num_cus();
@@ -172,7 +179,8 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     if (gen != 3 && small_ld) {
         const bool ring3 = gen == 5 || ((gen == 0 || gen >= 6) && !AK);   // (6, 7: gemm6.h / gemm7.h for the shapes they take, the default otherwise)
         const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
-        // experiment (XCLIP_GEMM=7): four waves of 128 x 128 per tile, one per SIMD (gemm7.h)
+#ifdef XCLIP_MEASURE
+        // experiment (XCLIP_GEMM=7): four waves of 128 x 128 per tile, one per SIMD (measure/gemm7.h)
         if (gen == 7 && !AK && !BK_ && !terms && p.partial == nullptr && splits == 1 && p.M % G2_BM == 0 && p.N % G2_BN == 0 && p.K / G2_BK >= 2) {
             XC_ALLOW_LDS(gemm7_kernel, G5_LDS_BYTES);
             hipLaunchKernelGGL(gemm7_kernel, pgrid, dim3(G7_THREADS), G5_LDS_BYTES, st, p);
@@ -182,7 +190,7 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
         // whose tiles are all interior (gemm6.h)
         if (gen == 6 && !AK && !BK_ && !terms && p.partial == nullptr && splits == 1 && p.M % G6_BM == 0 && p.N % G6_BN == 0 &&
             p.K % G6_BK == 0 && p.K / G6_BK >= 4) {
-            static const int maxk = [] { const char* e = getenv("XCLIP_GEMM6_MAXK"); return e ? atoi(e) : 1024; }();
+            static const int maxk = measure_env("XCLIP_GEMM6_MAXK", 1024);
             if (p.K <= maxk) {
                 const int tiles6 = (p.M / G6_BM) * (p.N / G6_BN);
                 const int g6 = tiles6 < 2 * cus ? tiles6 : 2 * cus;
@@ -191,6 +199,7 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
                 return;
             }
         }
+#endif
         const bool res_only = p.residual != nullptr && p.bias == nullptr && p.addrows == nullptr && p.ldr < (1L << 22);
         if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(p, pgrid, ring3, st);
         else if (res_only) launch_gemm4<AK, BK_, G4_RES>(p, pgrid, ring3, st);
@@ -198,12 +207,14 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
         else launch_gemm4<AK, BK_, G4_PLAIN>(p, pgrid, ring3, st);
         return;
     }
-    static const int abl = [] { const char* e = getenv("XCLIP_GEMM_ABL"); return e ? atoi(e) : 0; }();
+#ifdef XCLIP_MEASURE
+    static const int abl = measure_env("XCLIP_GEMM_ABL", 0);
     if (abl != 0 && !AK && !BK_) {                      // measurement-only variants of the NT kernel
 #define XC_ABL(N) case N: XC_ALLOW_LDS((gemm3_kernel<false, false, N>), G3_LDS_BYTES); hipLaunchKernelGGL((gemm3_kernel<false, false, N>), pgrid, block, G3_LDS_BYTES, st, p); return;
         switch (abl) { XC_ABL(1) XC_ABL(2) XC_ABL(4) XC_ABL(8) XC_ABL(3) XC_ABL(9) XC_ABL(10) XC_ABL(11) XC_ABL(14) XC_ABL(15) XC_ABL(25) XC_ABL(41) XC_ABL(64) XC_ABL(73) XC_ABL(105) default: break; }
 #undef XC_ABL
     }
+#endif
     XC_ALLOW_LDS((gemm3_kernel<AK, BK_>), G3_LDS_BYTES);
     hipLaunchKernelGGL((gemm3_kernel<AK, BK_>), pgrid, block, G3_LDS_BYTES, st, p);
 }
@@ -683,10 +694,10 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
         q.tiles_m = (int)((M + G2_BM - 1) / G2_BM); q.tiles_n = (int)((N + G2_BN - 1) / G2_BN);
         // an output that cannot stay in the 8 x 4 MiB of L2 anyway is streamed past it: the A / B panels the sibling tiles share then
         // survive a round's 32 MiB of output (XCLIP_GEMM_NT=0 / 1 forces the policy, for measurement)
-        static const int nt_env = [] { const char* e = getenv("XCLIP_GEMM_NT"); return e ? atoi(e) : -1; }();
+        static const int nt_env = measure_env("XCLIP_GEMM_NT", -1);
         q.stream_out = nt_env >= 0 ? nt_env : (M * N * 2 > (int64_t)(48 << 20) ? 1 : 0);
         // more than 8 N tiles (FF1: 16): banded tile order for the ring kernel (XCLIP_GEMM_BAND=<tiles per band>, 0 = off, for measurement)
-        static const int band_env = [] { const char* e = getenv("XCLIP_GEMM_BAND"); return e ? atoi(e) : -1; }();
+        static const int band_env = measure_env("XCLIP_GEMM_BAND", -1);
         // FF1 forward in the step: 1227 -> 1155 us (profiles/r02_run22_gemm_banded_order.log); the widest band of 4..8 tiles that divides
         // the N tiles, none if there is none (9 tiles) or the operand fits anyway (<= 8 tiles)
         q.band_n = 0;

@@ -74,7 +74,7 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
         const int nwq = a3_waves((int)n);
         // half a head's time (13 us at n = 257, growing with n^2) between the two work-groups of a CU: 0.413 -> 0.376 ms at
         // b = 1024, n = 257 (profiles/r02_run20_attention_stagger_sweep.log); XCLIP_ATTN_STAGGER_FWD=<10 ns ticks> overrides
-        static const int stag = [] { const char* e = getenv("XCLIP_ATTN_STAGGER_FWD"); return e ? atoi(e) : -1; }();
+        static const int stag = measure_env("XCLIP_ATTN_STAGGER_FWD", -1);
         const int half_head = (int)(1300.0 * (double)n * (double)n / (257.0 * 257.0));
         p.stagger_10ns = (attn3_fwd_lds_bytes((int)n) <= 80 * 1024 && batch * heads >= 1024) ? (stag >= 0 ? stag : half_head) : 0;
         if (causal) {
@@ -113,10 +113,10 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         const int nwq = a3_bwd_waves((int)n);
-        static const int abl = [] { const char* e = getenv("XCLIP_ATTN_ABL"); return e ? atoi(e) : 0; }();   // measurement only
+        static const int abl = measure_env("XCLIP_ATTN_ABL", 0);   // measurement build only
         p.chunks = abl;
         // (measured: no effect on the backward -- its two work-groups are latency-bound chains that already overlap)
-        static const int stag = [] { const char* e = getenv("XCLIP_ATTN_STAGGER_BWD"); return e ? atoi(e) : 0; }();
+        static const int stag = measure_env("XCLIP_ATTN_STAGGER_BWD", 0);
         p.stagger_10ns = (attn3_bwd_lds_bytes((int)n) <= 80 * 1024 && batch * heads >= 1024) ? stag : 0;
         if (causal) {
             XC_ALLOW_LDS(attn3_bwd_kernel<true>, 160 * 1024);
