@@ -43,7 +43,7 @@ def model_flops_per_pair(model, n_text_tokens, n_img_tokens, n_patches_embedded)
     return f
 
 
-def cpu_baseline(budget_s=30.0):
+def cpu_baseline(budget_s=45.0):
     """the CPU oracle (oracle/clip_oracle.py = torch-CPU restatement of the reference, pinned to reference golden vectors) timed on
     a bounded sample of the same workload -- default architecture, patch dropout 0.5, forward + backward -- at the settings that
     are BEST for the CPU: the thread count is swept at batch 8 (oversubscribing a small batch with every hardware thread is slower
@@ -68,19 +68,23 @@ def cpu_baseline(budget_s=30.0):
             loss = O.clip_forward(sd, cfg, text, image, keep_idx=keep)
             loss.backward()
         step()                                                       # warm-up (allocator, oneDNN primitive caches)
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        rates = []
+        for _ in range(steps):                                       # every step timed on its own: median + spread, not one sample
+            t0 = time.perf_counter()
             step()
-        return b * steps / (time.perf_counter() - t0)
+            rates.append(b / (time.perf_counter() - t0))
+        rates.sort()
+        return rates[len(rates) // 2], rates[0], rates[-1]
 
     before = torch.get_num_threads()
     runs = []
+    TIMED = 3                                                        # timed steps per setting (after one warm-up step)
     # thread sweep at batch 8, smallest first, stopped at the first setting that is slower than the one before it: past the knee a
     # small batch only gets slower with more threads (measured on the 256-thread host of the MI355X box: 8 -> 11.5, 16 -> 18.9,
     # 32 -> 12.0, 64 -> 5.7 pairs/s, and 256 threads took 8 minutes for one step), so the sweep never goes beyond 64
     for th in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu}):
-        v = bench(torch.float32, 8, th, 1)
-        runs.append(("fp32", 8, th, v))
+        v, lo, hi = bench(torch.float32, 8, th, TIMED)
+        runs.append(("fp32", 8, th, v, lo, hi))
         if len(runs) > 1 and v < runs[-2][3]:
             break
         if time.perf_counter() - t_start > 0.5 * budget_s:
@@ -88,13 +92,14 @@ def cpu_baseline(budget_s=30.0):
     best_th = max(runs, key=lambda r: r[3])[2]
     for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
         if time.perf_counter() - t_start < budget_s:
-            runs.append((name, 32, best_th, bench(dt, 32, best_th, 1)))
+            runs.append((name, 32, best_th, *bench(dt, 32, best_th, TIMED)))
     torch.set_num_threads(before)
     best = max(runs, key=lambda r: r[3])
     return {"value": round(best[3], 3), "unit": "pairs/s", "cores": best[2], "kind": "port", "dtype": best[0], "batch": best[1],
             "host_cpus": ncpu,
-            "sweep": [{"dtype": d, "batch": b, "threads": t, "pairs_per_s": round(v, 3)} for d, b, t, v in runs],
-            "sample": f"oracle/clip_oracle.py clip_forward+backward, default CLIP, patch dropout 0.5, 1 timed step per setting after a warm-up; "
+            "sweep": [{"dtype": d, "batch": b, "threads": t, "pairs_per_s": round(v, 3), "min": round(lo, 3), "max": round(hi, 3)}
+                      for d, b, t, v, lo, hi in runs],
+            "sample": f"oracle/clip_oracle.py clip_forward+backward, default CLIP, patch dropout 0.5, {TIMED} timed steps per setting after a warm-up (median; min / max in `sweep`); "
                       f"best = {best[0]} batch {best[1]} on {best[2]} of {ncpu} host threads ({time.perf_counter() - t_start:.0f} s of CPU work in all). "
                       f"The reference itself, measured in the build container on 8 vCPUs (BASELINE.md section 2): 6.9 pairs/s fp32 b=8, "
                       f"5.7 fp32 b=32, 18.2 bf16 b=32"}
@@ -229,6 +234,10 @@ def main():
     fwd_flops = views * model_flops_per_pair(model, model.text_seq_len + 1, n_keep, n_keep)
     pairs = b * world * args.steps
     value = pairs / elapsed
+    plain_default = args.config == "default" and not (args.filip or args.simsiam or args.causal)
+    # what a committed out-of-process measurement (the PMC traffic figure) must have been taken on to be quoted with this run
+    workload_tag = f"{args.config}{'-filip' if args.filip else ''}{'-simsiam' if args.simsiam else ''}{'-causal' if args.causal else ''}-" \
+                   f"{'dcl' if args.dcl else 'infonce'}-b{b}"
     out = {
         "metric": "image-text pairs/sec (fwd+bwd) at global batch; MFMA% + HBM GB/s",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -237,10 +246,13 @@ def main():
         "config": {"workload": ("BASELINE configs[4] per GPU: ViT-L/14 image 336 (dim 1024 depth 24) + text dim 768 depth 12 seq 77, latent 768, multiview "
                                 "(1 aug text + 1 aug image), activation checkpointing (1/3 more forward work than the algorithmic count), " if args.config == "vitl" else
                                 "BASELINE configs[3] (FILIP): dim 512 depth 6/6 image 224 patch 16 text seq 77, " if args.filip else
-                                "BASELINE configs[1]: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, ") +
+                                "BASELINE configs[2] per GPU: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, local batch 4096, "
+                                if (args.dcl and b == 4096 and plain_default) else
+                                "BASELINE configs[1]: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, " if (plain_default and not args.dcl and b == 1024) else
+                                "default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256 (own measurement, not a BASELINE configuration as run), ") +
                                "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ("" if not args.simsiam else " + SimSiam side loss") +
                                ("" if not args.causal else ", causal text encoder") + ", fwd+bwd",
-                   "local_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
+                   "workload_tag": workload_tag, "local_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                    "gflop_per_pair_fwd_bwd": round(3 * fwd_flops / 1e9, 3)},
         "model_mfma_frac": round(value * 3 * fwd_flops / (world * MFMA_PEAK_BF16), 4),
         "loss": round(loss_val, 5),
@@ -274,14 +286,15 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as f:
                 tj = json.load(f)
-            if tj.get("kernel_generation") == ops.GEMM_GENERATION:
+            if tj.get("kernel_generation") == ops.GEMM_GENERATION and tj.get("workload_tag", "default-infonce-b1024") == workload_tag:
                 traffic, traffic_src = round(tj["bytes_per_launch"]), tj.get("source")
         except Exception:
             pass
         out["roofline"] = {"kernel": "xclip_gemm (gemm5_kernel<bf16> NT/NN + gemm4_kernel<bf16> TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": traffic,
-                           "traffic_note": f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command ({traffic_src})",
+                           "traffic_note": (f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command ({traffic_src})"
+                                            if traffic is not None else f"null: no committed PMC passes for this workload ({workload_tag}) and kernel generation"),
                            "algorithmic_bytes_per_launch": round(probe.algorithmic_bytes / max(launches, 1)),
                            "launches_per_step": launches // max(args.steps, 1),
                            "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),

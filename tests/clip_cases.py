@@ -8,9 +8,11 @@ libxclip_hip.so on an MI355X).  Two kinds of checks:
 
 Tolerances: fp32 storage -> the north star's 1e-5 (loss) and a few 1e-5 relative on gradients (fp32 accumulation order
 differs from ATen's); bf16 storage -> oracle evaluated in fp64 on the bf16-rounded parameters; the network compounds
-one bf16 rounding per stored activation: loss 2e-3 (measured 1e-4 at depth 6), gradients 15 % relative / cosine 0.99 -- the per-kernel
-1e-3-class bound lives in tests/kernel_cases.py (the reference's own bf16 run is 1.3e-2 off its
-fp32 run).
+one bf16 rounding per stored activation.  The default bf16 bars are 2x what the suite measured on the MI355X (profiles/
+r02_final_parity_report_gpu.txt: loss <= 1.2e-4, worst gradient 3.8 %, cosine >= 0.9997 on every CLS-mode architecture): loss 3e-4,
+gradients 8 % relative and cosine 0.999; cases whose measured error is larger (FILIP's arg-max ties, SimSiam's cancelling bias sums, the
+dim-64 toy model) pass their own bars, each <= 2x its measurement, at the call site.  The per-kernel 1-ulp bound lives in
+tests/kernel_cases.py (the reference's own bf16 run is 1.3e-2 off its fp32 run).
 """
 import json
 import os
@@ -144,8 +146,8 @@ def oracle_run(cfg, sd64, text, image64, aug_t, aug_i64, keep, mlm=None, ssl_run
 REPORT = {}
 
 
-def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_image=0, patch_keep=None, seed=7, bf16_cos=0.99,
-                   bf16_rel=0.15, bf16_loss=2e-3, label=None, **extra):
+def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_image=0, patch_keep=None, seed=7, bf16_cos=0.999,
+                   bf16_rel=0.08, bf16_loss=3e-4, label=None, **extra):
     """product vs. the fp64 oracle on the same (dtype-rounded) parameters and inputs; every gradient in full.  bf16: the oracle runs
     in fp64 on the bf16-rounded parameters WITH THE bf16 LayerNorm epsilon (1e-3, x_clip.py:118) -- the model the product computes"""
     sd = O.make_state_dict(cfg, seed, torch.float32)
@@ -273,3 +275,64 @@ def case_pluggable_encoders_head_only(dev, B=24, d=64):
     assert abs(float(loss.detach()) - want["loss"]) < 1e-5
     assert abs(float(m.temperature.grad) - want["dtau"]) < 1e-5
     assert xt.grad is not None and torch.isfinite(xt.grad).all()
+
+
+def case_live_rows(dev, cfg: O.ClipConfig, b, live, dtype=torch.bfloat16, seed=4321, label="live rows", bf16_latent_bar=1e-3):
+    """the encoders are row independent: a step over `b` samples whose upstream latent gradient is non-zero on the samples `live` only
+    must give the oracle's parameter gradients for those samples alone (and the product's own, run on them alone)"""
+    torch.manual_seed(0)
+    m = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.5).to(dtype).to(dev).train()
+    g = torch.Generator().manual_seed(seed)
+    n, d = cfg.text_seq_len, cfg.dim_latent
+    text = torch.randint(1, cfg.num_text_tokens, (b, n), generator=g)
+    text[live[1], n - n // 4:] = cfg.text_pad_id                          # one live row with a padded tail (key mask path)
+    image = torch.randn(b, cfg.channels, cfg.visual_image_size, cfg.visual_image_size, generator=g).to(dtype)
+    nkeep = max(1, cfg.num_patches // 2)
+    keep = torch.randn(b, cfg.num_patches, generator=g).topk(nkeep, dim=-1).indices
+    live = torch.as_tensor(live)
+    Gt, Gi = torch.zeros(b, d), torch.zeros(b, d)
+    Gt[live] = torch.randn(len(live), d, generator=g)
+    Gi[live] = torch.randn(len(live), d, generator=g)
+    Gt, Gi = Gt.to(dtype), Gi.to(dtype)
+
+    def product_step(rows):
+        m.zero_grad(set_to_none=True)
+        m.visual_transformer.keep_indices_override = keep[rows].to(torch.int32).to(dev)
+        tl, il = m(text[rows].to(dev), image[rows].to(dev), return_latents=True)
+        torch.autograd.backward([tl, il], [Gt[rows].to(dev), Gi[rows].to(dev)])
+        return (tl.detach().float().cpu(), il.detach().float().cpu(),
+                {k: p.grad.double().cpu() for k, p in m.named_parameters() if p.grad is not None})
+
+    tl, il, grads = product_step(torch.arange(b))
+    tl8, il8, grads8 = product_step(live)
+    m.visual_transformer.keep_indices_override = None
+    assert torch.equal(tl[live], tl8) and torch.equal(il[live], il8), "latents must not depend on the batch a row travels in"
+
+    fp32 = dtype == torch.float32
+    sd = {k: v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items() if v.is_floating_point()}
+    with O.layer_norm_eps(1e-5 if fp32 else 1e-3):
+        otl, oil = O.clip_forward(sd, cfg, text[live], image[live].double(), keep_idx=keep[live], return_latents=True)
+        torch.autograd.backward([otl, oil], [Gt[live].double(), Gi[live].double()])
+    lat_err = max(float((tl8.double() - otl.detach()).abs().max()), float((il8.double() - oil.detach()).abs().max()))
+    assert lat_err < (1e-5 if fp32 else bf16_latent_bar), lat_err           # the north star's output bars, on unit-norm latents
+    rec = {"loss_err": lat_err, "worst_rel": (0.0, ""), "worst_cos": (1.0, "")}
+    REPORT[f"{label}, {len(live)} live rows vs oracle (loss column = worst latent element)"] = rec
+    self_rel = (0.0, "")
+    for k, p in m.named_parameters():
+        rg = sd[k].grad
+        if rg is None or float(rg.abs().max()) == 0.0:
+            assert k not in grads or float(grads[k].abs().max()) == 0.0, k
+            continue
+        gfull = grads[k]
+        assert torch.isfinite(gfull).all(), k
+        rel = float((gfull - rg).norm() / rg.norm())
+        cos = float((gfull * rg).sum() / (gfull.norm() * rg.norm()))
+        if rel > rec["worst_rel"][0]:
+            rec["worst_rel"] = (rel, k)
+        if cos < rec["worst_cos"][0]:
+            rec["worst_cos"] = (cos, k)
+        assert (rel < 2e-4) if fp32 else (rel < 0.08 and cos > 0.999), (k, rel, cos)
+        rs = float((gfull - grads8[k]).norm() / grads8[k].norm())
+        self_rel = max(self_rel, (rs, k))
+        assert rs < (1e-4 if fp32 else 1e-2), (k, rs)                    # same rows, same arithmetic: summation order only
+    REPORT[f"{label} vs the product's own {len(live)}-row step (rel only)"] = {"loss_err": 0.0, "worst_rel": self_rel, "worst_cos": (1.0, "")}

@@ -127,6 +127,47 @@ def worker_filip(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu"):
     dist.destroy_process_group()
 
 
+def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_text=0, n_aug_image=0, gradsync=False, dtype_name="float32"):
+    """any world size, any per-rank batch sizes, any head: rank r holds rows sum(sizes[:r]) ... of the global batch of every view"""
+    dev = setup(rank, world, port, kind)
+    from x_clip_amd import CLIP
+    from x_clip_amd.distributed import GradSync
+    from oracle import clip_oracle as O
+    dtype = getattr(torch, dtype_name)
+    cfg = O.ClipConfig(**cfg_kwargs)
+    sd = O.make_state_dict(cfg, 25, torch.float32)
+    sd = {k: (v.to(dtype).float() if v.is_floating_point() else v) for k, v in sd.items()}
+    text, image, aug_t, aug_i = O.make_inputs(cfg, sum(sizes), 26, n_aug_text, n_aug_image)
+    lo = sum(sizes[:rank])
+    sl = slice(lo, lo + sizes[rank])
+    model = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)
+    model.load_state_dict(sd)
+    model = model.to(dtype).to(dev).train()
+    sync = GradSync(model) if gradsync else None
+    kw = {}
+    if n_aug_text:
+        kw["aug_text"] = [a[sl].to(dev) for a in aug_t]
+    if n_aug_image:
+        kw["aug_image"] = [a[sl].to(dtype).to(dev) for a in aug_i]
+    for step in range(2 if gradsync else 1):                  # GradSync: a second step reuses the persistent flat buffers
+        model.zero_grad(set_to_none=True)
+        loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, **kw)
+        loss.backward()
+        if sync is not None:
+            sync.finish()
+            # every weight-gradient GEMM of both towers and the latent projections wrote straight into its bucket slice
+            n_gemm = 4 * (cfg.text_enc_depth + cfg.visual_enc_depth) + 2 * (2 if cfg.extra_latent_projection else 1)
+            assert sync.stats["in_place"] >= n_gemm, (sync.stats, n_gemm)
+            for p in model.parameters():
+                if p.grad is not None:
+                    assert p.grad.data_ptr() == sync._view(p).data_ptr()
+    if kind == "cuda":
+        torch.cuda.synchronize()
+    grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
 def worker_nccl_probe(rank, world, port, tmp):
     """does RCCL accept two ranks on ONE device?  Records the outcome; never raises."""
     out = {"rank": rank}
@@ -190,7 +231,8 @@ def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, r
             assert rel < rel_bar, (k, rel)
             if cos_bar is not None:
                 assert float((g * want).sum() / (g.norm() * want.norm())) > cos_bar, k
-        assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k     # the all-reduced gradients are the same bits on both ranks
+        for o in outs[1:]:
+            assert torch.equal(outs[0]["grads"][k], o["grads"][k]), k       # the all-reduced gradients are the same bits on every rank
     return worst
 
 
@@ -210,3 +252,35 @@ def check_filip(tmp, cfg, batch, world=2):
         tot = (g0 + g1).double() / (world if k == "temperature" else 1)
         rel = float((tot - v.grad).norm() / v.grad.norm().clamp_min(1e-30))
         assert rel < 3e-4, (k, rel)
+
+
+def check_ragged(tmp, cfg, sizes, n_aug_text=0, n_aug_image=0, gradsync=False, dtype=torch.float32, rel_bar=3e-4, loss_bar=1e-5):
+    """every rank's loss = the oracle's loss on the concatenated global batch; without GradSync the rank-SUMMED parameter gradients
+    equal the oracle's (temperature sits downstream of the gather: every rank holds the full gradient, x_clip/distributed.py:51-54);
+    with GradSync every rank holds (1/W) x that sum, bit-identical across ranks"""
+    from oracle import clip_oracle as O
+    world = len(sizes)
+    outs = [torch.load(os.path.join(tmp, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    sd = O.make_state_dict(cfg, 25, torch.float32)
+    sd = {k: (v.to(dtype).double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    text, image, aug_t, aug_i = O.make_inputs(cfg, sum(sizes), 26, n_aug_text, n_aug_image)
+    with O.layer_norm_eps(1e-5 if dtype == torch.float32 else 1e-3):
+        ref = O.clip_forward(sd, cfg, text, image.to(dtype).double(), aug_t, [a.to(dtype).double() for a in aug_i])
+        ref.backward()
+    for o in outs:
+        assert abs(o["loss"] - float(ref.detach())) < loss_bar * max(1.0, abs(float(ref.detach()))), (o["loss"], float(ref.detach()))
+    worst = (0.0, "")
+    for k, v in sd.items():
+        if not torch.is_tensor(v) or not v.is_floating_point() or v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        gs = [o["grads"][k].double() for o in outs]
+        if gradsync:
+            for g in gs[1:]:
+                assert torch.equal(g, gs[0]), k
+            got = gs[0] * (1 if k == "temperature" else world)
+        else:
+            got = sum(gs) / (world if k == "temperature" else 1)
+        rel = float((got - v.grad).norm() / v.grad.norm().clamp_min(1e-30))
+        worst = max(worst, (rel, k))
+        assert rel < rel_bar, (k, rel)
+    return worst

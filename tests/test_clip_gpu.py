@@ -35,7 +35,8 @@ def test_clip_matches_reference_fixture(name):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_cfg1_vs_oracle(dtype):
-    C.case_vs_oracle(DEV, dtype, O.CFG1, 4)
+    # (bf16: the dim-64 toy model's loss is the least accurate of the suite -- measured 6.6e-4; every other case holds 3e-4)
+    C.case_vs_oracle(DEV, dtype, O.CFG1, 4, bf16_loss=1.4e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
@@ -75,7 +76,7 @@ def test_filip_mid_vs_oracle(dtype):
     cfg = dataclasses.replace(MID, use_all_token_embeds=True)
     # bf16: the token scores are rounded to bf16 before the max, so near-ties can route through a different token than the fp64
     # oracle (as the reference's own bf16 run would); the small, attention-only gradients (cls_token) show it most
-    C.case_vs_oracle(DEV, dtype, cfg, 24, bf16_cos=0.98, bf16_rel=0.25)      # measured on the MI355X: rel 0.123, cosine 0.9924
+    C.case_vs_oracle(DEV, dtype, cfg, 24, bf16_cos=0.985, bf16_rel=0.16)     # measured on the MI355X: rel 0.123, cosine 0.9924
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
@@ -124,7 +125,7 @@ def test_mid_simsiam_vs_oracle(dtype):
     import dataclasses
     cfg = dataclasses.replace(MID, use_visual_ssl=True, image_ssl_loss_weight=0.3, ssl_projection_size=256, ssl_projection_hidden_size=1024)
     # (bf16: the worst tensor is the last predictor bias, a sum over rows of vectors tangent to the unit sphere -- heavy cancellation)
-    C.case_vs_oracle(DEV, dtype, cfg, 16)                                     # measured (bf16): rel 0.088, cosine 0.9961 (the last predictor bias)
+    C.case_vs_oracle(DEV, dtype, cfg, 16, bf16_cos=0.992, bf16_rel=0.16)      # measured (bf16): rel 0.088, cosine 0.9961 (the last predictor bias)
 
 
 def test_simclr_bf16_patch_dropout_runs():
@@ -202,7 +203,7 @@ def test_filip_odd_chunks_vs_oracle(monkeypatch):
     cfg = dataclasses.replace(MID, use_all_token_embeds=True, visual_image_size=96)
     monkeypatch.setattr(losses, "_FILIP_CHUNK_BYTES", 22 * cfg.text_seq_len * 9 * 4 * 5)       # ~5 images per chunk
     C.case_vs_oracle(DEV, torch.float32, cfg, 22)
-    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 22, bf16_cos=0.98, bf16_rel=0.25)    # measured: rel 0.080, cosine 0.9968
+    C.case_vs_oracle(DEV, torch.bfloat16, cfg, 22, bf16_cos=0.993, bf16_rel=0.16)   # measured: rel 0.080, cosine 0.9968
 
 
 def test_vit_l_like_shapes_vs_oracle():
@@ -212,6 +213,41 @@ def test_vit_l_like_shapes_vs_oracle():
                        text_heads=12, visual_enc_depth=2, visual_image_size=56, visual_patch_size=14, visual_heads=16)
     C.case_vs_oracle(DEV, torch.float32, cfg, 8, n_aug_text=1, n_aug_image=1, patch_keep=8)
     C.case_vs_oracle(DEV, torch.bfloat16, cfg, 8, n_aug_text=1, n_aug_image=1, patch_keep=8)
+
+
+# ---- BASELINE configs[4] and configs[3] at their REAL architectures against the fp64 oracle -------
+VITL = O.ClipConfig(dim_text=768, dim_image=1024, dim_latent=768, num_text_tokens=49408, text_enc_depth=12, text_seq_len=77,
+                    text_heads=12, visual_enc_depth=24, visual_image_size=336, visual_patch_size=14, visual_heads=16,
+                    decoupled_contrastive_learning=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_vit_l_14_336_full_depth_vs_oracle(dtype):
+    """what `bench.py --config vitl` times, tower for tower: ViT-L/14 at 336 (576 patches, 288 kept = attention3's A3_MAX_N, depth 24,
+    dim 1024, 16 heads, 588-wide patch rows padded to 592), text dim 768 depth 12 length 77, latent 768, DCL, one augmented text + one
+    augmented image (four view pairs), activation checkpointing; batch 2 (x 2 views), every parameter gradient in full"""
+    C.case_vs_oracle(DEV, dtype, VITL, 2, n_aug_text=1, n_aug_image=1, patch_keep=288, seed=51, checkpoint_during_training=True,
+                     label=f"configs[4] arch ViT-L/14-336 depth 24/12 DCL multiview b=2 keep=288 ckpt [{'fp32' if dtype == torch.float32 else 'bf16'}]")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_filip_config3_real_arch_vs_oracle(dtype):
+    """what `bench.py --filip` times: default towers (dim 512, depth 6 / 6) on image 224 / patch 16 (196 patches, 98 kept), text length
+    77, fine-grained token-patch similarity (77 x 98 per pair); batch 8"""
+    import dataclasses
+    cfg = dataclasses.replace(O.ClipConfig(), use_all_token_embeds=True, visual_image_size=224, visual_patch_size=16, text_seq_len=77)
+    C.case_vs_oracle(DEV, dtype, cfg, 8, patch_keep=98, seed=61, bf16_cos=0.985, bf16_rel=0.16,
+                     label=f"configs[3] arch FILIP 224/16 seq 77 depth 6/6 b=8 keep=98 [{'fp32' if dtype == torch.float32 else 'bf16'}]")
+
+
+def test_full_size_step_eight_live_rows_vs_oracle():
+    """BASELINE configs[1] at its full size (local batch 1024, bf16, patch dropout 0.5) pinned to the ORACLE, not to itself: the encoders
+    are row independent, so with an upstream latent gradient that is non-zero on 8 samples only, every parameter gradient of the
+    1024-sample step must equal the oracle's gradient on those 8 samples alone.  The other 1016 samples still walk through every
+    kernel at full size (M = 263,168-row GEMMs, split-K weight gradients, streamed stores, 8192-head attention launches) and must
+    contribute exact zeros -- any stale slab, stray tile or cross-row leak shows up in the comparison.  Also compared with the
+    PRODUCT's own 8-sample step (same bf16 arithmetic per row: only the split-K summation order differs)."""
+    C.case_live_rows(DEV, O.ClipConfig(), 1024, [0, 5, 255, 256, 511, 640, 1022, 1023], torch.bfloat16, label="configs[1] FULL SIZE b=1024 bf16")
 
 
 def test_filip_config4_like_bf16_runs_at_scale():

@@ -50,3 +50,29 @@ def test_two_ranks_filip_vs_oracle(tmp_path, dcl):
     port = 33500 + (os.getpid() % 2000) + (1 if dcl else 0)
     mp.spawn(D.worker_filip, args=(world, port, dataclasses.asdict(cfg), batch, str(tmp_path)), nprocs=world, join=True)
     D.check_filip(str(tmp_path), cfg, batch, world)
+
+
+# ---- more than two ranks, ragged per-rank batches: the peer-chunk loops of the loss kernels iterate W - 1 times,
+# the padded-on-the-wire gathers carry different sizes per rank, one rank holds a single sample ----------------------------------------
+RAGGED = {
+    # name: (world sizes, config overrides, augmented text views, augmented image views, GradSync)
+    "w4_dcl": ([3, 1, 4, 2], dict(decoupled_contrastive_learning=True), 0, 0, False),
+    "w4_simreg_extra_dcl": ([3, 1, 4, 2], dict(decoupled_contrastive_learning=True, extra_latent_projection=True, sim_reg_loss_weight=0.5), 0, 0, False),
+    "w4_multiview_m3n2": ([2, 3, 1, 2], dict(), 2, 1, False),
+    "w4_filip_dcl": ([2, 1, 3, 2], dict(use_all_token_embeds=True, decoupled_contrastive_learning=True), 0, 0, False),
+    "w4_filip_multiview_m2n3": ([2, 1, 2, 1], dict(use_all_token_embeds=True), 1, 2, False),
+    "w8_infonce_gradsync": ([2, 1, 3, 2, 1, 2, 4, 1], dict(), 0, 0, True),
+    "w8_dcl_extra_multiview_m2n2_gradsync": ([1, 2, 1, 3, 2, 1, 1, 2], dict(decoupled_contrastive_learning=True, extra_latent_projection=True), 1, 1, True),
+    "w8_filip": ([1, 2, 1, 1, 2, 1, 1, 1], dict(use_all_token_embeds=True), 0, 0, False),
+}
+
+
+@pytest.mark.parametrize("name", list(RAGGED))
+def test_many_ranks_ragged_vs_oracle(tmp_path, name):
+    from oracle import clip_oracle as O
+    sizes, over, n_t, n_i, gs = RAGGED[name]
+    cfg = dataclasses.replace(O.CFG1, **over)
+    world = len(sizes)
+    port = 35500 + (os.getpid() % 2000) + list(RAGGED).index(name)
+    mp.spawn(D.worker_ragged, args=(world, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", n_t, n_i, gs), nprocs=world, join=True)
+    D.check_ragged(str(tmp_path), cfg, sizes, n_t, n_i, gs)

@@ -50,7 +50,7 @@ def test_two_ranks_on_gpu_mid_bf16_overlap_streams(tmp_path):
                        decoupled_contrastive_learning=True)
     port = 32700 + (os.getpid() % 2000)
     mp.spawn(D.worker_even, args=(2, port, dataclasses.asdict(cfg), 16, str(tmp_path), "cuda", "bfloat16", 8), nprocs=2, join=True)
-    worst = D.check_even(str(tmp_path), cfg, 16, 2, dtype=torch.bfloat16, patch_keep=8, rel_bar=0.2, loss_bar=2e-2, cos_bar=0.98)
+    worst = D.check_even(str(tmp_path), cfg, 16, 2, dtype=torch.bfloat16, patch_keep=8, rel_bar=0.08, loss_bar=3e-4, cos_bar=0.999)      # the single-process bf16 bars (clip_cases.case_vs_oracle)
     print("worst gradient relative error (2 ranks, bf16):", worst)
 
 
@@ -61,6 +61,32 @@ def test_two_ranks_on_gpu_filip_vs_oracle(tmp_path, dcl):
     port = 33700 + (os.getpid() % 2000) + (1 if dcl else 0)
     mp.spawn(D.worker_filip, args=(2, port, dataclasses.asdict(cfg), 4, str(tmp_path), "cuda"), nprocs=2, join=True)
     D.check_filip(str(tmp_path), cfg, 4, 2)
+
+
+@pytest.mark.parametrize("name", ["w4_dcl", "w4_simreg_extra_dcl", "w4_multiview_m3n2", "w4_filip_dcl", "w8_dcl_extra_multiview_m2n2_gradsync"])
+def test_many_ranks_on_gpu_ragged_vs_oracle(tmp_path, name):
+    """four / eight processes on cuda:0 (libxclip_hip.so, real HIP streams, gloo carrying the bytes), ragged per-rank batches: the
+    peer-chunk loops run W - 1 times, GradSync reduces persistent flat buckets whose slices the weight-gradient GEMMs wrote in place"""
+    from oracle import clip_oracle as O
+    from test_distributed_gloo import RAGGED
+    sizes, over, n_t, n_i, gs = RAGGED[name]
+    cfg = dataclasses.replace(O.CFG1, **over)
+    world = len(sizes)
+    port = 36700 + (os.getpid() % 2000) + list(RAGGED).index(name)
+    mp.spawn(D.worker_ragged, args=(world, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cuda", n_t, n_i, gs), nprocs=world, join=True)
+    D.check_ragged(str(tmp_path), cfg, sizes, n_t, n_i, gs)
+
+
+def test_four_ranks_on_gpu_mid_bf16_gradsync(tmp_path):
+    """the dim-512 bf16 model of the 2-rank test on FOUR ranks (aligned batches: the chunked G path with three peer chunks)"""
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig(dim_text=512, dim_image=512, dim_latent=512, num_text_tokens=2000, text_enc_depth=2, text_seq_len=70,
+                       text_heads=8, visual_enc_depth=2, visual_image_size=128, visual_patch_size=32, visual_heads=8,
+                       decoupled_contrastive_learning=True)
+    port = 37700 + (os.getpid() % 2000)
+    mp.spawn(D.worker_even, args=(4, port, dataclasses.asdict(cfg), 8, str(tmp_path), "cuda", "bfloat16", 8), nprocs=4, join=True)
+    worst = D.check_even(str(tmp_path), cfg, 8, 4, dtype=torch.bfloat16, patch_keep=8, rel_bar=0.08, loss_bar=3e-4, cos_bar=0.999)
+    print("worst gradient relative error (4 ranks, bf16):", worst)
 
 
 def test_rccl_two_ranks_one_device_probe(tmp_path):

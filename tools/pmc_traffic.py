@@ -51,7 +51,8 @@ def main():
             import os
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             from x_clip_amd.ops import GEMM_GENERATION
-            json.dump({"kernel_family": fam + "*_kernel", "kernel_generation": GEMM_GENERATION, "bytes_per_launch": per * 1e6, "launches": n,
+            json.dump({"kernel_family": fam + "*_kernel", "kernel_generation": GEMM_GENERATION, "workload_tag": os.environ.get("XCLIP_WORKLOAD_TAG", "default-infonce-b1024"),
+                       "bytes_per_launch": per * 1e6, "launches": n,
                        "source": "tools/pmc_traffic.py over rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (FETCH_SIZE x2 gfx950 correction)"}, f, indent=1)
 
 

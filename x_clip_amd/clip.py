@@ -430,6 +430,10 @@ class CLIP(nn.Module):
         bs = b // k
         on_gpu = dev.type == "cuda"                              # (CPU = the test build: the slices simply run one after the other)
         main = torch.cuda.current_stream(dev) if on_gpu else None
+        # the fork point: everything the inputs depend on has been issued to `main` by now.  Recorded BEFORE slice 0 is issued, so the
+        # side streams wait for the inputs only -- not for slice 0's kernels (a wait_stream(main) after slice 0 had been issued put every
+        # later slice behind the whole of slice 0 and serialised the forward)
+        fork = main.record_event() if on_gpu else None
         outs = []
         for i in range(k):
             args_i = tuple(a[i * bs: (i + 1) * bs] for a in text_args)
@@ -437,7 +441,7 @@ class CLIP(nn.Module):
                 outs.append(model_forward_with_context(fn=self.text_transformer, args=args_i, freeze=freeze))
                 continue
             st = self._side_stream(dev, which=i)
-            st.wait_stream(main)
+            st.wait_event(fork)
             with torch.cuda.stream(st):
                 outs.append(model_forward_with_context(fn=self.text_transformer, args=args_i, freeze=freeze))
         for i in range(1, k if on_gpu else 1):

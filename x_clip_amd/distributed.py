@@ -136,12 +136,25 @@ all_gather = AllGather.apply
 
 
 # ---- data-parallel gradient averaging (the reference leaves this to the user's DDP wrapper; bench.py needs it) -----------
+_ALIGN = 128        # bytes: every parameter's slice of a flat bucket starts on a cache line (GEMM outputs need 16)
+
+
 class GradSync:
-    """Bucketed gradient all-reduce overlapped with the backward: parameters are grouped into buckets (one per top-level
-    sub-module: vision tower, text tower, head); when the last gradient of a bucket has been produced the bucket is
-    flattened and all-reduced asynchronously on the process group's stream (RCCL over xGMI on MI355X) while autograd
-    keeps running the remaining backward.  `finish()` waits, scales by 1/world and points each `.grad` at its slice of
-    the reduced flat buffer.  Equivalent to DistributedDataParallel's mean-reduction for this model."""
+    """Bucketed gradient all-reduce overlapped with the backward, over PERSISTENT flat buffers.
+
+    Parameters are grouped into buckets (one per large top-level sub-module: vision tower, text tower; the rest together); each bucket
+    owns one flat buffer allocated once, in which every parameter has a fixed, 128-byte aligned slice.  The backward's weight-gradient
+    GEMMs write straight into those slices (`claim`, reached through x_clip_amd.functional's grad sink; autograd then adopts the slice as
+    `.grad` without a copy), gradients produced elsewhere (gains, embeddings, biases: a few % of the bytes) are copied into their slices
+    when the bucket is launched -- no per-step `torch.cat` of the whole gradient.  When the last gradient of a bucket has been
+    accumulated the bucket is all-reduced asynchronously on the process group's stream (RCCL over xGMI on MI355X) while autograd keeps
+    running the remaining backward; `finish()` waits and scales by 1/world.  Equivalent to DistributedDataParallel's mean reduction.
+
+    Stream ordering is explicit, not inherited: the towers' backward nodes run on different HIP streams (the vision tower on its side
+    stream, weight gradients on theirs), so every post-accumulate hook records an event on the stream its gradient was accumulated on and
+    the launching stream waits for all events of the bucket before the collective is enqueued (gloo would hide a missing edge here --
+    its GPU collectives are host-staged and synchronous -- NCCL / RCCL would not).  Buckets always have the same byte size on every rank
+    (a parameter without a gradient contributes zeros), so ranks cannot disagree about a collective's size."""
 
     def __init__(self, module: torch.nn.Module, group=None):
         self.group = group
@@ -164,46 +177,106 @@ class GradSync:
                 rest += ps
         if rest:
             self.buckets.append(rest)
-        self._pending = []
+        # one flat buffer per (bucket, dtype, device): offsets are fixed for the life of the object
+        self.flats = []                                      # per bucket: list of flat tensors
+        self._slot = {}                                      # id(param) -> (bucket, flat index, offset in elements)
+        self._by_ptr = {}                                    # param.data_ptr() -> param (the grad sink is asked by weight storage)
+        for bi, ps in enumerate(self.buckets):
+            groups = {}
+            for p in ps:
+                groups.setdefault((p.dtype, p.device), []).append(p)
+            flats = []
+            for (dtype, device), gps in groups.items():
+                step = max(1, _ALIGN // gps[0].element_size())
+                off = 0
+                for p in gps:
+                    self._slot[id(p)] = (bi, len(flats), off)
+                    self._by_ptr[p.data_ptr()] = p
+                    off += (p.numel() + step - 1) // step * step
+                flats.append(torch.zeros(off, dtype=dtype, device=device))
+            self.flats.append(flats)
         self._count = [0] * len(self.buckets)
+        self._events = [[] for _ in self.buckets]
+        self._claimed = set()
+        self._step_open = False
+        self.stats = {"in_place": 0, "copied": 0, "unused": 0}     # of the last step: gradients written straight into their slice / copied / absent
         self._works = []
         self._handles = []
         for bi, ps in enumerate(self.buckets):
             for p in ps:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        from . import functional as XF
+        XF.set_grad_sink(self)
 
+    # ---- the slices ----
+    def _view(self, p: Tensor) -> Tensor:
+        """a FRESH view object of p's slice (autograd adopts a gradient without copying only if nobody else holds that tensor object)"""
+        bi, fi, off = self._slot[id(p)]
+        return self.flats[bi][fi][off: off + p.numel()].view(p.shape)
+
+    def claim(self, weight: Tensor, shape, dtype) -> Optional[Tensor]:
+        """grad sink protocol: the buffer a backward kernel should write the gradient of the parameter stored at `weight` into, or None
+        (unknown tensor, shape / dtype mismatch, the parameter already holds a gradient -- accumulation across backward calls or a tower
+        that runs twice in one step -- in which cases autograd's own accumulation into the slice applies)"""
+        p = self._by_ptr.get(weight.data_ptr())
+        if p is None or tuple(p.shape) != tuple(shape) or p.dtype != dtype or p.grad is not None or id(p) in self._claimed:
+            return None
+        self._claimed.add(id(p))
+        return self._view(p)
+
+    # ---- hooks ----
     def _make_hook(self, bi):
         def hook(param):
+            if param.is_cuda:                                # the stream this gradient was accumulated on (see the class docstring)
+                self._events[bi].append(torch.cuda.current_stream(param.device).record_event())
             self._count[bi] += 1
             if self._count[bi] == len(self.buckets[bi]):
                 self._launch(bi)
         return hook
 
     def _launch(self, bi):
-        ps = [p for p in self.buckets[bi] if p.grad is not None]
-        if not ps:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._works.append((work, flat, ps))
+        ps = self.buckets[bi]
+        if not self._step_open:                              # first launch of a step: fresh statistics
+            self._step_open, self.stats = True, dict.fromkeys(self.stats, 0)
+        if ps[0].is_cuda:
+            cur = torch.cuda.current_stream(ps[0].device)
+            for ev in self._events[bi]:
+                cur.wait_event(ev)
+        self._events[bi] = []
+        with torch.no_grad():
+            for p in ps:
+                v = self._view(p)
+                if p.grad is None:
+                    v.zero_()                                # unused this step: zeros on the wire, .grad stays None
+                    self.stats["unused"] += 1
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    p.grad = v
+                    self.stats["copied"] += 1
+                else:
+                    self.stats["in_place"] += 1
+        for flat in self.flats[bi]:
+            self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
+        self._count[bi] = -1                                 # launched
 
     def finish(self):
         """call after loss.backward(): buckets whose hook count never completed (unused parameters) are flushed too"""
         for bi in range(len(self.buckets)):
-            if 0 < self._count[bi] < len(self.buckets[bi]):
+            if self._count[bi] > 0:
                 self._launch(bi)
             self._count[bi] = 0
-        for work, flat, ps in self._works:
-            work.wait()
+        for work, flat in self._works:
+            if work is not None:
+                work.wait()                                  # orders the current stream behind the collective
             flat.mul_(1.0 / self.world)
-            off = 0
-            for p in ps:
-                n = p.numel()
-                p.grad = flat[off: off + n].view_as(p)
-                off += n
         self._works = []
+        self._claimed.clear()
+        self._step_open = False
 
     def remove(self):
         for h in self._handles:
             h.remove()
         self._handles = []
+        from . import functional as XF
+        if XF.grad_sink() is self:
+            XF.set_grad_sink(None)

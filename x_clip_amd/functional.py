@@ -37,6 +37,25 @@ Tensor = torch.Tensor
 OVERLAP_WGRAD = True
 _wgrad_streams = {}
 
+# Optional destination for parameter gradients (x_clip_amd.distributed.GradSync registers itself): an object whose
+# `claim(weight, shape, dtype)` returns the buffer the gradient of the parameter stored at `weight` should be written into -- a slice of
+# a persistent flat all-reduce bucket -- or None.  The backward then produces that gradient in place instead of into a fresh tensor.
+_grad_sink = None
+
+
+def set_grad_sink(sink) -> None:
+    global _grad_sink
+    _grad_sink = sink
+
+
+def grad_sink():
+    return _grad_sink
+
+
+def _grad_out(weight: Optional[Tensor], shape, dtype, device) -> Tensor:
+    out = _grad_sink.claim(weight, shape, dtype) if (_grad_sink is not None and weight is not None) else None
+    return out if out is not None else torch.empty(*shape, dtype=dtype, device=device)
+
 
 class _SideGemm:
     def __init__(self, device):
@@ -50,11 +69,11 @@ class _SideGemm:
         self.keep = []                                           # operands of the current layer's side-stream GEMMs
         self.pending = []                                        # [(event, operands)] of finished layers, oldest first
 
-    def wgrad(self, dy: Tensor, x: Tensor, N1: int, N2: int, M: int) -> Tensor:
-        """dW [N1, N2] = dy^T x (contraction over the M token rows), issued on the side stream"""
+    def wgrad(self, dy: Tensor, x: Tensor, N1: int, N2: int, M: int, w: Optional[Tensor] = None) -> Tensor:
+        """dW [N1, N2] = dy^T x (contraction over the M token rows), issued on the side stream; `w`: the weight it is the gradient of"""
+        out = _grad_out(w, (N1, N2), dy.dtype, dy.device)             # main-stream memory (or a bucket slice): consumed after join()
         if self.side is None:
-            return ops.gemm(dy, x, N1, N2, M, a_kmajor=True, b_kmajor=True)
-        out = torch.empty(N1, N2, dtype=dy.dtype, device=dy.device)   # main-stream memory: consumed there after join()
+            return ops.gemm(dy, x, N1, N2, M, a_kmajor=True, b_kmajor=True, out=out)
         self.side.wait_stream(self.main)                     # dy was just produced on the main stream
         with torch.cuda.stream(self.side):
             ops.gemm(dy, x, N1, N2, M, a_kmajor=True, b_kmajor=True, out=out)
@@ -148,24 +167,24 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     Fh = F2 // 2
     # feed-forward block
     da = ops.gemm(dx2, w_ff2, M, Fh, D, b_kmajor=True)
-    d_ff2 = sg.wgrad(dx2, a, D, Fh, M) if need_w[3] else None
+    d_ff2 = sg.wgrad(dx2, a, D, Fh, M, w_ff2) if need_w[3] else None
     du, _ = ops.layernorm_bwd(da, u, g_inner, m4, r4, geglu=True, dg=dg_inner)
     del da
     dh2 = ops.gemm(du, w_ff1, M, D, F2, b_kmajor=True)
-    d_ff1 = sg.wgrad(du, h2, F2, D, M) if need_w[2] else None
+    d_ff1 = sg.wgrad(du, h2, F2, D, M, w_ff1) if need_w[2] else None
     del du
     # PreNorm backward + skip, then to_out's LayerNorm backward (the attention block), one pass over the rows
     dx1, dp = ops.layernorm_chain_bwd(dh2, x1, g_ff, m3, r3, dx2, p, g_out, m2, r2, dg_ff, dg_out)
     del dh2
     do = ops.gemm(dp, w_out, M, inner, D, b_kmajor=True)
-    d_out = sg.wgrad(dp, o.view(M, inner), D, inner, M) if need_w[1] else None
+    d_out = sg.wgrad(dp, o.view(M, inner), D, inner, M, w_out) if need_w[1] else None
     del dp
     dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, scale, causal)
     del do
     if rotary is not None:
         ops.rotary_(dqkv.view(M, 3 * inner), n, rotary, inverse=True)      # the saved qkv is the rotated one; R^T maps its gradient back
     dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
-    d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M) if need_w[0] else None
+    d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M, w_qkv) if need_w[0] else None
     del dqkv
     dx, _ = ops.layernorm_bwd(dh, x, g_attn, m1, r1, dres=dx1, dg=dg_attn)
     return dx, [d_qkv, d_out, d_ff1, d_ff2]
@@ -426,7 +445,7 @@ class _LinearFn(torch.autograd.Function):
         N = w.shape[0]
         dy2 = ops._c(dy).view(M, N)
         dx = ops.gemm(dy2, w, M, K, N, b_kmajor=True).view(*ctx.lead, K) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm(dy2, x2, N, K, M, a_kmajor=True, b_kmajor=True) if ctx.needs_input_grad[1] else None
+        dw = ops.gemm(dy2, x2, N, K, M, a_kmajor=True, b_kmajor=True, out=_grad_out(w, (N, K), dy2.dtype, dy2.device)) if ctx.needs_input_grad[1] else None
         return dx, dw
 
 
