@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 12
+#define XCLIP_ABI_VERSION 13
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -120,17 +120,19 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
                const void* addrows, const int32_t* rowidx, int64_t ld_add, void* workspace, int64_t workspace_bytes,
                int dtype, void* stream);
 
-/* ---- fused attention (reference Attention.forward x_clip.py:213-245; dim_head = 64) -------------------------------
- * qkv [batch, n, 3, heads, 64] = output of the to_qkv Linear; mask [batch, n] bytes (1 = attend) or NULL;
- * out [batch, n, heads*64]; lse [batch, heads, n] fp32 saved for the backward.  scale = dim_head^-0.5.
+/* ---- fused attention (reference Attention.forward x_clip.py:201-245; any dim_head up to 128) ----------------------
+ * head_dim = the width of a head slot in memory: 64 (the reference default; the head-resident kernels) or 128 (wide heads: two
+ * 64-wide halves per head through the tiled kernels).  A model head narrower than its slot is zero-padded by the caller.
+ * qkv [batch, n, 3, heads, head_dim] = output of the to_qkv Linear; mask [batch, n] bytes (1 = attend) or NULL;
+ * out [batch, n, heads*head_dim]; lse [batch, heads, n] fp32 saved for the backward.  scale = dim_head^-0.5 (the MODEL's dim_head).
  * causal != 0: key j is hidden from query i when j > i (the causal text encoder, x_clip.py:231-234), on top of the key mask.
  * A query with no visible key gets output 0 (the reference's softmax over all -max scores gives the uniform average there). */
 int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n,
-                        int64_t heads, float scale, int causal, int dtype, void* stream);
-/* delta_ws: [batch, heads, n] fp32 scratch; dqkv [batch, n, 3, heads, 64] fully overwritten */
+                        int64_t heads, int64_t head_dim, float scale, int causal, int dtype, void* stream);
+/* delta_ws: [batch, heads, n] fp32 scratch; dqkv [batch, n, 3, heads, head_dim] fully overwritten */
 int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
-                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int causal, int dtype,
-                        void* stream);
+                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, int64_t head_dim, float scale, int causal,
+                        int dtype, void* stream);
 
 /* ---- contrastive head (similarity + InfoNCE / DCL, x_clip.py:813-847) ---------------------------------------------
  * S = scale * exp(*log_scale) * Q K^T, Q [nq, d], K [nk, d]; log_scale (device fp32 scalar, may be NULL) is the
@@ -201,11 +203,11 @@ int xclip_dwconv4s2_fwd(const void* x, const void* w, void* y, int64_t batch, in
 int xclip_dwconv4s2_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw_accum, void* workspace, int64_t workspace_bytes,
                         int64_t batch, int64_t h, int64_t C, int dtype, void* stream);
 /* Rotary position embedding (RotaryEmbedding / apply_rotary_pos_emb, x_clip.py:155-176; applied to q, k and v, :221-223), in
- * place on rows of `slots` 64-wide head slots (the packed qkv activation: slots = 3 * heads).  Token position = row % n; in
- * every slot the first 32 features are rotated pairwise (j, j + 16) by pos * inv_freq[j]; inv_freq: 16 device fp32 values, the
+ * place on rows of `slots` head slots of `slot_width` (64 or 128) features (the packed qkv activation: slots = 3 * heads).  Token
+ * position = row % n; in every slot the first 32 features are rotated pairwise (j, j + 16) by pos * inv_freq[j]; inv_freq: 16 device fp32 values, the
  * module's `inv_freq` buffer 10000^(-2 j / 32).  inverse != 0 applies the transposed rotation = the backward of the forward call. */
-int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, const float* inv_freq, int inverse, int dtype,
-                 void* stream);
+int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, int64_t slot_width, const float* inv_freq, int inverse,
+                 int dtype, void* stream);
 /* Similarity regularisation (x_clip.py:773-784): D[r,c] = A[r,c] - C[r,c] for two materialised similarity blocks (text-text and
  * image-image, [rows, cols] in the model dtype, row strides lda / ldc), 0 where c == r + diag_off (the global diagonal);
  * *sumsq_accum += sum D^2 (fp32, of the unrounded differences).  D (row stride ldd, model dtype) is the gradient factor:

@@ -254,21 +254,22 @@ def case_gemm(dev, dtype, M, N, K, layout, epilogue=False, alpha=1.0, residual_o
     close(c, r, dtype, f"gemm {layout} {M}x{N}x{K}", scale=max(scale, float(r.abs().max())))
 
 
-def _attention_ref(qkv64, mask, heads, scale, causal=False):
+def _attention_ref(qkv64, mask, heads, scale, causal=False, hd=64):
     b, n, _ = qkv64.shape
-    q, k, v = qkv64.view(b, n, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv64.view(b, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
     s = (q * scale) @ k.transpose(-1, -2)
     if mask is not None:
         s = s.masked_fill(~mask[:, None, None, :], -torch.finfo(s.dtype).max)
     if causal:                                                  # x_clip.py:231-234
         s = s.masked_fill(torch.ones(n, n, dtype=torch.bool).triu(1), -torch.finfo(s.dtype).max)
     p = torch.softmax(s, dim=-1)
-    return (p @ v).permute(0, 2, 1, 3).reshape(b, n, heads * 64)
+    return (p @ v).permute(0, 2, 1, 3).reshape(b, n, heads * hd)
 
 
-def case_attention(dev, dtype, batch, n, heads, masked, causal=False):
-    qkv = rnd((batch, n, 3 * heads * 64), dtype, 22)
-    dout = rnd((batch, n, heads * 64), dtype, 23)
+def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64):
+    """hd = features per head slot: 64, or 128 (wide heads, reference Attention(dim_head > 64), x_clip.py:201-212)"""
+    qkv = rnd((batch, n, 3 * heads * hd), dtype, 22)
+    dout = rnd((batch, n, heads * hd), dtype, 23)
     mask = None
     if masked:
         mask = torch.ones(batch, n, dtype=torch.bool)
@@ -278,14 +279,15 @@ def case_attention(dev, dtype, batch, n, heads, masked, causal=False):
                 mask[bi, n - k:] = False
             if n > 3:
                 mask[bi, 2] = bi % 2 == 0           # a hole in the middle as well
-    scale = 64 ** -0.5
-    out, lse = ops.attention_fwd(qkv.to(dev), None if mask is None else mask.to(dev), heads, scale, causal)
+    scale = hd ** -0.5
+    out, lse = ops.attention_fwd(qkv.to(dev), None if mask is None else mask.to(dev), heads, scale, causal, hd)
     q64 = ref64(qkv).requires_grad_(True)
-    r = _attention_ref(q64, mask, heads, scale, causal)
+    r = _attention_ref(q64, mask, heads, scale, causal, hd)
     r.backward(ref64(dout))
-    close(out, r, dtype, "attn out", ulps=2.0, unit="scale")
-    dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale, causal)
-    close(dqkv, q64.grad, dtype, "attn dqkv", mult=3.0, ulps=2.0, unit="scale")
+    tag = "" if hd == 64 else f" (head slot {hd})"
+    close(out, r, dtype, "attn out" + tag, ulps=2.0, unit="scale")
+    dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale, causal, hd)
+    close(dqkv, q64.grad, dtype, "attn dqkv" + tag, mult=3.0, ulps=2.0, unit="scale")
 
 
 def case_attention_spike(dev, dtype):
@@ -490,17 +492,18 @@ def case_simreg_diff(dev, dtype, rows, cols, diag_off):
     assert abs(float(acc) - want) <= 1e-4 * max(1.0, want), (float(acc), want)
 
 
-def case_rotary(dev, dtype, batch, n, heads):
-    """rotary embedding on packed q | k | v head slots, forward and its transposed (backward) form (x_clip.py:155-176)"""
+def case_rotary(dev, dtype, batch, n, heads, hd=64):
+    """rotary embedding on packed q | k | v head slots (hd = 64 or 128 features each), forward and its transposed (backward) form
+    (x_clip.py:155-176)"""
     slots = 3 * heads
-    x = rnd((batch * n, slots * 64), dtype, 51)
+    x = rnd((batch * n, slots * hd), dtype, 51)
     inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
-    y = ops.rotary_(x.to(dev).clone(), n, inv_freq)
-    fr = O.rotary_freqs(n, 64, torch.float64)                                  # [n, 32]
-    x64 = ref64(x).view(batch, n, slots, 64)
-    ref = O.apply_rotary(fr[None, :, None, :], x64).reshape(batch * n, slots * 64)
+    y = ops.rotary_(x.to(dev).clone(), n, inv_freq, head_dim=hd)
+    fr = O.rotary_freqs(n, hd, torch.float64)                                  # [n, 32]
+    x64 = ref64(x).view(batch, n, slots, hd)
+    ref = O.apply_rotary(fr[None, :, None, :], x64).reshape(batch * n, slots * hd)
     close(y, ref, dtype, "rotary fwd")
-    z = ops.rotary_(y.clone(), n, inv_freq, inverse=True)                      # R^T R = identity
+    z = ops.rotary_(y.clone(), n, inv_freq, inverse=True, head_dim=hd)         # R^T R = identity
     close(z, ref64(x), dtype, "rotary inverse", mult=2.0, ulps=2.0, unit="scale")
 
 

@@ -51,9 +51,18 @@ def test_narrow_heads_vs_oracle():
     import dataclasses
     C.case_vs_oracle(DEV, torch.float32, dataclasses.replace(O.CFG1, text_dim_head=32, visual_dim_head=24, text_rotary_pos_emb=True), 4)
     with pytest.raises(NotImplementedError):
-        C.build_clip(dataclasses.replace(O.CFG1, text_dim_head=128), {}, DEV, torch.float32)
+        C.build_clip(dataclasses.replace(O.CFG1, text_dim_head=160), {}, DEV, torch.float32)
     with pytest.raises(NotImplementedError):
         C.build_clip(dataclasses.replace(O.CFG1, text_dim_head=16, text_rotary_pos_emb=True), {}, DEV, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_wide_heads_vs_oracle(dtype):
+    """dim_head above 64 (ordinary ViT shapes: 80, 96, 128; x_clip.py:201-212 accepts any): 128-feature head slots = two 64-wide
+    halves per head, narrower-than-slot heads zero-padded; rotary on the first 32 features of the 96-wide text heads"""
+    import dataclasses
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(O.CFG1, text_dim_head=96, visual_dim_head=128, text_rotary_pos_emb=True, text_heads=2,
+                                                     visual_heads=2), 4, bf16_loss=1.4e-3)
 
 
 def test_bare_transformer_with_rotary_table_and_mask():

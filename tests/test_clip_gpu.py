@@ -97,6 +97,16 @@ def test_mid_narrow_heads_vs_oracle(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dh_text,dh_image", [(80, 96), (128, 80), (96, 128)])
+def test_mid_wide_heads_vs_oracle(dtype, dh_text, dh_image):
+    """text_dim_head / visual_dim_head in {80, 96, 128} (ordinary ViT head widths; the reference accepts any, x_clip.py:201-212):
+    128-feature head slots = two 64-wide halves per head in the tiled attention kernels, narrower-than-slot heads zero-padded; the
+    text heads are rotary (first 32 features of every slot rotated)"""
+    import dataclasses
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, text_dim_head=dh_text, visual_dim_head=dh_image, text_rotary_pos_emb=True), 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_mid_rotary_vs_oracle(dtype):
     """rotary text encoder (no absolute position table; q, k and v rotated over n + 1 positions, x_clip.py:155-176,221-223,328-330)"""
     import dataclasses

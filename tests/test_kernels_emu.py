@@ -84,6 +84,13 @@ def test_attention_causal(dtype, n, masked):
     K.case_attention(DEV, dtype, 2, n, 2, masked, causal=True)
 
 
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("n,masked,causal", [(33, False, False), (70, True, False), (97, True, True), (130, False, True)])
+def test_attention_wide_heads(dtype, n, masked, causal):
+    """128-feature head slots (reference Attention accepts any dim_head, x_clip.py:201-212): two 64-wide halves per head"""
+    K.case_attention(DEV, dtype, 2, n, 2, masked, causal=causal, hd=128)
+
+
 @pytest.mark.parametrize("n", [257, 320])
 def test_attention_causal_long_bf16(n):
     """n = 257: the cooperative-tail path of the head-resident kernels; n = 320: the tiled kernels for long sequences"""
@@ -188,6 +195,7 @@ def test_simreg_diff(dtype, rows, cols, diag_off):
 @pytest.mark.parametrize("batch,n,heads", [(2, 5, 1), (1, 33, 2)])
 def test_rotary(dtype, batch, n, heads):
     K.case_rotary(DEV, dtype, batch, n, heads)
+    K.case_rotary(DEV, dtype, batch, n, heads, hd=128)
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])

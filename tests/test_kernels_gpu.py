@@ -119,6 +119,14 @@ def test_attention_causal(dtype, n, heads, masked):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("n,heads,masked,causal", [(33, 2, False, False), (70, 3, True, False), (257, 8, True, False), (288, 2, False, False),
+                                                   (97, 2, True, True), (320, 2, True, True)])
+def test_attention_wide_heads(dtype, n, heads, masked, causal):
+    """128-feature head slots (reference Attention accepts any dim_head, x_clip.py:201-212): two 64-wide halves per head"""
+    K.case_attention(DEV, dtype, 3, n, heads, masked, causal=causal, hd=128)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 def test_attention_rescale_spike(dtype):
     K.case_attention_spike(DEV, dtype)
 
@@ -189,6 +197,7 @@ def test_simreg_diff(dtype, rows, cols, diag_off):
 @pytest.mark.parametrize("batch,n,heads", [(2, 5, 1), (7, 257, 8), (3, 33, 4)])
 def test_rotary(dtype, batch, n, heads):
     K.case_rotary(DEV, dtype, batch, n, heads)
+    K.case_rotary(DEV, dtype, batch, n, heads, hd=128)
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)

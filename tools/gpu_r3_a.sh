@@ -23,7 +23,6 @@ for CFG in "vitl:--config vitl --batch 2048 --steps 1 --warmup 0" "filip:--filip
 done
 cd $R
 # untraced lines of the same two configurations
-timeout 600 python bench.py --config vitl --batch 2048 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_vitl.log 2>&1; tail -1 gpurun_out/${TAG}_bench_vitl.log | cut -c1-900
 timeout 300 python bench.py --filip --batch 512 --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_filip.log 2>&1; tail -1 gpurun_out/${TAG}_bench_filip.log | cut -c1-900
 # the N = 8 launch line of the driver, on ONE device with gloo: the multi-rank bench path end to end (GradSync, gathers, barrier, max-over-ranks)
 XCLIP_BENCH_ONE_DEVICE=1 XCLIP_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29611 \

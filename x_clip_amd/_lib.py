@@ -43,14 +43,14 @@ _SIGNATURES = {
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),
-    "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, F, I, I, P]),
-    "xclip_attention_bwd": (c_int, [P, P, P, P, P, P, P, L, L, L, F, I, I, P]),
+    "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, L, F, I, I, P]),
+    "xclip_attention_bwd": (c_int, [P, P, P, P, P, P, P, L, L, L, L, F, I, I, P]),
     "xclip_filip_reduce": (c_int, [P, L, P, P, P, P, L, P, P, P, L, L, L, L, L, L, I, P]),
     "xclip_filip_route": (c_int, [P, L, P, P, P, P, L, P, P, P, L, L, L, L, L, L, I, P]),
     "xclip_rowlse": (c_int, [P, L, L, L, L, I, F, P, P, P]),
     "xclip_rowgrad": (c_int, [P, L, P, L, L, L, I, F, P, P, L, P, P]),
     "xclip_simreg_diff": (c_int, [P, L, P, L, P, L, L, L, L, P, I, P]),
-    "xclip_rotary": (c_int, [P, L, L, L, L, P, I, I, P]),
+    "xclip_rotary": (c_int, [P, L, L, L, L, L, P, I, I, P]),
     "xclip_layernorm_chain_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, L, F, I, P]),
     "xclip_layernorm_chain_bwd_workspace_bytes": (c_int64, [L, L]),
     "xclip_layernorm_chain_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, L, I, P]),
@@ -72,7 +72,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 def _bind(path: str):

@@ -8,8 +8,8 @@ the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is n
 on an MI355X.
 
 Not on this path (constructor raises NotImplementedError): the causal text encoder together with rotary embeddings, FILIP or
-MLM (each fails inside the reference's own forward); attention / feed-forward dropout; dim_head > 64 (narrower heads run
-zero-padded to the kernels' 64: Transformer.stack_params).
+MLM (each fails inside the reference's own forward); attention / feed-forward dropout; dim_head > 128 (heads of up to 64
+dimensions run in 64-feature head slots, 65 ... 128 in 128-feature slots, zero-padded where narrower: Transformer.stack_params).
 """
 from __future__ import annotations
 
@@ -114,9 +114,10 @@ class Transformer(nn.Module):
         dh, h = self.dim_head, self.heads
         for attn, ff in self.layers:
             w_qkv, w_out = attn.fn.to_qkv.weight, attn.fn.to_out[0].weight
-            if dh < 64:                                       # heads narrower than the kernels' 64: zero rows / columns (StackSpec)
-                w_qkv = F.pad(w_qkv.view(3, h, dh, -1), (0, 0, 0, 64 - dh)).reshape(3 * h * 64, -1)
-                w_out = F.pad(w_out.view(-1, h, dh), (0, 64 - dh)).reshape(-1, h * 64)
+            hs = 64 if dh <= 64 else 128                      # the kernels' head slot (StackSpec.head_slot)
+            if dh < hs:                                       # heads narrower than their slot: zero rows / columns (StackSpec)
+                w_qkv = F.pad(w_qkv.view(3, h, dh, -1), (0, 0, 0, hs - dh)).reshape(3 * h * hs, -1)
+                w_out = F.pad(w_out.view(-1, h, dh), (0, hs - dh)).reshape(-1, h * hs)
             ps += [attn.norm.g, w_qkv, w_out, attn.fn.to_out[1].g,
                    ff.norm.g, ff.fn.net[0].weight, ff.fn.net[2].g, ff.fn.net[4].weight]
         ps.append(self.norm_out.g)

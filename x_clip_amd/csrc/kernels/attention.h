@@ -19,7 +19,10 @@
 //     probability exactly 0 (reference: masked_fill(-finfo.max) then softmax -> 0 as well).
 //   * backward = two kernels (dQ over query tiles, dK/dV over key tiles), each recomputing its score tile from
 //     Q, K and the saved log-sum-exp: no atomics, deterministic.
-// Head width is fixed at 64 (the reference default and the value in every BASELINE config).
+// Head width: 64 (the reference default and the value in every BASELINE config) is what every layout above is built for.  Heads of
+// up to 128 dimensions (reference Attention accepts any dim_head, x_clip.py:201-212) run through the same kernels with NH = 2: a
+// 128-wide head is two 64-wide halves -- two K / V (Q / dO) tile sets, scores accumulated over both halves' k-blocks, twice the
+// output accumulators -- and the packed layout is [b, n, 3, h, 128].  Narrower widths are zero-padded by the caller (functional.py).
 #pragma once
 #include "common.h"
 
@@ -29,7 +32,7 @@ constexpr int ATT_DH = 64;
 constexpr float ATT_NEG = -3.0e38f;
 
 struct AttnParams {
-    const void* qkv;             // [batch, n, 3, heads, 64]
+    const void* qkv;             // [batch, n, 3, heads, 64]   (wide heads: 128)
     const unsigned char* mask;   // [batch, n], 1 = attend, or null
     void* out;                   // [batch, n, heads*64]
     float* lse;                  // [batch, heads, n]   log-sum-exp of the scaled, masked scores
@@ -121,43 +124,51 @@ XC_DEV void store_rows_via_lds(T* Os, const f32x16 (&acc)[2], float mul, T* dst,
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
-template <typename T, int NW>
+template <typename T, int NW, int NH = 1>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     typedef AttCfg<T> C;
     constexpr int NT = NW * 64;
+    constexpr int DH = ATT_DH * NH;                    // head width: NH halves of 64
     XC_LDS_DYNAMIC(lds);
-    T* Ks = reinterpret_cast<T*>(lds);                 // [64 keys][LD]
-    T* Vt = Ks + C::TILE;                              // [64 d][LD]  (keys contiguous)
-    T* Os = Vt + C::TILE;                              // [NW*32][LD]
+    T* Ks = reinterpret_cast<T*>(lds);                 // NH x [64 keys][LD]
+    T* Vt = Ks + NH * C::TILE;                         // NH x [64 d][LD]  (keys contiguous)
+    T* Os = Vt + NH * C::TILE;                         // [NW*32][LD]
     unsigned char* Ms = reinterpret_cast<unsigned char*>(Os + NW * 32 * C::LD);   // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c31 = lane & 31;
     const int logical = xcd_remap(blockIdx.x, p.batch * p.heads * p.chunks);
     const int qc = logical % p.chunks, bh = logical / p.chunks;
     const int hh = bh % p.heads, bi = bh / p.heads;
     const int n = p.n;
-    const long ldq = 3L * p.heads * ATT_DH;
-    const T* Qb = reinterpret_cast<const T*>(p.qkv) + (long)bi * n * ldq + hh * ATT_DH;
-    const T* Kb = Qb + (long)p.heads * ATT_DH;
-    const T* Vb = Kb + (long)p.heads * ATT_DH;
+    const long ldq = 3L * p.heads * DH;
+    const T* Qb = reinterpret_cast<const T*>(p.qkv) + (long)bi * n * ldq + hh * DH;
+    const T* Kb = Qb + (long)p.heads * DH;
+    const T* Vb = Kb + (long)p.heads * DH;
     const int q0 = (qc * NW + wave) * 32;
     const int qrow = q0 + c31;
     const int qld = qrow < n ? qrow : n - 1;
     const int qlim = p.causal ? qrow : 0x7fffffff;         // last key this lane's query may attend to
-    u32x4 qf[C::DKB];
+    u32x4 qf[NH][C::DKB];
 #pragma unroll
-    for (int kb = 0; kb < C::DKB; ++kb) qf[kb] = ld16(Qb + (long)qld * ldq + kb * C::KB + h * C::VEC);
+    for (int e = 0; e < NH; ++e)
+#pragma unroll
+        for (int kb = 0; kb < C::DKB; ++kb) qf[e][kb] = ld16(Qb + (long)qld * ldq + e * ATT_DH + kb * C::KB + h * C::VEC);
 
-    f32x16 o[2];
+    f32x16 o[NH][2];
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int e = 0; e < NH; ++e)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[e][db][r] = 0.f;
     float m = ATT_NEG, l = 0.f;
 
     for (int kt0 = 0; kt0 < n; kt0 += 64) {
         sync();                                        // the previous tile has been consumed by every wave
-        stage_rows<T, NT>(Ks, Kb, ldq, kt0, n, tid);
-        stage_rows_transposed<T, NT>(Vt, Vb, ldq, kt0, n, tid);
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            stage_rows<T, NT>(Ks + e * C::TILE, Kb + e * ATT_DH, ldq, kt0, n, tid);
+            stage_rows_transposed<T, NT>(Vt + e * C::TILE, Vb + e * ATT_DH, ldq, kt0, n, tid);
+        }
         if (tid < 64) Ms[tid] = (kt0 + tid < n) && (p.mask == nullptr || p.mask[(long)bi * n + kt0 + tid] != 0);
         sync();
         f32x16 s[2];
@@ -166,8 +177,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < C::DKB; ++kb)
-                s[t] = mma_kblock(ld16(Ks + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), qf[kb], s[t], (T*)nullptr);
+            for (int e = 0; e < NH; ++e)
+#pragma unroll
+                for (int kb = 0; kb < C::DKB; ++kb)
+                    s[t] = mma_kblock(ld16(Ks + e * C::TILE + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), qf[e][kb], s[t], (T*)nullptr);
         }
         float mx = ATT_NEG;
 #pragma unroll
@@ -195,34 +208,40 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
         l = l * alpha + rs;
         m = m_new;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int e = 0; e < NH; ++e)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[e][db][r] *= alpha;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int blk = 0; blk < C::NKB; ++blk) {
                 const u32x4 pf = frag_from_acc(s[t], blk, (T*)nullptr);
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    o[db] = mma_kblock(load_tr_frag(Vt + (db * 32 + c31) * C::LD, t * 32, blk, h), pf, o[db], (T*)nullptr);
+                for (int e = 0; e < NH; ++e)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        o[e][db] = mma_kblock(load_tr_frag(Vt + e * C::TILE + (db * 32 + c31) * C::LD, t * 32, blk, h), pf, o[e][db], (T*)nullptr);
             }
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    T* out = reinterpret_cast<T*>(p.out) + (long)bi * n * p.heads * ATT_DH + hh * ATT_DH;
-    store_rows_via_lds<T, NW>(Os, o, inv, out, (long)p.heads * ATT_DH, q0, n, lane, wave);
+    T* out = reinterpret_cast<T*>(p.out) + (long)bi * n * p.heads * DH + hh * DH;
+#pragma unroll
+    for (int e = 0; e < NH; ++e)
+        store_rows_via_lds<T, NW>(Os, o[e], inv, out + e * ATT_DH, (long)p.heads * DH, q0, n, lane, wave);
     if (h == 0 && qrow < n) p.lse[((long)bi * p.heads + hh) * n + qrow] = m + logf(l);
 }
 
 // ---- delta_i = sum_d dO[i, d] O[i, d] per (batch, head, row) ----------------------------------------------
-template <typename T>
+template <typename T, int NH = 1>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
                                                          float* __restrict__ delta, int batch, int n, int heads) {
-    constexpr int VEC = Elem<T>::VEC, LPH = ATT_DH / VEC;          // lanes per head
+    constexpr int VEC = Elem<T>::VEC, LPH = NH * ATT_DH / VEC;     // lanes per head
     const int lane = lane_id();
     const long row = (long)blockIdx.x * 4 + wave_id();
     if (row >= (long)batch * n) return;
-    const int width = heads * ATT_DH;
+    const int width = heads * NH * ATT_DH;
     for (int c0 = 0; c0 < width / VEC; c0 += 64) {
         const int c = c0 + lane;
         float acc = 0.f;
@@ -244,49 +263,57 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 // ---- dQ -----------------------------------------------------------------------------------------------------
-template <typename T, int NW>
+template <typename T, int NW, int NH = 1>
 __global__ __launch_bounds__(NW * 64) void attn_dq_kernel(AttnParams p) {
     typedef AttCfg<T> C;
     constexpr int NT = NW * 64;
+    constexpr int DH = ATT_DH * NH;
     XC_LDS_DYNAMIC(lds);
-    T* Ks = reinterpret_cast<T*>(lds);                 // [64 keys][LD]
-    T* Kt = Ks + C::TILE;                              // [64 d][LD]
-    T* Vs = Kt + C::TILE;                              // [64 keys][LD]
-    T* Os = Vs + C::TILE;                              // [NW*32][LD]
+    T* Ks = reinterpret_cast<T*>(lds);                 // NH x [64 keys][LD]
+    T* Kt = Ks + NH * C::TILE;                         // NH x [64 d][LD]
+    T* Vs = Kt + NH * C::TILE;                         // NH x [64 keys][LD]
+    T* Os = Vs + NH * C::TILE;                         // [NW*32][LD]
     unsigned char* Ms = reinterpret_cast<unsigned char*>(Os + NW * 32 * C::LD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c31 = lane & 31;
     const int logical = xcd_remap(blockIdx.x, p.batch * p.heads * p.chunks);
     const int qc = logical % p.chunks, bh = logical / p.chunks;
     const int hh = bh % p.heads, bi = bh / p.heads;
     const int n = p.n;
-    const long ldq = 3L * p.heads * ATT_DH, ldo = (long)p.heads * ATT_DH;
-    const T* Qb = reinterpret_cast<const T*>(p.qkv) + (long)bi * n * ldq + hh * ATT_DH;
-    const T* Kb = Qb + (long)p.heads * ATT_DH;
-    const T* Vb = Kb + (long)p.heads * ATT_DH;
-    const T* dOb = reinterpret_cast<const T*>(p.dout) + (long)bi * n * ldo + hh * ATT_DH;
+    const long ldq = 3L * p.heads * DH, ldo = (long)p.heads * DH;
+    const T* Qb = reinterpret_cast<const T*>(p.qkv) + (long)bi * n * ldq + hh * DH;
+    const T* Kb = Qb + (long)p.heads * DH;
+    const T* Vb = Kb + (long)p.heads * DH;
+    const T* dOb = reinterpret_cast<const T*>(p.dout) + (long)bi * n * ldo + hh * DH;
     const int q0 = (qc * NW + wave) * 32;
     const int qrow = q0 + c31;
     const int qld = qrow < n ? qrow : n - 1;
     const int qlim = p.causal ? qrow : 0x7fffffff;         // last key this lane's query may attend to
-    u32x4 qf[C::DKB], dof[C::DKB];
+    u32x4 qf[NH][C::DKB], dof[NH][C::DKB];
 #pragma unroll
-    for (int kb = 0; kb < C::DKB; ++kb) {
-        qf[kb] = ld16(Qb + (long)qld * ldq + kb * C::KB + h * C::VEC);
-        dof[kb] = ld16(dOb + (long)qld * ldo + kb * C::KB + h * C::VEC);
-    }
+    for (int e = 0; e < NH; ++e)
+#pragma unroll
+        for (int kb = 0; kb < C::DKB; ++kb) {
+            qf[e][kb] = ld16(Qb + (long)qld * ldq + e * ATT_DH + kb * C::KB + h * C::VEC);
+            dof[e][kb] = ld16(dOb + (long)qld * ldo + e * ATT_DH + kb * C::KB + h * C::VEC);
+        }
     const float lse_q = p.lse[((long)bi * p.heads + hh) * n + qld];
     const float delta_q = p.delta[((long)bi * p.heads + hh) * n + qld];
-    f32x16 dq[2];
+    f32x16 dq[NH][2];
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int e = 0; e < NH; ++e)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[e][db][r] = 0.f;
 
     for (int kt0 = 0; kt0 < n; kt0 += 64) {
         sync();
-        stage_rows<T, NT>(Ks, Kb, ldq, kt0, n, tid);
-        stage_rows_transposed<T, NT>(Kt, Kb, ldq, kt0, n, tid);
-        stage_rows<T, NT>(Vs, Vb, ldq, kt0, n, tid);
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            stage_rows<T, NT>(Ks + e * C::TILE, Kb + e * ATT_DH, ldq, kt0, n, tid);
+            stage_rows_transposed<T, NT>(Kt + e * C::TILE, Kb + e * ATT_DH, ldq, kt0, n, tid);
+            stage_rows<T, NT>(Vs + e * C::TILE, Vb + e * ATT_DH, ldq, kt0, n, tid);
+        }
         if (tid < 64) Ms[tid] = (kt0 + tid < n) && (p.mask == nullptr || p.mask[(long)bi * n + kt0 + tid] != 0);
         sync();
 #pragma unroll
@@ -295,10 +322,12 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-            for (int kb = 0; kb < C::DKB; ++kb) {
-                s = mma_kblock(ld16(Ks + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), qf[kb], s, (T*)nullptr);
-                dp = mma_kblock(ld16(Vs + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), dof[kb], dp, (T*)nullptr);
-            }
+            for (int e = 0; e < NH; ++e)
+#pragma unroll
+                for (int kb = 0; kb < C::DKB; ++kb) {
+                    s = mma_kblock(ld16(Ks + e * C::TILE + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), qf[e][kb], s, (T*)nullptr);
+                    dp = mma_kblock(ld16(Vs + e * C::TILE + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), dof[e][kb], dp, (T*)nullptr);
+                }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kj = t * 32 + mfma_row(r, lane);
@@ -309,38 +338,43 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_kernel(AttnParams p) {
             for (int blk = 0; blk < C::NKB; ++blk) {
                 const u32x4 df = frag_from_acc(s, blk, (T*)nullptr);
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    dq[db] = mma_kblock(load_tr_frag(Kt + (db * 32 + c31) * C::LD, t * 32, blk, h), df, dq[db], (T*)nullptr);
+                for (int e = 0; e < NH; ++e)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        dq[e][db] = mma_kblock(load_tr_frag(Kt + e * C::TILE + (db * 32 + c31) * C::LD, t * 32, blk, h), df, dq[e][db], (T*)nullptr);
             }
         }
     }
-    T* dQ = reinterpret_cast<T*>(p.dqkv) + (long)bi * n * ldq + hh * ATT_DH;
-    store_rows_via_lds<T, NW>(Os, dq, 1.0f, dQ, ldq, q0, n, lane, wave);
+    T* dQ = reinterpret_cast<T*>(p.dqkv) + (long)bi * n * ldq + hh * DH;
+#pragma unroll
+    for (int e = 0; e < NH; ++e) store_rows_via_lds<T, NW>(Os, dq[e], 1.0f, dQ + e * ATT_DH, ldq, q0, n, lane, wave);
 }
 
 // ---- dK, dV -------------------------------------------------------------------------------------------------
-template <typename T, int NW>
+template <typename T, int NW, int NH = 1>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(AttnParams p) {
     typedef AttCfg<T> C;
     constexpr int NT = NW * 64;
+    constexpr int DH = ATT_DH * NH;
     XC_LDS_DYNAMIC(lds);
-    T* Qs = reinterpret_cast<T*>(lds);                 // [64 q][LD]
-    T* Qt = Qs + C::TILE;                              // [64 d][LD]
-    T* dOs = Qt + C::TILE;                             // [64 q][LD]
-    T* dOt = dOs + C::TILE;                            // [64 d][LD]
-    T* Os = dOt + C::TILE;                             // [NW*32][LD]
-    float* Ls = reinterpret_cast<float*>(Os + NW * 32 * C::LD);   // [64] lse of the staged queries
+    T* Qs = reinterpret_cast<T*>(lds);                 // NH x [64 q][LD]
+    T* Qt = Qs + NH * C::TILE;                         // NH x [64 d][LD]
+    T* dOs = Qt + NH * C::TILE;                        // NH x [64 q][LD]
+    T* dOt = dOs + NH * C::TILE;                       // NH x [64 d][LD]
+    // (wide heads: eight fp32 tiles are 139 KB, so the output staging tile lies over the first tiles once the loop is done)
+    T* Os = NH == 1 ? dOt + C::TILE : Qs;              // [NW*32][LD]
+    float* Ls = reinterpret_cast<float*>(dOt + NH * C::TILE + (NH == 1 ? NW * 32 * C::LD : 0));   // [64] lse of the staged queries
     float* Ds = Ls + 64;                               // [64] delta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c31 = lane & 31;
     const int logical = xcd_remap(blockIdx.x, p.batch * p.heads * p.chunks);
     const int kc = logical % p.chunks, bh = logical / p.chunks;
     const int hh = bh % p.heads, bi = bh / p.heads;
     const int n = p.n;
-    const long ldq = 3L * p.heads * ATT_DH, ldo = (long)p.heads * ATT_DH;
-    const T* Qb = reinterpret_cast<const T*>(p.qkv) + (long)bi * n * ldq + hh * ATT_DH;
-    const T* Kb = Qb + (long)p.heads * ATT_DH;
-    const T* Vb = Kb + (long)p.heads * ATT_DH;
-    const T* dOb = reinterpret_cast<const T*>(p.dout) + (long)bi * n * ldo + hh * ATT_DH;
+    const long ldq = 3L * p.heads * DH, ldo = (long)p.heads * DH;
+    const T* Qb = reinterpret_cast<const T*>(p.qkv) + (long)bi * n * ldq + hh * DH;
+    const T* Kb = Qb + (long)p.heads * DH;
+    const T* Vb = Kb + (long)p.heads * DH;
+    const T* dOb = reinterpret_cast<const T*>(p.dout) + (long)bi * n * ldo + hh * DH;
     const float* lse = p.lse + ((long)bi * p.heads + hh) * n;
     const float* delta = p.delta + ((long)bi * p.heads + hh) * n;
     const int k0 = (kc * NW + wave) * 32;
@@ -348,24 +382,31 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(AttnParams p) {
     const int kld = krow < n ? krow : n - 1;
     const bool kvalid = krow < n && (p.mask == nullptr || p.mask[(long)bi * n + kld] != 0);
     const int kmin = p.causal ? krow : 0;                  // first query that may attend to this lane's key
-    u32x4 kf[C::DKB], vf[C::DKB];
+    u32x4 kf[NH][C::DKB], vf[NH][C::DKB];
 #pragma unroll
-    for (int kb = 0; kb < C::DKB; ++kb) {
-        kf[kb] = ld16(Kb + (long)kld * ldq + kb * C::KB + h * C::VEC);
-        vf[kb] = ld16(Vb + (long)kld * ldq + kb * C::KB + h * C::VEC);
-    }
-    f32x16 dk[2], dv[2];
+    for (int e = 0; e < NH; ++e)
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+        for (int kb = 0; kb < C::DKB; ++kb) {
+            kf[e][kb] = ld16(Kb + (long)kld * ldq + e * ATT_DH + kb * C::KB + h * C::VEC);
+            vf[e][kb] = ld16(Vb + (long)kld * ldq + e * ATT_DH + kb * C::KB + h * C::VEC);
+        }
+    f32x16 dk[NH][2], dv[NH][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    for (int e = 0; e < NH; ++e)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[e][db][r] = 0.f; dv[e][db][r] = 0.f; }
 
     for (int qt0 = 0; qt0 < n; qt0 += 64) {
         sync();
-        stage_rows<T, NT>(Qs, Qb, ldq, qt0, n, tid);
-        stage_rows_transposed<T, NT>(Qt, Qb, ldq, qt0, n, tid);
-        stage_rows<T, NT>(dOs, dOb, ldo, qt0, n, tid);
-        stage_rows_transposed<T, NT>(dOt, dOb, ldo, qt0, n, tid);
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            stage_rows<T, NT>(Qs + e * C::TILE, Qb + e * ATT_DH, ldq, qt0, n, tid);
+            stage_rows_transposed<T, NT>(Qt + e * C::TILE, Qb + e * ATT_DH, ldq, qt0, n, tid);
+            stage_rows<T, NT>(dOs + e * C::TILE, dOb + e * ATT_DH, ldo, qt0, n, tid);
+            stage_rows_transposed<T, NT>(dOt + e * C::TILE, dOb + e * ATT_DH, ldo, qt0, n, tid);
+        }
         if (tid < 64) {
             const bool v = qt0 + tid < n;
             Ls[tid] = v ? lse[qt0 + tid] : 0.f;
@@ -378,10 +419,12 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-            for (int kb = 0; kb < C::DKB; ++kb) {
-                s = mma_kblock(ld16(Qs + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), kf[kb], s, (T*)nullptr);
-                dp = mma_kblock(ld16(dOs + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), vf[kb], dp, (T*)nullptr);
-            }
+            for (int e = 0; e < NH; ++e)
+#pragma unroll
+                for (int kb = 0; kb < C::DKB; ++kb) {
+                    s = mma_kblock(ld16(Qs + e * C::TILE + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), kf[e][kb], s, (T*)nullptr);
+                    dp = mma_kblock(ld16(dOs + e * C::TILE + (t * 32 + c31) * C::LD + kb * C::KB + h * C::VEC), vf[e][kb], dp, (T*)nullptr);
+                }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = t * 32 + mfma_row(r, lane);
@@ -394,24 +437,30 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(AttnParams p) {
                 const u32x4 pf = frag_from_acc(s, blk, (T*)nullptr);
                 const u32x4 df = frag_from_acc(dp, blk, (T*)nullptr);
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dv[db] = mma_kblock(load_tr_frag(dOt + (db * 32 + c31) * C::LD, t * 32, blk, h), pf, dv[db], (T*)nullptr);
-                    dk[db] = mma_kblock(load_tr_frag(Qt + (db * 32 + c31) * C::LD, t * 32, blk, h), df, dk[db], (T*)nullptr);
-                }
+                for (int e = 0; e < NH; ++e)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        dv[e][db] = mma_kblock(load_tr_frag(dOt + e * C::TILE + (db * 32 + c31) * C::LD, t * 32, blk, h), pf, dv[e][db], (T*)nullptr);
+                        dk[e][db] = mma_kblock(load_tr_frag(Qt + e * C::TILE + (db * 32 + c31) * C::LD, t * 32, blk, h), df, dk[e][db], (T*)nullptr);
+                    }
             }
         }
     }
-    T* dK = reinterpret_cast<T*>(p.dqkv) + (long)bi * n * ldq + (long)p.heads * ATT_DH + hh * ATT_DH;
-    T* dV = dK + (long)p.heads * ATT_DH;
-    store_rows_via_lds<T, NW>(Os, dk, 1.0f, dK, ldq, k0, n, lane, wave);
-    store_rows_via_lds<T, NW>(Os, dv, 1.0f, dV, ldq, k0, n, lane, wave);
+    if (NH > 1) sync();                                // the staging tile lies over Qs / Qt: every wave must be through with them
+    T* dK = reinterpret_cast<T*>(p.dqkv) + (long)bi * n * ldq + (long)p.heads * DH + hh * DH;
+    T* dV = dK + (long)p.heads * DH;
+#pragma unroll
+    for (int e = 0; e < NH; ++e) {
+        store_rows_via_lds<T, NW>(Os, dk[e], 1.0f, dK + e * ATT_DH, ldq, k0, n, lane, wave);
+        store_rows_via_lds<T, NW>(Os, dv[e], 1.0f, dV + e * ATT_DH, ldq, k0, n, lane, wave);
+    }
 }
 
-template <typename T, int NW>
-constexpr int attn_fwd_lds_bytes() { return (2 * AttCfg<T>::TILE + NW * 32 * AttCfg<T>::LD) * (int)sizeof(T) + 64; }
-template <typename T, int NW>
-constexpr int attn_dq_lds_bytes() { return (3 * AttCfg<T>::TILE + NW * 32 * AttCfg<T>::LD) * (int)sizeof(T) + 64; }
-template <typename T, int NW>
-constexpr int attn_dkv_lds_bytes() { return (4 * AttCfg<T>::TILE + NW * 32 * AttCfg<T>::LD) * (int)sizeof(T) + 512; }
+template <typename T, int NW, int NH = 1>
+constexpr int attn_fwd_lds_bytes() { return (2 * NH * AttCfg<T>::TILE + NW * 32 * AttCfg<T>::LD) * (int)sizeof(T) + 64; }
+template <typename T, int NW, int NH = 1>
+constexpr int attn_dq_lds_bytes() { return (3 * NH * AttCfg<T>::TILE + NW * 32 * AttCfg<T>::LD) * (int)sizeof(T) + 64; }
+template <typename T, int NW, int NH = 1>
+constexpr int attn_dkv_lds_bytes() { return (4 * NH * AttCfg<T>::TILE + (NH == 1 ? NW * 32 * AttCfg<T>::LD : 0)) * (int)sizeof(T) + 512; }
 
 }  // namespace xc

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restr
 // (the reference applies it to q, k AND v).  sign = +1: forward; -1: the transposed rotation = its backward.  In place; one
 // lane owns the two 16-byte chunks that hold a set of pairs, so no exchange is needed.
 template <typename T>
-__global__ __launch_bounds__(256) void rotary_kernel(T* __restrict__ X, long ld, long rows, int n, int slots,
+__global__ __launch_bounds__(256) void rotary_kernel(T* __restrict__ X, long ld, long rows, int n, int slots, int slot_width,
                                                      const float* __restrict__ inv_freq, float sign) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int HALF = 16;                                   // ROT / 2
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* __restrict__ X, long ld,
         const int slot = (int)(rs % slots);
         const long row = rs / slots;
         const float pos = (float)(row % n);
-        T* p = X + row * ld + slot * 64 + c * VEC;
+        T* p = X + row * ld + slot * slot_width + c * VEC;
         float a[VEC], b[VEC];
         load_vec<T>(p, a);                                     // features j      = c VEC + (0 .. VEC-1)
         load_vec<T>(p + HALF, b);                              // features j + 16

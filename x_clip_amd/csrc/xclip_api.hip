@@ -640,10 +640,11 @@ int xclip_cross_entropy_bwd(void* logits, int64_t ld, const int64_t* labels, con
     return check_launch(__func__);
 }
 
-int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, const float* inv_freq, int inverse, int dtype,
-                 void* stream) {
+int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, int64_t slot_width, const float* inv_freq, int inverse,
+                 int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
-    XC_REQUIRE(rows >= 0 && n > 0 && slots > 0 && ld >= slots * 64 && ld % vec_of(dtype) == 0, "bad shape (64-wide head slots)");
+    XC_REQUIRE(slot_width == 64 || slot_width == 128, "head slots are 64 or 128 wide");
+    XC_REQUIRE(rows >= 0 && n > 0 && slots > 0 && ld >= slots * slot_width && ld % vec_of(dtype) == 0, "bad shape");
     XC_REQUIRE(x && aligned16(x) && inv_freq, "null or misaligned pointer");
     if (rows == 0) return 0;
     const int64_t items = rows * slots * (16 / vec_of(dtype));
@@ -652,9 +653,9 @@ int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, co
     dim3 grid((unsigned)blocks), block(256);
     const float sign = inverse ? -1.0f : 1.0f;
     if (dtype == XCLIP_BF16)
-        hipLaunchKernelGGL((rotary_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)x, (long)ld, (long)rows, (int)n, (int)slots, inv_freq, sign);
+        hipLaunchKernelGGL((rotary_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)x, (long)ld, (long)rows, (int)n, (int)slots, (int)slot_width, inv_freq, sign);
     else
-        hipLaunchKernelGGL((rotary_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)x, (long)ld, (long)rows, (int)n, (int)slots, inv_freq, sign);
+        hipLaunchKernelGGL((rotary_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)x, (long)ld, (long)rows, (int)n, (int)slots, (int)slot_width, inv_freq, sign);
     return check_launch(__func__);
 }
 

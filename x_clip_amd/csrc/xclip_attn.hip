@@ -14,21 +14,21 @@ using namespace xcapi;
 
 namespace {
 
-template <typename T, int NW>
+template <typename T, int NW, int NH = 1>
 void launch_attn_fwd(AttnParams p, hipStream_t st) {
     p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
-    constexpr int lds = attn_fwd_lds_bytes<T, NW>();
-    XC_ALLOW_LDS((attn_fwd_kernel<T, NW>), lds);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
+    constexpr int lds = attn_fwd_lds_bytes<T, NW, NH>();
+    XC_ALLOW_LDS((attn_fwd_kernel<T, NW, NH>), lds);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NW, NH>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds, st, p);
 }
-template <typename T, int NW>
+template <typename T, int NW, int NH = 1>
 void launch_attn_bwd(AttnParams p, hipStream_t st) {
     p.chunks = (p.n + NW * 32 - 1) / (NW * 32);
-    constexpr int lds_q = attn_dq_lds_bytes<T, NW>(), lds_kv = attn_dkv_lds_bytes<T, NW>();
-    XC_ALLOW_LDS((attn_dq_kernel<T, NW>), lds_q);
-    XC_ALLOW_LDS((attn_dkv_kernel<T, NW>), lds_kv);
-    hipLaunchKernelGGL((attn_dq_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_q, st, p);
-    hipLaunchKernelGGL((attn_dkv_kernel<T, NW>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_kv, st, p);
+    constexpr int lds_q = attn_dq_lds_bytes<T, NW, NH>(), lds_kv = attn_dkv_lds_bytes<T, NW, NH>();
+    XC_ALLOW_LDS((attn_dq_kernel<T, NW, NH>), lds_q);
+    XC_ALLOW_LDS((attn_dkv_kernel<T, NW, NH>), lds_kv);
+    hipLaunchKernelGGL((attn_dq_kernel<T, NW, NH>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_q, st, p);
+    hipLaunchKernelGGL((attn_dkv_kernel<T, NW, NH>), dim3(p.batch * p.heads * p.chunks), dim3(NW * 64), lds_kv, st, p);
 }
 template <int NW>
 void launch_attn2_fwd(AttnParams p, hipStream_t st) {
@@ -59,9 +59,10 @@ int attn_waves(int64_t n) {
 extern "C" {
 
 int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n, int64_t heads,
-                        float scale, int causal, int dtype, void* stream) {
+                        int64_t head_dim, float scale, int causal, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
+    XC_REQUIRE(head_dim == 64 || head_dim == 128, "head_dim must be 64 or 128 (narrower / in-between widths are zero-padded by the caller)");
     XC_REQUIRE(aligned16(qkv) && aligned16(out), "pointers must be 16-byte aligned");
     if (batch == 0) return 0;
     AttnParams p;
@@ -69,6 +70,14 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     p.qkv = qkv; p.mask = mask; p.out = out; p.lse = lse;
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale; p.causal = causal != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 128) {                                     // wide heads: the tiled kernels with two 64-wide halves per head
+        const int nw = attn_waves(n);
+#define W(T) switch (nw) { case 1: launch_attn_fwd<T, 1, 2>(p, st); break; case 2: launch_attn_fwd<T, 2, 2>(p, st); break; \
+                           case 3: launch_attn_fwd<T, 3, 2>(p, st); break; default: launch_attn_fwd<T, 4, 2>(p, st); break; }
+        if (dtype == XCLIP_BF16) { W(bf16_t) } else { W(float) }
+#undef W
+        return check_launch(__func__);
+    }
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // head-resident kernel: one work-group per (batch, head)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         const int nwq = a3_waves((int)n);
@@ -98,10 +107,11 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
 }
 
 int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
-                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, float scale, int causal, int dtype,
-                        void* stream) {
+                        float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, int64_t head_dim, float scale, int causal,
+                        int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
+    XC_REQUIRE(head_dim == 64 || head_dim == 128, "head_dim must be 64 or 128 (narrower / in-between widths are zero-padded by the caller)");
     XC_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "pointers must be 16-byte aligned");
     if (batch == 0) return 0;
     AttnParams p;
@@ -110,6 +120,20 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     p.delta = delta_ws; p.dqkv = dqkv;
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale; p.causal = causal != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 128) {                                     // wide heads: delta pass + the tiled dQ / dK, dV kernels on two halves
+        XC_REQUIRE(delta_ws != nullptr, "wide heads need the [batch, heads, n] fp32 delta workspace");
+        dim3 wgrid((unsigned)((batch * n + 3) / 4)), wblock(256);
+        if (dtype == XCLIP_BF16)
+            hipLaunchKernelGGL((attn_delta_kernel<bf16_t, 2>), wgrid, wblock, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta_ws, (int)batch, (int)n, (int)heads);
+        else
+            hipLaunchKernelGGL((attn_delta_kernel<float, 2>), wgrid, wblock, 0, st, (const float*)out, (const float*)dout, delta_ws, (int)batch, (int)n, (int)heads);
+        const int nw = attn_waves(n);
+#define W(T) switch (nw) { case 1: launch_attn_bwd<T, 1, 2>(p, st); break; case 2: launch_attn_bwd<T, 2, 2>(p, st); break; \
+                           case 3: launch_attn_bwd<T, 3, 2>(p, st); break; default: launch_attn_bwd<T, 4, 2>(p, st); break; }
+        if (dtype == XCLIP_BF16) { W(bf16_t) } else { W(float) }
+#undef W
+        return check_launch(__func__);
+    }
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         const int nwq = a3_bwd_waves((int)n);

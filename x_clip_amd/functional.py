@@ -110,13 +110,19 @@ class StackSpec:
     causal: bool = False                    # causal attention (the autoregressive text encoder), x_clip.py:231-234
 
     def __post_init__(self):
-        # the attention kernels hold 64-wide heads.  A narrower head runs as a 64-wide one whose extra q / k / v columns are zero
+        # the attention kernels hold head slots of 64 features (the head-resident kernels) or 128 (wide heads: two 64-wide halves
+        # through the tiled kernels).  A head narrower than its slot runs with its extra q / k / v columns zero
         # (clip.Transformer.stack_params pads to_qkv / to_out with zero rows / columns: q.k and the softmax are unchanged, the
         # padded output columns are zero and meet zero weights); only the scale dim_head^-0.5 is the head's own.
-        if not 1 <= self.dim_head <= 64:
-            raise NotImplementedError("x_clip_amd attention kernels hold heads of up to 64 dimensions (the reference default is 64)")
+        if not 1 <= self.dim_head <= 128:
+            raise NotImplementedError("x_clip_amd attention kernels hold heads of up to 128 dimensions (the reference default is 64)")
         if self.rotary is not None and self.dim_head < 32:
             raise NotImplementedError("rotary embedding with dim_head < 32 (the kernel rotates the first 32 dimensions of a head)")
+
+    @property
+    def head_slot(self) -> int:
+        """features per head slot in the packed qkv / attention output: 64, or 128 for heads wider than 64"""
+        return 64 if self.dim_head <= 64 else 128
 
 
 class _GainGrads:
@@ -137,15 +143,15 @@ class _GainGrads:
 
 # ---- one pre-norm residual block pair (x_clip.py:285-289) --------------------------------------------------------------
 def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor], rotary: Optional[Tensor] = None,
-                   causal: bool = False, scale: float = 0.125):
+                   causal: bool = False, scale: float = 0.125, hs: int = 64):
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     M, D = x.shape
-    inner = heads * 64
+    inner = heads * hs                                                                 # hs: features per head slot (64 | 128)
     h, m1, r1 = ops.layernorm_fwd(x, g_attn)                                           # PreNorm           :126
     qkv = ops.gemm(h, w_qkv, M, 3 * inner, D)                                          # to_qkv            :216
     if rotary is not None:
-        ops.rotary_(qkv, n, rotary)                                                            # q, k, v rotated   :221-223
-    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, scale, causal)   # scale/mask/softmax :217-244
+        ops.rotary_(qkv, n, rotary, head_dim=hs)                                               # q, k, v rotated   :221-223
+    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, scale, causal, hs)   # scale/mask/softmax :217-244
     p = ops.gemm(o.view(M, inner), w_out, M, D, inner)                                 # to_out.0          :245
     x1, m2, r2, h2, m3, r3 = ops.layernorm_chain_fwd(p, g_out, x, g_ff)                # to_out.1 + skip :245,288 and PreNorm :126, one pass
     u = ops.gemm(h2, w_ff1, M, w_ff1.shape[0], D)                                      # net.0             :191
@@ -156,13 +162,13 @@ def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, m
 
 def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
                     gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm", rotary: Optional[Tensor] = None,
-                    causal: bool = False, scale: float = 0.125):
+                    causal: bool = False, scale: float = 0.125, hs: int = 64):
     """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2])"""
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     dg_attn, dg_out, dg_ff, dg_inner = gain_acc
     x, h, m1, r1, qkv, o, lse, p, m2, r2, x1, h2, m3, r3, u, a, m4, r4 = saved
     M, D = x.shape
-    inner = heads * 64
+    inner = heads * hs
     F2 = w_ff1.shape[0]
     Fh = F2 // 2
     # feed-forward block
@@ -179,10 +185,10 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     do = ops.gemm(dp, w_out, M, inner, D, b_kmajor=True)
     d_out = sg.wgrad(dp, o.view(M, inner), D, inner, M, w_out) if need_w[1] else None
     del dp
-    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, scale, causal)
+    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, scale, causal, hs)
     del do
     if rotary is not None:
-        ops.rotary_(dqkv.view(M, 3 * inner), n, rotary, inverse=True)      # the saved qkv is the rotated one; R^T maps its gradient back
+        ops.rotary_(dqkv.view(M, 3 * inner), n, rotary, inverse=True, head_dim=hs)      # the saved qkv is the rotated one; R^T maps its gradient back
     dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
     d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M, w_qkv) if need_w[0] else None
     del dqkv
@@ -200,7 +206,7 @@ def stack_forward(x0: Tensor, B: int, n: int, spec: StackSpec, params: Sequence[
     layers = []
     for l in range(spec.depth):
         W = params[1 + LAYER_PARAMS * l: 1 + LAYER_PARAMS * (l + 1)]
-        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5)
+        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot)
         if keep_tape:
             layers.append((saved[0],) if spec.checkpoint else saved)
         x = x_next
@@ -223,9 +229,9 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
         W = params[base: base + LAYER_PARAMS]
         saved = layers[l]
         if spec.checkpoint:                      # re-run the layer forward from its saved input
-            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5)
+            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot)
         need_w = [need[base + 1], need[base + 2], need[base + 5], need[base + 7]]
-        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal, spec.dim_head ** -0.5)
+        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot)
         layers[l] = None                         # release this layer's activations
         sg.layer_done()
         grads[base + 1], grads[base + 2], grads[base + 5], grads[base + 7] = dws

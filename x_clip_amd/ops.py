@@ -412,31 +412,33 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
 
 
 # ---- attention --------------------------------------------------------------------------------------------------------
-def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float, causal: bool = False) -> Tuple[Tensor, Tensor]:
-    """qkv [b, n, 3*heads*64]; mask bool [b, n] or None; causal: key j hidden from query i < j -> out [b, n, heads*64], lse fp32 [b, heads, n]"""
+def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float, causal: bool = False,
+                  head_dim: int = 64) -> Tuple[Tensor, Tensor]:
+    """qkv [b, n, 3*heads*head_dim] (head slots of 64 or 128 features); mask bool [b, n] or None; causal: key j hidden from query i < j
+    -> out [b, n, heads*head_dim], lse fp32 [b, heads, n]"""
     _dev_check(qkv, mask)
     qkv = _c(qkv)
     b, n, w = qkv.shape
-    assert w == 3 * heads * 64, "x_clip_amd attention kernels are built for dim_head = 64"
-    out = torch.empty(b, n, heads * 64, dtype=qkv.dtype, device=qkv.device)
+    assert head_dim in (64, 128) and w == 3 * heads * head_dim, "x_clip_amd attention kernels hold head slots of 64 or 128 features"
+    out = torch.empty(b, n, heads * head_dim, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(b, heads, n, dtype=torch.float32, device=qkv.device)
     if mask is not None:
         assert mask.dtype == torch.bool and tuple(mask.shape) == (b, n)
         mask = _c(mask)
-    _lib.check(_lib.lib().xclip_attention_fwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), lse.data_ptr(), b, n, heads, scale,
+    _lib.check(_lib.lib().xclip_attention_fwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), lse.data_ptr(), b, n, heads, head_dim, scale,
                                               int(causal), dtype_code(qkv), _stream(qkv)), "xclip_attention_fwd")
     return out, lse
 
 
 def attention_bwd(qkv: Tensor, mask: Optional[Tensor], out: Tensor, dout: Tensor, lse: Tensor, heads: int, scale: float,
-                  causal: bool = False) -> Tensor:
+                  causal: bool = False, head_dim: int = 64) -> Tensor:
     _dev_check(qkv, mask, out, dout)
     dout = _c(dout)
     b, n, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(b, heads, n, dtype=torch.float32, device=qkv.device)
     _lib.check(_lib.lib().xclip_attention_bwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                              delta.data_ptr(), dqkv.data_ptr(), b, n, heads, scale, int(causal), dtype_code(qkv),
+                                              delta.data_ptr(), dqkv.data_ptr(), b, n, heads, head_dim, scale, int(causal), dtype_code(qkv),
                                               _stream(qkv)), "xclip_attention_bwd")
     return dqkv
 
@@ -567,14 +569,15 @@ def simreg_diff(A: Tensor, C: Tensor, diag_off: int, sumsq_accum: Tensor) -> Ten
     return A
 
 
-def rotary_(x: Tensor, n: int, inv_freq: Tensor, inverse: bool = False) -> Tensor:
-    """in-place rotary position embedding on x [rows, slots * 64] (packed q | k | v head slots), position = row % n, angles
-    pos * inv_freq[j] (x_clip.py:155-176, 221-223); inverse=True is the backward of the forward call"""
+def rotary_(x: Tensor, n: int, inv_freq: Tensor, inverse: bool = False, head_dim: int = 64) -> Tensor:
+    """in-place rotary position embedding on x [rows, slots * head_dim] (packed q | k | v head slots of 64 or 128 features), position =
+    row % n, angles pos * inv_freq[j] on the first 32 features of every slot (x_clip.py:155-176, 221-223); inverse=True is the backward
+    of the forward call"""
     _dev_check(x, inv_freq)
-    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 64 == 0
+    assert x.dim() == 2 and x.stride(1) == 1 and head_dim in (64, 128) and x.shape[1] % head_dim == 0
     assert inv_freq.dtype == torch.float32 and inv_freq.numel() == 16 and inv_freq.is_contiguous()
-    _lib.check(_lib.lib().xclip_rotary(x.data_ptr(), x.stride(0), x.shape[0], n, x.shape[1] // 64, inv_freq.data_ptr(), int(inverse),
-                                       dtype_code(x), _stream(x)), "xclip_rotary")
+    _lib.check(_lib.lib().xclip_rotary(x.data_ptr(), x.stride(0), x.shape[0], n, x.shape[1] // head_dim, head_dim, inv_freq.data_ptr(),
+                                       int(inverse), dtype_code(x), _stream(x)), "xclip_rotary")
     return x
 
 
