@@ -236,7 +236,9 @@ def test_vit_l_14_336_full_depth_vs_oracle(dtype):
     """what `bench.py --config vitl` times, tower for tower: ViT-L/14 at 336 (576 patches, 288 kept = attention3's A3_MAX_N, depth 24,
     dim 1024, 16 heads, 588-wide patch rows padded to 592), text dim 768 depth 12 length 77, latent 768, DCL, one augmented text + one
     augmented image (four view pairs), activation checkpointing; batch 2 (x 2 views), every parameter gradient in full"""
-    C.case_vs_oracle(DEV, dtype, VITL, 2, n_aug_text=1, n_aug_image=1, patch_keep=288, seed=51, checkpoint_during_training=True,
+    # (bf16 loss bar: at batch 2 with DCL the loss itself is 0.07 and 36 bf16 layers put ~1e-3 on the unit-norm latents: measured 6.8e-4;
+    #  every gradient holds the default bars -- measured 2.1 % / cosine 0.99977)
+    C.case_vs_oracle(DEV, dtype, VITL, 2, n_aug_text=1, n_aug_image=1, patch_keep=288, seed=51, checkpoint_during_training=True, bf16_loss=1.4e-3,
                      label=f"configs[4] arch ViT-L/14-336 depth 24/12 DCL multiview b=2 keep=288 ckpt [{'fp32' if dtype == torch.float32 else 'bf16'}]")
 
 

@@ -180,9 +180,11 @@ def test_scatter_sorted_and_gelu(dtype):
 
 
 @pytest.mark.parametrize("dcl", [False, True])
-def test_simloss_on_gemm3_loop(dcl):
-    """bf16 problems at least a tile wide run on the persistent gemm3 loop (simloss3.h): ragged rows and columns, 2 x 2 tiles"""
+def test_simloss_on_gemm_loop(dcl):
+    """bf16 problems at least a tile wide run on the production GEMM loop (simloss5.h on g5_run): ragged rows and columns, 2 x 2
+    tiles; then 2 x 4 tiles of which (0, 2) is interior and off the diagonal -- the whole-line G epilogue -- over two K steps"""
     K.case_simloss(DEV, torch.bfloat16, 264, 392, 64, dcl, diag_off=100)
+    K.case_simloss(DEV, torch.bfloat16, 264, 776, 128, dcl, diag_off=100)
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])

@@ -181,8 +181,9 @@ def test_scatter_sorted_and_gelu(dtype):
 
 
 @pytest.mark.parametrize("dcl", [False, True])
-def test_simloss_on_gemm3_loop(dcl):
+def test_simloss_on_gemm_loop(dcl):
     K.case_simloss(DEV, torch.bfloat16, 264, 392, 64, dcl, diag_off=100)
+    K.case_simloss(DEV, torch.bfloat16, 264, 776, 128, dcl, diag_off=100)
     K.case_simloss(DEV, torch.bfloat16, 1024, 4096, 512, dcl, diag_off=2048)
     K.case_simloss_closed_form(DEV, torch.bfloat16, 1032, 512, dcl)
 

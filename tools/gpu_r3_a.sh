@@ -6,7 +6,7 @@ TAG=${1:-r03_a}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$PWD
-( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+( time timeout 1500 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1
 tail -25 gpurun_out/${TAG}_pytest_gpu.log
 cp gpurun_out/parity_report_gpu.txt gpurun_out/${TAG}_parity_report_gpu.txt 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/${TAG}_smoke.log

@@ -3,7 +3,9 @@ columns, d = 512, bf16 (row block of the rank-sharded loss)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from x_clip_amd import ops
+from x_clip_amd import _lib, ops
+if "--measure" in sys.argv:          # libxclip_hip_measure.so: XCLIP_SIM=3 selects the round-1 loop (simloss3.h) for the A/B
+    _lib.use_measurement_build()
 dev = torch.device("cuda:0")
 b, B, d = 4096, 32768, 512
 

@@ -424,7 +424,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             // the four A pieces the next K step would issue in its k-block 0, THEN the stores
             unsigned char* const freed = ldsA + (sa3 == 0 ? 2 : sa3 - 1) * G2_OPER_BYTES;
             u32x4 o[4][4];
-            epi.pack_lines(acc, freed + mine, o);
+            epi.pack_lines(acc, freed + mine, o, m0, n0);
             lds_drain();
 #pragma unroll
             for (int q = 0; q < 4; ++q) piece_a(q, freed);
@@ -554,7 +554,7 @@ struct G4GemmEpilogue {
     }
     // may this tile go through pack_lines / store_lines?  (uniform)
     XC_DEV bool packs_lines(int m0, int n0) const { return MODE == G4_PLAIN && (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N); }
-    XC_DEV void pack_lines(f32x16 (&acc)[4][2], unsigned char* scratch, u32x4 (&o)[4][4]) const {
+    XC_DEV void pack_lines(f32x16 (&acc)[4][2], unsigned char* scratch, u32x4 (&o)[4][4], int = 0, int = 0) const {
         if (p.alpha == 1.f) pack_lines_t<true>(acc, scratch, o);                    // (most products: no multiplies)
         else pack_lines_t<false>(acc, scratch, o);
     }
@@ -724,7 +724,7 @@ struct G4ProbeEpilogue {
     }
     XC_DEV bool packs_lines(int, int) const { return false; }
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return (*this)(acc, m0, n0); }
-    XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4]) const {}
+    XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4], int = 0, int = 0) const {}
     template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
 };
 

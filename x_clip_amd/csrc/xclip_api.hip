@@ -15,7 +15,7 @@
 #endif
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
-#include "kernels/simloss3.h"
+#include "kernels/simloss5.h"
 #include "kernels/tokens.h"
 
 using namespace xc;
@@ -853,8 +853,14 @@ int xclip_simloss_partial(const void* Q, const void* K, int64_t nq, int64_t nk, 
     p.part_m = (float*)workspace + tile_slot0 * nq; p.part_l = (float*)workspace + (tile_slots + tile_slot0) * nq; p.pos = pos;
     hipStream_t st = (hipStream_t)stream;
     if (use_sim3(nq, nk, d, dtype)) {
-        XC_ALLOW_LDS(sim3_lse_kernel, G2_LDS_BYTES);
-        hipLaunchKernelGGL(sim3_lse_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
+        static const int gen = measure_env("XCLIP_SIM", 5);      // measurement build: 3 = the round-1 two-stage loop (simloss3.h)
+        if (gen == 3) {
+            XC_ALLOW_LDS(sim3_lse_kernel, G2_LDS_BYTES);
+            hipLaunchKernelGGL(sim3_lse_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
+        } else {
+            XC_ALLOW_LDS(sim5_lse_kernel, G5_LDS_BYTES);
+            hipLaunchKernelGGL(sim5_lse_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+        }
         return check_launch(__func__);
     }
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
@@ -902,8 +908,14 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
     p.lse_q = lse_q; p.lse_k = lse_k; p.a = a; p.c = c; p.e = e; p.G = G; p.ldg = ldg; p.dtau = dtau_accum;
     hipStream_t st = (hipStream_t)stream;
     if (use_sim3(nq, nk, d, dtype)) {
-        XC_ALLOW_LDS(sim3_grad_kernel, G2_LDS_BYTES);
-        hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
+        static const int gen = measure_env("XCLIP_SIM", 5);      // measurement build: 3 = the round-1 two-stage loop (simloss3.h)
+        if (gen == 3) {
+            XC_ALLOW_LDS(sim3_grad_kernel, G2_LDS_BYTES);
+            hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
+        } else {
+            XC_ALLOW_LDS(sim5_grad_kernel, G5_LDS_BYTES);
+            hipLaunchKernelGGL(sim5_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+        }
         return check_launch(__func__);
     }
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
