@@ -118,6 +118,8 @@ def main():
                     "(use this for rocprofv3 kernel-trace runs whose per-kernel averages should be of kernels running alone)")
     ap.add_argument("--dcl", action="store_true")
     ap.add_argument("--text-slices", type=int, default=1, help="CLIP.text_micro_batches: slices of the text batch on separate streams")
+    ap.add_argument("--image-slices", type=int, default=None, help="CLIP.image_micro_batches: sequential slices of the image batch through the "
+                    "vision tower (bounds the recompute transient; default 2 for --config vitl, else 1)")
     ap.add_argument("--filip", action="store_true", help="BASELINE configs[3] instead of the headline configs[1]: use_all_token_embeds, "
                     "image 224 / patch 16, text length 77 (own measurements; the driver's line is the default configuration)")
     ap.add_argument("--simsiam", action="store_true", help="own measurement of the README configuration `use_visual_ssl = True`: SimSiam around "
@@ -197,6 +199,7 @@ def main():
         model.overlap_towers = on and which in ("both", "towers")
         model.text_micro_batches = args.text_slices if on else 1
     model.text_micro_batches = args.text_slices
+    model.image_micro_batches = args.image_slices if args.image_slices is not None else (2 if args.config == "vitl" else 1)
 
     if args.no_overlap:
         set_overlap(False)

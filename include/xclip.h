@@ -176,6 +176,15 @@ int xclip_filip_reduce(const void* S, int64_t lds, const uint8_t* mask, const fl
 int xclip_filip_route(void* P, int64_t ldp, const uint8_t* mask, const float* log_temp, const float* g1, const float* g2, int64_t ldg,
                       const int16_t* kmax, const int16_t* tmax, const float* cnt, int64_t bx, int64_t nt, int64_t yc, int64_t ni,
                       int64_t y0, int64_t ytotal, int dtype, void* stream);
+/* The same forward with the reductions INSIDE the token-similarity GEMM (x_clip.py:797-811 fused: the 'x t d, y i d -> x y t i' block is
+ * never written): X [bx * nt, d] text-token latents, Y [yc * ni, d] image-token latents of images [y0, y0 + yc), both bf16 row-major
+ * with row stride d; outputs as xclip_filip_reduce.  Needs dtype bf16, d a multiple of 64, nt >= 64, ni >= 64 (xclip_filip_fused_ok);
+ * workspace: xclip_filip_fused_workspace_bytes(bx, nt, yc, ni) bytes of 4-byte partials {bf16 max | int16 arg-max}. */
+int xclip_filip_fused_ok(int64_t nt, int64_t ni, int64_t d, int dtype);
+int64_t xclip_filip_fused_workspace_bytes(int64_t bx, int64_t nt, int64_t yc, int64_t ni);
+int xclip_filip_fused_fwd(const void* X, const uint8_t* mask, const void* Y, const float* log_temp, float* t2i, float* i2t, int64_t ldo,
+                          int16_t* kmax, int16_t* tmax, float* cnt, void* workspace, int64_t workspace_bytes, int64_t bx, int64_t nt,
+                          int64_t yc, int64_t ni, int64_t d, int64_t y0, int64_t ytotal, int dtype, void* stream);
 /* InfoNCE / DCL over the rows of a MATERIALISED fp32 logit matrix S [rows, cols] (x_clip.py:821-847): lse[r] = log sum_c exp
  * S[r,c] (column r + diag_off left out when dcl), *loss_accum += coef * sum_r (lse[r] - S[r, r+diag_off]);
  * grad: G[r,c] = gmul * coef * (exp(S[r,c] - lse[r]) (1 - dcl [c == r+diag_off]) - [c == r+diag_off]); *dtau_accum += sum G o S. */

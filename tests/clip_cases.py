@@ -306,7 +306,10 @@ def case_live_rows(dev, cfg: O.ClipConfig, b, live, dtype=torch.bfloat16, seed=4
     tl, il, grads = product_step(torch.arange(b))
     tl8, il8, grads8 = product_step(live)
     m.visual_transformer.keep_indices_override = None
-    assert torch.equal(tl[live], tl8) and torch.equal(il[live], il8), "latents must not depend on the batch a row travels in"
+    # the same rows in a batch of `b` and alone: the same arithmetic per row, but GEMMs of very different heights may split their
+    # contraction differently (split-K slabs for short outputs), i.e. fp32 sums in another order -> equal to the storage rounding
+    same = max(float((tl[live] - tl8).abs().max()), float((il[live] - il8).abs().max()))
+    assert same <= (2e-6 if dtype == torch.float32 else 1e-3), ("latents must not depend on the batch a row travels in", same)
 
     fp32 = dtype == torch.float32
     sd = {k: v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items() if v.is_floating_point()}

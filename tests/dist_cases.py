@@ -230,7 +230,8 @@ def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, r
             worst = max(worst, (rel, k))
             assert rel < rel_bar, (k, rel)
             if cos_bar is not None:
-                assert float((g * want).sum() / (g.norm() * want.norm())) > cos_bar, k
+                cos = float((g * want).sum() / (g.norm() * want.norm()))
+                assert cos > cos_bar, (k, cos)
         for o in outs[1:]:
             assert torch.equal(outs[0]["grads"][k], o["grads"][k]), k       # the all-reduced gradients are the same bits on every rank
     return worst

@@ -689,3 +689,66 @@ def case_gemm_fuzz(dev, cases=150, seed=1):
         scale = float(want.abs().max())
         err = float((got - want).abs().max())
         assert bool(torch.isfinite(got).all()) and err <= scale * 2.0 ** -7, f"gemm {lay} {M}x{N}x{K} res={res} alpha={alpha}: {err:.3e} vs {scale:.3e}"
+
+
+def case_filip_fused(dev, bx, nt, by, ni, d, seed=61, chunks=1):
+    """the FILIP forward with its reductions inside the token-similarity GEMM (filip5.h, x_clip.py:797-811) against an fp64 evaluation of
+    the same bf16 latents: t2i / i2t to the bf16 ulp of the scores they average, the arg-max maps up to ties within that ulp; and against
+    the chunked form (materialised similarities + filip_reduce) whose t2i / i2t it must reproduce to the same bar"""
+    dtype = torch.bfloat16
+    X = O.l2_normalize(rnd((bx, nt, d), torch.float32, seed)).to(dtype)
+    Y = O.l2_normalize(rnd((by, ni, d), torch.float32, seed + 1)).to(dtype)
+    g = torch.Generator().manual_seed(seed + 2)
+    mask = torch.ones(bx, nt, dtype=torch.bool)
+    for x in range(bx):                                          # ragged text lengths, one text with a hole, one with a single token
+        L = nt if x == 0 else int(torch.randint(1, nt + 1, (1,), generator=g))
+        mask[x, L:] = False
+    if bx > 2:
+        mask[2, 1] = False
+    if bx > 1:
+        mask[1, 1:] = False
+    assert ops.filip_fused_ok(nt, ni, d, dtype)
+    tau = torch.tensor([0.37], dtype=torch.float32)
+    temp = math.exp(0.37)
+    t2i = torch.full((bx, by), float("nan"), dtype=torch.float32, device=dev)
+    i2t = torch.full((bx, by), float("nan"), dtype=torch.float32, device=dev)
+    kmax = torch.full((bx, nt, by), -1, dtype=torch.int16, device=dev)
+    tmax = torch.full((bx, by, ni), -1, dtype=torch.int16, device=dev)
+    cnt = torch.zeros(bx, dtype=torch.float32, device=dev)
+    yc = (by + chunks - 1) // chunks
+    ws = torch.full((ops.filip_fused_workspace_bytes(bx, nt, yc, ni),), 0xFF, dtype=torch.uint8, device=dev)
+    m8 = mask.to(torch.uint8).to(dev)
+    for y0 in range(0, by, yc):
+        ops.filip_fused_fwd(X.to(dev), m8, Y[y0: y0 + yc].contiguous().to(dev), tau.to(dev), t2i, i2t, kmax, tmax, cnt, ws, y0)
+    S = temp * torch.einsum("xtd,yid->xyti", ref64(X), ref64(Y))                     # [bx, by, nt, ni]
+    w = mask.double()
+    rowmax, rowarg = S.max(dim=-1)                                                    # [bx, by, nt]
+    t2i_r = (rowmax * w[:, None, :]).sum(-1) / w.sum(-1).clamp_min(1e-6)[:, None]
+    Sm = S.masked_fill(~mask[:, None, :, None], -float("inf"))
+    colmax, colarg = Sm.max(dim=2)                                                    # [bx, by, ni]
+    i2t_r = colmax.mean(-1)
+    ulp = temp * 2.0 ** -8                                                            # a bf16 ulp of a score of magnitude <= 1
+    assert float((t2i.double().cpu() - t2i_r).abs().max()) <= 0.75 * ulp, float((t2i.double().cpu() - t2i_r).abs().max())
+    assert float((i2t.double().cpu() - i2t_r).abs().max()) <= 0.75 * ulp, float((i2t.double().cpu() - i2t_r).abs().max())
+    assert torch.equal(cnt.cpu(), mask.sum(-1).float())
+    # arg-max maps: the chosen position's score is within a bf16 ulp of the true maximum (ties under rounding may pick a neighbour)
+    km = kmax.cpu().long().permute(0, 2, 1)                                           # [bx, by, nt]
+    assert int(km.min()) >= 0 and int(km.max()) < ni
+    got = S.gather(-1, km[..., None]).squeeze(-1)
+    live = mask[:, None, :].expand_as(got)
+    assert float(((rowmax - got) * live).max()) <= ulp, float(((rowmax - got) * live).max())
+    exact = float(((km == rowarg) | ~live).double().mean())
+    tm = tmax.cpu().long()                                                            # [bx, by, ni]
+    assert int(tm.min()) >= 0 and int(tm.max()) < nt
+    assert bool(mask.gather(1, tm.reshape(bx, -1)).all()), "a padding token was chosen as arg-max"
+    got = S.gather(2, tm[:, :, None, :]).squeeze(2)
+    assert float((colmax - got).max()) <= ulp, float((colmax - got).max())
+    _record("filip fused t2i", dtype, float((t2i.double().cpu() - t2i_r).abs().max()) / ulp, 0.75, "bf16 ulp of a score")
+    _record("filip fused i2t", dtype, float((i2t.double().cpu() - i2t_r).abs().max()) / ulp, 0.75, "bf16 ulp of a score")
+    # the chunked form on the same operands
+    S16 = ops.gemm(X.to(dev).view(bx * nt, d), Y.to(dev).view(by * ni, d), bx * nt, by * ni, d)
+    t2i_c, i2t_c = torch.empty_like(t2i), torch.empty_like(i2t)
+    kmax_c, tmax_c, cnt_c = torch.empty_like(kmax), torch.empty_like(tmax), torch.zeros_like(cnt)
+    ops.filip_reduce(S16, m8, tau.to(dev), t2i_c, i2t_c, kmax_c, tmax_c, cnt_c, nt, ni, by, 0)
+    assert float((t2i - t2i_c).abs().max()) <= 0.75 * ulp and float((i2t - i2t_c).abs().max()) <= 0.75 * ulp
+    return exact

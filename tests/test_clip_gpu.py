@@ -188,6 +188,17 @@ def test_filip_multiview_extra_dcl_patchdrop_fp32():
     C.case_vs_oracle(DEV, torch.float32, cfg, 12, n_aug_text=1, n_aug_image=1, patch_keep=8)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_filip_mid_fused_shape_vs_oracle(dtype):
+    """MID with 64 image tokens and 70 text tokens: in bf16 the forward runs with its reductions inside the token-similarity GEMM
+    (filip5.h; fp32 keeps the chunked form), DCL + one augmented text view"""
+    import dataclasses
+    from x_clip_amd import ops
+    cfg = dataclasses.replace(MID, use_all_token_embeds=True, visual_image_size=256, decoupled_contrastive_learning=True)
+    assert ops.filip_fused_ok(70, 64, 512, torch.bfloat16) and not ops.filip_fused_ok(70, 64, 512, torch.float32)
+    C.case_vs_oracle(DEV, dtype, cfg, 12, n_aug_text=1, bf16_cos=0.985, bf16_rel=0.16)
+
+
 def test_filip_chunked_workspace_matches_single_chunk(monkeypatch):
     """the image-chunked evaluation (bounded workspace) gives the same loss and gradients as one chunk"""
     import dataclasses

@@ -295,3 +295,10 @@ def test_gemm6_gemm7_experimental_kernels():
         env = dict(os.environ, XCLIP_GEMM=gen)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "gemm6 ok" in out.stdout, (gen, out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2)])
+def test_filip_fused(bx, nt, by, ni, d, chunks):
+    """the FILIP forward with its reductions inside the GEMM epilogue: 385 x 392 (2 x 2 tiles, ragged both ways, text / image segments
+    cut by wave blocks and tiles), segment = wave block (64), long segments spanning tiles + two image chunks"""
+    K.case_filip_fused(DEV, bx, nt, by, ni, d, chunks=chunks)

@@ -263,3 +263,11 @@ def test_attention_random_lengths_bf16():
 def test_gemm_banded_tile_order(layout, M, N, K_):
     """more than 8 N tiles: the ring kernel's banded tile order (bands of 8 / 6 / 8 tiles) visits every tile exactly once"""
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout)
+
+
+@pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2), (64, 77, 96, 98, 512, 1),
+                                                  (48, 77, 40, 196, 512, 3), (16, 77, 24, 288, 768, 1)])
+def test_filip_fused(bx, nt, by, ni, d, chunks):
+    """the FILIP forward with its reductions inside the GEMM epilogue (filip5.h): emulator shapes, then configs[3]-like token counts
+    (77 x 98, 77 x 196 in three image chunks) over hundreds of tiles and the ViT-L FILIP token count (288) at d = 768"""
+    K.case_filip_fused(DEV, bx, nt, by, ni, d, chunks=chunks)

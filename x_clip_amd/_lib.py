@@ -46,6 +46,9 @@ _SIGNATURES = {
     "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, L, F, I, I, P]),
     "xclip_attention_bwd": (c_int, [P, P, P, P, P, P, P, L, L, L, L, F, I, I, P]),
     "xclip_filip_reduce": (c_int, [P, L, P, P, P, P, L, P, P, P, L, L, L, L, L, L, I, P]),
+    "xclip_filip_fused_ok": (c_int, [L, L, L, I]),
+    "xclip_filip_fused_workspace_bytes": (c_int64, [L, L, L, L]),
+    "xclip_filip_fused_fwd": (c_int, [P, P, P, P, P, P, L, P, P, P, P, L, L, L, L, L, L, L, L, I, P]),
     "xclip_filip_route": (c_int, [P, L, P, P, P, P, L, P, P, P, L, L, L, L, L, L, I, P]),
     "xclip_rowlse": (c_int, [P, L, L, L, L, I, F, P, P, P]),
     "xclip_rowgrad": (c_int, [P, L, P, L, L, L, I, F, P, P, L, P, P]),

@@ -403,6 +403,12 @@ class CLIP(nn.Module):
         # independent, so the result is the same; weight gradients are summed over the slices by autograd.
         self.text_micro_batches = 1
         self._micro_batch_min_rows = 64            # smaller slices than this are not worth a stream
+        # >1: the image batch (all views) runs through the vision tower in that many slices ONE AFTER THE OTHER on the same stream --
+        # a memory knob, not an overlap one: with checkpoint_during_training the tower keeps one input per layer for the whole batch
+        # but re-materialises a full layer (qkv, the 8D-wide feed-forward activations and their gradients) inside the backward; with k
+        # slices that transient is 1/k as large (ViT-L/14-336, 2 x 2048 images: 279 -> ~200 GB reserved with 2 slices).  Row
+        # independent, so the result is the same; weight gradients are summed over the slices by autograd.
+        self.image_micro_batches = 1
         self._streams = {}
 
         self.sim_reg_loss_weight = sim_reg_loss_weight
@@ -449,6 +455,23 @@ class CLIP(nn.Module):
             main.wait_stream(self._side_stream(dev, which=i))
             outs[i].record_stream(main)
         return outs
+
+    def _encode_image(self, image, freeze):
+        k, b = int(self.image_micro_batches), image.shape[0]
+        if k <= 1 or b % k != 0 or not isinstance(self.visual_transformer, VisionTransformer):
+            return model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze)
+        bs = b // k
+        vt = self.visual_transformer
+        keep_all = vt.keep_indices_override
+        outs = []
+        try:
+            for i in range(k):
+                if keep_all is not None:                         # an injected PatchDropout draw is per image: slice it too
+                    vt.keep_indices_override = keep_all[i * bs: (i + 1) * bs]
+                outs.append(model_forward_with_context(fn=vt, args=(image[i * bs: (i + 1) * bs],), freeze=freeze))
+        finally:
+            vt.keep_indices_override = keep_all
+        return torch.cat(outs, dim=0)
 
     def forward(
         self,
@@ -508,13 +531,13 @@ class CLIP(nn.Module):
             main = torch.cuda.current_stream(image.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
+                enc_image = self._encode_image(image, freeze_image_encoder)
             enc_text_parts = self._encode_text(text_args, freeze_text_encoder)
             main.wait_stream(side)
             enc_image.record_stream(main)
         else:
             enc_text_parts = self._encode_text(text_args, freeze_text_encoder)
-            enc_image = model_forward_with_context(fn=self.visual_transformer, args=(image,), freeze=freeze_image_encoder)
+            enc_image = self._encode_image(image, freeze_image_encoder)
         # (the CLS path below only needs row 0 of every sample: the slices are joined after that selection, not before)
         cls_only = (len(enc_text_parts) > 1 and not self.text_causal_mask and not return_encodings and not self.use_all_token_embeds
                     and enc_text_parts[0].ndim == 3)

@@ -528,29 +528,32 @@ struct G4GemmEpilogue {
     // Two phases, because the caller puts its next four DMA pieces BETWEEN them: the CU's vector-memory path is a queue, and pieces
     // issued behind 128 KiB of stores reached the L2 ~2000 cycles late -- the second and third K step of every tile then waited for
     // them (3000-4100 cycles instead of 2440: profiles/r02_run17_gemm5_step_stamps.log).
+    // one 32-row group: the wave's accumulator blocks acc_i[j] -> the four line pieces o_i[k] (rows 8 k + lane / 8 of the group)
     template <bool UNIT_ALPHA>
-    XC_DEV void pack_lines_t(f32x16 (&acc)[4][2], unsigned char* scratch, u32x4 (&o)[4][4]) const {
+    XC_DEV void pack_lines_i(f32x16 (&acc_i)[2], unsigned char* scratch, u32x4 (&o_i)[4]) const {
         const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
         unsigned char* const wr = scratch + r * 128 + 8 * h;                        // + chunk position * 16
         const unsigned char* const rd = scratch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + 1024 per 8 rows
         const float al = p.alpha;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {                                       // columns 32 j + 8 q + 4 h + (0..3) of row r
-                    const float* a = reinterpret_cast<const float*>(&acc[i][j]) + 4 * q;
-                    const u32x2 v = UNIT_ALPHA ? u32x2{f2bf_pk(a[0], a[1]), f2bf_pk(a[2], a[3])}
-                                               : u32x2{f2bf_pk(a[0] * al, a[1] * al), f2bf_pk(a[2] * al, a[3] * al)};
-                    *reinterpret_cast<u32x2*>(wr + (((4 * j + q) ^ (r & 7)) << 4)) = v;
-                }
+            for (int q = 0; q < 4; ++q) {                                           // columns 32 j + 8 q + 4 h + (0..3) of row r
+                const float* a = reinterpret_cast<const float*>(&acc_i[j]) + 4 * q;
+                const u32x2 v = UNIT_ALPHA ? u32x2{f2bf_pk(a[0], a[1]), f2bf_pk(a[2], a[3])}
+                                           : u32x2{f2bf_pk(a[0] * al, a[1] * al), f2bf_pk(a[2] * al, a[3] * al)};
+                *reinterpret_cast<u32x2*>(wr + (((4 * j + q) ^ (r & 7)) << 4)) = v;
             }
-            lds_fence();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[i][k] = *reinterpret_cast<const u32x4*>(rd + k * 1024);
-            lds_fence();                                                            // (the next 32 rows overwrite the slice)
         }
+        lds_fence();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o_i[k] = *reinterpret_cast<const u32x4*>(rd + k * 1024);
+        lds_fence();                                                                // (the next 32 rows overwrite the slice)
+    }
+    template <bool UNIT_ALPHA>
+    XC_DEV void pack_lines_t(f32x16 (&acc)[4][2], unsigned char* scratch, u32x4 (&o)[4][4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pack_lines_i<UNIT_ALPHA>(acc[i], scratch, o[i]);
     }
     // may this tile go through pack_lines / store_lines?  (uniform)
     XC_DEV bool packs_lines(int m0, int n0) const { return MODE == G4_PLAIN && (m0 + G2_BM <= p.M) && (n0 + G2_BN <= p.N); }

@@ -1,10 +1,10 @@
 // simloss5.h -- the contrastive head (simloss3.h: S = scale * Q K^T reduced to log-sum-exp partials in the forward, turned into the
 // gradient factor G in the backward; reference x_clip.py:813-847) on the PRODUCTION GEMM loop of gemm4.h (g5_run): the Q operand --
 // the one that streams, K's column panel is re-read from L2 by every tile of its column -- in a ring of three LDS stages, descriptor-
-// addressed LDS DMA, the counted waits, and for G the tile boundary of the plain GEMM: the finished tile leaves as whole 128-byte
-// lines through the wave-private LDS transposition, with the next K step's Q pieces issued between the packing and the stores.
-// simloss3.h (the same epilogue arithmetic on the round-1 two-stage loop) measured 178 us forward / 372 us G at the configs[2]
-// per-rank block 4096 x 32768 x 512 (profiles/r01_step10_sim_kernels_32k.log); it stays as the measurement build's A/B partner.
+// addressed LDS DMA, the counted waits.  Forward (log-sum-exp partials, nothing stored): 177 -> 157 us = 876 TFLOP/s at the configs[2]
+// per-rank block 4096 x 32768 x 512 (the same-shape plain GEMM that WRITES the logits: 144 us; profiles/r03_b_sim_kernels_32k.log).
+// The G kernel was moved too (whole-line epilogue, the next tile's early Q pieces) and got slower, 423 against 362 us: it stays on
+// simloss3.h in the product and lives on here for the measurement build only.
 #pragma once
 #include "gemm4.h"
 #include "simloss3.h"
@@ -21,7 +21,8 @@ struct Sim5LseEpilogue {
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return Sim3LseEpilogue{p}(acc, m0, n0); }
 };
 
-// backward: interior tiles off the diagonal (all but O(tiles_m) of them) turn their accumulators into G in place and leave through
+#ifdef XCLIP_MEASURE
+// backward (measurement build only, XCLIP_SIM=5: measured SLOWER than simloss3.h's form, see xclip_simloss_grad): interior tiles off the diagonal (all but O(tiles_m) of them) turn their accumulators into G in place and leave through
 // the plain GEMM's pack_lines / store_lines; the others keep simloss3.h's row-per-lane form with its range and diagonal tests
 struct Sim5GradEpilogue {
     const SimParams& p;
@@ -48,6 +49,9 @@ struct Sim5GradEpilogue {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ek[j][q][k] = (c != 0.f) ? c * fast_exp(scale - u2f(t[k])) : 0.f;
             }
+        const G4GemmEpilogue<G4_PLAIN> lines{gp};
+        // one 32-row group at a time: its 32 accumulators become G in place and go straight into the line exchange, so the group's
+        // registers are free again before the next group's exponentials (all four groups first: 220 spilled registers)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
@@ -64,9 +68,9 @@ struct Sim5GradEpilogue {
                         dt += v * s_;
                         acc[i][j][4 * q + k] = v * gs;
                     }
+            lines.template pack_lines_i<true>(acc[i], scratch, o[i]);
         }
         slow.dt_acc += dt;
-        G4GemmEpilogue<G4_PLAIN>{gp}.template pack_lines_t<true>(acc, scratch, o);
     }
     template <bool NT = false> XC_DEV void store_lines(const u32x4 (&o)[4][4], int m0, int n0) const {
         G4GemmEpilogue<G4_PLAIN>{gp}.template store_lines<NT>(o, m0, n0);
@@ -74,11 +78,14 @@ struct Sim5GradEpilogue {
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) { return slow(acc, m0, n0) == 16 ? 16 : 0; }
 };
 
+#endif
+
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_lse_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
     const Gemm2Params g = sim3_gemm_params(p);
     g5_run<false, false, Sim5LseEpilogue>(g, lds, Sim5LseEpilogue{p});
 }
+#ifdef XCLIP_MEASURE
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
     Gemm2Params g = sim3_gemm_params(p);
@@ -87,5 +94,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_kernel(SimParams p) {
     g.stream_out = (long)p.nq * p.ldg * 2 > (48L << 20);             // G larger than the L2s can hold anyway: streamed stores
     g5_run<false, false, Sim5GradEpilogue>(g, lds, Sim5GradEpilogue{p, g, Sim3GradEpilogue{p}});
 }
+#endif
 
 }  // namespace xc

@@ -5,6 +5,7 @@
 #include "api_common.h"
 #include "kernels/colnorm.h"
 #include "kernels/filip.h"
+#include "kernels/filip5.h"
 #include "kernels/gemm.h"
 #include "kernels/gemm2.h"
 #include "kernels/gemm3.h"
@@ -794,6 +795,40 @@ int xclip_filip_reduce(const void* S, int64_t lds, const uint8_t* mask, const fl
     return check_launch(__func__);
 }
 
+int xclip_filip_fused_ok(int64_t nt, int64_t ni, int64_t d, int dtype) {
+    return dtype == XCLIP_BF16 && d > 0 && d % G2_BK == 0 && nt >= 64 && ni >= 64 && nt <= 32767 && ni <= 32767;
+}
+int64_t xclip_filip_fused_workspace_bytes(int64_t bx, int64_t nt, int64_t yc, int64_t ni) {
+    const int64_t M = bx * nt, N = yc * ni;
+    return (M * ((N + 63) / 64) * 2 + ((M + 127) / 128) * 3 * N) * 4;
+}
+int xclip_filip_fused_fwd(const void* X, const uint8_t* mask, const void* Y, const float* log_temp, float* t2i, float* i2t, int64_t ldo,
+                          int16_t* kmax, int16_t* tmax, float* cnt, void* workspace, int64_t workspace_bytes, int64_t bx, int64_t nt,
+                          int64_t yc, int64_t ni, int64_t d, int64_t y0, int64_t ytotal, int dtype, void* stream) {
+    XC_REQUIRE(xclip_filip_fused_ok(nt, ni, d, dtype), "the fused FILIP forward needs bf16, d % 64 == 0, nt >= 64, ni >= 64");
+    XC_REQUIRE(bx > 0 && yc > 0 && y0 >= 0 && y0 + yc <= ytotal && ldo >= ytotal, "bad chunk geometry");
+    XC_REQUIRE(bx * nt < (1LL << 31) && yc * ni < (1LL << 31), "problem too large for 32-bit tile indices");
+    XC_REQUIRE(X && Y && mask && log_temp && t2i && i2t && kmax && tmax && cnt && aligned16(X) && aligned16(Y), "null or misaligned pointer");
+    XC_REQUIRE(workspace && workspace_bytes >= xclip_filip_fused_workspace_bytes(bx, nt, yc, ni), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Filip5Params f;
+    f.mask = mask;
+    f.M = (int)(bx * nt); f.N = (int)(yc * ni); f.nt = (int)nt; f.ni = (int)ni; f.nblk64 = (int)((f.N + 63) / 64);
+    f.rowpart = (uint32_t*)workspace;
+    f.colpart = f.rowpart + (int64_t)f.M * f.nblk64 * 2;
+    const int64_t tiles = ((f.M + G2_BM - 1) / G2_BM) * (int64_t)((f.N + G2_BN - 1) / G2_BN);
+    const int cus = xc_num_cus();
+    XC_ALLOW_LDS(filip5_kernel, G5_LDS_BYTES);
+    hipLaunchKernelGGL(filip5_kernel, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(G2_THREADS), G5_LDS_BYTES, st, (const bf16_t*)X,
+                       (const bf16_t*)Y, (int)d, f);
+    hipLaunchKernelGGL(filip5_merge_rows_kernel, dim3((unsigned)bx, (unsigned)((yc + 255) / 256)), dim3(256), 0, st, f.rowpart, mask, log_temp, t2i,
+                       (long)ldo, kmax, cnt, (int)nt, (int)ni, (int)yc, f.nblk64, (int)y0, (int)ytotal);
+    const int ypb = (int)(256 / ni > 0 ? 256 / ni : 1);
+    hipLaunchKernelGGL(filip5_merge_cols_kernel, dim3((unsigned)bx, (unsigned)((yc + ypb - 1) / ypb)), dim3(256), (size_t)ypb * ni * 4, st, f.colpart,
+                       log_temp, i2t, (long)ldo, tmax, (int)nt, (int)ni, (int)yc, f.N, ypb, (int)y0, (int)ytotal);
+    return check_launch(__func__);
+}
+
 int xclip_filip_route(void* P, int64_t ldp, const uint8_t* mask, const float* log_temp, const float* g1, const float* g2, int64_t ldg,
                       const int16_t* kmax, const int16_t* tmax, const float* cnt, int64_t bx, int64_t nt, int64_t yc, int64_t ni,
                       int64_t y0, int64_t ytotal, int dtype, void* stream) {
@@ -908,14 +943,20 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
     p.lse_q = lse_q; p.lse_k = lse_k; p.a = a; p.c = c; p.e = e; p.G = G; p.ldg = ldg; p.dtau = dtau_accum;
     hipStream_t st = (hipStream_t)stream;
     if (use_sim3(nq, nk, d, dtype)) {
-        static const int gen = measure_env("XCLIP_SIM", 5);      // measurement build: 3 = the round-1 two-stage loop (simloss3.h)
-        if (gen == 3) {
-            XC_ALLOW_LDS(sim3_grad_kernel, G2_LDS_BYTES);
-            hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
-        } else {
+        // G stays on the two-stage loop with row-per-lane stores (simloss3.h): on the ring loop with the whole-line epilogue
+        // (simloss5.h sim5_grad_kernel) the 128 exponentials per lane and tile sit in front of the line exchange, the kernel needs
+        // ~240 more registers than it has, and the next tile's early A pieces wait for all of it -- 423 us against 362 at
+        // 4096 x 32768 x 512 (profiles/r03_b_sim_kernels_32k.log).  XCLIP_SIM=5 (measurement build) selects it for the A/B.
+#ifdef XCLIP_MEASURE
+        static const int gen = measure_env("XCLIP_SIM", 3);
+        if (gen == 5) {
             XC_ALLOW_LDS(sim5_grad_kernel, G5_LDS_BYTES);
             hipLaunchKernelGGL(sim5_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+            return check_launch(__func__);
         }
+#endif
+        XC_ALLOW_LDS(sim3_grad_kernel, G2_LDS_BYTES);
+        hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
         return check_launch(__func__);
     }
     dim3 grid(p.tiles_m * p.tiles_n), block(256);

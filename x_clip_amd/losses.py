@@ -287,6 +287,7 @@ def sim_reg_loss(text_latents: Tensor, image_latents: Tensor, text_latents_extra
 # fine-grained (FILIP) head: use_all_token_embeds = True  (x_clip.py:797-811 + the shared InfoNCE / DCL tail :821-868)
 # =========================================================================================================================
 _FILIP_CHUNK_BYTES = 1 << 30          # workspace bound for one chunk of token similarities / routing matrix
+FILIP_FUSED = True                    # forward reductions inside the token-similarity GEMM where the shape allows (ops.filip_fused_ok)
 
 
 class _FilipBlock:
@@ -339,6 +340,16 @@ class _FilipBlock:
         return Yp, cols
 
     def forward(self):
+        if FILIP_FUSED and ops.filip_fused_ok(self.nt, self.ni, self.d, self.X.dtype):
+            # the reductions run in the epilogue of the token-similarity GEMM (filip5.h): nothing of size bx * by * nt * ni exists, only
+            # 4-byte partials per (token row, 64-column block) / (token column, 128-row block); images in chunks that bound them
+            per_img = max(1, ops.filip_fused_workspace_bytes(self.bx, self.nt, 1, self.ni))
+            yc = max(1, min(self.by, _FILIP_CHUNK_BYTES // per_img))
+            ws = torch.empty(ops.filip_fused_workspace_bytes(self.bx, self.nt, yc, self.ni), dtype=torch.uint8, device=self.X.device)
+            Xc, Yc = ops._c(self.X), ops._c(self.Y)
+            for y0 in range(0, self.by, yc):
+                ops.filip_fused_fwd(Xc, self.mask, Yc[y0: y0 + yc], self.tau32, self.t2i, self.i2t, self.kmax, self.tmax, self.cnt, ws, y0)
+            return self
         X2 = self.X.reshape(self.bx * self.nt, self.d)
         for y0 in range(0, self.by, self.yc):
             yc = min(self.yc, self.by - y0)

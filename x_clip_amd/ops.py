@@ -152,21 +152,27 @@ def l2norm_bwd(dy: Tensor, y: Tensor, rn: Tensor) -> Tensor:
 # ---- embeddings / patches ---------------------------------------------------------------------------------------------
 class _TokenFlag:
     """Out-of-range token ids, reported without a host sync: the embedding kernel sets a device flag (and writes NaN rows, so the
-    step's loss is already loudly wrong); after each launch the flag is copied to pinned host memory behind an event, and the NEXT
-    call that finds that event completed raises the IndexError the reference's nn.Embedding raises (x_clip.py:320).  CPU tensors
-    (the emulator build) are checked on the spot.  `XCLIP_CHECK_TOKENS=1` checks synchronously on the GPU too (debugging)."""
-    _per_device = {}
+    step's loss is already loudly wrong); after each launch the flag is copied to pinned host memory behind an event, and the next
+    natural point that finds that event completed -- the backward of the same encoder pass (`text_embed_bwd`), the next forward, or
+    an explicit `ops.check_tokens()` (which waits for it: call it after an inference batch, or once per step next to the optimizer)
+    -- raises the IndexError the reference's nn.Embedding raises (x_clip.py:320), naming the launch that saw the bad id.  One flag
+    per (device, stream): text slices on side streams do not share state.  CPU tensors (the emulator build) are checked on the spot.
+    `XCLIP_CHECK_TOKENS=1` checks synchronously on the GPU too (debugging)."""
+    _per_stream = {}
 
     def __init__(self, device):
         self.flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.host = torch.zeros(1, dtype=torch.int32).pin_memory() if device.type == "cuda" else None
         self.event = None
+        self.launches = 0                 # embedding launches on this (device, stream) so far
+        self.pending = 0                  # the launch whose flag copy `event` guards
 
     @classmethod
     def get(cls, device) -> "_TokenFlag":
-        f = cls._per_device.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+        f = cls._per_stream.get(key)
         if f is None:
-            f = cls._per_device[device] = cls(device)
+            f = cls._per_stream[key] = cls(device)
         return f
 
     def _raise(self, vocab):
@@ -174,17 +180,23 @@ class _TokenFlag:
         if self.host is not None:
             self.host.zero_()
         self.event = None
-        raise IndexError(f"index out of range in self: a text token id lies outside [0, {vocab}) (num_text_tokens)")
+        raise IndexError(f"index out of range in self: a text token id lies outside [0, {vocab}) (num_text_tokens) -- seen by embedding "
+                         f"launch #{self.pending} on this stream (its output rows for those ids are NaN)")
 
-    def poll(self, vocab):
-        """before a launch: report what an EARLIER launch found, if its flag copy has already landed"""
-        if self.event is not None and self.event.query():
+    def poll(self, vocab, wait=False):
+        """report what an EARLIER launch found, if its flag copy has already landed (wait=True: wait for it)"""
+        if self.event is not None and (wait or self.event.query()):
+            if wait:
+                self.event.synchronize()
             self.event = None
             if int(self.host[0]) != 0:
                 self._raise(vocab)
 
     def after_launch(self, vocab):
         import os
+        self.launches += 1
+        self.pending = self.launches
+        self.vocab = vocab
         if self.host is None:
             if int(self.flag[0]) != 0:
                 self._raise(vocab)
@@ -193,8 +205,14 @@ class _TokenFlag:
         self.event = torch.cuda.Event()
         self.event.record(torch.cuda.current_stream(self.flag.device))
         if os.environ.get("XCLIP_CHECK_TOKENS") == "1":
-            self.event.synchronize()
-            self.poll(vocab)
+            self.poll(vocab, wait=True)
+
+
+def check_tokens() -> None:
+    """wait for the outstanding token-range checks of every stream and raise IndexError if an embedding launch saw an id outside its
+    vocabulary (inference loops: call after a batch; training: the encoder's backward polls by itself)"""
+    for tf in list(_TokenFlag._per_stream.values()):
+        tf.poll(getattr(tf, "vocab", 0), wait=True)
 
 
 def text_embed_fwd(tokens: Tensor, E: Tensor, P: Optional[Tensor], cls: Optional[Tensor]) -> Tensor:
@@ -221,6 +239,7 @@ def text_embed_bwd(dout: Tensor, tokens: Tensor, vocab: int, has_pos: bool, has_
     dout, tokens = _c(dout), _c(tokens)
     b, n = tokens.shape
     dim = dout.shape[-1]
+    _TokenFlag.get(dout.device).poll(vocab)                  # the forward of this pass is long done: its range check has landed
     dE = torch.zeros(vocab, dim, dtype=torch.float32, device=dout.device)
     dP = torch.zeros(n, dim, dtype=torch.float32, device=dout.device) if has_pos else None
     dcls = torch.zeros(dim, dtype=torch.float32, device=dout.device) if has_cls else None
@@ -524,6 +543,33 @@ def filip_reduce(S: Tensor, mask: Tensor, log_temp: Tensor, t2i: Tensor, i2t: Te
     _lib.check(_lib.lib().xclip_filip_reduce(S.data_ptr(), S.stride(0), mask.data_ptr(), log_temp.data_ptr(), t2i.data_ptr(),
                                              i2t.data_ptr(), ytotal, kmax.data_ptr(), tmax.data_ptr(), cnt.data_ptr(), bx, nt, yc, ni,
                                              y0, ytotal, dtype_code(S), _stream(S)), "xclip_filip_reduce")
+
+
+def filip_fused_ok(nt: int, ni: int, d: int, dtype) -> bool:
+    """can the token similarity + reductions run as ONE fused GEMM launch (filip5.h)?  bf16, d % 64 == 0, nt >= 64, ni >= 64"""
+    return dtype in _DTYPES and bool(_lib.lib().xclip_filip_fused_ok(nt, ni, d, _DTYPES[dtype]))
+
+
+def filip_fused_workspace_bytes(bx: int, nt: int, yc: int, ni: int) -> int:
+    return int(_lib.lib().xclip_filip_fused_workspace_bytes(bx, nt, yc, ni))
+
+
+def filip_fused_fwd(X: Tensor, mask: Tensor, Y: Tensor, log_temp: Tensor, t2i: Tensor, i2t: Tensor, kmax: Tensor, tmax: Tensor,
+                    cnt: Tensor, ws: Tensor, y0: int):
+    """X [bx, nt, d] text-token latents, Y [yc, ni, d] image-token latents of images [y0, y0 + yc) -> those columns of t2i / i2t
+    [bx, ytotal] and of the arg-max maps, the token similarities never leaving the GEMM (x_clip.py:797-811)"""
+    _dev_check(X, mask, Y, log_temp, t2i, i2t, kmax, tmax, cnt, ws)
+    bx, nt, d = X.shape
+    yc, ni, _ = Y.shape
+    ytotal = t2i.shape[1]
+    assert X.is_contiguous() and Y.is_contiguous() and X.dtype == Y.dtype and Y.shape[2] == d
+    assert mask.dtype == torch.uint8 and mask.is_contiguous() and tuple(mask.shape) == (bx, nt)
+    assert kmax.dtype == torch.int16 and tuple(kmax.shape) == (bx, nt, ytotal) and tuple(tmax.shape) == (bx, ytotal, ni)
+    assert t2i.dtype == torch.float32 and t2i.is_contiguous() and i2t.is_contiguous() and i2t.shape == t2i.shape
+    assert ws.dtype == torch.uint8 and ws.is_contiguous()
+    _lib.check(_lib.lib().xclip_filip_fused_fwd(X.data_ptr(), mask.data_ptr(), Y.data_ptr(), log_temp.data_ptr(), t2i.data_ptr(), i2t.data_ptr(),
+                                                ytotal, kmax.data_ptr(), tmax.data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(), bx, nt, yc, ni,
+                                                d, y0, ytotal, dtype_code(X), _stream(X)), "xclip_filip_fused_fwd")
 
 
 def filip_route(P: Tensor, mask: Tensor, log_temp: Tensor, g1: Tensor, g2: Tensor, kmax: Tensor, tmax: Tensor, cnt: Tensor,
