@@ -151,7 +151,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from x_clip_amd import CLIP, functional, ops
+    from x_clip_amd import CLIP, functional, losses, ops
+    if os.environ.get("XCLIP_FILIP_FUSED") == "0":           # own A/B: the chunked FILIP forward (materialised similarities + reduction passes)
+        losses.FILIP_FUSED = False
     from x_clip_amd.distributed import GradSync
 
     torch.manual_seed(0)

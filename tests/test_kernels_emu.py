@@ -297,8 +297,9 @@ def test_gemm6_gemm7_experimental_kernels():
         assert out.returncode == 0 and "gemm6 ok" in out.stdout, (gen, out.stderr[-2000:])
 
 
-@pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2)])
+@pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2), (4, 70, 3, 65, 64, 1)])
 def test_filip_fused(bx, nt, by, ni, d, chunks):
     """the FILIP forward with its reductions inside the GEMM epilogue: 385 x 392 (2 x 2 tiles, ragged both ways, text / image segments
-    cut by wave blocks and tiles), segment = wave block (64), long segments spanning tiles + two image chunks"""
+    cut by wave blocks and tiles), segment = wave block (64), long segments spanning tiles + two image chunks, 280 rows (the second
+    row tile's lower wave block lies wholly past M: no text exists there -- an out-of-bounds partial once) x 195 columns (odd)"""
     K.case_filip_fused(DEV, bx, nt, by, ni, d, chunks=chunks)

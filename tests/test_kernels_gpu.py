@@ -66,17 +66,22 @@ def test_gemm_layouts(dtype, layout, M, N, K_):
     K.case_gemm(DEV, dtype, M, N, K_, layout)
 
 
-@pytest.mark.parametrize("layout,M,N,K_", [("nt", 263168, 1536, 512), ("nn", 263168, 512, 1536), ("nt", 131584, 512, 512), ("tn", 1536, 512, 263168)])
-def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_):
+@pytest.mark.parametrize("layout,M,N,K_,res", [("nt", 263168, 1536, 512, False), ("nn", 263168, 512, 1536, False), ("nt", 131584, 512, 512, False),
+                                               ("tn", 1536, 512, 263168, False), ("nt", 263168, 512, 2048, True), ("tn", 512, 2048, 263168, False),
+                                               ("nt", 65536, 4096, 512, False)])
+def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_, res):
     """text-tower shapes at full size, every CU streaming (the regime the counted DMA waits and the stores left in flight across the
-    tile boundary have to be right in -- the emulator lands every DMA piece at once and cannot see an early read): every output
-    element against an fp32-accumulated reference product of the same bf16 operands, and ten launches bit-identical"""
+    tile boundary have to be right in -- the emulator lands every DMA piece at once and cannot see an early read, nor a missing wait
+    state in front of an asm store): every output element against an fp32-accumulated reference product of the same bf16 operands,
+    and ten launches bit-identical.  Covers every interior-tile epilogue of gemm4.h: plain whole-line stores (nt / nn), the fp32
+    split-K slab (tn), the residual form (res: FF2 + skip), and the streamed (> 48 MiB) + banded (16 N tiles) FF1 output."""
     from x_clip_amd import ops
     a_k, b_k = layout == "tn", layout in ("nn", "tn")
     g = torch.Generator(device="cpu").manual_seed(3)
     a = torch.randn((K_, M) if a_k else (M, K_), generator=g).to(torch.bfloat16).to(DEV)
     b = torch.randn((K_, N) if b_k else (N, K_), generator=g).to(torch.bfloat16).to(DEV)
-    outs = [ops.gemm(a, b, M, N, K_, a_k, b_k) for _ in range(10)]
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV) if res else None
+    outs = [ops.gemm(a, b, M, N, K_, a_k, b_k, residual=r) for _ in range(10 if M * N <= (1 << 28) else 4)]
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "the same launch must give the same bits"
@@ -86,6 +91,8 @@ def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_):
     worst = 0.0
     for r0 in range(0, M, rows):
         ref = A[r0: r0 + rows].float() @ B.float()
+        if res:
+            ref = ref + r[r0: r0 + rows].float()
         got = outs[0][r0: r0 + rows].float()
         scale = float(ref.abs().max())
         worst = max(worst, float((got - ref.to(torch.bfloat16).float()).abs().max()) / (scale * 2.0 ** -8))

@@ -107,6 +107,24 @@ class Transformer(nn.Module):
             ]))
         self.norm_in = LayerNorm(dim)
         self.norm_out = LayerNorm(dim)
+        self._pad_cache = {}                                  # narrow heads: padded weights of no-grad passes (stack_params)
+        self._rotary_ok = None                                # (data_ptr, version, shape) of the last validated rotary table
+
+    def _padded(self, w_qkv: Tensor, w_out: Tensor, dh: int, h: int, hs: int):
+        """zero rows / columns up to the head slot, as differentiable views of the parameters; rebuilt only while autograd needs the
+        graph (training) -- inference calls reuse the padded copies until a parameter changes (its version counter moves)"""
+        def pad():
+            return (F.pad(w_qkv.view(3, h, dh, -1), (0, 0, 0, hs - dh)).reshape(3 * h * hs, -1),
+                    F.pad(w_out.view(-1, h, dh), (0, hs - dh)).reshape(-1, h * hs))
+        if torch.is_grad_enabled() and (w_qkv.requires_grad or w_out.requires_grad):
+            return pad()
+        key = (w_qkv.data_ptr(), w_qkv._version, w_out.data_ptr(), w_out._version, w_qkv.dtype, w_qkv.device)
+        hit = self._pad_cache.get(id(w_qkv))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, pad())
+            self._pad_cache[id(w_qkv)] = hit
+        return hit[1]
 
     def stack_params(self):
         """flat parameter list in the order x_clip_amd.functional.stack_forward expects"""
@@ -116,8 +134,7 @@ class Transformer(nn.Module):
             w_qkv, w_out = attn.fn.to_qkv.weight, attn.fn.to_out[0].weight
             hs = 64 if dh <= 64 else 128                      # the kernels' head slot (StackSpec.head_slot)
             if dh < hs:                                       # heads narrower than their slot: zero rows / columns (StackSpec)
-                w_qkv = F.pad(w_qkv.view(3, h, dh, -1), (0, 0, 0, hs - dh)).reshape(3 * h * hs, -1)
-                w_out = F.pad(w_out.view(-1, h, dh), (0, hs - dh)).reshape(-1, h * hs)
+                w_qkv, w_out = self._padded(w_qkv, w_out, dh, h, hs)
             ps += [attn.norm.g, w_qkv, w_out, attn.fn.to_out[1].g,
                    ff.norm.g, ff.fn.net[0].weight, ff.fn.net[2].g, ff.fn.net[4].weight]
         ps.append(self.norm_out.g)
@@ -136,10 +153,14 @@ class Transformer(nn.Module):
             if t.dim() != 2 or t.shape[1] != 32 or t.shape[0] < max(2, x.shape[1]):
                 raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): a [n, 32] angle table covering the sequence")
             rotary = t[1, :16].contiguous()
-            want = torch.outer(torch.arange(t.shape[0], device=t.device, dtype=torch.float32), rotary).repeat(1, 2)
-            if not torch.allclose(t, want, rtol=1e-5, atol=1e-6):
-                raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): only tables of the form position x frequency "
-                                          "(RotaryEmbedding.forward) are supported by the rotary kernel")
+            # the check reads the table on the host (a sync): once per table -- the same tensor, unmodified, is not checked again
+            key = (rotary_pos_emb.data_ptr(), rotary_pos_emb._version, tuple(rotary_pos_emb.shape), rotary_pos_emb.dtype)
+            if self._rotary_ok != key:
+                want = torch.outer(torch.arange(t.shape[0], device=t.device, dtype=torch.float32), rotary).repeat(1, 2)
+                if not torch.allclose(t, want, rtol=1e-5, atol=1e-6):
+                    raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): only tables of the form position x frequency "
+                                              "(RotaryEmbedding.forward) are supported by the rotary kernel")
+                self._rotary_ok = key
         return XF.transformer(x, self.stack_params(), self.spec(rotary), mask)
 
 

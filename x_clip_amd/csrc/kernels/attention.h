@@ -44,6 +44,7 @@ struct AttnParams {
     int chunks;                  // row chunks (of NW*32) per (batch, head)
     int causal;                  // != 0: key j is visible to query i only if j <= i (reference Attention.forward, x_clip.py:231-234)
     int stagger_10ns;            // head-resident kernels: start delay of a CU's second work-group (attention3.h a3_stagger), 0 = none
+    int first_round;             // ... applied to work-groups [0, first_round) = the first dispatch round: 2 x the device's CUs
 };
 
 template <typename T>

@@ -131,10 +131,12 @@ XC_DEV void a3_fwd_step_auto(const unsigned char* Ks, const unsigned char* Vs, c
 // Two work-groups share a CU and every head takes the same time, so left alone they load together and compute together.  The one
 // that was given the upper part of the CU's LDS in the FIRST round of work-groups waits half a head's time once: from then on one
 // streams its images from HBM while the other is in its MFMA phases.
-XC_DEV void a3_stagger(int ticks_10ns) {
-    if (ticks_10ns > 0 && blockIdx.x < 2u * 256u && lds_base_granule() != 0) {
+XC_DEV void a3_stagger(int ticks_10ns, int first_round) {
+    // first_round = 2 x the device's CUs (the host passes it: work-groups of the first dispatch round); the wait is bounded by an
+    // iteration count as well as by the clock, so a misbehaving realtime counter cannot hold a work-group
+    if (ticks_10ns > 0 && (int)blockIdx.x < first_round && lds_base_granule() != 0) {
         const uint64_t until = realtime_10ns() + (uint64_t)ticks_10ns;
-        while (realtime_10ns() < until) nap();
+        for (int spin = 0; spin < 4 * ticks_10ns && realtime_10ns() < until; ++spin) nap();
     }
 }
 // ---- forward ----------------------------------------------------------------------------------------------------------
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
     float* Ts = reinterpret_cast<float*>(Ms + npad);           // [nwaves][A3_TAIL_MAX][A3_TAIL_REC] tail partials
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c31 = lane & 31;
     const int wave = uniform(tid >> 6), nwaves = blockDim.x >> 6;
-    a3_stagger(p.stagger_10ns);
+    a3_stagger(p.stagger_10ns, p.first_round);
     const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
     const int hh = bh % p.heads, bi = bh / p.heads;
     const long ldq = 3L * p.heads * ATT_DH;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
     float* Tp = Ds + npad;                                     // [nwaves][A3_TAIL_MAX][128] tail partials: dQ (phase A), dK | dV (phase B)
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c31 = lane & 31;
     const int wave = uniform(tid >> 6), nwaves = blockDim.x >> 6;
-    a3_stagger(p.stagger_10ns);
+    a3_stagger(p.stagger_10ns, p.first_round);
     const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
     const int hh = bh % p.heads, bi = bh / p.heads;
     const long ldq = 3L * p.heads * ATT_DH, ldo = (long)p.heads * ATT_DH;

@@ -133,7 +133,9 @@ struct Filip5Epilogue {
             for (int r = 0; r < 32; ++r) {
                 const int rb = i * 32 + r;                              // block-relative row
                 if (rb == next_change) {                                // (uniform) the text changes here: leave the finished entry
-                    if (col_ok) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
+                    // (a text whose rows inside this block all lie past M does not exist: the last row tile's padding)
+                    const int first = next_change - f.nt > 0 ? next_change - f.nt : 0;
+                    if (col_ok && gr0 + first < f.M) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
                     cval = NEG; carg = 0;
                     ++slot;
                     next_change += f.nt;
@@ -148,7 +150,10 @@ struct Filip5Epilogue {
             lds_fence();                                                // (the next 32 rows overwrite the slice)
         }
         // the last text of the block (only if the block's first row of it exists)
-        if (slot < 3 && gr0 + (next_change - f.nt) < f.M && col_ok) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
+        {
+            const int first = next_change - f.nt > 0 ? next_change - f.nt : 0;
+            if (slot < 3 && gr0 + first < f.M && col_ok) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
+        }
         return 0;
     }
 };

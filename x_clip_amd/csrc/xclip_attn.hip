@@ -69,6 +69,7 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     memset(&p, 0, sizeof(p));
     p.qkv = qkv; p.mask = mask; p.out = out; p.lse = lse;
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale; p.causal = causal != 0;
+    p.first_round = 2 * xc_num_cus();
     hipStream_t st = (hipStream_t)stream;
     if (head_dim == 128) {                                     // wide heads: the tiled kernels with two 64-wide halves per head
         const int nw = attn_waves(n);
@@ -119,6 +120,7 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     p.qkv = qkv; p.mask = mask; p.out = const_cast<void*>(out); p.lse = const_cast<float*>(lse); p.dout = dout;
     p.delta = delta_ws; p.dqkv = dqkv;
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale; p.causal = causal != 0;
+    p.first_round = 2 * xc_num_cus();
     hipStream_t st = (hipStream_t)stream;
     if (head_dim == 128) {                                     // wide heads: delta pass + the tiled dQ / dK, dV kernels on two halves
         XC_REQUIRE(delta_ws != nullptr, "wide heads need the [batch, heads, n] fp32 delta workspace");
