@@ -279,6 +279,11 @@ inline bool wave_all(bool pred) {
     for (int m = 32; m >= 1; m >>= 1) v &= shfl_xor(v, m);
     return v != 0;
 }
+inline uint32_t wave_ballot32(bool pred) {                 // bit l = the predicate of lane l, lanes 0..31
+    int v = (pred && lane_id() < 32) ? (int)(1u << lane_id()) : 0;
+    for (int m = 32; m >= 1; m >>= 1) v |= shfl_xor(v, m);
+    return (uint32_t)v;
+}
 inline bool wave_any(bool pred) {
     int v = pred ? 1 : 0;
     for (int m = 32; m >= 1; m >>= 1) v |= shfl_xor(v, m);

@@ -77,6 +77,8 @@ XC_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
 // wave-wide votes (the result is uniform)
 XC_DEV bool wave_all(bool pred) { return __all(pred) != 0; }
 XC_DEV bool wave_any(bool pred) { return __any(pred) != 0; }
+// bit l = the predicate of lane l, lanes 0..31 (wave-uniform result)
+XC_DEV uint32_t wave_ballot32(bool pred) { return (uint32_t)__ballot(pred); }
 
 XC_DEV float wave_sum(float v) {
 #pragma unroll

@@ -127,29 +127,46 @@ struct Filip5Epilogue {
                     const u32x2 v = {f2bf_pk(a[0], a[1]), f2bf_pk(a[2], a[3])};
                     *reinterpret_cast<u32x2*>(wr + (((4 * j + q) ^ (r31 & 7)) << 4)) = v;
                 }
-            const int mv = (grow < f.M) ? (int)f.mask[grow] : 0;        // this lane's row: real token?
+            const uint32_t live = wave_ballot32(grow < f.M && f.mask[grow] != 0);   // bit r: row r of the group is a real token (uniform)
             lds_fence();
-#pragma unroll 4
-            for (int r = 0; r < 32; ++r) {
-                const int rb = i * 32 + r;                              // block-relative row
-                if (rb == next_change) {                                // (uniform) the text changes here: leave the finished entry
-                    // (a text whose rows inside this block all lie past M does not exist: the last row tile's padding)
-                    const int first = next_change - f.nt > 0 ? next_change - f.nt : 0;
-                    if (col_ok && gr0 + first < f.M) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
-                    cval = NEG; carg = 0;
-                    ++slot;
-                    next_change += f.nt;
+            const unsigned char* const col = scratch + (lane & 7) * 2;  // + r * 128 + ((chunk ^ (r & 7)) << 4): column `lane`, chunk lane >> 3
+            const int chunk = lane >> 3;
+            auto flush = [&]() {
+                // (a text whose rows inside this block all lie past M does not exist: the last row tile's padding)
+                const int first = next_change - f.nt > 0 ? next_change - f.nt : 0;
+                if (col_ok && gr0 + first < f.M) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
+                cval = NEG; carg = 0;
+                ++slot;
+                next_change += f.nt;
+            };
+            if (next_change == i * 32) flush();                         // (uniform) the text changes at the group's first row
+            if (live == 0xffffffffu && (next_change <= i * 32 || next_change >= i * 32 + 32)) {
+                // the common group: 32 real tokens of one text.  All 32 reads are issued before the first compare (one dependent
+                // LDS round trip per row was the whole cost of this direction: ~100 cycles x 128 rows per tile)
+                const int t0 = gr0 + i * 32 - (x0 + slot) * f.nt;       // token index of the group's first row inside its text
+                bf16_t raw[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) raw[r] = *reinterpret_cast<const bf16_t*>(col + r * 128 + ((chunk ^ (r & 7)) << 4));
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const float s = bf2f(raw[r]);
+                    if (s > cval) { cval = s; carg = t0 + r; }
                 }
-                if (uniform(shfl(mv, r)) != 0) {                        // (uniform) padding tokens take no part
-                    const unsigned char* p = scratch + r * 128 + ((((lane >> 3) ^ (r & 7))) << 4) + (lane & 7) * 2;
-                    const float s = bf2f(*reinterpret_cast<const bf16_t*>(p));
-                    const int t = gr0 + rb - (x0 + slot) * f.nt;        // token index inside the text
-                    if (s > cval) { cval = s; carg = t; }
+            } else {
+#pragma unroll 4
+                for (int r = 0; r < 32; ++r) {
+                    const int rb = i * 32 + r;                          // block-relative row
+                    if (r != 0 && rb == next_change) flush();           // (uniform) the text changes here: leave the finished entry
+                    if ((live >> r) & 1u) {                             // (uniform) padding tokens take no part
+                        const float s = bf2f(*reinterpret_cast<const bf16_t*>(col + r * 128 + ((chunk ^ (r & 7)) << 4)));
+                        const int t = gr0 + rb - (x0 + slot) * f.nt;    // token index inside the text
+                        if (s > cval) { cval = s; carg = t; }
+                    }
                 }
             }
             lds_fence();                                                // (the next 32 rows overwrite the slice)
         }
-        // the last text of the block (only if the block's first row of it exists)
+        // the last text of the block (only if a row of it exists)
         {
             const int first = next_change - f.nt > 0 ? next_change - f.nt : 0;
             if (slot < 3 && gr0 + first < f.M && col_ok) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
