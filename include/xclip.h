@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 13
+#define XCLIP_ABI_VERSION 14
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -126,13 +126,21 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
  * qkv [batch, n, 3, heads, head_dim] = output of the to_qkv Linear; mask [batch, n] bytes (1 = attend) or NULL;
  * out [batch, n, heads*head_dim]; lse [batch, heads, n] fp32 saved for the backward.  scale = dim_head^-0.5 (the MODEL's dim_head).
  * causal != 0: key j is hidden from query i when j > i (the causal text encoder, x_clip.py:231-234), on top of the key mask.
+ * dropout_p > 0: attention dropout on the softmax probabilities (Attention.dropout, x_clip.py:212,241): probability (b, h, i, j) is kept,
+ * and scaled by 1 / (1 - p), iff the 32-bit mix of (dropout_seed, ((b heads + h) n + i) n + j) is >= p 2^32 (csrc/kernels/common.h
+ * drop_hash) -- the backward (and a checkpointed re-run of the forward) must be given the same seed.  Runs the tiled kernels.
  * A query with no visible key gets output 0 (the reference's softmax over all -max scores gives the uniform average there). */
 int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n,
-                        int64_t heads, int64_t head_dim, float scale, int causal, int dtype, void* stream);
+                        int64_t heads, int64_t head_dim, float scale, int causal, float dropout_p, uint64_t dropout_seed, int dtype,
+                        void* stream);
 /* delta_ws: [batch, heads, n] fp32 scratch; dqkv [batch, n, 3, heads, head_dim] fully overwritten */
 int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
                         float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, int64_t head_dim, float scale, int causal,
-                        int dtype, void* stream);
+                        float dropout_p, uint64_t dropout_seed, int dtype, void* stream);
+/* Feed-forward dropout (nn.Dropout between the inner LayerNorm and the second Linear, x_clip.py:193-194): y[i] = x[i] keep(i) / (1 - p)
+ * over n contiguous elements (n a multiple of the 16-byte chunk), keep(i) iff drop_hash(seed, i) >= p 2^32.  The same call on the
+ * gradient is the backward; y == x is allowed. */
+int xclip_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 
 /* ---- contrastive head (similarity + InfoNCE / DCL, x_clip.py:813-847) ---------------------------------------------
  * S = scale * exp(*log_scale) * Q K^T, Q [nq, d], K [nk, d]; log_scale (device fp32 scalar, may be NULL) is the

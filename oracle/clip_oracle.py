@@ -156,8 +156,27 @@ def apply_rotary(freqs: Tensor, t: Tensor) -> Tensor:
     return torch.cat((a * freqs.cos() + half * freqs.sin(), rest), dim=-1)
 
 
+def dropout_keep(seed: int, count: int, p: float) -> Tensor:
+    """the keep-mask the product's kernels use for element indices 0 .. count-1 under `seed` (x_clip_amd/csrc/kernels/common.h
+    drop_hash: a stateless 32-bit mix of the seed words and the 64-bit element index; keep iff hash >= p * 2^32), rebuilt with numpy.
+    This is NOT the reference's RNG stream (torch's Philox cannot be matched from a fused kernel): the parity tests evaluate the
+    reference's dropout arithmetic (x_clip.py:193-194,241: mask / (1 - p) after the softmax / after the inner LayerNorm) on THIS mask."""
+    M = np.uint64(0xFFFFFFFF)
+    idx = np.arange(count, dtype=np.uint64)
+    seed = np.uint64(seed & ((1 << 64) - 1))
+    with np.errstate(over="ignore"):
+        h = (seed & M) ^ (((seed >> np.uint64(32)) * np.uint64(0x85EBCA77)) & M) ^ (((idx & M) * np.uint64(0x9E3779B1)) & M) \
+            ^ (((idx >> np.uint64(32)) * np.uint64(0xC2B2AE3D)) & M)
+        h ^= h >> np.uint64(16); h = (h * np.uint64(0x7FEB352D)) & M
+        h ^= h >> np.uint64(15); h = (h * np.uint64(0x846CA68B)) & M
+        h ^= h >> np.uint64(16)
+    thresh = 0 if p <= 0 else int(np.float32(p).astype(np.float64) * 4294967296.0)
+    return torch.from_numpy((h >= np.uint64(thresh)))
+
+
 def attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: int,
-              key_mask: Optional[Tensor], rotary: Optional[Tensor] = None, causal: bool = False) -> Tensor:
+              key_mask: Optional[Tensor], rotary: Optional[Tensor] = None, causal: bool = False,
+              drop: Optional[Tuple[float, int]] = None) -> Tensor:
     """Attention.forward (x_clip.py:213-245): bias-free fused qkv projection, q scaled by
     dim_head**-0.5, key padding mask, optional causal mask (:231-234), softmax in fp32 (or wider), bias-free out
     projection followed by a LayerNorm."""
@@ -174,29 +193,37 @@ def attention(x: Tensor, sd: Dict[str, Tensor], pfx: str, heads: int, dim_head: 
         scores = scores.masked_fill(torch.ones(n, n, dtype=torch.bool).triu(1), -torch.finfo(scores.dtype).max)
     sm_dtype = torch.float32 if scores.dtype != torch.float64 else torch.float64
     probs = torch.softmax(scores.to(sm_dtype), dim=-1).to(scores.dtype)
+    if drop is not None and drop[0] > 0:                        # Attention.dropout (x_clip.py:212,241), mask over (b, h, i, j)
+        keep = dropout_keep(drop[1], b * heads * n * n, drop[0]).view(b, heads, n, n)
+        probs = probs * keep.to(probs.dtype) / (1.0 - float(np.float32(drop[0])))
     o = (probs @ v).permute(0, 2, 1, 3).reshape(b, n, heads * dim_head)
     o = o @ sd[pfx + "to_out.0.weight"].t()
     return layer_norm(o, sd[pfx + "to_out.1.g"])
 
 
-def feed_forward(x: Tensor, sd: Dict[str, Tensor], pfx: str) -> Tensor:
-    """FeedForward (x_clip.py:185-199): Linear(D, 8D) -> GEGLU -> LayerNorm(4D) -> Linear(4D, D), no
-    biases (dropout prob is 0)."""
+def feed_forward(x: Tensor, sd: Dict[str, Tensor], pfx: str, drop: Optional[Tuple[float, int]] = None) -> Tensor:
+    """FeedForward (x_clip.py:185-199): Linear(D, 8D) -> GEGLU -> LayerNorm(4D) -> Dropout -> Linear(4D, D), no biases."""
     y = x @ sd[pfx + "net.0.weight"].t()
     h = layer_norm(geglu(y), sd[pfx + "net.2.g"])
+    if drop is not None and drop[0] > 0:                        # net.3 (x_clip.py:194), mask over the flat [rows, 4D] activation
+        keep = dropout_keep(drop[1], h.numel(), drop[0]).view(h.shape)
+        h = h * keep.to(h.dtype) / (1.0 - float(np.float32(drop[0])))
     return h @ sd[pfx + "net.4.weight"].t()
 
 
 def transformer(x: Tensor, sd: Dict[str, Tensor], pfx: str, depth: int, heads: int, dim_head: int,
-                key_mask: Optional[Tensor], rotary: Optional[Tensor] = None, causal: bool = False) -> Tensor:
+                key_mask: Optional[Tensor], rotary: Optional[Tensor] = None, causal: bool = False,
+                dropout: Optional[Tuple[float, float, int]] = None) -> Tensor:
     """Transformer.forward (x_clip.py:274-291): norm_in, pre-norm residual attention + feed-forward
     blocks, norm_out."""
     x = layer_norm(x, sd[pfx + "norm_in.g"])
     for l in range(depth):
         a = f"{pfx}layers.{l}.0."
         f = f"{pfx}layers.{l}.1."
-        x = attention(layer_norm(x, sd[a + "norm.g"]), sd, a + "fn.", heads, dim_head, key_mask, rotary, causal) + x
-        x = feed_forward(layer_norm(x, sd[f + "norm.g"]), sd, f + "fn.") + x
+        da = (dropout[0], dropout[2] + 2 * l) if dropout is not None else None          # (attn p, ff p, the pass's seed): layer l uses
+        df = (dropout[1], dropout[2] + 2 * l + 1) if dropout is not None else None      # seed + 2 l / seed + 2 l + 1, as the product does
+        x = attention(layer_norm(x, sd[a + "norm.g"]), sd, a + "fn.", heads, dim_head, key_mask, rotary, causal, da) + x
+        x = feed_forward(layer_norm(x, sd[f + "norm.g"]), sd, f + "fn.", df) + x
     return layer_norm(x, sd[pfx + "norm_out.g"])
 
 

@@ -254,7 +254,7 @@ def case_gemm(dev, dtype, M, N, K, layout, epilogue=False, alpha=1.0, residual_o
     close(c, r, dtype, f"gemm {layout} {M}x{N}x{K}", scale=max(scale, float(r.abs().max())))
 
 
-def _attention_ref(qkv64, mask, heads, scale, causal=False, hd=64):
+def _attention_ref(qkv64, mask, heads, scale, causal=False, hd=64, drop=None):
     b, n, _ = qkv64.shape
     q, k, v = qkv64.view(b, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
     s = (q * scale) @ k.transpose(-1, -2)
@@ -263,11 +263,14 @@ def _attention_ref(qkv64, mask, heads, scale, causal=False, hd=64):
     if causal:                                                  # x_clip.py:231-234
         s = s.masked_fill(torch.ones(n, n, dtype=torch.bool).triu(1), -torch.finfo(s.dtype).max)
     p = torch.softmax(s, dim=-1)
+    if drop is not None:                                        # (p, seed): the product's keep-mask over (b, h, i, j), rebuilt on the host
+        p = p * O.dropout_keep(drop[1], b * heads * n * n, drop[0]).view(b, heads, n, n).double() / (1.0 - float(np.float32(drop[0])))
     return (p @ v).permute(0, 2, 1, 3).reshape(b, n, heads * hd)
 
 
-def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64):
-    """hd = features per head slot: 64, or 128 (wide heads, reference Attention(dim_head > 64), x_clip.py:201-212)"""
+def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64, drop=None):
+    """hd = features per head slot: 64, or 128 (wide heads, reference Attention(dim_head > 64), x_clip.py:201-212); drop = (p, seed):
+    attention dropout (x_clip.py:212,241) with the product's own stateless keep-mask"""
     qkv = rnd((batch, n, 3 * heads * hd), dtype, 22)
     dout = rnd((batch, n, heads * hd), dtype, 23)
     mask = None
@@ -280,13 +283,14 @@ def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64):
             if n > 3:
                 mask[bi, 2] = bi % 2 == 0           # a hole in the middle as well
     scale = hd ** -0.5
-    out, lse = ops.attention_fwd(qkv.to(dev), None if mask is None else mask.to(dev), heads, scale, causal, hd)
+    dk = {} if drop is None else dict(dropout_p=drop[0], dropout_seed=drop[1])
+    out, lse = ops.attention_fwd(qkv.to(dev), None if mask is None else mask.to(dev), heads, scale, causal, hd, **dk)
     q64 = ref64(qkv).requires_grad_(True)
-    r = _attention_ref(q64, mask, heads, scale, causal, hd)
+    r = _attention_ref(q64, mask, heads, scale, causal, hd, drop)
     r.backward(ref64(dout))
-    tag = "" if hd == 64 else f" (head slot {hd})"
+    tag = ("" if hd == 64 else f" (head slot {hd})") + ("" if drop is None else " + dropout")
     close(out, r, dtype, "attn out" + tag, ulps=2.0, unit="scale")
-    dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale, causal, hd)
+    dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale, causal, hd, **dk)
     close(dqkv, q64.grad, dtype, "attn dqkv" + tag, mult=3.0, ulps=2.0, unit="scale")
 
 
@@ -758,3 +762,18 @@ def case_filip_fused(dev, bx, nt, by, ni, d, seed=61, chunks=1):
     ops.filip_reduce(S16, m8, tau.to(dev), t2i_c, i2t_c, kmax_c, tmax_c, cnt_c, nt, ni, by, 0)
     assert float((t2i - t2i_c).abs().max()) <= 0.75 * ulp and float((i2t - i2t_c).abs().max()) <= 0.75 * ulp
     return exact
+
+
+def case_dropout(dev, dtype, n=4096 + 8 * 37, p=0.3, seed=0x1234567890ABCDEF):
+    """the feed-forward dropout kernel (x_clip.py:193-194): element i kept iff the stateless hash of (seed, i) says so -- compared with
+    the numpy rebuild of that hash; kept fraction near 1 - p; the same call on a gradient is the backward; in place"""
+    x = rnd((n,), dtype, 71)
+    y = ops.dropout(x.to(dev), p, seed)
+    keep = O.dropout_keep(seed, n, p)
+    want = ref64(x) * keep.double() / (1.0 - float(np.float32(p)))
+    close(y, want, dtype, "dropout")
+    assert abs(float(keep.double().mean()) - (1 - p)) < 0.03
+    z = x.to(dev).clone()
+    ops.dropout(z, p, seed, out=z)
+    assert torch.equal(z, y)
+    assert torch.equal(ops.dropout(x.to(dev), 0.0, seed), x.to(dev))

@@ -310,3 +310,61 @@ def test_filip_fused_path_vs_oracle_and_chunked():
         losses.FILIP_FUSED = True
         ops_mod.filip_fused_fwd = orig
     assert abs(l_fused - l_chunk) < 2e-3, (l_fused, l_chunk)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_transformer_dropout_vs_oracle(dtype):
+    """Transformer(attn_dropout, ff_dropout) (x_clip.py:185-212,241,247-291) in training mode: forward and every gradient against the
+    oracle evaluating the reference's dropout arithmetic on the product's keep-masks (rebuilt on the host from the pass's seed);
+    activation checkpointing re-runs the layer with the same masks (bit-identical gradients); eval mode applies no dropout"""
+    from x_clip_amd import functional as XF
+    from x_clip_amd.clip import Transformer
+    torch.manual_seed(5)
+    dim, depth, heads, dh, b, n = 64, 2, 2, 32, 3, 20
+    net = Transformer(dim, depth=depth, heads=heads, dim_head=dh, attn_dropout=0.2, ff_dropout=0.1).to(dtype).train()
+    ck = Transformer(dim, depth=depth, heads=heads, dim_head=dh, attn_dropout=0.2, ff_dropout=0.1, checkpoint_during_training=True).to(dtype).train()
+    ck.load_state_dict(net.state_dict())
+    x = torch.randn(b, n, dim).to(dtype)
+    mask = torch.ones(b, n, dtype=torch.bool)
+    mask[1, 13:] = False
+    g = torch.randn(b, n, dim).to(dtype)
+    seed = 0x2545F4914F6CDD1
+    orig = XF._draw_seed
+    XF._draw_seed = lambda: seed
+    try:
+        outs = []
+        for m in (net, ck):
+            xi = x.clone().requires_grad_(True)
+            y = m(xi, mask=mask)
+            y.backward(g)
+            outs.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in m.named_parameters()}))
+    finally:
+        XF._draw_seed = orig
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        if k.endswith(".g"):
+            torch.testing.assert_close(outs[0][2][k], outs[1][2][k], rtol=1e-4, atol=1e-6)      # fp32 atomics: order varies
+        else:
+            assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+    sd = {"t." + k: v.detach().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    x64 = x.double().requires_grad_(True)
+    fp32 = dtype == torch.float32
+    with O.layer_norm_eps(1e-5 if fp32 else 1e-3):
+        ref = O.transformer(x64, sd, "t.", depth, heads, dh, mask, dropout=(0.2, 0.1, seed))
+        ref.backward(g.double())
+    y, dx, grads = outs[0]
+    tol = 2e-5 if fp32 else 3e-2
+    assert float((y.double() - ref.detach()).abs().max()) < tol * float(ref.detach().abs().max()), float((y.double() - ref.detach()).abs().max())
+    assert float((dx.double() - x64.grad).norm() / x64.grad.norm()) < (2e-4 if fp32 else 5e-2)
+    for k, gr in grads.items():
+        rg = sd["t." + k].grad
+        rel = float((gr.double() - rg).norm() / rg.norm())
+        assert rel < (2e-4 if fp32 else 8e-2), (k, rel)
+    # without the masks the same oracle is far away: the dropout is really applied
+    with O.layer_norm_eps(1e-5 if fp32 else 1e-3):
+        plain = O.transformer(x.double(), {k: v.detach() for k, v in sd.items()}, "t.", depth, heads, dh, mask)
+    assert float((y.double() - plain).abs().max()) > 0.05
+    net.eval()
+    with torch.no_grad():
+        ye = net(x, mask=mask)
+    assert float((ye.double() - plain).abs().max()) < (1e-4 if fp32 else 6e-2)

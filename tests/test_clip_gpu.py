@@ -359,3 +359,40 @@ def test_no_kernel_reads_unwritten_memory():
                        text_heads=12, visual_enc_depth=2, visual_image_size=56, visual_patch_size=14, visual_heads=16)
     with C.poisoned_empty():
         C.case_vs_oracle(DEV, torch.bfloat16, cfg, 8, n_aug_text=1, n_aug_image=1, patch_keep=8)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_transformer_dropout_vs_oracle(dtype):
+    """Transformer(attn_dropout = 0.2, ff_dropout = 0.1) (x_clip.py:185-212,241) at dim 512 / 8 heads / 71 tokens in training mode: output
+    and every gradient against the oracle evaluating the reference's dropout arithmetic on the product's keep-masks"""
+    from x_clip_amd import functional as XF
+    from x_clip_amd.clip import Transformer
+    torch.manual_seed(5)
+    dim, depth, heads, dh, b, n = 512, 2, 8, 64, 6, 71
+    net = Transformer(dim, depth=depth, heads=heads, dim_head=dh, attn_dropout=0.2, ff_dropout=0.1).to(dtype).to(DEV).train()
+    x = torch.randn(b, n, dim).to(dtype)
+    mask = torch.ones(b, n, dtype=torch.bool)
+    mask[1, 40:] = False
+    g = torch.randn(b, n, dim).to(dtype)
+    seed = 0x2545F4914F6CDD1
+    orig = XF._draw_seed
+    XF._draw_seed = lambda: seed
+    try:
+        xi = x.to(DEV).requires_grad_(True)
+        y = net(xi, mask=mask.to(DEV))
+        y.backward(g.to(DEV))
+    finally:
+        XF._draw_seed = orig
+    sd = {"t." + k: v.detach().double().cpu().requires_grad_(True) for k, v in net.state_dict().items()}
+    x64 = x.double().requires_grad_(True)
+    fp32 = dtype == torch.float32
+    with O.layer_norm_eps(1e-5 if fp32 else 1e-3):
+        ref = O.transformer(x64, sd, "t.", depth, heads, dh, mask, dropout=(0.2, 0.1, seed))
+        ref.backward(g.double())
+    err = float((y.detach().double().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
+    assert err < (2e-5 if fp32 else 3e-2), err
+    assert float((xi.grad.double().cpu() - x64.grad).norm() / x64.grad.norm()) < (2e-4 if fp32 else 5e-2)
+    for k, p in net.named_parameters():
+        rg = sd["t." + k].grad
+        rel = float((p.grad.double().cpu() - rg).norm() / rg.norm())
+        assert rel < (2e-4 if fp32 else 8e-2), (k, rel)

@@ -303,3 +303,16 @@ def test_filip_fused(bx, nt, by, ni, d, chunks):
     cut by wave blocks and tiles), segment = wave block (64), long segments spanning tiles + two image chunks, 280 rows (the second
     row tile's lower wave block lies wholly past M: no text exists there -- an out-of-bounds partial once) x 195 columns (odd)"""
     K.case_filip_fused(DEV, bx, nt, by, ni, d, chunks=chunks)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("n,masked,causal,hd", [(33, False, False, 64), (97, True, True, 64), (70, True, False, 128)])
+def test_attention_dropout(dtype, n, masked, causal, hd):
+    """attention dropout (Attention.dropout, x_clip.py:212,241) in the tiled kernels, forward and backward, against the reference
+    arithmetic on the same keep-mask"""
+    K.case_attention(DEV, dtype, 2, n, 2, masked, causal=causal, hd=hd, drop=(0.25, 0xC0FFEE1234567))
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+def test_dropout(dtype):
+    K.case_dropout(DEV, dtype)

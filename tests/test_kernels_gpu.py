@@ -278,3 +278,15 @@ def test_filip_fused(bx, nt, by, ni, d, chunks):
     """the FILIP forward with its reductions inside the GEMM epilogue (filip5.h): emulator shapes, then configs[3]-like token counts
     (77 x 98, 77 x 196 in three image chunks) over hundreds of tiles and the ViT-L FILIP token count (288) at d = 768"""
     K.case_filip_fused(DEV, bx, nt, by, ni, d, chunks=chunks)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("n,heads,masked,causal,hd", [(33, 2, False, False, 64), (257, 8, True, False, 64), (97, 3, True, True, 64), (288, 2, True, False, 128)])
+def test_attention_dropout(dtype, n, heads, masked, causal, hd):
+    K.case_attention(DEV, dtype, 3, n, heads, masked, causal=causal, hd=hd, drop=(0.25, 0xC0FFEE1234567))
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+def test_dropout(dtype):
+    K.case_dropout(DEV, dtype)
+    K.case_dropout(DEV, dtype, n=(1 << 25) + 4096, p=0.1)              # many work-groups, grid-stride loop

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 import torch  # noqa: F401  (must be imported first: the .so binds to torch's libamdhip64)
 
@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libxclip_hip.so")
 _lib = None
 _is_emulator = False
 
-P, I, L, F = c_void_p, c_int, c_int64, c_float
+P, I, L, F, U = c_void_p, c_int, c_int64, c_float, c_uint64
 
 _SIGNATURES = {
     "xclip_abi_version": (c_int, []),
@@ -43,8 +43,9 @@ _SIGNATURES = {
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),
-    "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, L, F, I, I, P]),
-    "xclip_attention_bwd": (c_int, [P, P, P, P, P, P, P, L, L, L, L, F, I, I, P]),
+    "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, L, F, I, F, U, I, P]),
+    "xclip_attention_bwd": (c_int, [P, P, P, P, P, P, P, L, L, L, L, F, I, F, U, I, P]),
+    "xclip_dropout": (c_int, [P, P, L, F, U, I, P]),
     "xclip_filip_reduce": (c_int, [P, L, P, P, P, P, L, P, P, P, L, L, L, L, L, L, I, P]),
     "xclip_filip_fused_ok": (c_int, [L, L, L, I]),
     "xclip_filip_fused_workspace_bytes": (c_int64, [L, L, L, L]),
@@ -75,7 +76,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 def _bind(path: str):

@@ -8,7 +8,7 @@ the gfx950 kernels behind x_clip_amd.functional / x_clip_amd.losses.  There is n
 on an MI355X.
 
 Not on this path (constructor raises NotImplementedError): the causal text encoder together with rotary embeddings, FILIP or
-MLM (each fails inside the reference's own forward); attention / feed-forward dropout; dim_head > 128 (heads of up to 64
+MLM (each fails inside the reference's own forward); dim_head > 128 (heads of up to 64
 dimensions run in 64-feature head slots, 65 ... 128 in 128-feature slots, zero-padded where narrower: Transformer.stack_params).
 """
 from __future__ import annotations
@@ -62,8 +62,7 @@ class FeedForward(nn.Module):
 
     def __init__(self, dim, mult=4, dropout=0.):
         super().__init__()
-        if dropout != 0.:
-            raise NotImplementedError("ff_dropout != 0 is not on the accelerated path (reference default 0)")
+        assert 0. <= dropout < 1.
         inner_dim = int(dim * mult)
         self.net = nn.Sequential(
             nn.Linear(dim, inner_dim * 2, bias=False),
@@ -79,8 +78,7 @@ class Attention(nn.Module):
 
     def __init__(self, dim, dim_head=64, heads=8, causal=False, dropout=0.):
         super().__init__()
-        if dropout != 0.:
-            raise NotImplementedError("attn_dropout != 0 is not on the accelerated path (reference default 0)")
+        assert 0. <= dropout < 1.
         self.heads = heads
         self.causal = causal
         self.scale = dim_head ** -0.5
@@ -98,6 +96,7 @@ class Transformer(nn.Module):
         super().__init__()
         self.checkpoint_during_training = checkpoint_during_training
         self.dim, self.depth, self.heads, self.dim_head, self.causal = dim, depth, heads, dim_head, causal
+        self.attn_dropout, self.ff_dropout = float(attn_dropout), float(ff_dropout)
         XF.StackSpec(depth=depth, heads=heads, dim_head=dim_head)      # (raises for a head width the kernels do not hold)
         self.layers = nn.ModuleList([])
         for _ in range(depth):
@@ -141,8 +140,10 @@ class Transformer(nn.Module):
         return ps
 
     def spec(self, rotary: Optional[Tensor] = None) -> XF.StackSpec:
+        # (nn.Dropout semantics: active in training mode only)
         return XF.StackSpec(depth=self.depth, heads=self.heads, dim_head=self.dim_head,
-                            checkpoint=bool(self.training and self.checkpoint_during_training), rotary=rotary, causal=self.causal)
+                            checkpoint=bool(self.training and self.checkpoint_during_training), rotary=rotary, causal=self.causal,
+                            attn_dropout=self.attn_dropout if self.training else 0.0, ff_dropout=self.ff_dropout if self.training else 0.0)
 
     def forward(self, x, rotary_pos_emb=None, mask=None):
         rotary = None

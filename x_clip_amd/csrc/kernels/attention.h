@@ -45,6 +45,11 @@ struct AttnParams {
     int causal;                  // != 0: key j is visible to query i only if j <= i (reference Attention.forward, x_clip.py:231-234)
     int stagger_10ns;            // head-resident kernels: start delay of a CU's second work-group (attention3.h a3_stagger), 0 = none
     int first_round;             // ... applied to work-groups [0, first_round) = the first dispatch round: 2 x the device's CUs
+    // attention dropout (reference Attention.dropout on the softmax probabilities, x_clip.py:241): the tiled kernels of this file only.
+    // keep-mask of probability (batch, head, query i, key j) = drop_hash(drop_seed, ((batch * heads + head) * n + i) * n + j) >= drop_thresh
+    uint32_t drop_thresh;        // 0: no dropout
+    float drop_scale;            // 1 / (1 - p)
+    uint64_t drop_seed;
 };
 
 template <typename T>
@@ -201,9 +206,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = (s[t][r] > 0.5f * ATT_NEG) ? fast_exp(s[t][r] - m_new) : 0.f;
+                float pv = (s[t][r] > 0.5f * ATT_NEG) ? fast_exp(s[t][r] - m_new) : 0.f;
+                rs += pv;                                                          // (the normaliser sums the UNdropped probabilities)
+                if (p.drop_thresh) {
+                    const uint64_t e = ((uint64_t)bh * n + (uint32_t)qld) * n + (uint32_t)(kt0 + t * 32 + mfma_row(r, lane));
+                    pv = drop_hash(p.drop_seed, e) >= p.drop_thresh ? pv * p.drop_scale : 0.f;
+                }
                 s[t][r] = pv;
-                rs += pv;
             }
         rs += shfl_xor(rs, 32);
         l = l * alpha + rs;
@@ -333,7 +342,12 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int kj = t * 32 + mfma_row(r, lane);
                     const float pv = (Ms[kj] && kt0 + kj <= qlim) ? fast_exp(s[r] * p.scale - lse_q) : 0.f;
-                s[r] = pv * (dp[r] - delta_q) * p.scale;                       // dS^T (already times the q scale)
+                float dpr = dp[r];
+                if (p.drop_thresh) {                                           // d loss / d P = mask / (1 - p) o (dO V^T)
+                    const uint64_t e = ((uint64_t)bh * n + (uint32_t)qld) * n + (uint32_t)(kt0 + kj);
+                    dpr = drop_hash(p.drop_seed, e) >= p.drop_thresh ? dpr * p.drop_scale : 0.f;
+                }
+                s[r] = pv * (dpr - delta_q) * p.scale;                         // dS^T (already times the q scale)
             }
 #pragma unroll
             for (int blk = 0; blk < C::NKB; ++blk) {
@@ -430,8 +444,14 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int ql = t * 32 + mfma_row(r, lane);
                 const float pv = (kvalid && qt0 + ql < n && qt0 + ql >= kmin) ? fast_exp(s[r] * p.scale - Ls[ql]) : 0.f;
-                s[r] = pv;                                                     // P
-                dp[r] = pv * (dp[r] - Ds[ql]) * p.scale;                       // dS (times the q scale)
+                float keep = 1.f;
+                if (p.drop_thresh) {
+                    const int qi = qt0 + ql < n ? qt0 + ql : n - 1;
+                    const uint64_t e = ((uint64_t)bh * n + (uint32_t)qi) * n + (uint32_t)kld;
+                    keep = drop_hash(p.drop_seed, e) >= p.drop_thresh ? p.drop_scale : 0.f;
+                }
+                s[r] = pv * keep;                                              // P o mask / (1 - p): what multiplied V in the forward
+                dp[r] = pv * (dp[r] * keep - Ds[ql]) * p.scale;                // dS (times the q scale)
             }
 #pragma unroll
             for (int blk = 0; blk < C::NKB; ++blk) {

@@ -28,6 +28,17 @@ XC_DEV u32x4 zero16() {
 XC_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 XC_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+// ---- dropout (reference nn.Dropout in Attention / FeedForward, x_clip.py:185-212,241) -------------------------------------------------
+// keep-mask of element `idx` of the tensor a (seed, stream) pair names: a stateless 32-bit mix (the "lowbias32" finaliser over the seed
+// words and the 64-bit index), so the forward, the backward and a checkpointed re-run of the forward regenerate the SAME mask from
+// three integers, and a test can rebuild it on the host (oracle/clip_oracle.py dropout_keep).  keep iff hash >= thresh = p * 2^32.
+XC_HOST_DEV uint32_t drop_hash(uint64_t seed, uint64_t idx) {
+    uint32_t h = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85ebca77u) ^ ((uint32_t)idx * 0x9e3779b1u) ^ ((uint32_t)(idx >> 32) * 0xc2b2ae3du);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+XC_HOST_DEV uint32_t drop_thresh(float p) { return p <= 0.f ? 0u : (p >= 1.f ? 0xffffffffu : (uint32_t)((double)p * 4294967296.0)); }
+
 // 16 bytes -> VEC floats
 XC_DEV void unpack(const u32x4& r, float (&f)[4], float*) {
     f[0] = u2f(r[0]); f[1] = u2f(r[1]); f[2] = u2f(r[2]); f[3] = u2f(r[3]);

@@ -382,6 +382,23 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* __restrict__ X, long ld,
     }
 }
 
+// ---- feed-forward dropout (reference nn.Dropout between the inner LayerNorm and the second Linear, x_clip.py:193-194) -------------
+// y[i] = x[i] * keep(i) / (1 - p) over a contiguous [n] tensor, keep from drop_hash(seed, i) (common.h).  The same launch on the
+// gradient is the backward.  In place is fine.  One 16-byte chunk per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, uint32_t thresh, float scale,
+                                                      uint64_t seed) {
+    constexpr int VEC = Elem<T>::VEC;
+    const long chunks = n / VEC;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (long)gridDim.x * blockDim.x) {
+        float v[VEC];
+        load_vec<T>(x + c * VEC, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = drop_hash(seed, (uint64_t)(c * VEC + e)) >= thresh ? v[e] * scale : 0.f;
+        store_vec<T>(y + c * VEC, v);
+    }
+}
+
 // ---- depthwise 4 x 4 / stride 2 / pad 1 convolution over a square token grid (`downsample_image_embeds`, x_clip.py:560-568) ----
 // x [batch, h * h, C] token-major (channels contiguous), w [C, 16] (the Conv2d weight [C, 1, 4, 4]), y [batch, (h/2)^2, C]:
 //   y[b, (i, j), c] = sum_{u, v} w[c, 4 u + v] x[b, (2 i - 1 + u, 2 j - 1 + v), c]      (out-of-range taps are zero padding)

@@ -641,6 +641,22 @@ int xclip_cross_entropy_bwd(void* logits, int64_t ld, const int64_t* labels, con
     return check_launch(__func__);
 }
 
+int xclip_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(n >= 0 && n % vec_of(dtype) == 0 && p >= 0.f && p < 1.f, "n must be a whole number of 16-byte chunks, p in [0, 1)");
+    XC_REQUIRE(x && y && aligned16(x) && aligned16(y), "null or misaligned pointer");
+    if (n == 0) return 0;
+    int64_t blocks = (n / vec_of(dtype) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const uint32_t th = drop_thresh(p);
+    const float sc = 1.0f / (1.0f - p);
+    if (dtype == XCLIP_BF16)
+        hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)n, th, sc, seed);
+    else
+        hipLaunchKernelGGL((dropout_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, (long)n, th, sc, seed);
+    return check_launch(__func__);
+}
+
 int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, int64_t slot_width, const float* inv_freq, int inverse,
                  int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");

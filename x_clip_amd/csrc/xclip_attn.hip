@@ -59,7 +59,7 @@ int attn_waves(int64_t n) {
 extern "C" {
 
 int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n, int64_t heads,
-                        int64_t head_dim, float scale, int causal, int dtype, void* stream) {
+                        int64_t head_dim, float scale, int causal, float dropout_p, uint64_t dropout_seed, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
     XC_REQUIRE(head_dim == 64 || head_dim == 128, "head_dim must be 64 or 128 (narrower / in-between widths are zero-padded by the caller)");
@@ -70,6 +70,9 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     p.qkv = qkv; p.mask = mask; p.out = out; p.lse = lse;
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale; p.causal = causal != 0;
     p.first_round = 2 * xc_num_cus();
+    XC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must lie in [0, 1)");
+    p.drop_thresh = drop_thresh(dropout_p); p.drop_scale = 1.0f / (1.0f - dropout_p); p.drop_seed = dropout_seed;
+    const bool tiled_only = p.drop_thresh != 0;               // dropout lives in the tiled kernels (attention.h)
     hipStream_t st = (hipStream_t)stream;
     if (head_dim == 128) {                                     // wide heads: the tiled kernels with two 64-wide halves per head
         const int nw = attn_waves(n);
@@ -79,7 +82,7 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
 #undef W
         return check_launch(__func__);
     }
-    if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // head-resident kernel: one work-group per (batch, head)
+    if (dtype == XCLIP_BF16 && n <= A3_MAX_N && !tiled_only) {               // head-resident kernel: one work-group per (batch, head)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         const int nwq = a3_waves((int)n);
         // half a head's time (13 us at n = 257, growing with n^2) between the two work-groups of a CU: 0.413 -> 0.376 ms at
@@ -99,7 +102,8 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     const int nw = attn_waves(n);
 #define F(T) switch (nw) { case 1: launch_attn_fwd<T, 1>(p, st); break; case 2: launch_attn_fwd<T, 2>(p, st); break; \
                            case 3: launch_attn_fwd<T, 3>(p, st); break; default: launch_attn_fwd<T, 4>(p, st); break; }
-    if (dtype == XCLIP_BF16) {
+    if (dtype == XCLIP_BF16 && tiled_only) { F(bf16_t) }
+    else if (dtype == XCLIP_BF16) {
         switch (nw) { case 1: launch_attn2_fwd<1>(p, st); break; case 2: launch_attn2_fwd<2>(p, st); break;
                       case 3: launch_attn2_fwd<3>(p, st); break; default: launch_attn2_fwd<4>(p, st); break; }
     } else { F(float) }
@@ -109,7 +113,7 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
 
 int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
                         float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, int64_t head_dim, float scale, int causal,
-                        int dtype, void* stream) {
+                        float dropout_p, uint64_t dropout_seed, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(batch >= 0 && n > 0 && heads > 0, "bad shape");
     XC_REQUIRE(head_dim == 64 || head_dim == 128, "head_dim must be 64 or 128 (narrower / in-between widths are zero-padded by the caller)");
@@ -121,6 +125,9 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     p.delta = delta_ws; p.dqkv = dqkv;
     p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.scale = scale; p.causal = causal != 0;
     p.first_round = 2 * xc_num_cus();
+    XC_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must lie in [0, 1)");
+    p.drop_thresh = drop_thresh(dropout_p); p.drop_scale = 1.0f / (1.0f - dropout_p); p.drop_seed = dropout_seed;
+    const bool tiled_only = p.drop_thresh != 0;               // dropout lives in the tiled kernels (attention.h)
     hipStream_t st = (hipStream_t)stream;
     if (head_dim == 128) {                                     // wide heads: delta pass + the tiled dQ / dK, dV kernels on two halves
         XC_REQUIRE(delta_ws != nullptr, "wide heads need the [batch, heads, n] fp32 delta workspace");
@@ -136,7 +143,7 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
 #undef W
         return check_launch(__func__);
     }
-    if (dtype == XCLIP_BF16 && n <= A3_MAX_N) {               // merged head-resident backward (computes delta itself)
+    if (dtype == XCLIP_BF16 && n <= A3_MAX_N && !tiled_only) {               // merged head-resident backward (computes delta itself)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         const int nwq = a3_bwd_waves((int)n);
         static const int abl = measure_env("XCLIP_ATTN_ABL", 0);   // measurement build only
@@ -161,7 +168,8 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     const int nw = attn_waves(n);
 #define F(T) switch (nw) { case 1: launch_attn_bwd<T, 1>(p, st); break; case 2: launch_attn_bwd<T, 2>(p, st); break; \
                            case 3: launch_attn_bwd<T, 3>(p, st); break; default: launch_attn_bwd<T, 4>(p, st); break; }
-    if (dtype == XCLIP_BF16) {
+    if (dtype == XCLIP_BF16 && tiled_only) { F(bf16_t) }
+    else if (dtype == XCLIP_BF16) {
         switch (nw) { case 1: launch_attn2_bwd<1>(p, st); break; case 2: launch_attn2_bwd<2>(p, st); break;
                       case 3: launch_attn2_bwd<3>(p, st); break; default: launch_attn2_bwd<4>(p, st); break; }
     } else { F(float) }

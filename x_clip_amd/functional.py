@@ -97,6 +97,11 @@ class _SideGemm:
         self.keep, self.pending = [], []
 
 
+def _draw_seed() -> int:
+    """a fresh 62-bit seed from torch's default CPU generator (host side: no device sync)"""
+    return int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
+
+
 LAYER_PARAMS = 8          # attn_norm.g, to_qkv.w, to_out.w, to_out_norm.g, ff_norm.g, ff1.w, ff_inner_norm.g, ff2.w
 
 
@@ -108,6 +113,8 @@ class StackSpec:
     checkpoint: bool = False
     rotary: Optional[Tensor] = None         # rotary embedding on q, k, v: the inv_freq buffer (16 fp32), x_clip.py:155-176,221-223
     causal: bool = False                    # causal attention (the autoregressive text encoder), x_clip.py:231-234
+    attn_dropout: float = 0.0               # dropout on the softmax probabilities (x_clip.py:212,241); 0 outside training
+    ff_dropout: float = 0.0                 # dropout between the inner LayerNorm and the second Linear (x_clip.py:193-194)
 
     def __post_init__(self):
         # the attention kernels hold head slots of 64 features (the head-resident kernels) or 128 (wide heads: two 64-wide halves
@@ -118,6 +125,8 @@ class StackSpec:
             raise NotImplementedError("x_clip_amd attention kernels hold heads of up to 128 dimensions (the reference default is 64)")
         if self.rotary is not None and self.dim_head < 32:
             raise NotImplementedError("rotary embedding with dim_head < 32 (the kernel rotates the first 32 dimensions of a head)")
+        if not (0.0 <= self.attn_dropout < 1.0 and 0.0 <= self.ff_dropout < 1.0):
+            raise ValueError("dropout probabilities must lie in [0, 1)")
 
     @property
     def head_slot(self) -> int:
@@ -143,27 +152,31 @@ class _GainGrads:
 
 # ---- one pre-norm residual block pair (x_clip.py:285-289) --------------------------------------------------------------
 def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor], rotary: Optional[Tensor] = None,
-                   causal: bool = False, scale: float = 0.125, hs: int = 64):
+                   causal: bool = False, scale: float = 0.125, hs: int = 64, drop=(0.0, 0.0, 0)):
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     M, D = x.shape
     inner = heads * hs                                                                 # hs: features per head slot (64 | 128)
+    p_attn, p_ff, seed = drop                                                          # dropout probabilities, this layer's seed
     h, m1, r1 = ops.layernorm_fwd(x, g_attn)                                           # PreNorm           :126
     qkv = ops.gemm(h, w_qkv, M, 3 * inner, D)                                          # to_qkv            :216
     if rotary is not None:
         ops.rotary_(qkv, n, rotary, head_dim=hs)                                               # q, k, v rotated   :221-223
-    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, scale, causal, hs)   # scale/mask/softmax :217-244
+    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, scale, causal, hs, p_attn, seed)   # scale/mask/softmax(/dropout) :217-244
     p = ops.gemm(o.view(M, inner), w_out, M, D, inner)                                 # to_out.0          :245
     x1, m2, r2, h2, m3, r3 = ops.layernorm_chain_fwd(p, g_out, x, g_ff)                # to_out.1 + skip :245,288 and PreNorm :126, one pass
     u = ops.gemm(h2, w_ff1, M, w_ff1.shape[0], D)                                      # net.0             :191
     a, m4, r4 = ops.layernorm_fwd(u, g_inner, geglu=True)                              # GEGLU + net.2     :192-193
+    if p_ff > 0.0:
+        ops.dropout(a, p_ff, seed + 1, out=a)                                          # net.3 Dropout     :194 (in place: `a` is only read by net.4)
     x2 = ops.gemm(a, w_ff2, M, D, a.shape[1], residual=x1)                             # net.4 + skip      :195,289
     return x2, (x, h, m1, r1, qkv, o, lse, p, m2, r2, x1, h2, m3, r3, u, a, m4, r4)
 
 
 def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
                     gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm", rotary: Optional[Tensor] = None,
-                    causal: bool = False, scale: float = 0.125, hs: int = 64):
+                    causal: bool = False, scale: float = 0.125, hs: int = 64, drop=(0.0, 0.0, 0)):
     """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2])"""
+    p_attn, p_ff, seed = drop
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     dg_attn, dg_out, dg_ff, dg_inner = gain_acc
     x, h, m1, r1, qkv, o, lse, p, m2, r2, x1, h2, m3, r3, u, a, m4, r4 = saved
@@ -173,7 +186,9 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     Fh = F2 // 2
     # feed-forward block
     da = ops.gemm(dx2, w_ff2, M, Fh, D, b_kmajor=True)
-    d_ff2 = sg.wgrad(dx2, a, D, Fh, M, w_ff2) if need_w[3] else None
+    d_ff2 = sg.wgrad(dx2, a, D, Fh, M, w_ff2) if need_w[3] else None      # (`a` is the dropped activation: what net.4 saw)
+    if p_ff > 0.0:
+        ops.dropout(da, p_ff, seed + 1, out=da)                                         # the same mask on the gradient
     du, _ = ops.layernorm_bwd(da, u, g_inner, m4, r4, geglu=True, dg=dg_inner)
     del da
     dh2 = ops.gemm(du, w_ff1, M, D, F2, b_kmajor=True)
@@ -185,7 +200,7 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     do = ops.gemm(dp, w_out, M, inner, D, b_kmajor=True)
     d_out = sg.wgrad(dp, o.view(M, inner), D, inner, M, w_out) if need_w[1] else None
     del dp
-    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, scale, causal, hs)
+    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, scale, causal, hs, p_attn, seed)
     del do
     if rotary is not None:
         ops.rotary_(dqkv.view(M, 3 * inner), n, rotary, inverse=True, head_dim=hs)      # the saved qkv is the rotated one; R^T maps its gradient back
@@ -204,21 +219,25 @@ def stack_forward(x0: Tensor, B: int, n: int, spec: StackSpec, params: Sequence[
     g_in, g_out = params[0], params[-1]
     x, m_in, r_in = ops.layernorm_fwd(x0, g_in)
     layers = []
+    # dropout: one 64-bit seed per pass from torch's CPU generator (no device sync; torch.manual_seed makes it reproducible); layer l
+    # uses seed + 2 l (attention) and seed + 2 l + 1 (feed-forward); the backward and a checkpointed re-run regenerate the same masks
+    seed0 = _draw_seed() if (spec.attn_dropout > 0.0 or spec.ff_dropout > 0.0) else 0
     for l in range(spec.depth):
         W = params[1 + LAYER_PARAMS * l: 1 + LAYER_PARAMS * (l + 1)]
-        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot)
+        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
+                                       (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
         if keep_tape:
             layers.append((saved[0],) if spec.checkpoint else saved)
         x = x_next
     y, m_out, r_out = ops.layernorm_fwd(x, g_out, out=out, out_group=out_group)
-    tape = (x0, m_in, r_in, layers, x, m_out, r_out) if keep_tape else None
+    tape = (x0, m_in, r_in, layers, x, m_out, r_out, seed0) if keep_tape else None
     return y, tape
 
 
 def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Sequence[Tensor], mask: Optional[Tensor],
                    need: Sequence[bool]):
     """dy [B*n, D] contiguous -> (dx0, grads aligned with `params` (None where not needed))"""
-    x0, m_in, r_in, layers, x_last, m_out, r_out = tape
+    x0, m_in, r_in, layers, x_last, m_out, r_out, seed0 = tape
     gains = [params[0]] + [params[1 + LAYER_PARAMS * l + k] for l in range(spec.depth) for k in (0, 3, 4, 6)] + [params[-1]]
     gg = _GainGrads(gains)
     grads: List[Optional[Tensor]] = [None] * len(params)
@@ -229,9 +248,11 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
         W = params[base: base + LAYER_PARAMS]
         saved = layers[l]
         if spec.checkpoint:                      # re-run the layer forward from its saved input
-            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot)
+            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
+                                      (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
         need_w = [need[base + 1], need[base + 2], need[base + 5], need[base + 7]]
-        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot)
+        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
+                                     (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
         layers[l] = None                         # release this layer's activations
         sg.layer_done()
         grads[base + 1], grads[base + 2], grads[base + 5], grads[base + 7] = dws

@@ -13,6 +13,7 @@ from . import _lib
 Tensor = torch.Tensor
 
 _DTYPES = {torch.float32: 0, torch.bfloat16: 1}
+_U64 = (1 << 64) - 1
 
 
 def dtype_code(t: Tensor) -> int:
@@ -432,7 +433,7 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
 
 # ---- attention --------------------------------------------------------------------------------------------------------
 def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float, causal: bool = False,
-                  head_dim: int = 64) -> Tuple[Tensor, Tensor]:
+                  head_dim: int = 64, dropout_p: float = 0.0, dropout_seed: int = 0) -> Tuple[Tensor, Tensor]:
     """qkv [b, n, 3*heads*head_dim] (head slots of 64 or 128 features); mask bool [b, n] or None; causal: key j hidden from query i < j
     -> out [b, n, heads*head_dim], lse fp32 [b, heads, n]"""
     _dev_check(qkv, mask)
@@ -445,21 +446,32 @@ def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float,
         assert mask.dtype == torch.bool and tuple(mask.shape) == (b, n)
         mask = _c(mask)
     _lib.check(_lib.lib().xclip_attention_fwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), lse.data_ptr(), b, n, heads, head_dim, scale,
-                                              int(causal), dtype_code(qkv), _stream(qkv)), "xclip_attention_fwd")
+                                              int(causal), float(dropout_p), int(dropout_seed) & _U64, dtype_code(qkv), _stream(qkv)),
+               "xclip_attention_fwd")
     return out, lse
 
 
 def attention_bwd(qkv: Tensor, mask: Optional[Tensor], out: Tensor, dout: Tensor, lse: Tensor, heads: int, scale: float,
-                  causal: bool = False, head_dim: int = 64) -> Tensor:
+                  causal: bool = False, head_dim: int = 64, dropout_p: float = 0.0, dropout_seed: int = 0) -> Tensor:
     _dev_check(qkv, mask, out, dout)
     dout = _c(dout)
     b, n, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(b, heads, n, dtype=torch.float32, device=qkv.device)
     _lib.check(_lib.lib().xclip_attention_bwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                              delta.data_ptr(), dqkv.data_ptr(), b, n, heads, head_dim, scale, int(causal), dtype_code(qkv),
-                                              _stream(qkv)), "xclip_attention_bwd")
+                                              delta.data_ptr(), dqkv.data_ptr(), b, n, heads, head_dim, scale, int(causal), float(dropout_p),
+                                              int(dropout_seed) & _U64, dtype_code(qkv), _stream(qkv)), "xclip_attention_bwd")
     return dqkv
+
+
+def dropout(x: Tensor, p: float, seed: int, out: Optional[Tensor] = None) -> Tensor:
+    """y = x * keep / (1 - p) with the keep-mask of (seed, flat element index) (csrc/kernels/common.h drop_hash; reference nn.Dropout in
+    FeedForward, x_clip.py:193-194).  The same call on the gradient is the backward.  out=x works in place."""
+    _dev_check(x, out)
+    assert x.is_contiguous()
+    y = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().xclip_dropout(x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed) & _U64, dtype_code(x), _stream(x)), "xclip_dropout")
+    return y
 
 
 # ---- contrastive head ---------------------------------------------------------------------------------------------------
