@@ -127,7 +127,8 @@ def worker_filip(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu"):
     dist.destroy_process_group()
 
 
-def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_text=0, n_aug_image=0, gradsync=False, dtype_name="float32"):
+def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_text=0, n_aug_image=0, gradsync=False, dtype_name="float32",
+                  freeze_text=False):
     """any world size, any per-rank batch sizes, any head: rank r holds rows sum(sizes[:r]) ... of the global batch of every view"""
     dev = setup(rank, world, port, kind)
     from x_clip_amd import CLIP
@@ -151,12 +152,15 @@ def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_t
         kw["aug_image"] = [a[sl].to(dtype).to(dev) for a in aug_i]
     for step in range(2 if gradsync else 1):                  # GradSync: a second step reuses the persistent flat buffers
         model.zero_grad(set_to_none=True)
-        loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, **kw)
+        loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, freeze_text_encoder=freeze_text, **kw)
         loss.backward()
         if sync is not None:
             sync.finish()
+            if freeze_text:                                   # a whole bucket without gradients: zeros on the wire, .grad stays None
+                assert all(p.grad is None for p in model.text_transformer.parameters())
+                assert sync.stats["unused"] >= sum(1 for _ in model.text_transformer.parameters())
             # every weight-gradient GEMM of both towers and the latent projections wrote straight into its bucket slice
-            n_gemm = 4 * (cfg.text_enc_depth + cfg.visual_enc_depth) + 2 * (2 if cfg.extra_latent_projection else 1)
+            n_gemm = 4 * ((0 if freeze_text else cfg.text_enc_depth) + cfg.visual_enc_depth) + 2 * (2 if cfg.extra_latent_projection else 1)
             assert sync.stats["in_place"] >= n_gemm, (sync.stats, n_gemm)
             for p in model.parameters():
                 if p.grad is not None:
@@ -255,7 +259,8 @@ def check_filip(tmp, cfg, batch, world=2):
         assert rel < 3e-4, (k, rel)
 
 
-def check_ragged(tmp, cfg, sizes, n_aug_text=0, n_aug_image=0, gradsync=False, dtype=torch.float32, rel_bar=3e-4, loss_bar=1e-5):
+def check_ragged(tmp, cfg, sizes, n_aug_text=0, n_aug_image=0, gradsync=False, dtype=torch.float32, rel_bar=3e-4, loss_bar=1e-5,
+                 freeze_text=False):
     """every rank's loss = the oracle's loss on the concatenated global batch; without GradSync the rank-SUMMED parameter gradients
     equal the oracle's (temperature sits downstream of the gather: every rank holds the full gradient, x_clip/distributed.py:51-54);
     with GradSync every rank holds (1/W) x that sum, bit-identical across ranks"""
@@ -273,6 +278,9 @@ def check_ragged(tmp, cfg, sizes, n_aug_text=0, n_aug_image=0, gradsync=False, d
     worst = (0.0, "")
     for k, v in sd.items():
         if not torch.is_tensor(v) or not v.is_floating_point() or v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        if freeze_text and k.startswith("text_transformer."):
+            assert all(o["grads"][k] is None for o in outs), k   # LiT-style frozen tower (x_clip.py:394-408): no gradient on any rank
             continue
         gs = [o["grads"][k].double() for o in outs]
         if gradsync:

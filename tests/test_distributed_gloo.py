@@ -76,3 +76,15 @@ def test_many_ranks_ragged_vs_oracle(tmp_path, name):
     port = 35500 + (os.getpid() % 2000) + list(RAGGED).index(name)
     mp.spawn(D.worker_ragged, args=(world, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", n_t, n_i, gs), nprocs=world, join=True)
     D.check_ragged(str(tmp_path), cfg, sizes, n_t, n_i, gs)
+
+
+def test_gradsync_with_a_frozen_tower(tmp_path):
+    """freeze_text_encoder = True under GradSync (3 ranks, ragged): the text tower's bucket has no gradient on any rank -- its slices go
+    onto the wire as zeros and `.grad` stays None -- while the other buckets reduce as usual (a bucket whose hook count never completes
+    is flushed by finish(); every rank still issues the same collectives of the same size)"""
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True)
+    sizes = [2, 3, 1]
+    port = 38500 + (os.getpid() % 2000)
+    mp.spawn(D.worker_ragged, args=(3, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", 0, 0, True, "float32", True), nprocs=3, join=True)
+    D.check_ragged(str(tmp_path), cfg, sizes, gradsync=True, freeze_text=True)
