@@ -88,3 +88,17 @@ def test_gradsync_with_a_frozen_tower(tmp_path):
     port = 38500 + (os.getpid() % 2000)
     mp.spawn(D.worker_ragged, args=(3, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", 0, 0, True, "float32", True), nprocs=3, join=True)
     D.check_ragged(str(tmp_path), cfg, sizes, gradsync=True, freeze_text=True)
+
+
+def test_two_ranks_filip_fused_forward_bf16(tmp_path):
+    """the rank-sharded FILIP head on a shape that takes the fused forward (64 image tokens, 70 text tokens, bf16; filip5.h) in both of
+    its uses: the row block (local texts x all images) and, in the backward, the column block (all texts x local images); ragged 3 + 2"""
+    from oracle import clip_oracle as O
+    import torch
+    cfg = dataclasses.replace(O.CFG1, use_all_token_embeds=True, visual_image_size=256, text_seq_len=70, text_enc_depth=1, visual_enc_depth=1)
+    sizes = [3, 2]
+    port = 39500 + (os.getpid() % 2000)
+    mp.spawn(D.worker_ragged, args=(2, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", 0, 0, False, "bfloat16"), nprocs=2, join=True)
+    # (bf16 FILIP bars of the single-process toy-model test: arg-max ties under bf16 scores)
+    worst = D.check_ragged(str(tmp_path), cfg, sizes, dtype=torch.bfloat16, rel_bar=0.25, loss_bar=1.4e-3)
+    print("worst gradient relative error (2 ranks, fused FILIP, bf16):", worst)
