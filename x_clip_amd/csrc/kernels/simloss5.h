@@ -18,7 +18,8 @@ struct Sim5LseEpilogue {
     XC_DEV bool packs_lines(int, int) const { return false; }
     XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4], int, int) const {}
     template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
-    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return Sim3LseEpilogue{p}(acc, m0, n0); }
+    // (the epilogue's parameters are re-read from the kernarg segment per tile: kept live across the K loop they cost 54 SGPR spills)
+    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return Sim3LseEpilogue{params_in_memory(p)}(acc, m0, n0); }
 };
 
 #ifdef XCLIP_MEASURE
