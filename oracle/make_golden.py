@@ -92,6 +92,10 @@ CASES = {
                         visual_heads=3, visual_dim_head=16, visual_image_size=48, visual_patch_size=16,
                         text_seq_len=19, text_enc_depth=1, visual_enc_depth=3, num_text_tokens=257),
                    6, 0, 0, 0.0),
+    # heads wider than 64 (the reference accepts any dim_head, x_clip.py:201-212): 128-feature head slots in the product
+    "cfg1_wide_heads": (dict(text_dim_head=96, visual_dim_head=128, text_heads=2, visual_heads=2), 4, 0, 0, 0.0),
+    "cfg1_wide_heads_rotary_dcl": (dict(text_dim_head=80, visual_dim_head=96, text_heads=3, visual_heads=2, text_rotary_pos_emb=True,
+                                        decoupled_contrastive_learning=True), 4, 1, 0, 0.0),
 }
 PARAM_SEED = 20240901
 INPUT_SEED = 1234
