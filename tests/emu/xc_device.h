@@ -384,7 +384,6 @@ inline s16x4 lds_read_tr16(const void* p) {
     return out;
 }
 inline int uniform(int v) { return v; }
-template <class T> inline const T& params_in_memory(const T& p) { return p; }   // (GPU: re-read from the kernarg segment at the point of use)
 inline void wave_sync() { int z = 0; (void)xcemu::wave_exchange(&z, sizeof(z)); }      // lanes are fibres: rendezvous
 inline void lds_fence() { wave_sync(); }
 inline void lds_drain() { wave_sync(); }

@@ -210,16 +210,6 @@ XC_DEV void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // measurement builds: keep a register value alive / opaque to the optimiser
 template <class T> XC_DEV void reg_keep(T& v) { asm volatile("" : "+v"(v)); }
 // constant-rate (100 MHz) timestamp
-// The kernel's FIRST argument as it lies in the kernarg segment, through a pointer the optimiser cannot see through: fields read via the
-// returned reference are loaded (scalar loads, K-cache hits) where they are used instead of being kept in SGPRs from the kernel's entry
-// -- for parameters only a tile epilogue needs, in kernels whose K loop already uses every SGPR (simloss5.h: 54 spilled SGPRs whose
-// v_readlane reloads sat between the MFMAs).  `p` must be the kernel's first by-value parameter.
-template <class T> XC_DEV const T& params_in_memory(const T& p) {
-    (void)p;
-    const T* q = (const T*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(q));
-    return *q;
-}
 XC_DEV uint64_t realtime_10ns() { return __builtin_amdgcn_s_memrealtime(); }
 XC_DEV uint64_t shader_cycles() { return __builtin_amdgcn_s_memtime(); }
 // first LDS granule of this work-group on its CU (HW_REG_LDS_ALLOC[7:0]): 0 for the work-group that got the CU's LDS first

@@ -18,8 +18,10 @@ struct Sim5LseEpilogue {
     XC_DEV bool packs_lines(int, int) const { return false; }
     XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4], int, int) const {}
     template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
-    // (the epilogue's parameters are re-read from the kernarg segment per tile: kept live across the K loop they cost 54 SGPR spills)
-    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return Sim3LseEpilogue{params_in_memory(p)}(acc, m0, n0); }
+    // (measured and not kept: re-reading the epilogue's parameters from the kernarg segment per tile -- params_in_memory(), 54 -> 35
+    //  spilled SGPRs -- made the kernel SLOWER, 194 against 157 us: every field access became its own scalar load + wait;
+    //  profiles/r03_f_sim_kernels_32k.log)
+    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return Sim3LseEpilogue{p}(acc, m0, n0); }
 };
 
 #ifdef XCLIP_MEASURE
