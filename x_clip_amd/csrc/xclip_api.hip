@@ -151,10 +151,20 @@ void launch_gemm4(const Gemm2Params& p, dim3 pgrid, bool ring3, hipStream_t st) 
         }
     }
 #endif
-    if (ring3) {
-        XC_ALLOW_LDS((gemm5_kernel<AK, BK_, MODE>), G5_LDS_BYTES);
-        hipLaunchKernelGGL((gemm5_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
-    } else {
+#ifdef XCLIP_MEASURE
+    constexpr bool both = true;                                   // every layout on either loop (XCLIP_GEMM=4 / 5)
+#else
+    constexpr bool both = false;                                  // the product carries one loop per layout: ring for NT / NN, two-stage for TN
+    (void)ring3;
+#endif
+    if constexpr (both || !AK) {
+        if (both ? ring3 : true) {
+            XC_ALLOW_LDS((gemm5_kernel<AK, BK_, MODE>), G5_LDS_BYTES);
+            hipLaunchKernelGGL((gemm5_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+            return;
+        }
+    }
+    if constexpr (both || AK) {
         XC_ALLOW_LDS((gemm4_kernel<AK, BK_, MODE>), G5_LDS_BYTES);   // two stages + 32 KiB of epilogue scratch (gemm4.h g4_run)
         hipLaunchKernelGGL((gemm4_kernel<AK, BK_, MODE>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p);
     }
