@@ -186,7 +186,7 @@ int xclip_filip_route(void* P, int64_t ldp, const uint8_t* mask, const float* lo
                       int64_t y0, int64_t ytotal, int dtype, void* stream);
 /* The same forward with the reductions INSIDE the token-similarity GEMM (x_clip.py:797-811 fused: the 'x t d, y i d -> x y t i' block is
  * never written): X [bx * nt, d] text-token latents, Y [yc * ni, d] image-token latents of images [y0, y0 + yc), both bf16 row-major
- * with row stride d; outputs as xclip_filip_reduce.  Needs dtype bf16, d a multiple of 64, nt >= 64, ni >= 64 (xclip_filip_fused_ok);
+ * with row stride d; outputs as xclip_filip_reduce.  Needs dtype bf16, d a multiple of 64, nt >= 32, ni >= 32 (xclip_filip_fused_ok);
  * workspace: xclip_filip_fused_workspace_bytes(bx, nt, yc, ni) bytes of 4-byte partials {bf16 max | int16 arg-max}. */
 int xclip_filip_fused_ok(int64_t nt, int64_t ni, int64_t d, int dtype);
 int64_t xclip_filip_fused_workspace_bytes(int64_t bx, int64_t nt, int64_t yc, int64_t ni);

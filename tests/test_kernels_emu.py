@@ -297,11 +297,14 @@ def test_gemm6_gemm7_experimental_kernels():
         assert out.returncode == 0 and "gemm6 ok" in out.stdout, (gen, out.stderr[-2000:])
 
 
-@pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2), (4, 70, 3, 65, 64, 1)])
+@pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2), (4, 70, 3, 65, 64, 1),
+                                                  (9, 32, 9, 32, 64, 1), (7, 40, 8, 33, 64, 1), (3, 256, 6, 32, 64, 1)])
 def test_filip_fused(bx, nt, by, ni, d, chunks):
     """the FILIP forward with its reductions inside the GEMM epilogue: 385 x 392 (2 x 2 tiles, ragged both ways, text / image segments
     cut by wave blocks and tiles), segment = wave block (64), long segments spanning tiles + two image chunks, 280 rows (the second
-    row tile's lower wave block lies wholly past M: no text exists there -- an out-of-bounds partial once) x 195 columns (odd)"""
+    row tile's lower wave block lies wholly past M: no text exists there -- an out-of-bounds partial once) x 195 columns (odd); the
+    smallest segments (32 tokens a side, aligned: 288 x 288), misaligned short segments (40 x 33: three images per wave block, five
+    texts per 128 rows), and the README's FILIP model under patch dropout (256 text tokens x 32 kept patches)"""
     K.case_filip_fused(DEV, bx, nt, by, ni, d, chunks=chunks)
 
 

@@ -273,7 +273,7 @@ def test_gemm_banded_tile_order(layout, M, N, K_):
 
 
 @pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2), (64, 77, 96, 98, 512, 1),
-                                                  (48, 77, 40, 196, 512, 3), (16, 77, 24, 288, 768, 1)])
+                                                  (48, 77, 40, 196, 512, 3), (16, 77, 24, 288, 768, 1), (33, 40, 50, 33, 512, 1), (24, 256, 96, 32, 512, 2)])
 def test_filip_fused(bx, nt, by, ni, d, chunks):
     """the FILIP forward with its reductions inside the GEMM epilogue (filip5.h): emulator shapes, then configs[3]-like token counts
     (77 x 98, 77 x 196 in three image chunks) over hundreds of tiles and the ViT-L FILIP token count (288) at d = 768"""

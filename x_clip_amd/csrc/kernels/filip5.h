@@ -4,20 +4,21 @@
 // rows = text tokens (x, t) and columns = image tokens (y, k); the epilogue of a tile reduces its accumulators in both directions
 //     row direction   : max_k over the columns of one image y      -> t2i[x, y] = sum_t w[x,t] max_k s / cnt[x]   (x_clip.py:805-807)
 //     column direction: max_{t live} over the rows of one text x   -> i2t[x, y] = mean_k max_t s                  (x_clip.py:809-811)
-// down to 4-byte partials {bf16 value | int16 arg-max}: per (row, 64-column wave block, side of the one segment boundary such a block
-// can hold) and per (column, 128-row wave block, up to three text segments).  Two small merge kernels combine the partials of the
+// down to 4-byte partials {bf16 value | int16 arg-max}: per (row, 64-column wave block, image: such a block overlaps at most three)
+// and per (column, 128-row wave block, text: at most five).  Two small merge kernels combine the partials of the
 // blocks a segment spans into t2i / i2t and the int16 arg-max maps the backward routes through (filip.h filip_route_kernel: unchanged).
 // What the chunked form (filip.h filip_reduce_rows_kernel over a [b nt, yc ni] workspace of at most 1 GiB) paid per step at the
 // configs[3] shape -- the write and re-read of 4 GB of similarities and 4.1 ms of reduction passes -- becomes ~1000 vector
 // instructions per wave and tile behind the tile's 256 MFMAs.
 //
-// Requirements (the host falls back to the chunked form otherwise): bf16, d a whole number of K steps, ni >= 64 (a 64-column wave
-// block then overlaps at most two images) and nt >= 64 (a 128-row wave block overlaps at most three texts).
+// Requirements (the host falls back to the chunked form otherwise): bf16, d a whole number of K steps, ni >= 32 (a 64-column wave
+// block then overlaps at most F5_SIDES = 3 images) and nt >= 32 (a 128-row wave block overlaps at most F5_SLOTS = 5 texts) -- e.g. the
+// README's FILIP model under patch dropout (32 of 64 patches kept) as well as BASELINE configs[3] (77 x 98).
 //
 // Row direction, in the accumulator layout (MFMA operands swapped: a lane owns a row (lane & 31) and 32 of its wave block's 64 columns,
-// j * 32 + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)): the lane scans its columns in increasing order keeping (max, arg) for the part left
-// and right of the image boundary -- which side an 8-column group falls on is wave-uniform except for the one group the boundary
-// cuts --, meets its partner lane (lane ^ 32) once per 32-row block, and leaves two entries.  fp32 compares; first index wins ties
+// j * 32 + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)): the lane scans its columns in increasing order keeping a (max, arg) per image of
+// the block -- which image an 8-column group belongs to is wave-uniform except for the groups an image boundary cuts --, meets its
+// partner lane (lane ^ 32) once per 32-row block, and leaves up to three entries.  fp32 compares; first index wins ties
 // like torch.max.
 // Column direction, through the wave's private 4 KiB slice of the freed A stage (what the plain GEMM's whole-line epilogue uses): the
 // 32 x 64 block goes down as bf16 in the swizzled line layout, then lane = column walks the 32 rows, skipping padding tokens (their
@@ -28,11 +29,13 @@
 namespace xc {
 
 constexpr uint32_t F5_EMPTY = 0xff800000u;                      // value -inf, arg 0
+constexpr int F5_SIDES = 3;                                      // images a 64-column wave block can overlap (ni >= 32)
+constexpr int F5_SLOTS = 5;                                      // texts a 128-row wave block can overlap (nt >= 32)
 
 struct Filip5Params {
     const unsigned char* mask;       // [M] one byte per text-token row (x, t): 1 = real token
-    uint32_t* rowpart;               // [M][nblk64][2]      row-direction partials
-    uint32_t* colpart;               // [nrblk][3][N]       column-direction partials
+    uint32_t* rowpart;               // [M][nblk64][F5_SIDES]   row-direction partials
+    uint32_t* colpart;               // [nrblk][F5_SLOTS][N]    column-direction partials
     int M, N, nt, ni, nblk64;
 };
 
@@ -57,12 +60,14 @@ struct Filip5Epilogue {
         const float NEG = -3.0e38f;
         const int gc0 = n0 + wn * 64;                                   // first global column of the wave block
         const int gr0 = m0 + wm * 128;                                  // first global row
-        // ---- geometry of the row direction: the image boundary inside the 64 columns, the number of real columns ----
+        // ---- geometry of the row direction: the (at most two) image boundaries inside the 64 columns, the number of real columns ----
         const int yL = gc0 / f.ni;
-        int cb = (yL + 1) * f.ni - gc0;                                 // block-relative first column of image yL + 1 (>= 64: none)
         int cend = f.N - gc0;                                           // columns >= cend are padding of the operand (or past it)
         cend = cend < 64 ? cend : 64;
-        if (cb > cend) cb = cend;
+        int cb1 = (yL + 1) * f.ni - gc0;                                // block-relative first column of image yL + 1
+        int cb2 = cb1 + f.ni;                                           // ... of image yL + 2
+        if (cb1 > cend) cb1 = cend;
+        if (cb2 > cend) cb2 = cend;
         // ---- geometry of the column direction: texts x0, x0 + 1, x0 + 2 overlap the 128 rows ----
         const int x0 = gr0 / f.nt;
         int slot = 0;                                                   // text x0 + slot is being accumulated
@@ -71,7 +76,7 @@ struct Filip5Epilogue {
         int carg = 0;                                                   // carried over the four 32-row blocks
         const int rblk = gr0 >> 7;
         const bool col_ok = gc0 + lane < f.N;
-        uint32_t* const cdst = f.colpart + ((long)rblk * 3) * f.N + gc0 + lane;
+        uint32_t* const cdst = f.colpart + ((long)rblk * F5_SLOTS) * f.N + gc0 + lane;
 
         unsigned char* const wr = scratch + r31 * 128 + 8 * h;          // + chunk position * 16   (pack_lines_t's layout)
 #pragma unroll
@@ -79,42 +84,49 @@ struct Filip5Epilogue {
             const int grow = gr0 + i * 32 + r31;
             // ================= row direction =================
             if (cend > 0) {
-                float vL = NEG, vR = NEG;
-                int aL = 0, aR = 0;
+                float v0 = NEG, v1 = NEG, v2 = NEG;                     // (max, arg) over the lane's columns of image yL, yL + 1, yL + 2
+                int a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int g0 = j * 32 + 8 * q;                  // the 8-column group both half-waves' quads lie in
-                        if (g0 + 8 <= cb) {                             // (uniform) wholly left of the boundary
+                        if (g0 + 8 <= cb1) {                            // (uniform) wholly inside the first image
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) take(acc[i][j][4 * q + k], g0 + k, vL, aL);
-                        } else if (g0 >= cb && g0 + 8 <= cend) {        // (uniform) wholly right of it, all real columns
+                            for (int k = 0; k < 4; ++k) take(acc[i][j][4 * q + k], g0 + k, v0, a0);
+                        } else if (g0 >= cb1 && g0 + 8 <= cb2) {        // (uniform) wholly inside the second
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) take(acc[i][j][4 * q + k], g0 + k, vR, aR);
-                        } else if (g0 < cend) {                         // the group the boundary (or the operand's end) cuts
+                            for (int k = 0; k < 4; ++k) take(acc[i][j][4 * q + k], g0 + k, v1, a1);
+                        } else if (g0 >= cb2 && g0 + 8 <= cend) {       // (uniform) wholly inside the third, all real columns
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) take(acc[i][j][4 * q + k], g0 + k, v2, a2);
+                        } else if (g0 < cend) {                         // a group that a boundary (or the operand's end) cuts
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 const int c = g0 + k + 4 * h;
                                 const float s = acc[i][j][4 * q + k];
-                                if (c < cb) take(s, g0 + k, vL, aL);
-                                else if (c < cend) take(s, g0 + k, vR, aR);
+                                if (c < cb1) take(s, g0 + k, v0, a0);
+                                else if (c < cb2) take(s, g0 + k, v1, a1);
+                                else if (c < cend) take(s, g0 + k, v2, a2);
                             }
                         }
                     }
-                aL += 4 * h; aR += 4 * h;                               // (the lane's constant column offset)
+                a0 += 4 * h; a1 += 4 * h; a2 += 4 * h;                  // (the lane's constant column offset)
                 // partner lane: the same row, the interleaved other 32 columns; smaller column wins ties
-                const float pvL = shfl_xor(vL, 32), pvR = shfl_xor(vR, 32);
-                const int paL = shfl_xor(aL, 32), paR = shfl_xor(aR, 32);
-                if (pvL > vL || (pvL == vL && paL < aL)) { vL = pvL; aL = paL; }
-                if (pvR > vR || (pvR == vR && paR < aR)) { vR = pvR; aR = paR; }
+                const float p0 = shfl_xor(v0, 32), p1 = shfl_xor(v1, 32), p2 = shfl_xor(v2, 32);
+                const int q0 = shfl_xor(a0, 32), q1 = shfl_xor(a1, 32), q2 = shfl_xor(a2, 32);
+                if (p0 > v0 || (p0 == v0 && q0 < a0)) { v0 = p0; a0 = q0; }
+                if (p1 > v1 || (p1 == v1 && q1 < a1)) { v1 = p1; a1 = q1; }
+                if (p2 > v2 || (p2 == v2 && q2 < a2)) { v2 = p2; a2 = q2; }
                 if (grow < f.M) {
-                    // lane h = 0 leaves the left entry, h = 1 the right one: arg = token index inside the image
-                    const float v = h ? vR : vL;
-                    const int a = h ? aR : aL;
-                    const int k = gc0 + a - (yL + h) * f.ni;
-                    const uint32_t e = (v > 0.5f * NEG) ? f5_entry(v, k) : F5_EMPTY;
-                    f.rowpart[((long)grow * f.nblk64 + (gc0 >> 6)) * 2 + h] = e;
+                    // lane h = 0 leaves the entries of the first and third image, h = 1 that of the second: arg = token index inside the image
+                    uint32_t* const dst = f.rowpart + ((long)grow * f.nblk64 + (gc0 >> 6)) * F5_SIDES;
+                    if (h == 0) {
+                        dst[0] = (v0 > 0.5f * NEG) ? f5_entry(v0, gc0 + a0 - yL * f.ni) : F5_EMPTY;
+                        dst[2] = (v2 > 0.5f * NEG) ? f5_entry(v2, gc0 + a2 - (yL + 2) * f.ni) : F5_EMPTY;
+                    } else {
+                        dst[1] = (v1 > 0.5f * NEG) ? f5_entry(v1, gc0 + a1 - (yL + 1) * f.ni) : F5_EMPTY;
+                    }
                 }
             }
             // ================= column direction =================
@@ -169,7 +181,7 @@ struct Filip5Epilogue {
         // the last text of the block (only if a row of it exists)
         {
             const int first = next_change - f.nt > 0 ? next_change - f.nt : 0;
-            if (slot < 3 && gr0 + first < f.M && col_ok) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
+            if (slot < F5_SLOTS && gr0 + first < f.M && col_ok) cdst[(long)slot * f.N] = (cval > 0.5f * NEG) ? f5_entry(cval, carg) : F5_EMPTY;
         }
         return 0;
     }
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void filip5_kernel(const bf16_t* X, 
 
 // ---- merges ----------------------------------------------------------------------------------------------------------------------
 // t2i[x, y0 + y] = temp * sum_t w[x, t] max_k s / max(cnt[x], 1e-6),  kmax[x, t, y0 + y] = arg max_k:  one work-group per (text x,
-// 256 images); a thread owns an image and walks the text's tokens, combining the <= 3 wave blocks the image's columns span
+// 256 images); a thread owns an image and walks the text's tokens, combining the wave blocks the image's columns span
 __global__ __launch_bounds__(256) void filip5_merge_rows_kernel(const uint32_t* __restrict__ rowpart, const unsigned char* __restrict__ mask,
                                                                 const float* __restrict__ log_temp, float* __restrict__ t2i, long ldo,
                                                                 short* __restrict__ kmax, float* __restrict__ cnt, int nt, int ni, int by,
@@ -215,9 +227,8 @@ __global__ __launch_bounds__(256) void filip5_merge_rows_kernel(const uint32_t* 
             float best = -3.0e38f;
             int bk = 0;
             for (int b = b_lo; b <= b_hi; ++b) {
-                // image y is the block's LEFT part unless the block starts in an earlier image
-                const int side = ((b << 6) / ni == y) ? 0 : 1;
-                const uint32_t e = rowpart[(row * nblk64 + b) * 2 + side];
+                const int side = y - (b << 6) / ni;               // images are numbered from the one the block's first column lies in
+                const uint32_t e = rowpart[(row * nblk64 + b) * F5_SIDES + side];
                 const float v = u2f(e & 0xffff0000u);
                 if (v > best) { best = v; bk = (int)(e & 0xffffu); }
             }
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256) void filip5_merge_cols_kernel(const uint32_t* 
             const int col = yfirst * ni + c;
             for (int rb = rb_lo; rb <= rb_hi; ++rb) {
                 const int slot = x - (rb << 7) / nt;              // texts are numbered from the block's first row's text
-                const uint32_t e = colpart[((long)rb * 3 + slot) * N + col];
+                const uint32_t e = colpart[((long)rb * F5_SLOTS + slot) * N + col];
                 const float v = u2f(e & 0xffff0000u);
                 if (v > best) { best = v; bt = (int)(e & 0xffffu); }
             }

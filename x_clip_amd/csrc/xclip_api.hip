@@ -822,16 +822,16 @@ int xclip_filip_reduce(const void* S, int64_t lds, const uint8_t* mask, const fl
 }
 
 int xclip_filip_fused_ok(int64_t nt, int64_t ni, int64_t d, int dtype) {
-    return dtype == XCLIP_BF16 && d > 0 && d % G2_BK == 0 && nt >= 64 && ni >= 64 && nt <= 32767 && ni <= 32767;
+    return dtype == XCLIP_BF16 && d > 0 && d % G2_BK == 0 && nt >= 32 && ni >= 32 && nt <= 32767 && ni <= 32767;
 }
 int64_t xclip_filip_fused_workspace_bytes(int64_t bx, int64_t nt, int64_t yc, int64_t ni) {
     const int64_t M = bx * nt, N = yc * ni;
-    return (M * ((N + 63) / 64) * 2 + ((M + 127) / 128) * 3 * N) * 4;
+    return (M * ((N + 63) / 64) * F5_SIDES + ((M + 127) / 128) * F5_SLOTS * N) * 4;
 }
 int xclip_filip_fused_fwd(const void* X, const uint8_t* mask, const void* Y, const float* log_temp, float* t2i, float* i2t, int64_t ldo,
                           int16_t* kmax, int16_t* tmax, float* cnt, void* workspace, int64_t workspace_bytes, int64_t bx, int64_t nt,
                           int64_t yc, int64_t ni, int64_t d, int64_t y0, int64_t ytotal, int dtype, void* stream) {
-    XC_REQUIRE(xclip_filip_fused_ok(nt, ni, d, dtype), "the fused FILIP forward needs bf16, d % 64 == 0, nt >= 64, ni >= 64");
+    XC_REQUIRE(xclip_filip_fused_ok(nt, ni, d, dtype), "the fused FILIP forward needs bf16, d % 64 == 0, nt >= 32, ni >= 32");
     XC_REQUIRE(bx > 0 && yc > 0 && y0 >= 0 && y0 + yc <= ytotal && ldo >= ytotal, "bad chunk geometry");
     XC_REQUIRE(bx * nt < (1LL << 31) && yc * ni < (1LL << 31), "problem too large for 32-bit tile indices");
     XC_REQUIRE(X && Y && mask && log_temp && t2i && i2t && kmax && tmax && cnt && aligned16(X) && aligned16(Y), "null or misaligned pointer");
@@ -841,7 +841,7 @@ int xclip_filip_fused_fwd(const void* X, const uint8_t* mask, const void* Y, con
     f.mask = mask;
     f.M = (int)(bx * nt); f.N = (int)(yc * ni); f.nt = (int)nt; f.ni = (int)ni; f.nblk64 = (int)((f.N + 63) / 64);
     f.rowpart = (uint32_t*)workspace;
-    f.colpart = f.rowpart + (int64_t)f.M * f.nblk64 * 2;
+    f.colpart = f.rowpart + (int64_t)f.M * f.nblk64 * F5_SIDES;
     const int64_t tiles = ((f.M + G2_BM - 1) / G2_BM) * (int64_t)((f.N + G2_BN - 1) / G2_BN);
     const int cus = xc_num_cus();
     XC_ALLOW_LDS(filip5_kernel, G5_LDS_BYTES);

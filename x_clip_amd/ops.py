@@ -558,7 +558,7 @@ def filip_reduce(S: Tensor, mask: Tensor, log_temp: Tensor, t2i: Tensor, i2t: Te
 
 
 def filip_fused_ok(nt: int, ni: int, d: int, dtype) -> bool:
-    """can the token similarity + reductions run as ONE fused GEMM launch (filip5.h)?  bf16, d % 64 == 0, nt >= 64, ni >= 64"""
+    """can the token similarity + reductions run as ONE fused GEMM launch (filip5.h)?  bf16, d % 64 == 0, nt >= 32, ni >= 32"""
     return dtype in _DTYPES and bool(_lib.lib().xclip_filip_fused_ok(nt, ni, d, _DTYPES[dtype]))
 
 
