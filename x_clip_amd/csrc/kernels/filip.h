@@ -225,53 +225,56 @@ __global__ __launch_bounds__(256) void filip_reduce_rows_kernel(const T* __restr
 }
 
 // P[(x,t),(y,k)] = temp * ( g1[x,y0+y] * w[x,t] / cnt[x] * [k == kmax] + g2[x,y0+y] / ni * [t == tmax[.., k]] )
-// one thread per 16-byte output chunk of a row; rows are padded with zeros up to ldp
+// One work-group per ROW SLICE: blockIdx.y = the row (x, t), blockIdx.x = a run of 256 chunks of that row; a thread owns one 16-byte
+// output chunk.  Everything that depends on the row only (the text, the token, its mask bit, temp / cnt) is computed once per
+// work-group from scalars; the chunk's first (image, token) comes from ONE 32-bit division.  (The first version flattened (row, chunk)
+// into a 64-bit index and paid two 64-bit divisions per 16 bytes written: 0.64 ms = 1.5 TB/s per 1 GB chunk at configs[3],
+// profiles/r03_d_kernel_stats_filip.txt.)  Rows of padding tokens and the padding columns are written as zeros.
 template <typename T>
 __global__ __launch_bounds__(256) void filip_route_kernel(T* __restrict__ P, long ldp, const unsigned char* __restrict__ mask,
                                                           const float* __restrict__ log_temp, const float* __restrict__ g1,
                                                           const float* __restrict__ g2, long ldg, const short* __restrict__ kmax,
                                                           const short* __restrict__ tmax, const float* __restrict__ cnt, int bx, int nt,
-                                                          int yc, int ni, int y0, int ytotal) {
+                                                          int yc, int ni, int y0, int ytotal, long row0) {
     constexpr int VEC = Elem<T>::VEC;
-    const float temp = expf(*log_temp);
     const int nch = (int)(ldp / VEC);
-    const long total = (long)bx * nt * nch;
-    const float inv_ni = 1.0f / (float)ni;
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(id % nch);
-        const long row = id / nch;
-        const int x = (int)(row / nt), t = (int)(row % nt);
-        const bool w = mask[row] != 0;
-        float v[VEC];
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= nch) return;
+    const long row = row0 + blockIdx.y;                          // (x, t); the launch covers rows [row0, row0 + gridDim.y)
+    const int x = (int)(row / nt), t = (int)(row - (long)x * nt);
+    const bool w = mask[row] != 0;
+    float v[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = 0.f;
-        const int col0 = ch * VEC;
-        if (w && col0 < yc * ni) {                              // (rows of padding tokens and the padding columns stay zero)
-            // one division per chunk; the chunk's columns walk (y, k) from there.  Per image y: the arg-max token of this text row
-            // (kmax) and the two upstream gradients are loaded once, the per-column arg-max rows (tmax) are contiguous in the column
-            int y = col0 / ni, k = col0 - y * ni;
-            const float invc = temp / fmaxf(cnt[x], 1e-6f);
-            const short* tm = tmax + ((long)x * ytotal + y0) * ni + col0;
-            const short* km = kmax + ((long)x * nt + t) * ytotal + y0;
-            const float* g1r = g1 + (long)x * ldg + y0;
-            const float* g2r = g2 + (long)x * ldg + y0;
-            int kbest = km[y];
-            float a1 = g1r[y] * invc, a2 = g2r[y] * inv_ni * temp;
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    const int col0 = ch * VEC;
+    const int ncols = yc * ni;
+    if (w && col0 < ncols) {                                     // (rows of padding tokens and the padding columns stay zero)
+        // the chunk's columns walk (y, k) from its first one.  Per image y: the arg-max token of this text row (kmax) and the two
+        // upstream gradients are loaded once, the per-column arg-max rows (tmax) are contiguous in the column
+        const float temp = expf(*log_temp);
+        const float inv_ni = 1.0f / (float)ni;
+        int y = col0 / ni, k = col0 - y * ni;
+        const float invc = temp / fmaxf(cnt[x], 1e-6f);
+        const short* tm = tmax + ((long)x * ytotal + y0) * ni + col0;
+        const short* km = kmax + row * ytotal + y0;
+        const float* g1r = g1 + (long)x * ldg + y0;
+        const float* g2r = g2 + (long)x * ldg + y0;
+        int kbest = km[y];
+        float a1 = g1r[y] * invc, a2 = g2r[y] * inv_ni * temp;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                if (col0 + e < yc * ni) {
-                    float val = (k == kbest) ? a1 : 0.f;
-                    if (tm[e] == t) val += a2;
-                    v[e] = val;
-                    if (++k == ni && col0 + e + 1 < yc * ni) {
-                        k = 0; ++y;
-                        kbest = km[y]; a1 = g1r[y] * invc; a2 = g2r[y] * inv_ni * temp;
-                    }
+        for (int e = 0; e < VEC; ++e) {
+            if (col0 + e < ncols) {
+                float val = (k == kbest) ? a1 : 0.f;
+                if (tm[e] == t) val += a2;
+                v[e] = val;
+                if (++k == ni && col0 + e + 1 < ncols) {
+                    k = 0; ++y;
+                    kbest = km[y]; a1 = g1r[y] * invc; a2 = g2r[y] * inv_ni * temp;
                 }
             }
         }
-        store_vec<T>(P + row * ldp + ch * VEC, v);
     }
+    store_vec<T>(P + row * ldp + (long)ch * VEC, v);
 }
 
 // lse[r] = log sum_c exp(S[r, c]) (column r + diag_off left out when dcl); pos[r] = S[r, r + diag_off];
