@@ -225,11 +225,17 @@ __global__ __launch_bounds__(256) void filip_reduce_rows_kernel(const T* __restr
 }
 
 // P[(x,t),(y,k)] = temp * ( g1[x,y0+y] * w[x,t] / cnt[x] * [k == kmax] + g2[x,y0+y] / ni * [t == tmax[.., k]] )
-// One work-group per ROW SLICE: blockIdx.y = the row (x, t), blockIdx.x = a run of 256 chunks of that row; a thread owns one 16-byte
-// output chunk.  Everything that depends on the row only (the text, the token, its mask bit, temp / cnt) is computed once per
-// work-group from scalars; the chunk's first (image, token) comes from ONE 32-bit division.  (The first version flattened (row, chunk)
-// into a 64-bit index and paid two 64-bit divisions per 16 bytes written: 0.64 ms = 1.5 TB/s per 1 GB chunk at configs[3],
-// profiles/r03_d_kernel_stats_filip.txt.)  Rows of padding tokens and the padding columns are written as zeros.
+// One work-group per ROW SLICE: blockIdx.y = the row (x, t), blockIdx.x = a run of 256 chunks (2048 columns) of that row; a thread owns
+// one 16-byte output chunk.  What limits this kernel is the number of vector-memory INSTRUCTIONS, not bytes: the first versions issued
+// ~14 narrow global loads per 16 bytes written (eight 2-byte tmax entries, kmax, g1, g2 per image touched, mask, cnt) and ran at
+// 1.5 TB/s of output whatever the arithmetic around them cost (0.64 ms per 1 GB chunk at configs[3] with two 64-bit divisions per
+// chunk, 0.67 ms without them: profiles/r03_d / r03_h_kernel_stats_filip.txt).  Now: the row's per-image factors (kmax, g1 w / cnt,
+// g2 / ni) of the <= 2048 / ni + 2 images the slice spans are staged in LDS once per work-group, the eight tmax entries arrive as
+// one 16-byte load (4-byte aligned whenever ni is even), row-constant values are scalars.  Rows of padding tokens and the padding
+// columns are written as zeros.
+constexpr int ROUTE_MAX_IMG = 2050;                             // images a 2048-column slice can touch (ni >= 1)
+constexpr int ROUTE_LDS_BYTES = ROUTE_MAX_IMG * 10 + 12;
+
 template <typename T>
 __global__ __launch_bounds__(256) void filip_route_kernel(T* __restrict__ P, long ldp, const unsigned char* __restrict__ mask,
                                                           const float* __restrict__ log_temp, const float* __restrict__ g1,
@@ -237,39 +243,65 @@ __global__ __launch_bounds__(256) void filip_route_kernel(T* __restrict__ P, lon
                                                           const short* __restrict__ tmax, const float* __restrict__ cnt, int bx, int nt,
                                                           int yc, int ni, int y0, int ytotal, long row0) {
     constexpr int VEC = Elem<T>::VEC;
+    XC_LDS_DYNAMIC(lds);                                         // ROUTE_LDS_BYTES
+    float* const s_a1 = reinterpret_cast<float*>(lds);
+    float* const s_a2 = s_a1 + ROUTE_MAX_IMG;
+    short* const s_km = reinterpret_cast<short*>(s_a2 + ROUTE_MAX_IMG);
     const int nch = (int)(ldp / VEC);
     const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= nch) return;
     const long row = row0 + blockIdx.y;                          // (x, t); the launch covers rows [row0, row0 + gridDim.y)
     const int x = (int)(row / nt), t = (int)(row - (long)x * nt);
-    const bool w = mask[row] != 0;
+    const bool w = mask[row] != 0;                               // (uniform)
+    const int ncols = yc * ni;
+    const int slice0 = blockIdx.x * 256 * VEC;                   // first column of the work-group's slice
+    int y_first = 0;
+    if (w && slice0 < ncols) {
+        const float temp = expf(*log_temp);
+        const float invc = temp / fmaxf(cnt[x], 1e-6f), a2f = temp / (float)ni;
+        int last = slice0 + 256 * VEC - 1;
+        last = last < ncols - 1 ? last : ncols - 1;
+        y_first = slice0 / ni;
+        const int count = last / ni - y_first + 1;
+        const short* km = kmax + row * ytotal + y0 + y_first;
+        const float* g1r = g1 + (long)x * ldg + y0 + y_first;
+        const float* g2r = g2 + (long)x * ldg + y0 + y_first;
+        for (int i = threadIdx.x; i < count; i += 256) {
+            s_km[i] = km[i];
+            s_a1[i] = g1r[i] * invc;
+            s_a2[i] = g2r[i] * a2f;
+        }
+    }
+    sync();
+    if (ch >= nch) return;
     float v[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = 0.f;
     const int col0 = ch * VEC;
-    const int ncols = yc * ni;
     if (w && col0 < ncols) {                                     // (rows of padding tokens and the padding columns stay zero)
-        // the chunk's columns walk (y, k) from its first one.  Per image y: the arg-max token of this text row (kmax) and the two
-        // upstream gradients are loaded once, the per-column arg-max rows (tmax) are contiguous in the column
-        const float temp = expf(*log_temp);
-        const float inv_ni = 1.0f / (float)ni;
         int y = col0 / ni, k = col0 - y * ni;
-        const float invc = temp / fmaxf(cnt[x], 1e-6f);
-        const short* tm = tmax + ((long)x * ytotal + y0) * ni + col0;
-        const short* km = kmax + row * ytotal + y0;
-        const float* g1r = g1 + (long)x * ldg + y0;
-        const float* g2r = g2 + (long)x * ldg + y0;
-        int kbest = km[y];
-        float a1 = g1r[y] * invc, a2 = g2r[y] * inv_ni * temp;
+        const long tbase = ((long)x * ytotal + y0) * ni + col0;
+        short tmv[VEC];
+        if (VEC == 8 && (tbase & 1) == 0 && col0 + VEC <= ncols) {             // eight entries, 4-byte aligned: one 16-byte load
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // (dword-aligned 16-byte load)
+            const u32x4_a4 raw = *reinterpret_cast<const u32x4_a4*>(tmax + tbase);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tmv[2 * e] = (short)(raw[e] & 0xffffu); tmv[2 * e + 1] = (short)(raw[e] >> 16); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tmv[e] = (col0 + e < ncols) ? tmax[tbase + e] : (short)-1;
+        }
+        int yi = y - y_first;
+        int kbest = s_km[yi];
+        float a1 = s_a1[yi], a2 = s_a2[yi];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             if (col0 + e < ncols) {
                 float val = (k == kbest) ? a1 : 0.f;
-                if (tm[e] == t) val += a2;
+                if (tmv[e] == t) val += a2;
                 v[e] = val;
                 if (++k == ni && col0 + e + 1 < ncols) {
-                    k = 0; ++y;
-                    kbest = km[y]; a1 = g1r[y] * invc; a2 = g2r[y] * inv_ni * temp;
+                    k = 0; ++yi;
+                    kbest = s_km[yi]; a1 = s_a1[yi]; a2 = s_a2[yi];
                 }
             }
         }

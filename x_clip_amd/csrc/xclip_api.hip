@@ -869,9 +869,9 @@ int xclip_filip_route(void* P, int64_t ldp, const uint8_t* mask, const float* lo
         const int64_t rs = nrows - r0 < 65535 ? nrows - r0 : 65535;
         dim3 grid((unsigned)nchb, (unsigned)rs), block(256);
         if (dtype == XCLIP_BF16)
-            hipLaunchKernelGGL((filip_route_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal, (long)r0);
+            hipLaunchKernelGGL((filip_route_kernel<bf16_t>), grid, block, ROUTE_LDS_BYTES, (hipStream_t)stream, (bf16_t*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal, (long)r0);
         else
-            hipLaunchKernelGGL((filip_route_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal, (long)r0);
+            hipLaunchKernelGGL((filip_route_kernel<float>), grid, block, ROUTE_LDS_BYTES, (hipStream_t)stream, (float*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal, (long)r0);
     }
     return check_launch(__func__);
 }
