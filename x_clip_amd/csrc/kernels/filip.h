@@ -225,62 +225,62 @@ __global__ __launch_bounds__(256) void filip_reduce_rows_kernel(const T* __restr
 }
 
 // P[(x,t),(y,k)] = temp * ( g1[x,y0+y] * w[x,t] / cnt[x] * [k == kmax] + g2[x,y0+y] / ni * [t == tmax[.., k]] )
-// One work-group per ROW SLICE: blockIdx.y = the row (x, t), blockIdx.x = a run of 256 chunks (2048 columns) of that row; a thread owns
-// one 16-byte output chunk.  What limits this kernel is the number of vector-memory INSTRUCTIONS, not bytes: the first versions issued
-// ~14 narrow global loads per 16 bytes written (eight 2-byte tmax entries, kmax, g1, g2 per image touched, mask, cnt) and ran at
-// 1.5 TB/s of output whatever the arithmetic around them cost (0.64 ms per 1 GB chunk at configs[3] with two 64-bit divisions per
-// chunk, 0.67 ms without them: profiles/r03_d / r03_h_kernel_stats_filip.txt).  Now: the row's per-image factors (kmax, g1 w / cnt,
-// g2 / ni) of the <= 2048 / ni + 2 images the slice spans are staged in LDS once per work-group, the eight tmax entries arrive as
-// one 16-byte load (4-byte aligned whenever ni is even), row-constant values are scalars.  Rows of padding tokens and the padding
-// columns are written as zeros.
+// One work-group per (TEXT x, slice of 2048 columns); a thread owns one 16-byte chunk COLUMN and walks the text's nt rows.  What a
+// chunk needs besides the row's kmax entries does not depend on t: its eight tmax entries (one dword-aligned 16-byte load, kept in
+// registers), the images it spans and their factors g1 / cnt, g2 / ni (staged in LDS once per work-group); the kmax entries of a
+// batch of rows x the slice's images are staged in LDS per batch.  So the loop over the rows is loads-free: compare, select, one
+// 16-byte store per row.
+// History (configs[3], 1 GB chunk; profiles/r03_d / r03_h / r03_i_kernel_stats_filip.txt): a flat (row, chunk) index with two 64-bit
+// divisions and ~14 narrow global loads per 16 bytes written: 0.64 ms = 1.5 TB/s; divisions gone: 0.67 ms (not the arithmetic);
+// one work-group per (row, slice) with the per-image factors in LDS and one wide tmax load: 0.52 ms (276 k work-groups living ~4 us
+// each: launch- and latency-bound); this form: see DESIGN.md.  Rows of padding tokens and the padding columns are written as zeros.
 constexpr int ROUTE_MAX_IMG = 2050;                             // images a 2048-column slice can touch (ni >= 1)
-constexpr int ROUTE_LDS_BYTES = ROUTE_MAX_IMG * 10 + 12;
+constexpr int ROUTE_KM_ENTRIES = 16384;                         // staged kmax entries per batch of rows (32 KiB)
+constexpr int ROUTE_LDS_BYTES = ROUTE_MAX_IMG * 8 + ROUTE_KM_ENTRIES * 2 + 16;
 
 template <typename T>
 __global__ __launch_bounds__(256) void filip_route_kernel(T* __restrict__ P, long ldp, const unsigned char* __restrict__ mask,
                                                           const float* __restrict__ log_temp, const float* __restrict__ g1,
                                                           const float* __restrict__ g2, long ldg, const short* __restrict__ kmax,
                                                           const short* __restrict__ tmax, const float* __restrict__ cnt, int bx, int nt,
-                                                          int yc, int ni, int y0, int ytotal, long row0) {
+                                                          int yc, int ni, int y0, int ytotal) {
     constexpr int VEC = Elem<T>::VEC;
     XC_LDS_DYNAMIC(lds);                                         // ROUTE_LDS_BYTES
-    float* const s_a1 = reinterpret_cast<float*>(lds);
-    float* const s_a2 = s_a1 + ROUTE_MAX_IMG;
-    short* const s_km = reinterpret_cast<short*>(s_a2 + ROUTE_MAX_IMG);
+    float* const s_a1 = reinterpret_cast<float*>(lds);           // [count] temp g1[x, y] / cnt[x]
+    float* const s_a2 = s_a1 + ROUTE_MAX_IMG;                    // [count] temp g2[x, y] / ni
+    short* const s_km = reinterpret_cast<short*>(s_a2 + ROUTE_MAX_IMG);   // [rows of the batch][count]
     const int nch = (int)(ldp / VEC);
     const int ch = blockIdx.x * 256 + threadIdx.x;
-    const long row = row0 + blockIdx.y;                          // (x, t); the launch covers rows [row0, row0 + gridDim.y)
-    const int x = (int)(row / nt), t = (int)(row - (long)x * nt);
-    const bool w = mask[row] != 0;                               // (uniform)
+    const int x = blockIdx.y;
     const int ncols = yc * ni;
     const int slice0 = blockIdx.x * 256 * VEC;                   // first column of the work-group's slice
-    int y_first = 0;
-    if (w && slice0 < ncols) {
+    int last = slice0 + 256 * VEC - 1;
+    last = last < ncols - 1 ? last : ncols - 1;
+    const bool live_slice = slice0 < ncols;                      // (uniform) else: padding columns only
+    const int y_first = live_slice ? slice0 / ni : 0;
+    const int count = live_slice ? last / ni - y_first + 1 : 0;  // images the slice spans
+    if (live_slice) {
         const float temp = expf(*log_temp);
         const float invc = temp / fmaxf(cnt[x], 1e-6f), a2f = temp / (float)ni;
-        int last = slice0 + 256 * VEC - 1;
-        last = last < ncols - 1 ? last : ncols - 1;
-        y_first = slice0 / ni;
-        const int count = last / ni - y_first + 1;
-        const short* km = kmax + row * ytotal + y0 + y_first;
         const float* g1r = g1 + (long)x * ldg + y0 + y_first;
         const float* g2r = g2 + (long)x * ldg + y0 + y_first;
         for (int i = threadIdx.x; i < count; i += 256) {
-            s_km[i] = km[i];
             s_a1[i] = g1r[i] * invc;
             s_a2[i] = g2r[i] * a2f;
         }
     }
-    sync();
-    if (ch >= nch) return;
-    float v[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    // this thread's chunk: first (image, token), its eight tmax entries
     const int col0 = ch * VEC;
-    if (w && col0 < ncols) {                                     // (rows of padding tokens and the padding columns stay zero)
-        int y = col0 / ni, k = col0 - y * ni;
+    const bool live = ch < nch && col0 < ncols;
+    int yi0 = 0, k0 = 0;
+    short tmv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) tmv[e] = (short)-1;
+    if (live) {
+        const int y = col0 / ni;
+        yi0 = y - y_first;
+        k0 = col0 - y * ni;
         const long tbase = ((long)x * ytotal + y0) * ni + col0;
-        short tmv[VEC];
         if (VEC == 8 && (tbase & 1) == 0 && col0 + VEC <= ncols) {             // eight entries, 4-byte aligned: one 16-byte load
             typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // (dword-aligned 16-byte load)
             const u32x4_a4 raw = *reinterpret_cast<const u32x4_a4*>(tmax + tbase);
@@ -288,25 +288,46 @@ __global__ __launch_bounds__(256) void filip_route_kernel(T* __restrict__ P, lon
             for (int e = 0; e < 4; ++e) { tmv[2 * e] = (short)(raw[e] & 0xffffu); tmv[2 * e + 1] = (short)(raw[e] >> 16); }
         } else {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) tmv[e] = (col0 + e < ncols) ? tmax[tbase + e] : (short)-1;
+            for (int e = 0; e < VEC; ++e) if (col0 + e < ncols) tmv[e] = tmax[tbase + e];
         }
-        int yi = y - y_first;
-        int kbest = s_km[yi];
-        float a1 = s_a1[yi], a2 = s_a2[yi];
+    }
+    const int tb = count > 0 ? (ROUTE_KM_ENTRIES / count > 0 ? ROUTE_KM_ENTRIES / count : 1) : nt;      // rows per kmax batch
+    for (int t0 = 0; t0 < nt; t0 += tb) {
+        const int t1 = t0 + tb < nt ? t0 + tb : nt;
+        sync();                                                  // (the previous batch's entries are no longer read; s_a1 / s_a2 are in)
+        for (int i = threadIdx.x; i < (t1 - t0) * count; i += 256) {
+            const int r = i / count, c = i - r * count;
+            s_km[i] = kmax[((long)x * nt + t0 + r) * ytotal + y0 + y_first + c];
+        }
+        sync();
+        if (ch < nch) {
+            for (int t = t0; t < t1; ++t) {
+                const long row = (long)x * nt + t;
+                float v[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            if (col0 + e < ncols) {
-                float val = (k == kbest) ? a1 : 0.f;
-                if (tmv[e] == t) val += a2;
-                v[e] = val;
-                if (++k == ni && col0 + e + 1 < ncols) {
-                    k = 0; ++yi;
-                    kbest = s_km[yi]; a1 = s_a1[yi]; a2 = s_a2[yi];
+                for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+                if (live && mask[row] != 0) {                    // (rows of padding tokens and the padding columns stay zero)
+                    const short* kmr = s_km + (t - t0) * count;
+                    int yi = yi0, k = k0;
+                    int kbest = kmr[yi];
+                    float a1 = s_a1[yi], a2 = s_a2[yi];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if (col0 + e < ncols) {
+                            float val = (k == kbest) ? a1 : 0.f;
+                            if (tmv[e] == t) val += a2;
+                            v[e] = val;
+                            if (++k == ni && col0 + e + 1 < ncols) {
+                                k = 0; ++yi;
+                                kbest = kmr[yi]; a1 = s_a1[yi]; a2 = s_a2[yi];
+                            }
+                        }
+                    }
                 }
+                store_vec<T>(P + row * ldp + (long)ch * VEC, v);
             }
         }
     }
-    store_vec<T>(P + row * ldp + (long)ch * VEC, v);
 }
 
 // lse[r] = log sum_c exp(S[r, c]) (column r + diag_off left out when dcl); pos[r] = S[r, r + diag_off];

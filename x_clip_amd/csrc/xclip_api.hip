@@ -862,16 +862,15 @@ int xclip_filip_route(void* P, int64_t ldp, const uint8_t* mask, const float* lo
     XC_REQUIRE(bx > 0 && nt > 0 && yc > 0 && ni > 0, "bad shape");
     XC_REQUIRE(ldp % vec_of(dtype) == 0 && ldp >= yc * ni && aligned16(P), "ldp must cover a chunk row, 16-byte chunk aligned");
     XC_REQUIRE(P && mask && log_temp && g1 && g2 && kmax && tmax && cnt, "null pointer");
-    XC_REQUIRE(bx * nt < (1LL << 31) && ldp / vec_of(dtype) < (1LL << 31), "chunk too large for the launch grid");
-    // blockIdx.y = the row (x, t); the y dimension of a grid holds 65535 work-groups, so the rows go out in slabs
-    const int64_t nrows = bx * nt, nchb = (ldp / vec_of(dtype) + 255) / 256;
-    for (int64_t r0 = 0; r0 < nrows; r0 += 65535) {
-        const int64_t rs = nrows - r0 < 65535 ? nrows - r0 : 65535;
-        dim3 grid((unsigned)nchb, (unsigned)rs), block(256);
-        if (dtype == XCLIP_BF16)
-            hipLaunchKernelGGL((filip_route_kernel<bf16_t>), grid, block, ROUTE_LDS_BYTES, (hipStream_t)stream, (bf16_t*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal, (long)r0);
-        else
-            hipLaunchKernelGGL((filip_route_kernel<float>), grid, block, ROUTE_LDS_BYTES, (hipStream_t)stream, (float*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal, (long)r0);
+    XC_REQUIRE(bx * nt < (1LL << 31) && ldp / vec_of(dtype) < (1LL << 31) && bx <= 65535, "chunk too large for the launch grid");
+    // one work-group per (text x, slice of 256 chunks): blockIdx.y = x
+    dim3 grid((unsigned)((ldp / vec_of(dtype) + 255) / 256), (unsigned)bx), block(256);
+    if (dtype == XCLIP_BF16) {
+        XC_ALLOW_LDS((filip_route_kernel<bf16_t>), ROUTE_LDS_BYTES);
+        hipLaunchKernelGGL((filip_route_kernel<bf16_t>), grid, block, ROUTE_LDS_BYTES, (hipStream_t)stream, (bf16_t*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal);
+    } else {
+        XC_ALLOW_LDS((filip_route_kernel<float>), ROUTE_LDS_BYTES);
+        hipLaunchKernelGGL((filip_route_kernel<float>), grid, block, ROUTE_LDS_BYTES, (hipStream_t)stream, (float*)P, (long)ldp, mask, log_temp, g1, g2, (long)ldg, kmax, tmax, cnt, (int)bx, (int)nt, (int)yc, (int)ni, (int)y0, (int)ytotal);
     }
     return check_launch(__func__);
 }
