@@ -15,6 +15,15 @@ for p in (HERE, ROOT):
         sys.path.insert(0, p)
 
 
+def free_port() -> int:
+    """a TCP port nobody listens on right now (asked from the kernel): the parent test picks it and hands it to its workers -- ports
+    derived from the process id collided between parallel pytest workers once the suite grew"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _maybe_poison():
     """XCLIP_TEST_POISON=1: NaN-poison every torch.empty in the worker, see clip_cases.poisoned_empty"""
     if os.environ.get("XCLIP_TEST_POISON") == "1":

@@ -23,7 +23,7 @@ def test_two_ranks_match_reference_semantics(name, sizes, tmp_path):
         rec = json.load(f)
     if sum(sizes) != sum(rec["sizes"]):
         pytest.skip("fixture batch differs")
-    port = 29500 + (os.getpid() % 2000)
+    port = D.free_port()
     mp.spawn(D.worker_fixture, args=(2, port, name, sizes, str(tmp_path)), nprocs=2, join=True)
     D.check_fixture(str(tmp_path), name)
 
@@ -35,7 +35,7 @@ def test_two_ranks_even_batches_gradsync_vs_oracle(tmp_path):
     from oracle import clip_oracle as O
     cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True, extra_latent_projection=True)
     batch, world = 8, 2
-    port = 31500 + (os.getpid() % 2000)
+    port = D.free_port()
     mp.spawn(D.worker_even, args=(world, port, dataclasses.asdict(cfg), batch, str(tmp_path)), nprocs=world, join=True)
     D.check_even(str(tmp_path), cfg, batch, world)
 
@@ -47,7 +47,7 @@ def test_two_ranks_filip_vs_oracle(tmp_path, dcl):
     from oracle import clip_oracle as O
     cfg = dataclasses.replace(O.CFG1, use_all_token_embeds=True, decoupled_contrastive_learning=dcl)
     batch, world = 4, 2
-    port = 33500 + (os.getpid() % 2000) + (1 if dcl else 0)
+    port = D.free_port()
     mp.spawn(D.worker_filip, args=(world, port, dataclasses.asdict(cfg), batch, str(tmp_path)), nprocs=world, join=True)
     D.check_filip(str(tmp_path), cfg, batch, world)
 
@@ -73,7 +73,7 @@ def test_many_ranks_ragged_vs_oracle(tmp_path, name):
     sizes, over, n_t, n_i, gs = RAGGED[name]
     cfg = dataclasses.replace(O.CFG1, **over)
     world = len(sizes)
-    port = 35500 + (os.getpid() % 2000) + list(RAGGED).index(name)
+    port = D.free_port()
     mp.spawn(D.worker_ragged, args=(world, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", n_t, n_i, gs), nprocs=world, join=True)
     D.check_ragged(str(tmp_path), cfg, sizes, n_t, n_i, gs)
 
@@ -85,7 +85,7 @@ def test_gradsync_with_a_frozen_tower(tmp_path):
     from oracle import clip_oracle as O
     cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True)
     sizes = [2, 3, 1]
-    port = 38500 + (os.getpid() % 2000)
+    port = D.free_port()
     mp.spawn(D.worker_ragged, args=(3, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", 0, 0, True, "float32", True), nprocs=3, join=True)
     D.check_ragged(str(tmp_path), cfg, sizes, gradsync=True, freeze_text=True)
 
@@ -97,7 +97,7 @@ def test_two_ranks_filip_fused_forward_bf16(tmp_path):
     import torch
     cfg = dataclasses.replace(O.CFG1, use_all_token_embeds=True, visual_image_size=256, text_seq_len=70, text_enc_depth=1, visual_enc_depth=1)
     sizes = [3, 2]
-    port = 39500 + (os.getpid() % 2000)
+    port = D.free_port()
     mp.spawn(D.worker_ragged, args=(2, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", 0, 0, False, "bfloat16"), nprocs=2, join=True)
     # (bf16 FILIP bars of the single-process toy-model test: arg-max ties under bf16 scores)
     worst = D.check_ragged(str(tmp_path), cfg, sizes, dtype=torch.bfloat16, rel_bar=0.25, loss_bar=1.4e-3)

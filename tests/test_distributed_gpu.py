@@ -28,7 +28,7 @@ def poisoned_workers(monkeypatch):
 
 @pytest.mark.parametrize("name,sizes", [("dist2_infonce", [5, 3]), ("dist2_dcl", [5, 3]), ("dist2_simreg_extra", [5, 3])])
 def test_two_ranks_on_gpu_match_reference_semantics(name, sizes, tmp_path):
-    port = 29700 + (os.getpid() % 2000)
+    port = D.free_port()
     mp.spawn(D.worker_fixture, args=(2, port, name, sizes, str(tmp_path), "cuda"), nprocs=2, join=True)
     D.check_fixture(str(tmp_path), name)
 
@@ -36,7 +36,7 @@ def test_two_ranks_on_gpu_match_reference_semantics(name, sizes, tmp_path):
 def test_two_ranks_on_gpu_even_batches_gradsync_vs_oracle(tmp_path):
     from oracle import clip_oracle as O
     cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True, extra_latent_projection=True)
-    port = 31700 + (os.getpid() % 2000)
+    port = D.free_port()
     mp.spawn(D.worker_even, args=(2, port, dataclasses.asdict(cfg), 8, str(tmp_path), "cuda"), nprocs=2, join=True)
     D.check_even(str(tmp_path), cfg, 8, 2)
 
@@ -48,7 +48,7 @@ def test_two_ranks_on_gpu_mid_bf16_overlap_streams(tmp_path):
     cfg = O.ClipConfig(dim_text=512, dim_image=512, dim_latent=512, num_text_tokens=2000, text_enc_depth=2, text_seq_len=70,
                        text_heads=8, visual_enc_depth=2, visual_image_size=128, visual_patch_size=32, visual_heads=8,
                        decoupled_contrastive_learning=True)
-    port = 32700 + (os.getpid() % 2000)
+    port = D.free_port()
     mp.spawn(D.worker_even, args=(2, port, dataclasses.asdict(cfg), 16, str(tmp_path), "cuda", "bfloat16", 8), nprocs=2, join=True)
     worst = D.check_even(str(tmp_path), cfg, 16, 2, dtype=torch.bfloat16, patch_keep=8, rel_bar=0.08, loss_bar=3e-4, cos_bar=0.999)      # the single-process bf16 bars (clip_cases.case_vs_oracle)
     print("worst gradient relative error (2 ranks, bf16):", worst)
@@ -58,7 +58,7 @@ def test_two_ranks_on_gpu_mid_bf16_overlap_streams(tmp_path):
 def test_two_ranks_on_gpu_filip_vs_oracle(tmp_path, dcl):
     from oracle import clip_oracle as O
     cfg = dataclasses.replace(O.CFG1, use_all_token_embeds=True, decoupled_contrastive_learning=dcl)
-    port = 33700 + (os.getpid() % 2000) + (1 if dcl else 0)
+    port = D.free_port()
     mp.spawn(D.worker_filip, args=(2, port, dataclasses.asdict(cfg), 4, str(tmp_path), "cuda"), nprocs=2, join=True)
     D.check_filip(str(tmp_path), cfg, 4, 2)
 
@@ -72,7 +72,7 @@ def test_many_ranks_on_gpu_ragged_vs_oracle(tmp_path, name):
     sizes, over, n_t, n_i, gs = RAGGED[name]
     cfg = dataclasses.replace(O.CFG1, **over)
     world = len(sizes)
-    port = 36700 + (os.getpid() % 2000) + list(RAGGED).index(name)
+    port = D.free_port()
     mp.spawn(D.worker_ragged, args=(world, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cuda", n_t, n_i, gs), nprocs=world, join=True)
     D.check_ragged(str(tmp_path), cfg, sizes, n_t, n_i, gs)
 
@@ -83,7 +83,7 @@ def test_four_ranks_on_gpu_mid_bf16_gradsync(tmp_path):
     cfg = O.ClipConfig(dim_text=512, dim_image=512, dim_latent=512, num_text_tokens=2000, text_enc_depth=2, text_seq_len=70,
                        text_heads=8, visual_enc_depth=2, visual_image_size=128, visual_patch_size=32, visual_heads=8,
                        decoupled_contrastive_learning=True)
-    port = 37700 + (os.getpid() % 2000)
+    port = D.free_port()
     mp.spawn(D.worker_even, args=(4, port, dataclasses.asdict(cfg), 8, str(tmp_path), "cuda", "bfloat16", 8), nprocs=4, join=True)
     # (cosine 0.995: the patch-embedding bias gradient is a column sum of cancelling terms; here it is additionally summed over four
     #  ranks in bf16 by the all-reduce -- the 2-rank test above holds 0.999)
@@ -94,7 +94,7 @@ def test_four_ranks_on_gpu_mid_bf16_gradsync(tmp_path):
 def test_rccl_two_ranks_one_device_probe(tmp_path):
     """RCCL (`nccl` backend) with both ranks on cuda:0: recorded, not required -- the single-GPU box cannot give each rank its own
     device; the driver's multi-GPU scaling run is where RCCL itself executes"""
-    port = 34700 + (os.getpid() % 2000)
+    port = D.free_port()
     try:
         mp.spawn(D.worker_nccl_probe, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     except Exception as e:                                   # noqa: BLE001

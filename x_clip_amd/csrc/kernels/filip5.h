@@ -79,6 +79,14 @@ struct Filip5Epilogue {
         uint32_t* const cdst = f.colpart + ((long)rblk * F5_SLOTS) * f.N + gc0 + lane;
 
         unsigned char* const wr = scratch + r31 * 128 + 8 * h;          // + chunk position * 16   (pack_lines_t's layout)
+        // the four row groups' token-mask bytes of this lane's rows, requested before the row direction's arithmetic (one dependent
+        // global round trip per group sat in front of every column scan otherwise)
+        bool rowlive[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = gr0 + i * 32 + r31;
+            rowlive[i] = g < f.M && f.mask[g] != 0;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int grow = gr0 + i * 32 + r31;
@@ -139,7 +147,7 @@ struct Filip5Epilogue {
                     const u32x2 v = {f2bf_pk(a[0], a[1]), f2bf_pk(a[2], a[3])};
                     *reinterpret_cast<u32x2*>(wr + (((4 * j + q) ^ (r31 & 7)) << 4)) = v;
                 }
-            const uint32_t live = wave_ballot32(grow < f.M && f.mask[grow] != 0);   // bit r: row r of the group is a real token (uniform)
+            const uint32_t live = wave_ballot32(rowlive[i]);            // bit r: row r of the group is a real token (uniform)
             lds_fence();
             const unsigned char* const col = scratch + (lane & 7) * 2;  // + r * 128 + ((chunk ^ (r & 7)) << 4): column `lane`, chunk lane >> 3
             const int chunk = lane >> 3;
