@@ -137,7 +137,7 @@ def worker_filip(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu"):
 
 
 def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_text=0, n_aug_image=0, gradsync=False, dtype_name="float32",
-                  freeze_text=False):
+                  freeze_text=False, image_slices=1):
     """any world size, any per-rank batch sizes, any head: rank r holds rows sum(sizes[:r]) ... of the global batch of every view"""
     dev = setup(rank, world, port, kind)
     from x_clip_amd import CLIP
@@ -154,12 +154,13 @@ def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_t
     model.load_state_dict(sd)
     model = model.to(dtype).to(dev).train()
     sync = GradSync(model) if gradsync else None
+    model.image_micro_batches = image_slices              # > 1: the vision tower's parameters see that many backward passes per step
     kw = {}
     if n_aug_text:
         kw["aug_text"] = [a[sl].to(dev) for a in aug_t]
     if n_aug_image:
         kw["aug_image"] = [a[sl].to(dtype).to(dev) for a in aug_i]
-    for step in range(2 if gradsync else 1):                  # GradSync: a second step reuses the persistent flat buffers
+    for step in range(3 if gradsync else 1):                  # GradSync: later steps reuse the persistent flat buffers and launch from hooks
         model.zero_grad(set_to_none=True)
         loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, freeze_text_encoder=freeze_text, **kw)
         loss.backward()
@@ -169,7 +170,9 @@ def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_t
                 assert all(p.grad is None for p in model.text_transformer.parameters())
                 assert sync.stats["unused"] >= sum(1 for _ in model.text_transformer.parameters())
             # every weight-gradient GEMM of both towers and the latent projections wrote straight into its bucket slice
-            n_gemm = 4 * ((0 if freeze_text else cfg.text_enc_depth) + cfg.visual_enc_depth) + 2 * (2 if cfg.extra_latent_projection else 1)
+            n_gemm = 4 * ((0 if freeze_text else cfg.text_enc_depth) + (cfg.visual_enc_depth if image_slices == 1 else 0)) + 2 * (2 if cfg.extra_latent_projection else 1)
+            if step > 0 and not freeze_text:
+                assert all(e is not None for e in sync._expected)      # buckets complete on a learned firing count from step 2 on
             assert sync.stats["in_place"] >= n_gemm, (sync.stats, n_gemm)
             for p in model.parameters():
                 if p.grad is not None:

@@ -102,3 +102,15 @@ def test_two_ranks_filip_fused_forward_bf16(tmp_path):
     # (bf16 FILIP bars of the single-process toy-model test: arg-max ties under bf16 scores)
     worst = D.check_ragged(str(tmp_path), cfg, sizes, dtype=torch.bfloat16, rel_bar=0.25, loss_bar=1.4e-3)
     print("worst gradient relative error (2 ranks, fused FILIP, bf16):", worst)
+
+
+def test_gradsync_tower_walked_twice_per_step(tmp_path):
+    """image_micro_batches = 2 under GradSync (2 ragged ranks, 3 steps): every vision-tower parameter's hook fires twice per step, so
+    "all parameters fired once" must not launch the bucket -- the first step reduces in finish() and learns the count, the later steps
+    launch from the hook that completes it; gradients = (1 / W) x the oracle's"""
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True)
+    sizes = [4, 2]
+    port = D.free_port()
+    mp.spawn(D.worker_ragged, args=(2, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", 0, 0, True, "float32", False, 2), nprocs=2, join=True)
+    D.check_ragged(str(tmp_path), cfg, sizes, gradsync=True)

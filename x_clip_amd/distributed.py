@@ -150,15 +150,24 @@ class GradSync:
     accumulated the bucket is all-reduced asynchronously on the process group's stream (RCCL over xGMI on MI355X) while autograd keeps
     running the remaining backward; `finish()` waits and scales by 1/world.  Equivalent to DistributedDataParallel's mean reduction.
 
+    When is a bucket complete?  A parameter's post-accumulate hook fires once per backward pass THROUGH it, and a tower can be walked more
+    than once per step (the MLM side loss encodes the masked text with the same tower, SimSiam runs the vision tower four more times,
+    `image_micro_batches` slices it) -- so "every parameter has fired once" is not "the bucket is final".  The first step therefore
+    reduces every bucket in `finish()` and records how many firings each bucket saw; from the second step on a bucket is launched from
+    the hook that brings its count to that number (`overlap=False` keeps every launch in `finish()`: for graphs that change from step to
+    step).  A firing that arrives after its bucket was launched means the graph grew since the last step: that is an error, not a
+    silently wrong gradient.
+
     Stream ordering is explicit, not inherited: the towers' backward nodes run on different HIP streams (the vision tower on its side
     stream, weight gradients on theirs), so every post-accumulate hook records an event on the stream its gradient was accumulated on and
     the launching stream waits for all events of the bucket before the collective is enqueued (gloo would hide a missing edge here --
     its GPU collectives are host-staged and synchronous -- NCCL / RCCL would not).  Buckets always have the same byte size on every rank
     (a parameter without a gradient contributes zeros), so ranks cannot disagree about a collective's size."""
 
-    def __init__(self, module: torch.nn.Module, group=None):
+    def __init__(self, module: torch.nn.Module, group=None, overlap: bool = True):
         self.group = group
         self.world = dist.get_world_size(group)
+        self.overlap = overlap
         self.buckets = []
         seen = set()                                         # a tower shared with a side-loss wrapper (mlm.transformer, visual_ssl.net)
                                                              # is listed under both children: reduce every parameter once
@@ -196,6 +205,8 @@ class GradSync:
                 flats.append(torch.zeros(off, dtype=dtype, device=device))
             self.flats.append(flats)
         self._count = [0] * len(self.buckets)
+        self._seen = [0] * len(self.buckets)
+        self._expected = [None] * len(self.buckets)          # hook firings per step that complete a bucket (learned in the first step)
         self._events = [[] for _ in self.buckets]
         self._claimed = set()
         self._step_open = False
@@ -229,8 +240,12 @@ class GradSync:
         def hook(param):
             if param.is_cuda:                                # the stream this gradient was accumulated on (see the class docstring)
                 self._events[bi].append(torch.cuda.current_stream(param.device).record_event())
+            if self._count[bi] < 0:
+                raise RuntimeError("x_clip_amd GradSync: a gradient arrived for a bucket that was already all-reduced in this step -- the "
+                                   "autograd graph walks this tower more often than in the previous step.  Use GradSync(model, overlap=False) "
+                                   "for graphs that change between steps.")
             self._count[bi] += 1
-            if self._count[bi] == len(self.buckets[bi]):
+            if self.overlap and self._expected[bi] is not None and self._count[bi] == self._expected[bi]:
                 self._launch(bi)
         return hook
 
@@ -257,6 +272,7 @@ class GradSync:
                     self.stats["in_place"] += 1
         for flat in self.flats[bi]:
             self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
+        self._seen[bi] = self._count[bi]
         self._count[bi] = -1                                 # launched
 
     def finish(self):
@@ -264,6 +280,8 @@ class GradSync:
         for bi in range(len(self.buckets)):
             if self._count[bi] > 0:
                 self._launch(bi)
+            if self._count[bi] < 0:
+                self._expected[bi] = self._seen[bi]          # what completed this bucket in this step completes it in the next
             self._count[bi] = 0
         for work, flat in self._works:
             if work is not None:
