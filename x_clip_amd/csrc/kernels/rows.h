@@ -106,6 +106,60 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
     }
 }
 
+// The same LayerNorm forward (no GEGLU) with RPW rows per wave and every load of a row pair -- x, the residual, the gain -- requested
+// before the first reduction: with one 1 KiB row per wave the D = 512 kernels keep too little in flight (4.0 TB/s at 263 k rows where
+// the 8 KiB-row kernels reach 5.2) and every row pays the load -> reduce -> load gain / residual -> store chain in full.
+template <typename T, int MAXC, int RPW>
+__global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ g,
+                                                          const T* __restrict__ res, T* __restrict__ y,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          int rows, int D, float eps, long ldy, int y_grp) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long row0 = ((long)blockIdx.x * 4 + wave_id()) * RPW;
+    if (row0 >= rows) return;                      // whole wave leaves together; no barriers below
+    const int nch = D / VEC;
+    float v[RPW][MAXC][VEC], rv[RPW][MAXC][VEC], gv[MAXC][VEC];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const long row = row0 + r < rows ? row0 + r : rows - 1;                  // (a clamped duplicate of the last row: never stored)
+        load_row<T, MAXC, false>(x + row * ldx, D, lane, v[r]);
+        if (res != nullptr) load_row<T, MAXC, false>(res + row * (long)D, D, lane, rv[r]);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (lane + 64 * i < nch) load_vec<T>(g + (lane + 64 * i) * VEC, gv[i]);
+    float mean[RPW], var[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) row_stats<T, MAXC>(v[r], D, lane, mean[r], var[r]);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const long row = row0 + r;
+        if (row < rows) {
+            const float rstd = fast_rsqrt(var[r] + eps);
+            const long yrow = y_grp > 0 ? row + row / y_grp + 1 : row;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
+                    float o[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[j] = (v[r][i][j] - mean[r]) * rstd * gv[i][j];
+                    if (res != nullptr) {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) o[j] += rv[r][i][j];
+                    }
+                    store_vec<T>(y + yrow * ldy + c * VEC, o);
+                }
+            }
+            if (lane == 0) {
+                mean_out[row] = mean[r];
+                rstd_out[row] = rstd;
+            }
+        }
+    }
+}
+
 // ---- two chained LayerNorms in one pass over the rows ----------------------------------------------------------------------------
 // The residual block boundary of the Transformer (x_clip.py:245,288-289 then :126): x1 = LN(p) g1 + res (the attention block's
 // to_out LayerNorm + skip) is immediately followed by h2 = LN(x1) g2 (the feed-forward PreNorm).  Both are row-wise over the same

@@ -55,6 +55,18 @@ template <typename T, int MAXC>
 void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, int64_t ldy, int y_grp, float* mean,
                    float* rstd, int rows, int dim, float eps, int geglu, hipStream_t st) {
     dim3 grid((rows + 3) / 4), block(256);
+    if constexpr (MAXC <= 2) {
+        // narrow rows (D <= 1024 in bf16): several rows per wave, all loads ahead of the reductions (rows.h ln_fwd_rows_kernel).
+        // XCLIP_LN_FWD (measurement build): 0 = the one-row kernel, 1 / 2 / 4 = rows per wave
+        static const int rpw = measure_env("XCLIP_LN_FWD", 2);
+        if (!geglu && rpw > 0) {
+#define XC_LNR(R) { dim3 g2((rows + 4 * R - 1) / (4 * R)); hipLaunchKernelGGL((ln_fwd_rows_kernel<T, MAXC, R>), g2, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res, (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp); return; }
+            if (rpw == 1) XC_LNR(1)
+            if (rpw == 4) XC_LNR(4)
+            XC_LNR(2)
+#undef XC_LNR
+        }
+    }
     if (geglu)
         hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, true>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res,
                            (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
