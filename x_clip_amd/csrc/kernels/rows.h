@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
     }
 }
 
-// The same LayerNorm forward (no GEGLU) with RPW rows per wave and every load of a row pair -- x, the residual, the gain -- requested
+#ifdef XCLIP_MEASURE
+// (measurement build only: measured, not faster -- see launch_ln_fwd)  The same LayerNorm forward (no GEGLU) with RPW rows per wave and every load of a row pair -- x, the residual, the gain -- requested
 // before the first reduction: with one 1 KiB row per wave the D = 512 kernels keep too little in flight (4.0 TB/s at 263 k rows where
 // the 8 KiB-row kernels reach 5.2) and every row pays the load -> reduce -> load gain / residual -> store chain in full.
 template <typename T, int MAXC, int RPW>
@@ -159,6 +160,8 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const T* __restrict__ 
         }
     }
 }
+
+#endif
 
 // ---- two chained LayerNorms in one pass over the rows ----------------------------------------------------------------------------
 // The residual block boundary of the Transformer (x_clip.py:245,288-289 then :126): x1 = LN(p) g1 + res (the attention block's

@@ -55,10 +55,13 @@ template <typename T, int MAXC>
 void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, int64_t ldy, int y_grp, float* mean,
                    float* rstd, int rows, int dim, float eps, int geglu, hipStream_t st) {
     dim3 grid((rows + 3) / 4), block(256);
+#ifdef XCLIP_MEASURE
     if constexpr (MAXC <= 2) {
-        // narrow rows (D <= 1024 in bf16): several rows per wave, all loads ahead of the reductions (rows.h ln_fwd_rows_kernel).
-        // XCLIP_LN_FWD (measurement build): 0 = the one-row kernel, 1 / 2 / 4 = rows per wave
-        static const int rpw = measure_env("XCLIP_LN_FWD", 2);
+        // measured and not kept (profiles/r03_k_ln_fwd_rows_per_wave.log): several rows per wave with all loads ahead of the reductions
+        // (rows.h ln_fwd_rows_kernel; XCLIP_LN_FWD = 1 / 2 / 4 rows per wave).  263 k x 512: 108.7 us with the one-row kernel, 105 / 99 /
+        // 117 us; with the residual 137 against 141 / 147 / 168 us; 1.18 M x 1024: 796 (6.1 TB/s) against 904 / 1000 / 1514 us.  The
+        // one-row kernel is at the copy ceiling when it runs alone; its lower in-step figure is not a property of the kernel.
+        static const int rpw = measure_env("XCLIP_LN_FWD", 0);
         if (!geglu && rpw > 0) {
 #define XC_LNR(R) { dim3 g2((rows + 4 * R - 1) / (4 * R)); hipLaunchKernelGGL((ln_fwd_rows_kernel<T, MAXC, R>), g2, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res, (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp); return; }
             if (rpw == 1) XC_LNR(1)
@@ -67,6 +70,7 @@ void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, v
 #undef XC_LNR
         }
     }
+#endif
     if (geglu)
         hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, true>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res,
                            (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
