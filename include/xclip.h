@@ -20,10 +20,14 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 14
+#define XCLIP_ABI_VERSION 15
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
+/* which toolchain built this library, e.g. "hipcc HIP version: 7.2.26015-fc0010cf6a".  The hand-placed wait states around the asm
+ * buffer stores (csrc/hw/xc_device.h buf_st16) were validated with ROCm 7.2's code generation: after a toolchain change re-run the GPU
+ * gate tests (tests/test_kernels_gpu.py::test_gemm_full_size_every_element_and_repeatable, test_gemm_layouts, test_gemm_residual_epilogue). */
+const char* xclip_build_info(void);
 
 /* ---- LayerNorm family (reference LayerNorm x_clip.py:112-121; GEGLU x_clip.py:180-183) -----------------------
  * y[r,:] = (v - mean) * rstd * g (+ res[r,:]),  v = x[r,:dim]               (geglu = 0, ldx >= dim)

@@ -41,10 +41,19 @@ def build(force: bool = False, verbose: bool = False, measure: bool = False) -> 
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in _sources()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # the toolchain goes into the library (xclip_build_info): the wait states around the asm buffer stores were validated against ROCm 7.2's
+    # code generation -- another compiler means: run the GPU gate tests before trusting the GEMM epilogues
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True, check=True).stdout.splitlines()[0].strip()
+    except Exception:                                           # noqa: BLE001
+        ver = "unknown"
+    if "7.2." not in ver:
+        print(f"x_clip_amd.build: WARNING: built with '{ver}', validated with HIP 7.2 -- run tests/test_kernels_gpu.py (the full-size GEMM gate tests) on an MI355X", file=sys.stderr)
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-ffp-contract=fast",
               "-Wno-unused-value", "-I", os.path.join(CSRC, "hw"), "-I", CSRC]
     if verbose:
         common.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    common.append('-DXCLIP_BUILD_TOOLCHAIN="hipcc ' + ver.replace('"', "'") + '"')
     if measure:
         common.append("-DXCLIP_MEASURE")
     objdir = os.path.join(HERE, "_obj_measure" if measure else "_obj")

@@ -277,6 +277,10 @@ extern "C" {
 
 int xclip_abi_version(void) { return XCLIP_ABI_VERSION; }
 const char* xclip_last_error(void) { return g_err; }
+#ifndef XCLIP_BUILD_TOOLCHAIN
+#define XCLIP_BUILD_TOOLCHAIN "unknown toolchain"
+#endif
+const char* xclip_build_info(void) { return XCLIP_BUILD_TOOLCHAIN; }
 
 int xclip_layernorm_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, int64_t ldy, int64_t y_grp,
                         float* mean, float* rstd, int64_t rows, int64_t dim, float eps, int geglu, int dtype, void* stream) {
