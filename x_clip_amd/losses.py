@@ -287,6 +287,7 @@ def sim_reg_loss(text_latents: Tensor, image_latents: Tensor, text_latents_extra
 # fine-grained (FILIP) head: use_all_token_embeds = True  (x_clip.py:797-811 + the shared InfoNCE / DCL tail :821-868)
 # =========================================================================================================================
 _FILIP_CHUNK_BYTES = 1 << 30          # workspace bound for one chunk of token similarities / routing matrix
+_FILIP_BWD_FACTOR = 4                 # ... times this for the routing matrix of the backward when the forward is fused
 FILIP_FUSED = True                    # forward reductions inside the token-similarity GEMM where the shape allows (ops.filip_fused_ok)
 
 
@@ -302,8 +303,14 @@ class _FilipBlock:
         v = ops.vec(X.dtype)
         esize = X.element_size()
         per_img = self.bx * self.nt * self.ni * esize
-        yc = max(1, min(self.by, _FILIP_CHUNK_BYTES // max(per_img, 1)))
-        yc = max(1, min(yc, (256 * v * 8) // self.ni, 2048))   # rows the row-coalesced reduction keeps in registers (filip.h: FILIP_MAXCH)
+        self.fused = FILIP_FUSED and ops.filip_fused_ok(self.nt, self.ni, self.d, X.dtype)
+        if self.fused:
+            # the forward never sees a chunk (filip5.h); the backward's routing matrix P may then be _FILIP_BWD_FACTOR times larger:
+            # fewer, longer GEMMs and routing launches (configs[3] at b = 512: one 4 GB chunk instead of four)
+            yc = max(1, min(self.by, _FILIP_BWD_FACTOR * _FILIP_CHUNK_BYTES // max(per_img, 1)))
+        else:
+            yc = max(1, min(self.by, _FILIP_CHUNK_BYTES // max(per_img, 1)))
+            yc = max(1, min(yc, (256 * v * 8) // self.ni, 2048))   # rows the row-coalesced reduction keeps in registers (filip.h: FILIP_MAXCH)
         if yc < self.by:
             # the chunk width yc * ni is the contraction length of the backward GEMM dX = P Y: a multiple of the 64-deep K step keeps
             # it on the MFMA / LDS-DMA kernel (136 images x 98 tokens fell back to the register-staged 128^2 kernel: 1.47 ms per call)
@@ -340,7 +347,7 @@ class _FilipBlock:
         return Yp, cols
 
     def forward(self):
-        if FILIP_FUSED and ops.filip_fused_ok(self.nt, self.ni, self.d, self.X.dtype):
+        if self.fused:
             # the reductions run in the epilogue of the token-similarity GEMM (filip5.h): nothing of size bx * by * nt * ni exists, only
             # 4-byte partials per (token row, 64-column block) / (token column, 128-row block); images in chunks that bound them
             per_img = max(1, ops.filip_fused_workspace_bytes(self.bx, self.nt, 1, self.ni))
