@@ -287,7 +287,9 @@ def sim_reg_loss(text_latents: Tensor, image_latents: Tensor, text_latents_extra
 # fine-grained (FILIP) head: use_all_token_embeds = True  (x_clip.py:797-811 + the shared InfoNCE / DCL tail :821-868)
 # =========================================================================================================================
 _FILIP_CHUNK_BYTES = 1 << 30          # workspace bound for one chunk of token similarities / routing matrix
-_FILIP_BWD_FACTOR = 4                 # ... times this for the routing matrix of the backward when the forward is fused
+_FILIP_BWD_FACTOR = 1                 # ... times this for the routing matrix of the backward when the forward is fused.  Measured at
+                                      # configs[3], b = 512: 4 (one 4 GB chunk) 31.6 ms per step, 1 (four 1 GB chunks) 30.9 -- a 1 GB chunk is still
+                                      # partly in the 256 MB Infinity Cache when the two GEMMs read it (profiles/r03_m_*_bwd_one_chunk.*)
 FILIP_FUSED = True                    # forward reductions inside the token-similarity GEMM where the shape allows (ops.filip_fused_ok)
 
 
@@ -305,8 +307,7 @@ class _FilipBlock:
         per_img = self.bx * self.nt * self.ni * esize
         self.fused = FILIP_FUSED and ops.filip_fused_ok(self.nt, self.ni, self.d, X.dtype)
         if self.fused:
-            # the forward never sees a chunk (filip5.h); the backward's routing matrix P may then be _FILIP_BWD_FACTOR times larger:
-            # fewer, longer GEMMs and routing launches (configs[3] at b = 512: one 4 GB chunk instead of four)
+            # the forward never sees a chunk (filip5.h): the backward's routing matrix P is free of the reduction kernel's register cap
             yc = max(1, min(self.by, _FILIP_BWD_FACTOR * _FILIP_CHUNK_BYTES // max(per_img, 1)))
         else:
             yc = max(1, min(self.by, _FILIP_CHUNK_BYTES // max(per_img, 1)))
