@@ -154,6 +154,8 @@ def main():
     from x_clip_amd import CLIP, functional, losses, ops
     if os.environ.get("XCLIP_FILIP_FUSED") == "0":           # own A/B: the chunked FILIP forward (materialised similarities + reduction passes)
         losses.FILIP_FUSED = False
+    if os.environ.get("XCLIP_FILIP_CHUNK_MB"):                 # own A/B: size of the backward's routing-matrix chunks
+        losses._FILIP_CHUNK_BYTES = int(os.environ["XCLIP_FILIP_CHUNK_MB"]) << 20
     from x_clip_amd.distributed import GradSync
 
     torch.manual_seed(0)
