@@ -288,8 +288,9 @@ def sim_reg_loss(text_latents: Tensor, image_latents: Tensor, text_latents_extra
 # =========================================================================================================================
 _FILIP_CHUNK_BYTES = 1 << 30          # workspace bound for one chunk of token similarities / routing matrix
 _FILIP_BWD_FACTOR = 1                 # ... times this for the routing matrix of the backward when the forward is fused.  Measured at
-                                      # configs[3], b = 512: 4 (one 4 GB chunk) 31.6 ms per step, 1 (four 1 GB chunks) 30.9 -- a 1 GB chunk is still
-                                      # partly in the 256 MB Infinity Cache when the two GEMMs read it (profiles/r03_m_*_bwd_one_chunk.*)
+                                      # configs[3], b = 512 (profiles/r03_n_filip_bwd_chunk_sizes.log, one box): 128 MB chunks 33.6 ms per step,
+                                      # 256 MB 33.0, 512 MB 32.3, 1 GB 31.9; one 4 GB chunk on another box 31.6 against 30.9 -- within the pool's
+                                      # box-to-box spread: larger than 1 GB buys nothing, smaller costs launches
 FILIP_FUSED = True                    # forward reductions inside the token-similarity GEMM where the shape allows (ops.filip_fused_ok)
 
 
