@@ -187,6 +187,16 @@ def test_simloss_on_gemm_loop(dcl):
     K.case_simloss(DEV, torch.bfloat16, 264, 776, 128, dcl, diag_off=100)
 
 
+@pytest.mark.parametrize("nq,nk,diag_off", [(520, 1100, 300), (512, 1024, 0), (512, 1024, 384), (300, 700, -100), (256, 768, 5000), (768, 256, 0),
+                                            (1030, 520, 512)])
+def test_simloss_grad_interior_and_edge_launches(nq, nk, diag_off):
+    """G in two launches (simloss5.h): interior tiles off the diagonal through the spill-free ring-loop kernel, the tiles on the
+    diagonal / at a ragged edge through the tile list of the second launch -- every tile exactly once (d tau counts each logit once),
+    for diagonals that start inside, before or past the columns, ragged rows and / or columns, more rows than columns"""
+    K.case_simloss(DEV, torch.bfloat16, nq, nk, 64, True, diag_off=diag_off)
+    K.case_simloss(DEV, torch.bfloat16, nq, nk, 64, False, diag_off=diag_off)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
 @pytest.mark.parametrize("rows,cols,diag_off", [(5, 16, 0), (7, 24, 8)])
 def test_simreg_diff(dtype, rows, cols, diag_off):

@@ -77,13 +77,25 @@ constexpr int G3_LDS_BYTES = G2_LDS_BYTES;                    // the two 64 KiB 
 // C3 / C0 / C1 (+1.5 %), 2 per k-block (+3 %), all eight in one k-block with the two wave halves alternating (+12 %).
 XC_DEV constexpr int g3_dma_piece(int kk, int i) { return kk == 3 ? i : (kk == 0 ? 4 + i : -1); }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int ABL, class Epilogue>
-XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
+// which tiles a launch walks: every tile of the tiles_m x tiles_n grid in the XCD-aware order (the default), or a list of its own
+// (simloss5.h: only the tiles on the diagonal / at the ragged edges).  A list may name a tile with m0 >= p.M: it computes nothing useful
+// and its epilogue stores nothing (a hole in a list with a fixed number of slots per row tile).
+struct G3AllTiles {
+    XC_DEV int count(const Gemm2Params& p) const { return p.tiles_m * p.tiles_n; }
+    XC_DEV void origin(const Gemm2Params& p, int id, int& m0, int& n0) const {
+        const int tile = xcd_remap(id, p.tiles_m * p.tiles_n);
+        m0 = (tile / p.tiles_n) * G2_BM;
+        n0 = (tile % p.tiles_n) * G2_BN;
+    }
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR, int ABL, class Epilogue, class Tiles = G3AllTiles>
+XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi, Tiles tiles = Tiles{}) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = uniform(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int ntiles = p.tiles_m * p.tiles_n;
+    const int ntiles = tiles.count(p);
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
     const int nt = (kend - kbeg) / G2_BK;
@@ -93,11 +105,7 @@ XC_DEV void g3_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     // concurrently running work-groups of one XCD share A row-panels in that XCD's L2).  The K steps of consecutive tiles
     // form ONE stream through the two LDS stages; the DMA iterator (tile did, K step dt) runs up to two steps ahead of the
     // MFMAs, across tile boundaries, and the epilogue's stores drain under the next tile's first k-blocks.
-    auto tile_origin = [&](int id, int& m0, int& n0) {
-        const int tile = xcd_remap(id, ntiles);
-        m0 = (tile / p.tiles_n) * G2_BM;
-        n0 = (tile % p.tiles_n) * G2_BN;
-    };
+    auto tile_origin = [&](int id, int& m0, int& n0) { tiles.origin(p, id, m0, n0); };
     int did = blockIdx.x, dt = 0, dm = 0, dn = 0;
     bool dvalid = did < ntiles && nt > 0;
     if (!dvalid) return;                                      // (uniform over the work-group)

@@ -992,20 +992,35 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
     p.lse_q = lse_q; p.lse_k = lse_k; p.a = a; p.c = c; p.e = e; p.G = G; p.ldg = ldg; p.dtau = dtau_accum;
     hipStream_t st = (hipStream_t)stream;
     if (use_sim3(nq, nk, d, dtype)) {
-        // G stays on the two-stage loop with row-per-lane stores (simloss3.h): on the ring loop with the whole-line epilogue
-        // (simloss5.h sim5_grad_kernel) the 128 exponentials per lane and tile sit in front of the line exchange, the kernel needs
-        // ~240 more registers than it has, and the next tile's early A pieces wait for all of it -- 423 us against 362 at
-        // 4096 x 32768 x 512 (profiles/r03_b_sim_kernels_32k.log).  XCLIP_SIM=5 (measurement build) selects it for the A/B.
+        // two launches (simloss5.h): the interior tiles off the diagonal on the ring loop with a spill-free epilogue of their own, then
+        // the few tiles on the diagonal / at a ragged edge through simloss3.h's general epilogue over a tile list.  XCLIP_SIM (measurement
+        // build): 3 = simloss3.h alone (one launch, every tile through the general epilogue: 362 us at 4096 x 32768 x 512), 5 = the
+        // first ring form (whole-line epilogue with the general tile in the same function: 423 us)
 #ifdef XCLIP_MEASURE
-        static const int gen = measure_env("XCLIP_SIM", 3);
+        static const int gen = measure_env("XCLIP_SIM", 0);
         if (gen == 5) {
             XC_ALLOW_LDS(sim5_grad_kernel, G5_LDS_BYTES);
             hipLaunchKernelGGL(sim5_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
             return check_launch(__func__);
         }
+        if (gen == 3) {
+            XC_ALLOW_LDS(sim3_grad_kernel, G2_LDS_BYTES);
+            hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
+            return check_launch(__func__);
+        }
 #endif
-        XC_ALLOW_LDS(sim3_grad_kernel, G2_LDS_BYTES);
-        hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
+        if (nq * ldg * 2 > (48LL << 20)) {                          // G larger than the L2s can hold anyway: streamed stores
+            XC_ALLOW_LDS(sim5_grad_fast_kernel<true>, G5_LDS_BYTES);
+            hipLaunchKernelGGL(sim5_grad_fast_kernel<true>, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+        } else {
+            XC_ALLOW_LDS(sim5_grad_fast_kernel<false>, G5_LDS_BYTES);
+            hipLaunchKernelGGL(sim5_grad_fast_kernel<false>, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+        }
+        const int64_t tm = (nq + G2_BM - 1) / G2_BM, tn = (nk + G2_BN - 1) / G2_BN;
+        const int64_t nedge = 3 * tm + ((nq % G2_BM) ? tn : 0);
+        const int cus = xc_num_cus();
+        XC_ALLOW_LDS(sim5_grad_edge_kernel, G2_LDS_BYTES);
+        hipLaunchKernelGGL(sim5_grad_edge_kernel, dim3((unsigned)(nedge < cus ? nedge : cus)), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
         return check_launch(__func__);
     }
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
