@@ -36,6 +36,11 @@ dtau = torch.zeros(1, device=dev)
 G = torch.empty(b, B, dtype=torch.bfloat16, device=dev)
 t = timeit(lambda: ops.simloss_grad(T, I, 1.0, 0, True, 0.5 / B, 0.5 / B, 1.0 / B, lse, lk, dtau, log_scale=tau, times_scale=True, out=G))
 print(f"sim gradient factor G (bf16 [{b} x {B}] written once): {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s   HBM write {b*B*2/t/1e9:7.1f} GB/s ({b*B*2/t/8e12*100:4.1f} % of 8 TB/s)")
+G.zero_(); dtau.zero_()
+ops.simloss_grad(T, I, 1.0, 0, True, 0.5 / B, 0.5 / B, 1.0 / B, lse, lk, dtau, log_scale=tau, times_scale=True, out=G)
+print(f"   (check values: sum |G| = {float(G.float().abs().sum()):.6e}, G[0, 0] = {float(G[0, 0]):.4e}, G[4095, 32767] = {float(G[-1, -1]):.4e}, d tau = {float(dtau):.6e})")
+if "--g-only" in sys.argv:
+    sys.exit(0)
 t = timeit(lambda: ops.gemm(G, I, b, d, B, b_kmajor=True))
 print(f"dT = G I      (NN, K = {B}): {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s   reads G {b*B*2/t/1e9:7.1f} GB/s")
 t = timeit(lambda: ops.gemm(G, T, B, d, b, a_kmajor=True, b_kmajor=True))

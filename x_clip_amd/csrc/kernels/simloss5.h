@@ -39,16 +39,52 @@ XC_DEV bool sim5_plain_tile(const SimParams& p, int m0, int n0) {
 
 // (STREAM -- non-temporal stores for a G the L2s cannot hold anyway -- is a template parameter: as a run-time branch around the 16
 //  stores it cost this kernel 102 spilled registers)
-template <bool STREAM>
+// (LINES: the tile leaves through g5_run's pack_lines / store_lines pair -- the next tile's first four A pieces are issued between the
+//  two, in front of the stores -- instead of storing from with_scratch, group by group)
+template <bool STREAM, bool LINES = false>
 struct Sim5FastGradEpilogue {
     const SimParams& p;
     const Gemm2Params& gp;       // C = G, ldc = ldg, alpha = 1: what the line stores address
-    XC_DEV void finish() {}
-    XC_DEV bool packs_lines(int, int) const { return false; }
-    XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4], int, int) const {}
-    template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
-    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
-        if (!sim5_plain_tile(p, m0, n0)) return 0;                  // (uniform) the edge launch's tile
+    float dt_acc = 0.f;          // this lane's share of sum G o acc over the work-group's tiles (one register across the K loops)
+    XC_DEV void finish() {
+        const float dt = wave_sum(dt_acc) * (sim_scale(p) / (p.g_times_scale ? sim_scale(p) : 1.0f));
+        if ((threadIdx.x & 63) == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
+    }
+    XC_DEV bool packs_lines(int m0, int n0) const { return LINES && sim5_plain_tile(p, m0, n0); }
+    XC_DEV void pack_lines(f32x16 (&acc)[4][2], unsigned char* scratch, u32x4 (&o)[4][4], int m0, int n0) {
+        to_g(acc, m0, n0);
+        const G4GemmEpilogue<G4_PLAIN> lines{gp};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lines.template pack_lines_i<true>(acc[i], scratch, o[i]);
+    }
+    template <bool NT = false> XC_DEV void store_lines(const u32x4 (&o)[4][4], int m0, int n0) const {
+        G4GemmEpilogue<G4_PLAIN>{gp}.template store_lines<STREAM>(o, m0, n0);
+    }
+    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) {
+        if (LINES || !sim5_plain_tile(p, m0, n0)) return 0;         // (uniform) the edge launch's tile
+        to_g(acc, m0, n0);
+        const int lane = threadIdx.x & 63;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const G4GemmEpilogue<G4_PLAIN> lines{gp};
+        const BufRsrc rc = make_rsrc(gp.C + (long)m0 * gp.ldc + n0, 255u * (uint32_t)gp.ldc * 2u + 512u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)gp.ldc + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+        const uint32_t s8 = (uint32_t)gp.ldc * 16u;                  // 8 rows * ldc * 2 bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 o[4];
+            lines.template pack_lines_i<true>(acc[i], scratch, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (STREAM) buf_st16_nt<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
+                else buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
+            }
+        }
+        // the 16 stores are YOUNGER than the A / B pieces the next tile's first K step waits for and
+        // may stay in flight over it (g5_run: in_flight == 16) -- returning 0 here made that step wait for G to reach memory
+        return 16;
+    }
+    // the accumulators of an interior tile off the diagonal become G in place
+    XC_DEV void to_g(f32x16 (&acc)[4][2], int m0, int n0) {
         const int lane = threadIdx.x & 63, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
         const float scale = sim_scale(p);
@@ -82,24 +118,7 @@ struct Sim5FastGradEpilogue {
                         acc[i][j][4 * q + k] = g;
                     }
             }
-        dt *= scale / gs;
-        const G4GemmEpilogue<G4_PLAIN> lines{gp};
-        const BufRsrc rc = make_rsrc(gp.C + (long)m0 * gp.ldc + n0, 255u * (uint32_t)gp.ldc * 2u + 512u);
-        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)gp.ldc + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
-        const uint32_t s8 = (uint32_t)gp.ldc * 16u;                  // 8 rows * ldc * 2 bytes
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x4 o[4];
-            lines.template pack_lines_i<true>(acc[i], scratch, o);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (STREAM) buf_st16_nt<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
-                else buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
-            }
-        }
-        dt = wave_sum(dt);
-        if (lane == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
-        return 0;                                                    // (the next wait drains the 16 stores with everything else)
+        dt_acc += dt;
     }
 };
 
@@ -133,13 +152,14 @@ struct Sim5EdgeTiles {
     }
 };
 
-template <bool STREAM>
+template <bool STREAM, bool LINES = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_fast_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
     Gemm2Params g = sim3_gemm_params(p);
     g.C = reinterpret_cast<bf16_t*>(p.G);
     g.ldc = p.ldg;
-    g5_run<false, false, Sim5FastGradEpilogue<STREAM>>(g, lds, Sim5FastGradEpilogue<STREAM>{p, g});
+    g.stream_out = STREAM;
+    g5_run<false, false, Sim5FastGradEpilogue<STREAM, LINES>>(g, lds, Sim5FastGradEpilogue<STREAM, LINES>{p, g});
 }
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_edge_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);

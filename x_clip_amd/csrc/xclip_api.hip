@@ -1008,14 +1008,33 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
             hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
             return check_launch(__func__);
         }
+        // 6 = the interior launch through g5_run's pack_lines / store_lines pair (early A pieces in front of the stores), 7 = the
+        // interior launch alone, 8 = the edge launch alone (the split of the two)
+        const bool lines = gen == 6, skip_fast = gen == 8, skip_edge = gen == 7;
+#else
+        const bool skip_fast = false, skip_edge = false;
 #endif
-        if (nq * ldg * 2 > (48LL << 20)) {                          // G larger than the L2s can hold anyway: streamed stores
+        const bool stream = nq * ldg * 2 > (48LL << 20);            // G larger than the L2s can hold anyway: streamed stores
+#ifdef XCLIP_MEASURE
+        if (lines) {
+            if (stream) {
+                XC_ALLOW_LDS((sim5_grad_fast_kernel<true, true>), G5_LDS_BYTES);
+                hipLaunchKernelGGL((sim5_grad_fast_kernel<true, true>), sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+            } else {
+                XC_ALLOW_LDS((sim5_grad_fast_kernel<false, true>), G5_LDS_BYTES);
+                hipLaunchKernelGGL((sim5_grad_fast_kernel<false, true>), sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
+            }
+        } else
+#endif
+        if (skip_fast) {
+        } else if (stream) {
             XC_ALLOW_LDS(sim5_grad_fast_kernel<true>, G5_LDS_BYTES);
             hipLaunchKernelGGL(sim5_grad_fast_kernel<true>, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
         } else {
             XC_ALLOW_LDS(sim5_grad_fast_kernel<false>, G5_LDS_BYTES);
             hipLaunchKernelGGL(sim5_grad_fast_kernel<false>, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
         }
+        if (skip_edge) return check_launch(__func__);
         const int64_t tm = (nq + G2_BM - 1) / G2_BM, tn = (nk + G2_BN - 1) / G2_BN;
         const int64_t nedge = 3 * tm + ((nq % G2_BM) ? tn : 0);
         const int cus = xc_num_cus();
