@@ -190,11 +190,19 @@ def test_simloss_on_gemm_loop(dcl):
 @pytest.mark.parametrize("nq,nk,diag_off", [(520, 1100, 300), (512, 1024, 0), (512, 1024, 384), (300, 700, -100), (256, 768, 5000), (768, 256, 0),
                                             (1030, 520, 512)])
 def test_simloss_grad_interior_and_edge_launches(nq, nk, diag_off):
-    """G in two launches (simloss5.h): interior tiles off the diagonal through the spill-free ring-loop kernel, the tiles on the
-    diagonal / at a ragged edge through the tile list of the second launch -- every tile exactly once (d tau counts each logit once),
+    """G (simloss5.h): every full tile -- with a piece of the positive diagonal or without -- through the spill-free ring-loop kernel,
+    the tiles at a ragged edge through the tile list of the second launch -- every tile exactly once (d tau counts each logit once),
     for diagonals that start inside, before or past the columns, ragged rows and / or columns, more rows than columns"""
     K.case_simloss(DEV, torch.bfloat16, nq, nk, 64, True, diag_off=diag_off)
     K.case_simloss(DEV, torch.bfloat16, nq, nk, 64, False, diag_off=diag_off)
+
+
+@pytest.mark.parametrize("d", [64, 512])
+def test_simloss_grad_at_high_temperature(d):
+    """exp(tau) = 200 (the reference never clamps its temperature, x_clip.py:574,736): the one-exponential-per-logit form of G must not
+    depend on exp(scale - lse) being representable (it overflowed when the reference point was `scale`)"""
+    K.case_simloss(DEV, torch.bfloat16, 512, 1024, d, False, diag_off=384, tau=5.3)
+    K.case_simloss(DEV, torch.bfloat16, 264, 392, d, True, diag_off=100, tau=5.3)
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])

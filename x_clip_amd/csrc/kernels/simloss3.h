@@ -111,6 +111,7 @@ struct Sim3GradEpilogue {
         const bool plain = full && (m0 + p.diag_off + G2_BM <= n0 || m0 + p.diag_off >= n0 + G2_BN);
         if (plain) {
             // the lane's 32 columns (and their lse_k) are the same for all four row blocks: 8 float4 loads per tile
+            const float R = (a != 0.f) ? p.lse_q[m0 + wm * 128] : p.lse_k[n0 + wn * 64];      // (uniform) a log-sum-exp of the tile itself
             float ek[2][4][4];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -118,14 +119,14 @@ struct Sim3GradEpilogue {
                 for (int q = 0; q < 4; ++q) {
                     const u32x4 t = ld16(p.lse_k + n0 + wn * 64 + j * 32 + 4 * h + 8 * q);
 #pragma unroll
-                    // exp(s - lse) = exp(s - scale) exp(scale - lse): ONE exponential per logit (|cos| <= 1, so s <= scale and
-                    // exp(s - scale) <= 1); the per-row / per-column factors are computed once per tile
-                    for (int k = 0; k < 4; ++k) ek[j][q][k] = (c != 0.f) ? c * fast_exp(scale - u2f(t[k])) : 0.f;
+                    // exp(s - lse) = exp(s - R) exp(R - lse): ONE exponential per logit; the per-row / per-column factors are computed
+                    // once per tile (simloss5.h to_g: why R is one of the tile's own lse values and not `scale`)
+                    for (int k = 0; k < 4; ++k) ek[j][q][k] = (c != 0.f) ? c * fast_exp(R - u2f(t[k])) : 0.f;
                 }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
-                const float eq = (a != 0.f) ? a * fast_exp(scale - p.lse_q[gm]) : 0.f;
+                const float eq = (a != 0.f) ? a * fast_exp(R - p.lse_q[gm]) : 0.f;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int nb = n0 + wn * 64 + j * 32;
@@ -136,7 +137,7 @@ struct Sim3GradEpilogue {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float s_ = acc[i][j][4 * q + k] * scale;
-                            const float v = fast_exp(s_ - scale) * (eq + ek[j][q][k]);
+                            const float v = fast_exp(s_ - R) * (eq + ek[j][q][k]);
                             dt += v * s_;
                             g[k] = v * gs;
                         }

@@ -24,24 +24,24 @@ struct Sim5LseEpilogue {
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return Sim3LseEpilogue{p}(acc, m0, n0); }
 };
 
-// ---- backward: G in two launches -----------------------------------------------------------------------------------------------------
-// Why G was slow (362 us at 4096 x 32768 x 512 where the plain GEMM that stores the same 268 MB takes 144): both earlier forms keep the
-// general tile -- per-element range and diagonal tests -- in the same function as the interior one, and around the 128 accumulators the
-// compiler then spills 100 - 240 vector registers INTO THE INTERIOR PATH: ~23 us of epilogue per tile where the exponentials and the
-// stores account for ~9.  Here the interior tiles off the diagonal (all but O(tiles_m) of them) have a kernel of their own on the ring
-// loop: the accumulators become G in place, column quad by column quad (the four per-column factors live only that long), and leave
-// through the plain GEMM's line exchange as whole-line stores -- 217 registers, nothing spilled, no state carried across the K loop
-// (sum G o S: one atomic per wave and tile).  The tiles it skips -- on the diagonal, at a ragged edge -- are walked by a second,
-// small launch of simloss3.h's kernel over a tile LIST (Sim5EdgeTiles).
-XC_DEV bool sim5_plain_tile(const SimParams& p, int m0, int n0) {
-    return (m0 + G2_BM <= p.nq) && (n0 + G2_BN <= p.nk) && (m0 + p.diag_off + G2_BM <= n0 || m0 + p.diag_off >= n0 + G2_BN);
-}
+// ---- backward: G on the ring loop -----------------------------------------------------------------------------------------------------
+// Why G was slow (362 us at 4096 x 32768 x 512 where the plain GEMM that stores the same 268 MB takes 144 - 151): simloss3.h keeps the
+// general tile -- per-element range tests, masked loads -- in the same function as the interior one, and around the 128 accumulators
+// the compiler then spills 100 - 240 vector registers INTO THE INTERIOR PATH: ~23 us of epilogue per tile where the exponentials and
+// the stores account for ~9.  Here every FULL tile (on the diagonal or off it) is handled by a kernel of its own on the ring loop: the
+// accumulators become G in place, column quad by column quad (the four per-column factors live only that long), and leave through the
+// plain GEMM's line exchange as whole-line stores -- 226 registers, nothing spilled; across the K loops it carries one register (the
+// lane's share of sum G o S: per tile it would be 16k same-address atomics at 32k x 4k, each one in front of the next tile's first
+// counted wait -- measured: 258 against 165 us for this launch).  Tiles at a ragged edge are walked by a second, small launch of
+// simloss3.h's kernel over a tile LIST (Sim5EdgeTiles); batch sizes that are multiples of 256 never need it.
+// Measured at 4096 x 32768 x 512 (profiles/r03_q*_sim_g_variants.log, r03_r_*): 362 -> 292 (two launches, atomics per tile) -> 210
+// (atomic per wave) -> see xclip_simloss_grad for the current figure.
+XC_DEV bool sim5_full_tile(const SimParams& p, int m0, int n0) { return (m0 + G2_BM <= p.nq) && (n0 + G2_BN <= p.nk); }
+XC_DEV bool sim5_off_diagonal(const SimParams& p, int m0, int n0) { return m0 + p.diag_off + G2_BM <= n0 || m0 + p.diag_off >= n0 + G2_BN; }
 
 // (STREAM -- non-temporal stores for a G the L2s cannot hold anyway -- is a template parameter: as a run-time branch around the 16
 //  stores it cost this kernel 102 spilled registers)
-// (LINES: the tile leaves through g5_run's pack_lines / store_lines pair -- the next tile's first four A pieces are issued between the
-//  two, in front of the stores -- instead of storing from with_scratch, group by group)
-template <bool STREAM, bool LINES = false>
+template <bool STREAM>
 struct Sim5FastGradEpilogue {
     const SimParams& p;
     const Gemm2Params& gp;       // C = G, ldc = ldg, alpha = 1: what the line stores address
@@ -50,18 +50,11 @@ struct Sim5FastGradEpilogue {
         const float dt = wave_sum(dt_acc) * (sim_scale(p) / (p.g_times_scale ? sim_scale(p) : 1.0f));
         if ((threadIdx.x & 63) == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
     }
-    XC_DEV bool packs_lines(int m0, int n0) const { return LINES && sim5_plain_tile(p, m0, n0); }
-    XC_DEV void pack_lines(f32x16 (&acc)[4][2], unsigned char* scratch, u32x4 (&o)[4][4], int m0, int n0) {
-        to_g(acc, m0, n0);
-        const G4GemmEpilogue<G4_PLAIN> lines{gp};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lines.template pack_lines_i<true>(acc[i], scratch, o[i]);
-    }
-    template <bool NT = false> XC_DEV void store_lines(const u32x4 (&o)[4][4], int m0, int n0) const {
-        G4GemmEpilogue<G4_PLAIN>{gp}.template store_lines<STREAM>(o, m0, n0);
-    }
+    XC_DEV bool packs_lines(int, int) const { return false; }
+    XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4], int, int) const {}
+    template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) {
-        if (LINES || !sim5_plain_tile(p, m0, n0)) return 0;         // (uniform) the edge launch's tile
+        if (!sim5_full_tile(p, m0, n0)) return 0;                   // (uniform) the edge launch's tile
         to_g(acc, m0, n0);
         const int lane = threadIdx.x & 63;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
@@ -79,11 +72,18 @@ struct Sim5FastGradEpilogue {
                 else buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);
             }
         }
-        // the 16 stores are YOUNGER than the A / B pieces the next tile's first K step waits for and
-        // may stay in flight over it (g5_run: in_flight == 16) -- returning 0 here made that step wait for G to reach memory
+        // the 16 stores are YOUNGER than the A / B pieces the next tile's first K step waits for and may stay in flight over it
+        // (g5_run: in_flight == 16)
         return 16;
     }
-    // the accumulators of an interior tile off the diagonal become G in place
+    // The accumulators of a full tile become G in place.  Per logit: G = exp(s - R) (a' + c') with s = acc * scale,
+    // a' = gs a exp(R - lse_q), c' = gs c exp(R - lse_k) -- ONE exponential per logit, in the base-2 domain: one fma + a bare v_exp_f32;
+    // then an add, a multiply, and an fma for sum G o acc (d tau = that sum x scale / gs, applied once per wave).  The reference point R
+    // is a log-sum-exp of the tile itself (its first row's, or its first column's when a = 0): the three exponents then stay within
+    // the spread of the tile's lse values.  (R = scale -- valid since |cos| <= 1 -- was the first choice and is wrong at high
+    // temperatures: with scale = 200 and small cosines exp(scale - lse) overflows and exp(s - scale) flushes to zero.)  A tile that holds a piece of the positive diagonal (uniform test; O(tiles_m) tiles) corrects that logit per column
+    // quad, in two small blocks around the quad's arithmetic: G = (dcl ? 0 : the above) - gs e.  (As a second copy of the whole loop for
+    // those tiles the function spilled 255 registers; as a per-logit select in the one loop it would tax every tile.)
     XC_DEV void to_g(f32x16 (&acc)[4][2], int m0, int n0) {
         const int lane = threadIdx.x & 63, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
@@ -91,75 +91,91 @@ struct Sim5FastGradEpilogue {
         const float gm_ = p.gmul != nullptr ? *p.gmul : 1.0f;
         const float a = p.a * gm_, c = p.c * gm_;
         const float gs = p.g_times_scale ? scale : 1.0f;
-        // Per logit: G = exp(s - scale) (a' + c') with s = acc * scale, a' = gs a exp(scale - lse_q), c' = gs c exp(scale - lse_k) -- ONE
-        // exponential per logit (|cos| <= 1, so s <= scale), in the base-2 domain: one fma + a bare v_exp_f32; then an add, a multiply,
-        // and an fma for sum G o acc (d tau = that sum x scale / gs, applied once per tile).  Four vector instructions + the exponential
-        // (the first form spent eight: the epilogue's cost over the plain GEMM's was ~12 us per tile, all of it VALU).
-        const float scale2 = scale * 1.4426950408889634f;
+        const float egs = p.e * gm_ * gs, keep = p.dcl ? 0.f : 1.f;
+        const float R = (a != 0.f) ? p.lse_q[m0 + wm * 128] : p.lse_k[n0 + wn * 64];      // (uniform)
+        const float scale2 = scale * 1.4426950408889634f, R2 = R * 1.4426950408889634f;
+        const bool on_diag = !sim5_off_diagonal(p, m0, n0);          // (uniform)
         float dt = 0.f;
-        float eq[4];                                                 // gs a exp(scale - lse_q) of the lane's row in each 32-row group
+        float eq[4];                                                 // gs a exp(R - lse_q) of the lane's row in each 32-row group
+        int dl[4];                                                   // the row's diagonal column, relative to the lane's first column
 #pragma unroll
-        for (int i = 0; i < 4; ++i) eq[i] = gs * a * fast_exp(scale - p.lse_q[m0 + wm * 128 + i * 32 + (lane & 31)]);
+        for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
+            eq[i] = (a != 0.f) ? gs * a * fast_exp(R - p.lse_q[gm]) : 0.f;
+            dl[i] = gm + p.diag_off - (n0 + wn * 64 + 4 * h);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const u32x4 t = ld16(p.lse_k + n0 + wn * 64 + j * 32 + 4 * h + 8 * q);
-                float ek[4];                                         // gs c exp(scale - lse_k) of the quad's four columns
+                float ek[4];                                         // gs c exp(R - lse_k) of the quad's four columns
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ek[k] = gs * c * fast_exp(scale - u2f(t[k]));
+                for (int k = 0; k < 4; ++k) ek[k] = (c != 0.f) ? gs * c * fast_exp(R - u2f(t[k])) : 0.f;
+                float rawd[4] = {0.f, 0.f, 0.f, 0.f};                // the row's positive logit (unscaled), if it lies in this quad
+                if (on_diag) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) rawd[i] = (dl[i] == j * 32 + 8 * q + k) ? acc[i][j][4 * q + k] : rawd[i];
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float raw = acc[i][j][4 * q + k];
-                        const float g = fast_exp2(raw * scale2 - scale2) * (eq[i] + ek[k]);
+                        const float g = fast_exp2(raw * scale2 - R2) * (eq[i] + ek[k]);
                         dt += g * raw;
                         acc[i][j][4 * q + k] = g;
                     }
+                if (on_diag) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float delta = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float g = acc[i][j][4 * q + k];
+                            const bool sel = dl[i] == j * 32 + 8 * q + k;
+                            const float gd = g * keep - egs;
+                            delta += sel ? gd - g : 0.f;
+                            acc[i][j][4 * q + k] = sel ? gd : g;
+                        }
+                        dt += delta * rawd[i];
+                    }
+                }
             }
         dt_acc += dt;
     }
 };
 
-// the tiles Sim5FastGradEpilogue skips, as a list with a fixed number of slots: per row tile m the one or two column tiles its
-// diagonal segment [m0 + off, m0 + off + 256) touches (slots 0, 1) and the ragged last column tile (slot 2); then, if the last row
-// tile is ragged, all of its column tiles.  A slot whose tile does not exist, is interior after all, or is already named by an
-// earlier slot is a hole (m0 = rows of the padded grid: nothing is stored for it).
+// the tiles Sim5FastGradEpilogue skips, as a list: the ragged last column tile of every row tile (if the columns are ragged), then
+// every column tile of the ragged last row tile (if the rows are).  The corner both name is a hole in the first part (m0 = rows of the
+// padded grid: nothing is stored for it).
 struct Sim5EdgeTiles {
     const SimParams& s;
-    XC_DEV int count(const Gemm2Params& p) const { return 3 * p.tiles_m + ((s.nq % G2_BM) ? p.tiles_n : 0); }
+    XC_DEV int count(const Gemm2Params& p) const { return ((s.nk % G2_BN) ? p.tiles_m : 0) + ((s.nq % G2_BM) ? p.tiles_n : 0); }
     XC_DEV void origin(const Gemm2Params& p, int id, int& m0, int& n0) const {
-        const int hole = p.tiles_m * G2_BM;
         const bool ragged_rows = (s.nq % G2_BM) != 0, ragged_cols = (s.nk % G2_BN) != 0;
-        int m, c;
-        if (id >= 3 * p.tiles_m) {                                   // the ragged last row tile: every column tile
-            m = p.tiles_m - 1;
-            c = id - 3 * p.tiles_m;
+        const int ncol = ragged_cols ? p.tiles_m : 0;
+        if (id < ncol) {
+            const bool corner = ragged_rows && id == p.tiles_m - 1;
+            m0 = (corner ? p.tiles_m : id) * G2_BM;
+            n0 = corner ? 0 : (p.tiles_n - 1) * G2_BN;
         } else {
-            m = id / 3;
-            const int slot = id - 3 * m;
-            const int d0 = m * G2_BM + s.diag_off;                   // first diagonal column of the row tile
-            const int lo = d0 >= 0 ? d0 / G2_BN : -1, hi = d0 + G2_BM - 1 >= 0 ? (d0 + G2_BM - 1) / G2_BN : -1;
-            if (slot == 0) c = lo;
-            else if (slot == 1) c = hi != lo ? hi : -1;
-            else c = (ragged_cols && p.tiles_n - 1 != lo && p.tiles_n - 1 != hi) ? p.tiles_n - 1 : -1;
-            if (ragged_rows && m == p.tiles_m - 1) c = -1;           // that row tile is listed whole below
+            m0 = (p.tiles_m - 1) * G2_BM;
+            n0 = (id - ncol) * G2_BN;
         }
-        if (c < 0 || c >= p.tiles_n || sim5_plain_tile(s, m * G2_BM, c * G2_BN)) { m0 = hole; n0 = 0; return; }
-        m0 = m * G2_BM;
-        n0 = c * G2_BN;
     }
 };
 
-template <bool STREAM, bool LINES = false>
+template <bool STREAM>
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_fast_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
     Gemm2Params g = sim3_gemm_params(p);
     g.C = reinterpret_cast<bf16_t*>(p.G);
     g.ldc = p.ldg;
     g.stream_out = STREAM;
-    g5_run<false, false, Sim5FastGradEpilogue<STREAM, LINES>>(g, lds, Sim5FastGradEpilogue<STREAM, LINES>{p, g});
+    g5_run<false, false, Sim5FastGradEpilogue<STREAM>>(g, lds, Sim5FastGradEpilogue<STREAM>{p, g});
 }
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_edge_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
@@ -185,15 +201,16 @@ struct Sim5GradEpilogue {
         const float gm_ = p.gmul != nullptr ? *p.gmul : 1.0f;
         const float a = p.a * gm_, c = p.c * gm_;
         const float gs = p.g_times_scale ? scale : 1.0f;
+        const float R = (a != 0.f) ? p.lse_q[m0 + wm * 128] : p.lse_k[n0 + wn * 64];      // (uniform) see Sim5FastGradEpilogue::to_g
         float dt = 0.f;
-        float ek[2][4][4];                                           // c exp(scale - lse_k) of the lane's 32 columns, once per tile
+        float ek[2][4][4];                                           // c exp(R - lse_k) of the lane's 32 columns, once per tile
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const u32x4 t = ld16(p.lse_k + n0 + wn * 64 + j * 32 + 4 * h + 8 * q);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ek[j][q][k] = (c != 0.f) ? c * fast_exp(scale - u2f(t[k])) : 0.f;
+                for (int k = 0; k < 4; ++k) ek[j][q][k] = (c != 0.f) ? c * fast_exp(R - u2f(t[k])) : 0.f;
             }
         const G4GemmEpilogue<G4_PLAIN> lines{gp};
         // one 32-row group at a time: its 32 accumulators become G in place and go straight into the line exchange, so the group's
@@ -201,16 +218,16 @@ struct Sim5GradEpilogue {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
-            const float eq = (a != 0.f) ? a * fast_exp(scale - p.lse_q[gm]) : 0.f;
+            const float eq = (a != 0.f) ? a * fast_exp(R - p.lse_q[gm]) : 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        // exp(s - lse) = exp(s - scale) exp(scale - lse): ONE exponential per logit (|cos| <= 1, so s <= scale)
+                        // exp(s - lse) = exp(s - R) exp(R - lse): ONE exponential per logit
                         const float s_ = acc[i][j][4 * q + k] * scale;
-                        const float v = fast_exp(s_ - scale) * (eq + ek[j][q][k]);
+                        const float v = fast_exp(s_ - R) * (eq + ek[j][q][k]);
                         dt += v * s_;
                         acc[i][j][4 * q + k] = v * gs;
                     }

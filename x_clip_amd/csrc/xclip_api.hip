@@ -992,10 +992,10 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
     p.lse_q = lse_q; p.lse_k = lse_k; p.a = a; p.c = c; p.e = e; p.G = G; p.ldg = ldg; p.dtau = dtau_accum;
     hipStream_t st = (hipStream_t)stream;
     if (use_sim3(nq, nk, d, dtype)) {
-        // two launches (simloss5.h): the interior tiles off the diagonal on the ring loop with a spill-free epilogue of their own, then
-        // the few tiles on the diagonal / at a ragged edge through simloss3.h's general epilogue over a tile list.  XCLIP_SIM (measurement
-        // build): 3 = simloss3.h alone (one launch, every tile through the general epilogue: 362 us at 4096 x 32768 x 512), 5 = the
-        // first ring form (whole-line epilogue with the general tile in the same function: 423 us)
+        // simloss5.h: every full 256 x 256 tile (on the diagonal or off it) on the ring loop with a spill-free epilogue of its own; tiles at
+        // a ragged edge, if there are any, through simloss3.h's general epilogue over a tile list in a second launch.  XCLIP_SIM
+        // (measurement build): 3 = simloss3.h alone (one launch, every tile through the general epilogue: 355 - 368 us at
+        // 4096 x 32768 x 512), 5 = the first ring form (whole-line epilogue with the general tile in the same function: 423 us)
 #ifdef XCLIP_MEASURE
         static const int gen = measure_env("XCLIP_SIM", 0);
         if (gen == 5) {
@@ -1008,35 +1008,22 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
             hipLaunchKernelGGL(sim3_grad_kernel, sim3_grid(nq, nk), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
             return check_launch(__func__);
         }
-        // 6 = the interior launch through g5_run's pack_lines / store_lines pair (early A pieces in front of the stores), 7 = the
-        // interior launch alone, 8 = the edge launch alone (the split of the two)
-        const bool lines = gen == 6, skip_fast = gen == 8, skip_edge = gen == 7;
+        // 7 = the full-tile launch alone, 8 = the edge launch alone (the split of the two)
+        const bool skip_fast = gen == 8, skip_edge = gen == 7;
 #else
         const bool skip_fast = false, skip_edge = false;
 #endif
-        const bool stream = nq * ldg * 2 > (48LL << 20);            // G larger than the L2s can hold anyway: streamed stores
-#ifdef XCLIP_MEASURE
-        if (lines) {
-            if (stream) {
-                XC_ALLOW_LDS((sim5_grad_fast_kernel<true, true>), G5_LDS_BYTES);
-                hipLaunchKernelGGL((sim5_grad_fast_kernel<true, true>), sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
-            } else {
-                XC_ALLOW_LDS((sim5_grad_fast_kernel<false, true>), G5_LDS_BYTES);
-                hipLaunchKernelGGL((sim5_grad_fast_kernel<false, true>), sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
-            }
-        } else
-#endif
         if (skip_fast) {
-        } else if (stream) {
+        } else if (nq * ldg * 2 > (48LL << 20)) {                   // G larger than the L2s can hold anyway: streamed stores
             XC_ALLOW_LDS(sim5_grad_fast_kernel<true>, G5_LDS_BYTES);
             hipLaunchKernelGGL(sim5_grad_fast_kernel<true>, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
         } else {
             XC_ALLOW_LDS(sim5_grad_fast_kernel<false>, G5_LDS_BYTES);
             hipLaunchKernelGGL(sim5_grad_fast_kernel<false>, sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p);
         }
-        if (skip_edge) return check_launch(__func__);
         const int64_t tm = (nq + G2_BM - 1) / G2_BM, tn = (nk + G2_BN - 1) / G2_BN;
-        const int64_t nedge = 3 * tm + ((nq % G2_BM) ? tn : 0);
+        const int64_t nedge = ((nk % G2_BN) ? tm : 0) + ((nq % G2_BM) ? tn : 0);    // Sim5EdgeTiles::count
+        if (skip_edge || nedge == 0) return check_launch(__func__);
         const int cus = xc_num_cus();
         XC_ALLOW_LDS(sim5_grad_edge_kernel, G2_LDS_BYTES);
         hipLaunchKernelGGL(sim5_grad_edge_kernel, dim3((unsigned)(nedge < cus ? nedge : cus)), dim3(G2_THREADS), G2_LDS_BYTES, st, p);
