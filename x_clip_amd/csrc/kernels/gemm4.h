@@ -223,6 +223,10 @@ struct G5Iter {                                               // one operand's D
 // ABL (measurement only, XCLIP_GEMM_ABL; results are garbage): 1 no MFMA, 2 no DMA after the prologue, 4 no epilogue, 8 no fragment
 // reads, 16 no barrier, 32 no counted DMA wait, 64 coalesced stores of misplaced values, 128 the row-per-lane epilogue, 256 every other CU half a tile late,
 // 512 C[0..15] <- shader cycles and 10 ns ticks of work-group 0 (the effective clock).
+// (an epilogue whose with_scratch may return 8 -- that many small stores left in flight -- says so with `static constexpr bool LOOSE8`)
+template <class E, class = void> struct g5_loose8 { static constexpr bool value = false; };
+template <class E> struct g5_loose8<E, decltype((void)E::LOOSE8)> { static constexpr bool value = E::LOOSE8; };
+
 template <bool A_KMAJOR, bool B_KMAJOR, class Epilogue, int ABL = 0>
 XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int tid = threadIdx.x;
@@ -362,6 +366,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     //  -- the counter retires in issue order -- and may stay in flight for one more K step)
                     if (!(ABL & 32)) {
                         if (!(ABL & 1024) && t == 0 && in_flight == 16) XC_WAIT_VMEM_LE(20);
+                        else if (g5_loose8<Epilogue>::value && t == 0 && in_flight == 8) XC_WAIT_VMEM_LE(12);
                         else XC_WAIT_VMEM_LE(4);
                     }
                     if (!(ABL & 16)) barrier_nodrain();          // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more

@@ -16,10 +16,13 @@ namespace xc {
 struct Sim3LseEpilogue {
     XC_DEV void finish() {}
     const SimParams& p;
+    // scale = exp(tau) x host factor, read ONCE per work-group (the kernels pass sim_scale(p)): as a per-tile read of *log_scale it was
+    // a vector load + a full drain of the memory counter in front of every tile's epilogue (the compiler cannot use a scalar load past
+    // the previous tile's stores), the only load the interior path has
+    float scale;
     XC_DEV int operator()(f32x16 (&acc)[4][2], int m0, int n0) const {
         const int lane = threadIdx.x & 63, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
-        const float scale = sim_scale(p);
         const int c0 = n0 + wn * 64;                               // this wave's 64-column slot
         if (c0 >= p.nk) return 0;
         const long slot = c0 >> 6;
@@ -27,6 +30,7 @@ struct Sim3LseEpilogue {
         const bool plain = (m0 + G2_BM <= p.nq) && (n0 + G2_BN <= p.nk) &&
                            (m0 + p.diag_off + G2_BM <= n0 || m0 + p.diag_off >= n0 + G2_BN);
         if (plain) {
+            const float scale2 = scale * 1.4426950408889634f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
@@ -35,12 +39,13 @@ struct Sim3LseEpilogue {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
+                const float mx2 = mx * scale2;                       // (base-2 domain: one fma + a bare v_exp_f32 per logit)
                 mx *= scale;                                         // scale = exp(tau) x host factor > 0
                 float l = 0.f;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) l += fast_exp(acc[i][j][r] * scale - mx);
+                    for (int r = 0; r < 16; ++r) l += fast_exp2(acc[i][j][r] * scale2 - mx2);
                 const float m2 = shfl_xor(mx, 32), l2 = shfl_xor(l, 32);
                 const float mm = fmaxf(mx, m2);
                 const float ll = l * fast_exp(mx - mm) + l2 * fast_exp(m2 - mm);
@@ -49,7 +54,7 @@ struct Sim3LseEpilogue {
                     p.part_l[slot * p.nq + gm] = ll;
                 }
             }
-            return 0;
+            return 8;                                                // vector-memory instructions left behind (g5_run: LOOSE8)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -220,7 +225,7 @@ XC_DEV Gemm2Params sim3_gemm_params(const SimParams& p) {
 __global__ __launch_bounds__(G2_THREADS, 2) void sim3_lse_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
     const Gemm2Params g = sim3_gemm_params(p);
-    g3_run<false, false, 0>(g, lds, Sim3LseEpilogue{p});
+    g3_run<false, false, 0>(g, lds, Sim3LseEpilogue{p, sim_scale(p)});
 }
 __global__ __launch_bounds__(G2_THREADS, 2) void sim3_grad_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);

@@ -1,10 +1,10 @@
 // simloss5.h -- the contrastive head (simloss3.h: S = scale * Q K^T reduced to log-sum-exp partials in the forward, turned into the
 // gradient factor G in the backward; reference x_clip.py:813-847) on the PRODUCTION GEMM loop of gemm4.h (g5_run): the Q operand --
 // the one that streams, K's column panel is re-read from L2 by every tile of its column -- in a ring of three LDS stages, descriptor-
-// addressed LDS DMA, the counted waits.  Forward (log-sum-exp partials, nothing stored): 177 -> 157 us = 876 TFLOP/s at the configs[2]
-// per-rank block 4096 x 32768 x 512 (the same-shape plain GEMM that WRITES the logits: 144 us; profiles/r03_b_sim_kernels_32k.log).
-// The G kernel was moved too (whole-line epilogue, the next tile's early Q pieces) and got slower, 423 against 362 us: it stays on
-// simloss3.h in the product and lives on here for the measurement build only.
+// addressed LDS DMA, the counted waits.  At the configs[2] per-rank block 4096 x 32768 x 512 (the same-shape plain GEMM that WRITES the
+// logits: 144 - 151 us): forward (log-sum-exp partials, nothing stored) 177 -> 154 - 158 us = 893 TFLOP/s; G 362 -> 191 - 197 us
+// (profiles/r03_b_*, r03_o_* ... r03_u_*; DESIGN.md section 3 has the steps).  The first ring form of G (whole-line epilogue with the
+// general tile in the same function: 423 us) lives on in the measurement build.
 #pragma once
 #include "gemm4.h"
 #include "simloss3.h"
@@ -14,6 +14,10 @@ namespace xc {
 // forward: no stores at all -- the g5_run protocol's "nothing left in flight" epilogue
 struct Sim5LseEpilogue {
     const SimParams& p;
+    float scale;                 // sim_scale(p), read once per work-group (simloss3.h)
+    // an interior tile leaves exactly 8 small stores behind (its rows' partial maxima and sums); they are younger than the operand pieces
+    // the next tile's first K step waits for and may stay in flight over it, like the 16 line stores of a GEMM tile
+    static constexpr bool LOOSE8 = true;
     XC_DEV void finish() {}
     XC_DEV bool packs_lines(int, int) const { return false; }
     XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4], int, int) const {}
@@ -21,7 +25,7 @@ struct Sim5LseEpilogue {
     // (measured and not kept: re-reading the epilogue's parameters from the kernarg segment per tile -- params_in_memory(), 54 -> 35
     //  spilled SGPRs -- made the kernel SLOWER, 194 against 157 us: every field access became its own scalar load + wait;
     //  profiles/r03_f_sim_kernels_32k.log)
-    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return Sim3LseEpilogue{p}(acc, m0, n0); }
+    XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return Sim3LseEpilogue{p, scale}(acc, m0, n0); }   // 8 or 0
 };
 
 // ---- backward: G on the ring loop -----------------------------------------------------------------------------------------------------
@@ -35,7 +39,7 @@ struct Sim5LseEpilogue {
 // counted wait -- measured: 258 against 165 us for this launch).  Tiles at a ragged edge are walked by a second, small launch of
 // simloss3.h's kernel over a tile LIST (Sim5EdgeTiles); batch sizes that are multiples of 256 never need it.
 // Measured at 4096 x 32768 x 512 (profiles/r03_q*_sim_g_variants.log, r03_r_*): 362 -> 292 (two launches, atomics per tile) -> 210
-// (atomic per wave) -> see xclip_simloss_grad for the current figure.
+// (atomic per wave) -> 191 - 197 (diagonal tiles in this kernel too).
 XC_DEV bool sim5_full_tile(const SimParams& p, int m0, int n0) { return (m0 + G2_BM <= p.nq) && (n0 + G2_BN <= p.nk); }
 XC_DEV bool sim5_off_diagonal(const SimParams& p, int m0, int n0) { return m0 + p.diag_off + G2_BM <= n0 || m0 + p.diag_off >= n0 + G2_BN; }
 
@@ -45,9 +49,10 @@ template <bool STREAM>
 struct Sim5FastGradEpilogue {
     const SimParams& p;
     const Gemm2Params& gp;       // C = G, ldc = ldg, alpha = 1: what the line stores address
+    float scale, gmul;           // sim_scale(p) and *p.gmul (or 1), read once per work-group
     float dt_acc = 0.f;          // this lane's share of sum G o acc over the work-group's tiles (one register across the K loops)
     XC_DEV void finish() {
-        const float dt = wave_sum(dt_acc) * (sim_scale(p) / (p.g_times_scale ? sim_scale(p) : 1.0f));
+        const float dt = wave_sum(dt_acc) * (scale / (p.g_times_scale ? scale : 1.0f));
         if ((threadIdx.x & 63) == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
     }
     XC_DEV bool packs_lines(int, int) const { return false; }
@@ -87,8 +92,7 @@ struct Sim5FastGradEpilogue {
     XC_DEV void to_g(f32x16 (&acc)[4][2], int m0, int n0) {
         const int lane = threadIdx.x & 63, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
-        const float scale = sim_scale(p);
-        const float gm_ = p.gmul != nullptr ? *p.gmul : 1.0f;
+        const float gm_ = gmul;
         const float a = p.a * gm_, c = p.c * gm_;
         const float gs = p.g_times_scale ? scale : 1.0f;
         const float egs = p.e * gm_ * gs, keep = p.dcl ? 0.f : 1.f;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_fast_kernel(SimParams
     g.C = reinterpret_cast<bf16_t*>(p.G);
     g.ldc = p.ldg;
     g.stream_out = STREAM;
-    g5_run<false, false, Sim5FastGradEpilogue<STREAM>>(g, lds, Sim5FastGradEpilogue<STREAM>{p, g});
+    g5_run<false, false, Sim5FastGradEpilogue<STREAM>>(g, lds, Sim5FastGradEpilogue<STREAM>{p, g, sim_scale(p), p.gmul != nullptr ? *p.gmul : 1.0f});
 }
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_edge_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
@@ -246,7 +250,7 @@ struct Sim5GradEpilogue {
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_lse_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
     const Gemm2Params g = sim3_gemm_params(p);
-    g5_run<false, false, Sim5LseEpilogue>(g, lds, Sim5LseEpilogue{p});
+    g5_run<false, false, Sim5LseEpilogue>(g, lds, Sim5LseEpilogue{p, sim_scale(p)});
 }
 #ifdef XCLIP_MEASURE
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_kernel(SimParams p) {
