@@ -81,12 +81,17 @@ struct Filip5Epilogue {
         unsigned char* const wr = scratch + r31 * 128 + 8 * h;          // + chunk position * 16   (pack_lines_t's layout)
         // the four row groups' token-mask bytes of this lane's rows, requested before the row direction's arithmetic (one dependent
         // global round trip per group sat in front of every column scan otherwise)
-        bool rowlive[4];
+        // (read through a clamped index, unconditionally: behind `g < f.M &&` the compiler made each of the four a branch with its own
+        //  load and full drain of the memory counter -- four serialized round trips at the head of every tile's epilogue)
+        unsigned char mbyte[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int g = gr0 + i * 32 + r31;
-            rowlive[i] = g < f.M && f.mask[g] != 0;
+            mbyte[i] = f.mask[g < f.M ? g : f.M - 1];
         }
+        bool rowlive[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rowlive[i] = (gr0 + i * 32 + r31 < f.M) && mbyte[i] != 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int grow = gr0 + i * 32 + r31;
