@@ -2,7 +2,7 @@
 //
 // Same vocabulary as x_clip_amd/csrc/hw/xc_device.h, implemented on a functional wave64 emulator so
 // that the CPU test-suite (no GPU in the build container) executes the *same kernel sources* the
-// product compiles for gfx950.  One OS thread; every GPU thread of a workgroup is a fibre (ucontext);
+// product compiles for gfx950.  One OS thread; every GPU thread of a workgroup is a fibre (own stack, a six-register switch);
 // workgroups run one after another.  Fibres switch only at __syncthreads() and at wave collectives
 // (shuffles, MFMA), waves of a workgroup are scheduled in a seeded random order and the dynamic LDS is
 // poisoned per workgroup, so a missing barrier or a read of unwritten LDS shows up as a wrong result.
@@ -43,8 +43,43 @@ constexpr int kStack = 256 * 1024;
 constexpr int kMaxThreads = 1024;
 constexpr int kExBytes = 64;          // bytes one lane may deposit in a wave collective
 
+// Fibre switch.  glibc's swapcontext saves and restores the signal mask with a system call on every switch, and a wave collective
+// costs 128 switches: on x86-64 a switch here is the six callee-saved registers and the stack pointer (nothing in the kernels
+// touches the signal mask, MXCSR or the x87 control word).  Other hosts keep ucontext.
+#if defined(__x86_64__)
+#define XCEMU_FAST_SWITCH 1
+struct Context { void* sp = nullptr; };
+__attribute__((naked, noinline)) static void ctx_switch(void** /*save_sp: rdi*/, void* /*load_sp: rsi*/) {
+    __asm__ volatile(
+        "pushq %rbp\n\t pushq %rbx\n\t pushq %r12\n\t pushq %r13\n\t pushq %r14\n\t pushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t movq %rsi, %rsp\n\t"
+        "popq %r15\n\t popq %r14\n\t popq %r13\n\t popq %r12\n\t popq %rbx\n\t popq %rbp\n\t ret\n\t");
+}
+inline void ctx_swap(Context& from, Context& to) { ctx_switch(&from.sp, to.sp); }
+// a fresh context that enters `entry` (which never returns) on the given stack: six zeroed registers, the entry address as the
+// `ret` target, and a null return address above it so that the entry sees the stack alignment of a called function
+inline void ctx_make(Context& c, char* stack, size_t bytes, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;
+    *--sp = (void*)entry;
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    c.sp = sp;
+}
+#else
+struct Context { ucontext_t uc; };
+inline void ctx_swap(Context& from, Context& to) { swapcontext(&from.uc, &to.uc); }
+inline void ctx_make(Context& c, char* stack, size_t bytes, void (*entry)()) {
+    getcontext(&c.uc);
+    c.uc.uc_stack.ss_sp = stack;
+    c.uc.uc_stack.ss_size = bytes;
+    c.uc.uc_link = nullptr;
+    makecontext(&c.uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Context ctx;
     bool done = true;
     int tid = 0;
     unsigned coll = 0;                // number of wave collectives this lane has completed
@@ -59,7 +94,7 @@ struct State {
     Dim3 threadIdx, blockIdx, blockDim, gridDim;
     Fiber fibers[kMaxThreads];
     WaveState waves[kMaxThreads / 64];
-    ucontext_t sched;
+    Context sched;
     char* stacks = nullptr;
     unsigned char* lds = nullptr;
     int cur = -1, nthreads = 0, live = 0;
@@ -90,7 +125,7 @@ inline unsigned next_rand() {
 inline void yield() {
     State& s = S();
     Fiber& f = s.fibers[s.cur];
-    swapcontext(&f.ctx, &s.sched);
+    ctx_swap(f.ctx, s.sched);
 }
 
 inline void fiber_main() {
@@ -106,7 +141,8 @@ inline void fiber_main() {
         s.bar_arrived = 0;
         s.bar_gen++;
     }
-    swapcontext(&f.ctx, &s.sched);
+    ctx_swap(f.ctx, s.sched);
+    abort();                                              // (a finished fibre is never resumed)
 }
 
 inline void block_barrier() {
@@ -159,11 +195,7 @@ inline void run_block(const std::function<void()>& body, Dim3 grid, Dim3 block, 
     for (int t = 0; t < n; ++t) {
         Fiber& f = s.fibers[t];
         f.done = false; f.tid = t; f.coll = 0;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = s.stacks + (size_t)t * kStack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())fiber_main, 0);
+        ctx_make(f.ctx, s.stacks + (size_t)t * kStack, kStack, fiber_main);
     }
     std::vector<int> order(nw);
     for (int w = 0; w < nw; ++w) order[w] = w;
@@ -183,7 +215,7 @@ inline void run_block(const std::function<void()>& body, Dim3 grid, Dim3 block, 
                 if (f.done) continue;
                 s.cur = t;
                 s.threadIdx = Dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                swapcontext(&s.sched, &f.ctx);
+                ctx_swap(s.sched, f.ctx);
             }
         }
         if (!s.progressed) {
@@ -300,20 +332,21 @@ inline float wave_max(float v) {
 }
 
 inline f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
-    struct Dep { s16x8 a, b; } mine{a, b};
+    struct Dep { float a[8], b[8]; } mine;                // (converted once per lane, not once per product)
+    for (int k = 0; k < 8; ++k) { mine.a[k] = bf2f((bf16_t)a[k]); mine.b[k] = bf2f((bf16_t)b[k]); }
     auto tab = xcemu::wave_exchange(&mine, sizeof(Dep));
     const int l = lane_id();
+    const int j = l & 31;
+    float bj[16];
+    for (int k = 0; k < 16; ++k) bj[k] = reinterpret_cast<const Dep*>(tab[j + 32 * (k >> 3)])->b[k & 7];
     f32x16 d;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        const int j = l & 31;
+        const float* a0 = reinterpret_cast<const Dep*>(tab[i])->a;
+        const float* a1 = reinterpret_cast<const Dep*>(tab[i + 32])->a;
         float acc = c[r];
-        for (int k = 0; k < 16; ++k) {
-            Dep da, db;
-            memcpy(&da, tab[i + 32 * (k >> 3)], sizeof(Dep));
-            memcpy(&db, tab[j + 32 * (k >> 3)], sizeof(Dep));
-            acc += bf2f((bf16_t)da.a[k & 7]) * bf2f((bf16_t)db.b[k & 7]);
-        }
+        for (int k = 0; k < 8; ++k) acc += a0[k] * bj[k];
+        for (int k = 0; k < 8; ++k) acc += a1[k] * bj[8 + k];
         d[r] = acc;
     }
     return d;
