@@ -197,6 +197,14 @@ def test_simloss_grad_interior_and_edge_launches(nq, nk, diag_off):
     K.case_simloss(DEV, torch.bfloat16, nq, nk, 64, False, diag_off=diag_off)
 
 
+def test_simloss_banded_tile_order():
+    """more than 8 column tiles: the ring-loop kernels walk the tiles in bands of 4..8 column tiles (12 tiles -> bands of 6; 10 -> 5;
+    9 tiles + a ragged one = 10), every tile exactly once (lse / G / d tau all see each logit once)"""
+    K.case_simloss(DEV, torch.bfloat16, 512, 3072, 64, True, diag_off=1000)
+    K.case_simloss(DEV, torch.bfloat16, 300, 2560, 64, False, diag_off=0)
+    K.case_simloss(DEV, torch.bfloat16, 256, 2400, 64, False, diag_off=2100)
+
+
 @pytest.mark.parametrize("d", [64, 512])
 def test_simloss_grad_at_high_temperature(d):
     """exp(tau) = 200 (the reference never clamps its temperature, x_clip.py:574,736): the one-exponential-per-logit form of G must not

@@ -194,6 +194,9 @@ def test_simloss_on_gemm_loop(dcl):
     for nq, nk, off in [(520, 1100, 300), (512, 1024, 384), (300, 700, -100), (256, 768, 5000), (1030, 520, 512), (4096, 8200, 4096)]:
         K.case_simloss(DEV, torch.bfloat16, nq, nk, 512, dcl, diag_off=off)        # interior + edge launches of G (simloss5.h)
     K.case_simloss(DEV, torch.bfloat16, 1024, 4096, 512, dcl, diag_off=2048)
+    K.case_simloss(DEV, torch.bfloat16, 512, 3072, 512, dcl, diag_off=1000)          # > 8 column tiles: banded tile order (6 / 5 / 5)
+    K.case_simloss(DEV, torch.bfloat16, 300, 2560, 512, dcl, diag_off=0)
+    K.case_simloss(DEV, torch.bfloat16, 256, 2400, 512, dcl, diag_off=2100)
     for d in (64, 512):                                                             # exp(tau) = 200: no exp(scale - lse) anywhere
         K.case_simloss(DEV, torch.bfloat16, 512, 1024, d, dcl, diag_off=384, tau=5.3)
         K.case_simloss(DEV, torch.bfloat16, 264, 392, d, dcl, diag_off=100, tau=5.3)

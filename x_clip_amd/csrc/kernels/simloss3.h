@@ -218,7 +218,14 @@ XC_DEV Gemm2Params sim3_gemm_params(const SimParams& p) {
     g.bias = nullptr; g.residual = nullptr; g.ldr = 0; g.addrows = nullptr; g.rowidx = nullptr; g.ld_add = 0;
     g.partial = nullptr; g.k_per_split = p.d;
     g.tiles_m = (p.nq + G2_BM - 1) / G2_BM; g.tiles_n = (p.nk + G2_BN - 1) / G2_BN;
-    g.stream_out = 0; g.band_n = 0;
+    g.stream_out = 0;
+    // ring-loop kernels (simloss5.h on g5_run): banded tile order, as the GEMM's (xclip_gemm) -- an XCD keeps a band of K panels in its L2
+    // and walks the row tiles against it.  In plain order each XCD owns whole row tiles and streams EVERY K panel past them: at
+    // 4096 x 32768 x 512 the fabric delivered 557 MB per launch for 37.7 MB of operands (profiles/r03_x_sim_hbm_traffic_pmc.txt)
+    g.band_n = 0;
+    if (g.tiles_n > 8)
+        for (int b = 8; b >= 4 && g.band_n == 0; --b)
+            if (g.tiles_n % b == 0) g.band_n = b;
     return g;
 }
 
