@@ -567,6 +567,28 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restric
     if (wave == 0 && col < D) atomic_add(accum + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
+// the same for TWO accumulators whose partial rows are interleaved ([nrows, 2 D]: blockIdx.z picks the half) -- the chained LayerNorm
+// backward folds both gains' partials in one launch
+__global__ __launch_bounds__(256) void colsum_fold2_kernel(const float* __restrict__ partial, float* __restrict__ accum_a,
+                                                           float* __restrict__ accum_b, int nrows, int D) {
+    XC_LDS_DYNAMIC(lds);                                 // 4 x 64 floats
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(lds);
+    const int lane = lane_id(), wave = wave_id();
+    const int col = blockIdx.x * 64 + lane;
+    const int strips = gridDim.y * 4;
+    const int per = (nrows + strips - 1) / strips;
+    const int r0 = (blockIdx.y * 4 + wave) * per;
+    const int r1 = r0 + per < nrows ? r0 + per : nrows;
+    const float* src = partial + (long)blockIdx.z * D;
+    float* accum = blockIdx.z ? accum_b : accum_a;
+    float s = 0.f;
+    if (col < D)
+        for (int r = r0; r < r1; ++r) s += src[(long)r * (2 * D) + col];
+    red[wave][lane] = s;
+    sync();
+    if (wave == 0 && col < D) atomic_add(accum + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
 // ---- l2 normalisation -------------------------------------------------------------------------------------
 // y = x / max(||x||, 1e-12) ; rnorm saved for the backward: dx = (dy - y <y, dy>) rnorm.
 template <typename T, int MAXC>

@@ -364,10 +364,8 @@ int xclip_layernorm_chain_bwd(const void* dh2, const void* x1, const void* g2, c
 #undef F
     int slices = nblk / 64;
     if (slices < 1) slices = 1;
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices), dim3(256), 1024, (hipStream_t)stream,
-                       (const float*)partial, (long)(2 * dim), dg2_accum, nblk, (int)dim);
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices), dim3(256), 1024, (hipStream_t)stream,
-                       (const float*)(partial + dim), (long)(2 * dim), dg1_accum, nblk, (int)dim);
+    hipLaunchKernelGGL(colsum_fold2_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices, 2), dim3(256), 1024, (hipStream_t)stream,
+                       (const float*)partial, dg2_accum, dg1_accum, nblk, (int)dim);      // both gains' partials in one launch
     return check_launch(__func__);
 }
 
