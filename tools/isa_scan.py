@@ -12,6 +12,8 @@ three largest epilogue stalls (none of them visible in the source):
 
     python tools/isa_scan.py [--all]        # compiles x_clip_amd/csrc/xclip_api.hip and xclip_attn.hip to assembly under /tmp
 
+tests/test_isa_guard.py holds the hot kernels to what this scan reports today (no spilled vector registers, no atomics in tile loops).
+
 Streaming row kernels (LayerNorm family) legitimately wait for the row they just requested -- their latency is hidden by occupancy,
 not inside the wave -- so a count is a pointer to read the code, not a verdict."""
 import os
@@ -24,13 +26,28 @@ CSRC = os.path.join(ROOT, "x_clip_amd", "csrc")
 OUT = "/tmp/xclip_isa"
 
 
-def assemble(unit):
+def assemble(unit, extra=()):
+    """the unit's device assembly with exactly the flags x_clip_amd/build.py compiles it with"""
     os.makedirs(OUT, exist_ok=True)
     dst = os.path.join(OUT, unit.replace(".hip", ".s"))
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-ffp-contract=fast",
-           "-Wno-unused-value", "-I", os.path.join(CSRC, "hw"), "-I", CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, unit), "-o", dst]
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
+           "-ffp-contract=fast", "-Wno-unused-value", "-I", os.path.join(CSRC, "hw"), "-I", CSRC, *extra, "-S", "--cuda-device-only",
+           os.path.join(CSRC, unit), "-o", dst]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return dst
+
+
+def scan_product():
+    """{demangled kernel name: counters} over both translation units"""
+    sys.path.insert(0, ROOT)
+    from x_clip_amd.build import UNITS
+    out = {}
+    for unit, extra in UNITS:
+        st = scan(assemble(unit, extra))
+        names = demangle(list(st))
+        for n, v in st.items():
+            out[re.sub(r"\(.*$", "", names[n]).replace("void ", "").replace("xc::", "").replace("unsigned short", "bf16")] = v
+    return out
 
 
 def scan(path):
@@ -77,15 +94,11 @@ def demangle(names):
 def main():
     show_all = "--all" in sys.argv
     print(f"{'serial':>6s} {'loads':>6s} {'atomics':>7s} {'scratch':>7s} {'vspill':>6s} {'sspill':>6s}  kernel")
-    for unit in ("xclip_api.hip", "xclip_attn.hip"):
-        st = scan(assemble(unit))
-        names = demangle(list(st))
-        rows = sorted(st.items(), key=lambda kv: -(kv[1]["serial"] + kv[1]["scratch"] + kv[1]["vspill"]))
-        for n, s in rows:
-            if not show_all and s["serial"] < 2 and s["scratch"] == 0 and s["vspill"] == 0 and s["atomics"] == 0:
-                continue
-            short = re.sub(r"\(.*$", "", names[n]).replace("xc::", "").replace("unsigned short", "bf16")[:90]
-            print(f"{s['serial']:6d} {s['loads']:6d} {s['atomics']:7d} {s['scratch']:7d} {s['vspill']:6d} {s['sspill']:6d}  {short}")
+    rows = sorted(scan_product().items(), key=lambda kv: -(kv[1]["serial"] + kv[1]["scratch"] + kv[1]["vspill"]))
+    for n, s in rows:
+        if not show_all and s["serial"] < 2 and s["scratch"] == 0 and s["vspill"] == 0 and s["atomics"] == 0:
+            continue
+        print(f"{s['serial']:6d} {s['loads']:6d} {s['atomics']:7d} {s['scratch']:7d} {s['vspill']:6d} {s['sspill']:6d}  {n[:90]}")
 
 
 if __name__ == "__main__":

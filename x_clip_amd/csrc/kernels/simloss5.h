@@ -96,7 +96,16 @@ struct Sim5FastGradEpilogue {
         const float a = p.a * gm_, c = p.c * gm_;
         const float gs = p.g_times_scale ? scale : 1.0f;
         const float egs = p.e * gm_ * gs, keep = p.dcl ? 0.f : 1.f;
-        const float R = (a != 0.f) ? p.lse_q[m0 + wm * 128] : p.lse_k[n0 + wn * 64];      // (uniform)
+        // Every load of the tile is unconditional and requested ahead of its use -- both candidates for R, the four row lse values, then
+        // the column quads one quad ahead of the arithmetic.  Written as `a != 0 ? ... lse_q[gm] : 0` each of them was a branch with
+        // its own load and full drain of the memory counter: 12 serialized round trips per tile (tools/isa_scan.py).
+        const float Rq = p.lse_q[m0 + wm * 128], Rk = p.lse_k[n0 + wn * 64];
+        const float* const kcol = p.lse_k + n0 + wn * 64 + 4 * h;
+        float lq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lq[i] = p.lse_q[m0 + wm * 128 + i * 32 + (lane & 31)];
+        u32x4 t = ld16(kcol);
+        const float R = (a != 0.f) ? Rq : Rk;                        // (uniform)
         const float scale2 = scale * 1.4426950408889634f, R2 = R * 1.4426950408889634f;
         const bool on_diag = !sim5_off_diagonal(p, m0, n0);          // (uniform)
         float dt = 0.f;
@@ -105,14 +114,15 @@ struct Sim5FastGradEpilogue {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
-            eq[i] = (a != 0.f) ? gs * a * fast_exp(R - p.lse_q[gm]) : 0.f;
+            eq[i] = (a != 0.f) ? gs * a * fast_exp(R - lq[i]) : 0.f;
             dl[i] = gm + p.diag_off - (n0 + wn * 64 + 4 * h);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const u32x4 t = ld16(p.lse_k + n0 + wn * 64 + j * 32 + 4 * h + 8 * q);
+                u32x4 tn = t;
+                if (j * 4 + q < 7) tn = ld16(kcol + (j * 4 + q + 1 < 4 ? 0 : 32) + 8 * ((j * 4 + q + 1) & 3));   // the next quad's four lse_k
                 float ek[4];                                         // gs c exp(R - lse_k) of the quad's four columns
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ek[k] = (c != 0.f) ? gs * c * fast_exp(R - u2f(t[k])) : 0.f;
@@ -147,6 +157,7 @@ struct Sim5FastGradEpilogue {
                         dt += delta * rawd[i];
                     }
                 }
+                t = tn;
             }
         dt_acc += dt;
     }
