@@ -2,7 +2,7 @@
 // gradient factor G in the backward; reference x_clip.py:813-847) on the PRODUCTION GEMM loop of gemm4.h (g5_run): the Q operand --
 // the one that streams, K's column panel is re-read from L2 by every tile of its column -- in a ring of three LDS stages, descriptor-
 // addressed LDS DMA, the counted waits.  At the configs[2] per-rank block 4096 x 32768 x 512 (the same-shape plain GEMM that WRITES the
-// logits: 144 - 151 us): forward (log-sum-exp partials, nothing stored) 177 -> 154 - 158 us = 893 TFLOP/s; G 362 -> 191 - 197 us
+// logits: 144 - 151 us): forward (log-sum-exp partials, nothing stored) 177 -> 154 - 158 us = 893 TFLOP/s; G 362 -> 170 us
 // (profiles/r03_b_*, r03_o_* ... r03_u_*; DESIGN.md section 3 has the steps).  The first ring form of G (whole-line epilogue with the
 // general tile in the same function: 423 us) lives on in the measurement build.
 #pragma once
@@ -39,7 +39,7 @@ struct Sim5LseEpilogue {
 // counted wait -- measured: 258 against 165 us for this launch).  Tiles at a ragged edge are walked by a second, small launch of
 // simloss3.h's kernel over a tile LIST (Sim5EdgeTiles); batch sizes that are multiples of 256 never need it.
 // Measured at 4096 x 32768 x 512 (profiles/r03_q*_sim_g_variants.log, r03_r_*): 362 -> 292 (two launches, atomics per tile) -> 210
-// (atomic per wave) -> 191 - 197 (diagonal tiles in this kernel too).
+// (atomic per wave) -> 191 - 197 (diagonal tiles in this kernel too) -> 182 (banded tile order) -> 170 (lse loads unconditional and ahead).
 XC_DEV bool sim5_full_tile(const SimParams& p, int m0, int n0) { return (m0 + G2_BM <= p.nq) && (n0 + G2_BN <= p.nk); }
 XC_DEV bool sim5_off_diagonal(const SimParams& p, int m0, int n0) { return m0 + p.diag_off + G2_BM <= n0 || m0 + p.diag_off >= n0 + G2_BN; }
 
