@@ -1,0 +1,54 @@
+"""The hot kernels' gfx950 assembly is held to what tools/isa_scan.py reports today.  Round 3's three largest epilogue stalls were
+invisible in the source (an atomic per tile, scalar parameters re-read as vector loads behind a full drain, branch-guarded loads that
+serialize), and innocuous edits moved `sim5_grad_fast_kernel` from 0 to 102 / 199 / 255 spilled registers three times in one
+session -- this test compiles both translation units to assembly with the build's own flags (hipcc cross-compiles without a GPU) and
+checks the kernels that carry a step."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
+
+# kernel -> (max serialized load + drain pairs, max atomic instructions); every one of them: no spilled vector register, no scratch
+HOT = {
+    "gemm5_kernel<false, true, 0, 0>": (0, 0), "gemm5_kernel<false, false, 0, 0>": (0, 0),      # forward NT / dgrad NN, interior path only
+    "sim5_lse_kernel": (0, 0),                                                                  # no load at all in a tile's epilogue
+    "sim5_grad_fast_kernel<true>": (1, 1), "sim5_grad_fast_kernel<false>": (1, 1),              # one atomic per wave, in finish()
+    "filip5_kernel": (0, 0),
+    "attn3_fwd_kernel<false>": (1, 0), "attn3_bwd_kernel<false>": (5, 0), "attn3_bwd_kernel<true>": (5, 0),
+    "ln_geglu_bwd_kernel<bf16, 2, 2>": (0, 0), "ln_fwd_kernel<bf16, 4, true>": (4, 0), "ln_fwd_kernel<bf16, 1, false>": (2, 0),
+    "ln_bwd_kernel<bf16, 1, false>": (3, 0), "ln_chain_fwd_kernel<bf16, 1>": (2, 0), "ln_chain_bwd_kernel<bf16, 1>": (1, 0),
+    "splitk_reduce_kernel<bf16>": (0, 0),
+}
+# kernels whose ragged-tile path legitimately holds serialized loads (row gathers, residual rows): spills only
+NO_SPILL = ["gemm4_kernel<true, true, 1>", "gemm5_kernel<false, false, 3, 0>", "gemm5_kernel<false, true, 3, 0>", "filip_route_kernel<bf16>"]
+
+
+@pytest.fixture(scope="module")
+def isa():
+    import isa_scan
+    return isa_scan.scan_product()
+
+
+def test_hot_kernels_do_not_spill_or_stall(isa):
+    bad = []
+    for k, (serial, atomics) in HOT.items():
+        assert k in isa, f"{k}: not in the library any more -- update tests/test_isa_guard.py"
+        s = isa[k]
+        if s["vspill"] or s["scratch"]:
+            bad.append(f"{k}: {s['vspill']} spilled vector registers, {s['scratch']} scratch instructions")
+        if s["serial"] > serial:
+            bad.append(f"{k}: {s['serial']} load + full-drain pairs (was {serial})")
+        if s["atomics"] > atomics:
+            bad.append(f"{k}: {s['atomics']} atomic instructions (was {atomics})")
+    for k in NO_SPILL:
+        assert k in isa, f"{k}: not in the library any more -- update tests/test_isa_guard.py"
+        if isa[k]["vspill"] or isa[k]["scratch"]:
+            bad.append(f"{k}: {isa[k]['vspill']} spilled vector registers, {isa[k]['scratch']} scratch instructions")
+    assert not bad, "\n".join(bad)

@@ -42,8 +42,11 @@ def scan_product():
     sys.path.insert(0, ROOT)
     from x_clip_amd.build import UNITS
     out = {}
-    for unit, extra in UNITS:
-        st = scan(assemble(unit, extra))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(len(UNITS)) as ex:                  # the units compile side by side
+        paths = list(ex.map(lambda ue: assemble(*ue), UNITS))
+    for path in paths:
+        st = scan(path)
         names = demangle(list(st))
         for n, v in st.items():
             out[re.sub(r"\(.*$", "", names[n]).replace("void ", "").replace("xc::", "").replace("unsigned short", "bf16")] = v
