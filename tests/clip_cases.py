@@ -147,10 +147,12 @@ REPORT = {}
 
 
 def case_vs_oracle(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, n_aug_image=0, patch_keep=None, seed=7, bf16_cos=0.999,
-                   bf16_rel=0.08, bf16_loss=3e-4, label=None, **extra):
+                   bf16_rel=0.08, bf16_loss=3e-4, label=None, temperature=None, **extra):
     """product vs. the fp64 oracle on the same (dtype-rounded) parameters and inputs; every gradient in full.  bf16: the oracle runs
     in fp64 on the bf16-rounded parameters WITH THE bf16 LayerNorm epsilon (1e-3, x_clip.py:118) -- the model the product computes"""
     sd = O.make_state_dict(cfg, seed, torch.float32)
+    if temperature is not None:                                 # tau (the model multiplies by exp(tau); the reference never clamps it)
+        sd["temperature"] = torch.tensor(float(temperature), dtype=sd["temperature"].dtype)
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     text, image, aug_t, aug_i = O.make_inputs(cfg, batch, seed + 1, n_aug_text, n_aug_image)
     image = image.to(dtype)

@@ -46,6 +46,16 @@ def test_live_rows_vs_oracle(dtype):
     C.case_live_rows(DEV, O.CFG1, 7, [0, 3, 6], dtype, label="cfg1 b=7 (emulator)", bf16_latent_bar=5e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_high_temperature_vs_oracle(dtype):
+    """exp(tau) = 200 -- the reference multiplies by exp(tau) without a clamp (x_clip.py:574,736) and exponentiates without subtracting a
+    maximum (:826), so in fp32 it is at its own limit there; the product's log-sum-exp forms and one-exponential gradient must not be"""
+    import dataclasses
+    loose = dict(bf16_cos=0.97, bf16_rel=0.3, bf16_loss=5e-2)   # (bf16 logits of magnitude 100: the loss bar is absolute)
+    C.case_vs_oracle(DEV, dtype, O.CFG1, 5, temperature=5.3, **loose)
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True, use_all_token_embeds=True), 5, temperature=5.3, **loose)
+
+
 def test_narrow_heads_vs_oracle():
     """dim_head below the kernels' 64 (x_clip.py:201-211 accepts any): heads run zero-padded, the scale stays dim_head^-0.5, and the
     gradients of the real to_qkv / to_out weights come back through the padding; rotary with 32-wide heads rotates the whole head"""
