@@ -330,6 +330,13 @@ inline float wave_max(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
     return v;
 }
+inline void wave_max_min(float& hi, float& lo) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float h2 = shfl_xor(hi, m), l2 = shfl_xor(lo, m);
+        hi = fmaxf(hi, h2);
+        lo = fminf(lo, l2);
+    }
+}
 
 inline f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
     struct Dep { float a[8], b[8]; } mine;                // (converted once per lane, not once per product)

@@ -343,6 +343,43 @@ def case_simloss(dev, dtype, nq, nk, d, dcl, diag_off=0, tau=1.3):
     close(dtau.reshape(1), (Gr * S).sum().reshape(1), dtype, "dtau", scale=float((Gr * S).abs().sum()), mult=2.0)
 
 
+def case_simloss_spread(dev, dtype, nq, nk, d, dcl, diag_off=0, temp=200.0, matched=(0, 1, 2, 3)):
+    """exp(tau) = 200 with a few PERFECTLY matched pairs among unrelated ones -- matched rows / columns have
+    log-sum-exps of ~200, the rest ~10 - 60, so inside one 128 x 64 wave block the lse values spread by more than the ~88 a single
+    reference point of the one-exponential form exp(s - R) exp(R - lse) can bridge in fp32 (0 x inf = NaN in nearly every entry of
+    G with the round-3 kernel).  Forward and G with the REAL row / column log-sum-exps, InfoNCE and DCL (in DCL the positive is not
+    part of its own lse and exceeds it by ~150: exp(s - lse) itself overflows there and must never be formed)."""
+    T = O.l2_normalize(rnd((nq, d), torch.float32, 25)).to(dtype)
+    I = O.l2_normalize(rnd((nk, d), torch.float32, 26)).to(dtype)
+    for r in matched:
+        if 0 <= r + diag_off < nk and r < nq:
+            I[r + diag_off] = T[r]
+            I[(r + diag_off + 7) % nk] = T[r]        # a duplicate of the positive off the diagonal: DCL rows / columns see a logit of `temp` too
+    S = temp * ref64(T) @ ref64(I).t()
+    rows = torch.arange(nq)
+    diag = torch.zeros(nq, nk, dtype=torch.bool)
+    valid = (rows + diag_off < nk) & (rows + diag_off >= 0)
+    diag[rows[valid], (rows + diag_off)[valid]] = True
+    Sm = S.masked_fill(diag, -math.inf) if dcl else S
+    lse_r = torch.logsumexp(Sm, 1)
+    lse_c = torch.logsumexp(Sm, 0)
+    assert float(lse_r.max() - lse_r.min()) > 100.0 and float(lse_c.max() - lse_c.min()) > 100.0      # the case is the case
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    lse, pos = ops.simloss_fwd(T.to(dev), I.to(dev), temp, diag_off, dcl, 0.5, loss)
+    close(lse, lse_r, dtype, "lse (spread)", scale=float(lse_r.abs().max()))
+    a, c, e = 0.5 / nq, 0.5 / nq, 1.0 / nq
+    for aa, cc in ((a, c), (a, 0.0), (0.0, c)):
+        dtau = torch.zeros((), dtype=torch.float32, device=dev)
+        G = ops.simloss_grad(T.to(dev), I.to(dev), temp, diag_off, dcl, aa, cc, e, lse_r.float().to(dev), lse_c.float().to(dev), dtau)
+        off = (~diag).double() if dcl else torch.ones_like(S)
+        lq, lk = lse_r.float().double(), lse_c.float().double()
+        Gr = (aa * (Sm - lq[:, None]).exp() + cc * (Sm - lk[None, :]).exp()) * off - e * diag.double()
+        assert bool(torch.isfinite(G.float()).all()), f"G not finite (a={aa}, c={cc}, dcl={dcl})"
+        close(G[:, :nk], Gr, dtype, "G (spread)", mult=2.0)
+        want = (Gr * S).sum()
+        close(dtau.reshape(1), want.reshape(1), dtype, "dtau (spread)", scale=float((Gr * S).abs().sum()), mult=2.0)
+
+
 def case_simloss_closed_form(dev, dtype, B, d, dcl):
     """full head (two LSE passes + G + two GEMMs) against the numpy closed form of SURVEY Appendix C"""
     T = O.l2_normalize(rnd((B, d), torch.float32, 28)).to(dtype)

@@ -203,6 +203,17 @@ def test_simloss_on_gemm_loop(dcl):
     K.case_simloss_closed_form(DEV, torch.bfloat16, 1032, 512, dcl)
 
 
+@pytest.mark.parametrize("dcl", [False, True], ids=["infonce", "dcl"])
+@pytest.mark.parametrize("nq,nk,d,off", [(256, 256, 64, 0), (264, 392, 64, 100), (512, 1024, 512, 384), (1024, 4096, 512, 2048)])
+def test_simloss_grad_with_spread_lse(nq, nk, d, off, dcl):
+    """exp(tau) = 200 and four perfectly matched pairs: log-sum-exps 150 apart inside one wave block (NaN with the round-3 G)"""
+    K.case_simloss_spread(DEV, torch.bfloat16, nq, nk, d, dcl, diag_off=off)
+    # spread > 300: beyond what ANY single reference point bridges -- the wave blocks with matched rows take the two-exponential form
+    K.case_simloss_spread(DEV, torch.bfloat16, nq, nk, d, dcl, diag_off=off, temp=400.0)
+    if nq <= 264:
+        K.case_simloss_spread(DEV, torch.float32, nq, nk, d, dcl, diag_off=off)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 @pytest.mark.parametrize("rows,cols,diag_off", [(5, 16, 0), (1031, 4104, 512), (4096, 32768, 8192)])
 def test_simreg_diff(dtype, rows, cols, diag_off):

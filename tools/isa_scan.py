@@ -8,7 +8,8 @@ three largest epilogue stalls (none of them visible in the source):
     `filip5_kernel` tile;
   * atomics inside a persistent tile loop (the G kernel's per-tile `atomic_add(dtau)`: 16 k same-address atomics, each older than
     the next tile's first counted wait);
-  * scratch (spill) traffic and the spill counts of the kernel descriptor.
+  * scratch (spill) traffic and the spill counts of the kernel descriptor (`hot_scratch`: the scratch instructions behind the
+    kernel's first MFMA, i.e. in or after its tile loop -- a value parked during a persistent kernel's prologue costs nothing).
 
     python tools/isa_scan.py [--all]        # compiles x_clip_amd/csrc/xclip_api.hip and xclip_attn.hip to assembly under /tmp
 
@@ -60,7 +61,7 @@ def scan(path):
         m = re.match(r"^(_ZN2xc\S+):\s", l)
         if m:
             name = m.group(1)
-            stats[name] = dict(serial=0, loads=0, atomics=0, scratch=0, vspill=0, sspill=0)
+            stats[name] = dict(serial=0, loads=0, atomics=0, scratch=0, hot_scratch=0, vspill=0, sspill=0, _mfma=False)
             continue
         m = re.match(r"\s+\.name:\s+(_ZN2xc\S+)", l)
         if m and m.group(1) in stats:                      # kernel descriptor (metadata at the end of the file)
@@ -83,6 +84,10 @@ def scan(path):
             stats[name]["atomics"] += 1
         elif t.startswith("scratch_"):
             stats[name]["scratch"] += 1
+            if stats[name]["_mfma"]:                           # behind the kernel's first MFMA: inside (or after) its tile loop, not in its prologue
+                stats[name]["hot_scratch"] += 1
+        elif t.startswith("v_mfma"):
+            stats[name]["_mfma"] = True
     return stats
 
 

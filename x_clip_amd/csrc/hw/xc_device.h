@@ -90,6 +90,16 @@ XC_DEV float wave_max(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
     return v;
 }
+// hi <- max over the wave of hi, lo <- min over the wave of lo (both wave-uniform afterwards; the two butterfly chains are independent,
+// so their cross-lane latencies overlap)
+XC_DEV void wave_max_min(float& hi, float& lo) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float h2 = __shfl_xor(hi, m, 64), l2 = __shfl_xor(lo, m, 64);
+        hi = fmaxf(hi, h2);
+        lo = fminf(lo, l2);
+    }
+}
 
 // ---- matrix cores ---------------------------------------------------------------------------------
 // D = A*B + C, one wave.  32x32x16 bf16: lane l supplies A[i = l&31][k = 8*(l>>5) + 0..7] and

@@ -226,6 +226,11 @@ struct G5Iter {                                               // one operand's D
 // (an epilogue whose with_scratch may return 8 -- that many small stores left in flight -- says so with `static constexpr bool LOOSE8`)
 template <class E, class = void> struct g5_loose8 { static constexpr bool value = false; };
 template <class E> struct g5_loose8<E, decltype((void)E::LOOSE8)> { static constexpr bool value = E::LOOSE8; };
+// (an epilogue that needs the 24 registers the loop otherwise keeps live across a tile boundary -- the first fragments of the NEXT tile, read
+//  under the last k-block's MFMAs -- says so with `static constexpr bool DEFER_FRAGS`: those fragments are then read after the epilogue,
+//  at the price of one exposed LDS round trip per tile)
+template <class E, class = void> struct g5_defer_frags { static constexpr bool value = false; };
+template <class E> struct g5_defer_frags<E, decltype((void)E::DEFER_FRAGS)> { static constexpr bool value = E::DEFER_FRAGS; };
 
 template <bool A_KMAJOR, bool B_KMAJOR, class Epilogue, int ABL = 0>
 XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
@@ -370,7 +375,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                         else XC_WAIT_VMEM_LE(4);
                     }
                     if (!(ABL & 16)) barrier_nodrain();          // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more
-                    if (!(ABL & 8))
+                    if (!(ABL & 8) && !(g5_defer_frags<Epilogue>::value && t == nt - 1))
                     g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA + sa_next * G2_OPER_BYTES, ldsB + ((step + 1) & 1) * G2_OPER_BYTES, wm * 128, wn * 64,
                                                       0, lane, a[nxt], b[nxt]);
                 }
@@ -410,7 +415,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 if (kk == 0 && !early) next_a();
                 if (kk == 3) next_b();
                 sched_fence();
-                lds_wait<0>(a[nxt], b[nxt]);
+                if (!(g5_defer_frags<Epilogue>::value && kk == 3 && t == nt - 1)) lds_wait<0>(a[nxt], b[nxt]);
                 sched_fence();
             }
             sa3 = sa_next;
@@ -442,6 +447,10 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             // (residual / slab tiles take the same 4 KiB slice for their whole-line forms; ragged tiles and the general terms ignore it)
             in_flight = epi.with_scratch(acc, m0, n0, ldsA + (sa3 == 0 ? 2 : sa3 - 1) * G2_OPER_BYTES + mine);
             a_early = false;
+        }
+        if (g5_defer_frags<Epilogue>::value) {                  // the next tile's first fragments (after the work-group's last tile: never used)
+            g3_read_frags<A_KMAJOR, B_KMAJOR>(ldsA + sa3 * G2_OPER_BYTES, ldsB + (step & 1) * G2_OPER_BYTES, wm * 128, wn * 64, 0, lane, a[0], b[0]);
+            lds_wait<0>(a[0], b[0]);
         }
     }
     XC_WAIT_VMEM_LE(0);                                       // trailing (redundant) pieces must land before the LDS is released

@@ -51,6 +51,10 @@ struct Sim5FastGradEpilogue {
     const Gemm2Params& gp;       // C = G, ldc = ldg, alpha = 1: what the line stores address
     float scale, gmul;           // sim_scale(p) and *p.gmul (or 1), read once per work-group
     float dt_acc = 0.f;          // this lane's share of sum G o acc over the work-group's tiles (one register across the K loops)
+    // the epilogue works on all 128 accumulators at once beside ~50 registers of its own: it takes the 24 the loop would hold for the next
+    // tile's first fragments (gemm4.h g5_defer_frags) -- without them every further term of the arithmetic tipped the kernel into
+    // 30 - 250 spilled registers (tests/test_isa_guard.py)
+    static constexpr bool DEFER_FRAGS = true;
     XC_DEV void finish() {
         const float dt = wave_sum(dt_acc) * (scale / (p.g_times_scale ? scale : 1.0f));
         if ((threadIdx.x & 63) == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
@@ -83,10 +87,18 @@ struct Sim5FastGradEpilogue {
     }
     // The accumulators of a full tile become G in place.  Per logit: G = exp(s - R) (a' + c') with s = acc * scale,
     // a' = gs a exp(R - lse_q), c' = gs c exp(R - lse_k) -- ONE exponential per logit, in the base-2 domain: one fma + a bare v_exp_f32;
-    // then an add, a multiply, and an fma for sum G o acc (d tau = that sum x scale / gs, applied once per wave).  The reference point R
-    // is a log-sum-exp of the tile itself (its first row's, or its first column's when a = 0): the three exponents then stay within
-    // the spread of the tile's lse values.  (R = scale -- valid since |cos| <= 1 -- was the first choice and is wrong at high
-    // temperatures: with scale = 200 and small cosines exp(scale - lse) overflows and exp(s - scale) flushes to zero.)  A tile that holds a piece of the positive diagonal (uniform test; O(tiles_m) tiles) corrects that logit per column
+    // then an add, an fma, and an fma for sum G o acc (d tau = that sum x scale / gs, applied once per wave).
+    // The reference point R is the midpoint of the wave block's lse values (its 128 rows' when a != 0, its 64 columns' when c != 0; one
+    // interleaved max / min butterfly per tile): exp(R - lse) and exp(s - R) then stay inside fp32 as long as those values lie within
+    // ~120 of each other.  (History: R = scale -- valid since |cos| <= 1 -- overflowed exp(scale - lse) at exp(tau) = 200 with small
+    // cosines; R = the block's first row's lse failed as soon as the lse values themselves spread: exp(tau) = 200 with a few perfectly
+    // matched pairs among unrelated ones puts matched rows at ~200 and the others at ~40, and 0 x inf = NaN filled 65519 of 65536
+    // entries of the ADVICE r3 reproducer.)  When the spread is larger than that -- no single reference point can bridge it -- the
+    // SAME loop nest runs its exact form (`exact`, wave-uniform): G = gs a exp(s - lse_q) + gs c exp(s - lse_k), two exponentials per
+    // logit, as the other side of a branch around each row's four logits of a column quad, the per-row / per-column registers holding
+    // the lse values themselves instead of the factors.  (As a second copy of the loop nest -- to_g<EXACT> -- the kernel spilled 59
+    // registers; with the exact form's terms in registers of their own beside the fast form's, 46.)
+    // A tile that holds a piece of the positive diagonal (uniform test; O(tiles_m) tiles) corrects that logit per column
     // quad, in two small blocks around the quad's arithmetic: G = (dcl ? 0 : the above) - gs e.  (As a second copy of the whole loop for
     // those tiles the function spilled 255 registers; as a per-logit select in the one loop it would tax every tile.)
     XC_DEV void to_g(f32x16 (&acc)[4][2], int m0, int n0) {
@@ -96,25 +108,43 @@ struct Sim5FastGradEpilogue {
         const float a = p.a * gm_, c = p.c * gm_;
         const float gs = p.g_times_scale ? scale : 1.0f;
         const float egs = p.e * gm_ * gs, keep = p.dcl ? 0.f : 1.f;
-        // Every load of the tile is unconditional and requested ahead of its use -- both candidates for R, the four row lse values, then
-        // the column quads one quad ahead of the arithmetic.  Written as `a != 0 ? ... lse_q[gm] : 0` each of them was a branch with
-        // its own load and full drain of the memory counter: 12 serialized round trips per tile (tools/isa_scan.py).
-        const float Rq = p.lse_q[m0 + wm * 128], Rk = p.lse_k[n0 + wn * 64];
+        constexpr float LOG2E = 1.4426950408889634f;
+        // Every load of the tile is unconditional and requested ahead of its use -- the four row lse values, the wave block's 64
+        // column values (one per lane, for the spread), then the column quads one quad ahead of the arithmetic.  Written as
+        // `a != 0 ? ... lse_q[gm] : 0` each of them was a branch with its own load and full drain of the memory counter: 12 serialized
+        // round trips per tile (tools/isa_scan.py).
         const float* const kcol = p.lse_k + n0 + wn * 64 + 4 * h;
         float lq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) lq[i] = p.lse_q[m0 + wm * 128 + i * 32 + (lane & 31)];
+        const float lk1 = p.lse_k[n0 + wn * 64 + lane];
         u32x4 t = ld16(kcol);
-        const float R = (a != 0.f) ? Rq : Rk;                        // (uniform)
-        const float scale2 = scale * 1.4426950408889634f, R2 = R * 1.4426950408889634f;
+        float hi = -3.0e38f, lo = 3.0e38f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hi = (a != 0.f) ? fmaxf(hi, lq[i]) : hi;
+            lo = (a != 0.f) ? fminf(lo, lq[i]) : lo;
+        }
+        hi = (c != 0.f) ? fmaxf(hi, lk1) : hi;
+        lo = (c != 0.f) ? fminf(lo, lk1) : lo;
+        wave_max_min(hi, lo);
+        // (wave-uniform by construction; gfx950 has no scalar float arithmetic, so every derived value is brought back into an SGPR by hand)
+        auto sgpr = [](float v) { return u2f((uint32_t)uniform((int)f2u(v))); };
+        const bool exact = uniform((hi - lo) > 120.f ? 1 : 0) != 0;
+        const float R = sgpr(0.5f * (hi + lo));
+        const float scale2 = sgpr(scale * LOG2E), R2 = sgpr(R * LOG2E);
+        const float cx = sgpr((c != 0.f) ? gs * c : 0.f);
         const bool on_diag = !sim5_off_diagonal(p, m0, n0);          // (uniform)
         float dt = 0.f;
-        float eq[4];                                                 // gs a exp(R - lse_q) of the lane's row in each 32-row group
+        const float ax = sgpr((a != 0.f) ? gs * a : 0.f);
+        float rowv[4];                                               // the row's factor gs a exp(R - lse_q) -- exact form: its reference point lse_q, base 2
         int dl[4];                                                   // the row's diagonal column, relative to the lane's first column
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
-            eq[i] = (a != 0.f) ? gs * a * fast_exp(R - lq[i]) : 0.f;
+            const float f = (a != 0.f) ? ax * fast_exp(R - lq[i]) : 0.f;
+            // (a = 0 in the exact form: exp2(-huge) = 0, not 0 x exp2(junk))
+            rowv[i] = exact ? ((a != 0.f) ? lq[i] * LOG2E : 3.0e38f) : f;
             dl[i] = gm + p.diag_off - (n0 + wn * 64 + 4 * h);
         }
 #pragma unroll
@@ -123,25 +153,47 @@ struct Sim5FastGradEpilogue {
             for (int q = 0; q < 4; ++q) {
                 u32x4 tn = t;
                 if (j * 4 + q < 7) tn = ld16(kcol + (j * 4 + q + 1 < 4 ? 0 : 32) + 8 * ((j * 4 + q + 1) & 3));   // the next quad's four lse_k
-                float ek[4];                                         // gs c exp(R - lse_k) of the quad's four columns
+                float ek[4];                                         // gs c exp(R - lse_k) of the quad's four columns -- exact form: lse_k, base 2
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ek[k] = (c != 0.f) ? gs * c * fast_exp(R - u2f(t[k])) : 0.f;
+                for (int k = 0; k < 4; ++k) {
+                    const float lk = u2f(t[k]);
+                    const float f = (c != 0.f) ? cx * fast_exp(R - lk) : 0.f;
+                    ek[k] = exact ? ((c != 0.f) ? lk * LOG2E : 3.0e38f) : f;
+                }
                 float rawd[4] = {0.f, 0.f, 0.f, 0.f};                // the row's positive logit (unscaled), if it lies in this quad
                 if (on_diag) {
+                    // (DCL: the positive is not part of its row's / column's lse and may exceed it by any amount -- as exp(s - lse) it
+                    //  would be inf, and inf x 0 = NaN below: the logit leaves through the loop as exp2(-huge) = 0 instead)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) rawd[i] = (dl[i] == j * 32 + 8 * q + k) ? acc[i][j][4 * q + k] : rawd[i];
+                        for (int k = 0; k < 4; ++k) {
+                            const bool sel = dl[i] == j * 32 + 8 * q + k;
+                            rawd[i] = sel ? acc[i][j][4 * q + k] : rawd[i];
+                            if (p.dcl) acc[i][j][4 * q + k] = sel ? -1.0e30f : acc[i][j][4 * q + k];
+                        }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    if (exact) {                                     // (uniform; rare) two exponentials per logit, each with its own lse
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float raw = acc[i][j][4 * q + k];
-                        const float g = fast_exp2(raw * scale2 - R2) * (eq[i] + ek[k]);
-                        dt += g * raw;
-                        acc[i][j][4 * q + k] = g;
+                        for (int k = 0; k < 4; ++k) {
+                            const float raw = acc[i][j][4 * q + k];
+                            const float s2 = raw * scale2;
+                            const float g = ax * fast_exp2(s2 - rowv[i]) + cx * fast_exp2(s2 - ek[k]);
+                            dt += g * raw;
+                            acc[i][j][4 * q + k] = g;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float raw = acc[i][j][4 * q + k];
+                            const float g = fast_exp2(raw * scale2 - R2) * (rowv[i] + ek[k]);
+                            dt += g * raw;
+                            acc[i][j][4 * q + k] = g;
+                        }
                     }
+                }
                 if (on_diag) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -158,6 +210,7 @@ struct Sim5FastGradEpilogue {
                     }
                 }
                 t = tn;
+                sched_fence();
             }
         dt_acc += dt;
     }
