@@ -26,6 +26,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_BF16 = 2.5e15            # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+HBM_PEAK = 8.0e12                  # HBM3E peak bytes/s, same table
+
+
+def gpu_telemetry(index=0):
+    """what the driver exposes about the device's state without a tool: the active shader-clock level, socket power and temperature
+    from sysfs (amdgpu: pp_dpm_sclk, hwmon power1_average / temp*_input).  Every field is None where the file is absent."""
+    import glob
+    out = {"sclk_mhz": None, "power_w": None, "temp_c": None}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if cards:
+            base = os.path.dirname(cards[min(index, len(cards) - 1)])
+            for line in open(os.path.join(base, "pp_dpm_sclk")).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    out["sclk_mhz"] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()) or 0)
+            for hw in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+                for name, key, div in (("power1_average", "power_w", 1e6), ("power1_input", "power_w", 1e6), ("temp1_input", "temp_c", 1e3)):
+                    f = os.path.join(hw, name)
+                    if out[key] is None and os.path.exists(f):
+                        out[key] = round(int(open(f).read().strip()) / div, 1)
+    except Exception:                                                # noqa: BLE001  (diagnostics only)
+        pass
+    return out
 
 
 def model_flops_per_pair(model, n_text_tokens, n_img_tokens, n_patches_embedded):
@@ -220,15 +243,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    probe = None if args.no_probe else ops.GemmProbe()
+    probe = None if args.no_probe else ops.KernelProbe(clock_every=16)
     fence()
+    tele0 = gpu_telemetry(local_rank)
     ms0 = torch.cuda.memory_stats(dev)
+    # one event per step boundary on the main stream (every side stream of a step is joined back before its loss.backward() returns):
+    # the per-step spread of the timed region, so that one slow step, a slow box and a slow kernel can be told apart from the line
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     fence()
     ms1 = torch.cuda.memory_stats(dev)
     elapsed = time.perf_counter() - t0
+    tele1 = gpu_telemetry(local_rank)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -263,6 +294,10 @@ def main():
                    "gflop_per_pair_fwd_bwd": round(3 * fwd_flops / 1e9, 3)},
         "model_mfma_frac": round(value * 3 * fwd_flops / (world * MFMA_PEAK_BF16), 4),
         "loss": round(loss_val, 5),
+        # GPU time between consecutive step boundaries of the timed region (events on the main stream, this rank) and the device state
+        # sysfs reports right before / right after it; the shader clock sustained UNDER the load is `clock_mhz` (probe pass, below)
+        "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)},
+        "device_state": {"before": tele0, "after": tele1},
         # hipMalloc calls inside the timed region (0 once the caching allocator is warm) and the peak footprint
         "allocator": {"device_mallocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
                       "peak_reserved_gb": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 2)},
@@ -276,11 +311,14 @@ def main():
         set_overlap(False)
         step()
         fence()
+        tp = time.perf_counter()
         with probe:
             for _ in range(args.steps):
                 step()
         fence()
-        launches, flops, secs = probe.summary()
+        probe_elapsed = time.perf_counter() - tp
+        launches, flops, secs = probe.summary("gemm")
+        gemm_bytes = probe.algorithmic_bytes
         if os.environ.get("XCLIP_BENCH_GEMM_SHAPES") == "1":      # per-shape table of the probe pass, to stderr
             for (M, N, K, lay, res), (cnt, ms) in sorted(probe.by_shape().items(), key=lambda kv: -kv[1][1]):
                 print(f"  gemm {lay} M={M:7d} N={N:5d} K={K:7d}{' +res' if res else '     '}  x{cnt // max(args.steps, 1):3d}/step  "
@@ -302,11 +340,35 @@ def main():
                            "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4), "traffic": traffic,
                            "traffic_note": (f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes of this command ({traffic_src})"
                                             if traffic is not None else f"null: no committed PMC passes for this workload ({workload_tag}) and kernel generation"),
-                           "algorithmic_bytes_per_launch": round(probe.algorithmic_bytes / max(launches, 1)),
+                           "algorithmic_bytes_per_launch": round(gemm_bytes / max(launches, 1)),
                            "launches_per_step": launches // max(args.steps, 1),
                            "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
                            "measured": "HIP events around every xclip_gemm launch on its own stream, K steps on a single stream "
                                        "(kernels alone on the chip) right after the timed region"}
+        # the other two kernel families of the step, measured the same way in the same pass: attention against the MFMA peak (algorithmic
+        # 4 n^2 d per head forward, twice that backward) and its HBM floor; the LayerNorm family (LayerNorm, GEGLU-LayerNorm, the chained
+        # pair; forward and backward) against the HBM peak with its algorithmic bytes (every operand read once, every result written once)
+        fam = {"gemm": {"ms_per_step": round(secs / max(args.steps, 1) * 1e3, 3), "launches_per_step": launches // max(args.steps, 1)}}
+        n_at, f_at, s_at = probe.summary("attention")
+        b_at = probe.algorithmic_bytes
+        if n_at:
+            fam["attention"] = {"bound": "mfma", "achieved": round(f_at / s_at / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                                "frac": round(f_at / s_at / MFMA_PEAK_BF16, 4), "hbm_frac": round(b_at / s_at / HBM_PEAK, 4),
+                                "ms_per_step": round(s_at / max(args.steps, 1) * 1e3, 3), "launches_per_step": n_at // max(args.steps, 1)}
+        n_ln, _, s_ln = probe.summary("layernorm")
+        b_ln = probe.algorithmic_bytes
+        if n_ln:
+            fam["layernorm"] = {"bound": "hbm", "achieved": round(b_ln / s_ln / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                "frac": round(b_ln / s_ln / HBM_PEAK, 4), "algorithmic_gb_per_step": round(b_ln / max(args.steps, 1) / 1e9, 3),
+                                "ms_per_step": round(s_ln / max(args.steps, 1) * 1e3, 3), "launches_per_step": n_ln // max(args.steps, 1)}
+        out["roofline"]["families"] = fam
+        out["roofline"]["families_ms_per_step"] = round(sum(v["ms_per_step"] for v in fam.values()), 3)
+        out["roofline"]["probe_pass_ms_per_step"] = round(probe_elapsed / max(args.steps, 1) * 1e3, 3)
+        clk = probe.clock_mhz()
+        # shader cycles per 10 ns tick, sampled by a one-wave kernel queued after every 16th probed launch of the probe pass
+        out["clock_mhz"] = ({"min": round(clk[0]), "median": round(clk[len(clk) // 2]), "max": round(clk[-1]), "samples": len(clk),
+                             "measured": "xclip_clock_sample (s_memtime over 10 us of s_memrealtime) between the kernels of the probe pass"}
+                            if clk else None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

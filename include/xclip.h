@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 15
+#define XCLIP_ABI_VERSION 16
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -28,6 +28,10 @@ const char* xclip_last_error(void);
  * buffer stores (csrc/hw/xc_device.h buf_st16) were validated with ROCm 7.2's code generation: after a toolchain change re-run the GPU
  * gate tests (tests/test_kernels_gpu.py::test_gemm_full_size_every_element_and_repeatable, test_gemm_layouts, test_gemm_residual_epilogue). */
 const char* xclip_build_info(void);
+/* Diagnostics, not on the training path (no reference counterpart): one wave counts shader cycles against the constant 100 MHz counter for
+ * `ticks_10ns` ticks and writes out2[0] = shader cycles, out2[1] = ticks elapsed (device memory, two uint64).  Launched between the
+ * kernels of a step it reads the clock the part sustains under that load; bench.py puts it into its JSON line beside the step times. */
+int xclip_clock_sample(uint64_t* out2, int64_t ticks_10ns, void* stream);
 
 /* ---- LayerNorm family (reference LayerNorm x_clip.py:112-121; GEGLU x_clip.py:180-183) -----------------------
  * y[r,:] = (v - mean) * rstd * g (+ res[r,:]),  v = x[r,:dim]               (geglu = 0, ldx >= dim)

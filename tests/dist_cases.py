@@ -87,8 +87,11 @@ def worker_fixture(rank, world, port, name, sizes, tmp, kind="cpu"):
     dist.destroy_process_group()
 
 
-def worker_even(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", dtype_name="float32", patch_keep=None):
-    dev = setup(rank, world, port, kind)
+def worker_even(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", dtype_name="float32", patch_keep=None, backend="gloo", steps=1,
+                force_gather=False, reduce_dtype_name=None, second_sink=False):
+    """backend="nccl" with world = 1: RCCL itself on the one GPU of the box -- its collectives run on the process group's own stream and
+    Work.wait() has real stream semantics (force_gather: CLIP latches requires_all_gather only for world > 1, x_clip.py:591)"""
+    dev = setup(rank, world, port, kind, backend)
     from x_clip_amd import CLIP
     from x_clip_amd.distributed import GradSync
     from oracle import clip_oracle as O
@@ -107,12 +110,59 @@ def worker_even(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", dtype_nam
         keep = torch.randn(batch * world * 2, cfg.num_patches, generator=g).topk(patch_keep, dim=-1).indices
         # rows of this rank's images: the main view, then the augmented views in the order CLIP.forward concatenates them
         model.visual_transformer.keep_indices_override = keep[sl].to(torch.int32).to(dev)
-    sync = GradSync(model)
-    loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, aug_text=[aug_t[0][sl].to(dev)])
-    loss.backward()
-    sync.finish()
+    if force_gather:
+        model.requires_all_gather = True
+    other = None
+    if second_sink:                                           # a second GradSync (another model) must not displace the first
+        other = GradSync(torch.nn.Linear(8, 8).to(dev))
+    sync = GradSync(model, reduce_dtype=getattr(torch, reduce_dtype_name) if reduce_dtype_name else None)
+    if second_sink:
+        other2 = GradSync(torch.nn.Linear(8, 8).to(dev))      # ... whichever was registered last
+    for step in range(steps):                                 # steps > 1: the later steps launch buckets from the hooks, in the frozen order
+        model.zero_grad(set_to_none=True)
+        loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, aug_text=[aug_t[0][sl].to(dev)])
+        loss.backward()
+        sync.finish()
+        if reduce_dtype_name is None:
+            assert sync.stats["in_place"] >= 4 * (cfg.text_enc_depth + cfg.visual_enc_depth), sync.stats     # the weight-gradient GEMMs wrote into the bucket slices
+        if step > 0:
+            assert sync._agreed and all(e is not None for e in sync._expected)
     if kind == "cuda":
         torch.cuda.synchronize()
+    grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    for p in model.parameters():
+        assert p.grad is None or p.grad.dtype == p.dtype
+    torch.save({"loss": float(loss.detach()), "grads": grads, "overlap": sync.overlap}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def worker_disagreeing_ranks(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu"):
+    """rank 1 freezes its text tower (fewer hook firings than rank 0 -- what a data-dependent side loss skipped on one rank looks like):
+    the first step's agreement check must turn the overlap off on BOTH ranks; every bucket is then reduced in finish(), in index order"""
+    import warnings
+    dev = setup(rank, world, port, kind)
+    from x_clip_amd import CLIP
+    from x_clip_amd.distributed import GradSync
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig(**cfg_kwargs)
+    sd = O.make_state_dict(cfg, 5, torch.float32)
+    text, image, aug_t, _ = O.make_inputs(cfg, batch * world, 6, 1, 0)
+    sl = slice(rank * batch, (rank + 1) * batch)
+    model = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    model.assume_equal_batch = True
+    sync = GradSync(model)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for step in range(3):
+            model.zero_grad(set_to_none=True)
+            loss = model(text[sl].to(dev), image[sl].float().to(dev), return_loss=True, aug_text=[aug_t[0][sl].to(dev)],
+                         freeze_text_encoder=(rank == 1))
+            loss.backward()
+            sync.finish()
+    assert sync._agreed and sync.overlap is False, (sync._agreed, sync.overlap, sync._expected, rank)
+    assert any("walked their towers differently" in str(w.message) for w in caught)
     grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
     torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.destroy_process_group()
@@ -219,7 +269,7 @@ def check_fixture(tmp, name, world=2):
         assert abs(float(tot) - ref_norm) <= 5e-4 * ref_norm + 1e-7, (k, float(tot), ref_norm)
 
 
-def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, rel_bar=3e-4, loss_bar=1e-5, cos_bar=None):
+def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, rel_bar=3e-4, loss_bar=1e-5, cos_bar=None, measured=None, only_prefix=None):
     from oracle import clip_oracle as O
     outs = [torch.load(os.path.join(tmp, f"rank{r}.pt"), weights_only=False) for r in range(world)]
     sd = O.make_state_dict(cfg, 5, torch.float32)
@@ -235,8 +285,12 @@ def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, r
     for o in outs:
         assert abs(o["loss"] - float(ref.detach())) < loss_bar * max(1.0, abs(float(ref.detach()))), (o["loss"], float(ref.detach()))
     worst = (0.0, "")
+    worst_cos = (2.0, "")
+    failures = []
     for k, v in sd.items():
         if not torch.is_tensor(v) or not v.is_floating_point() or v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        if only_prefix is not None and not k.startswith(tuple(only_prefix)):
             continue
         # temperature: every rank computes the full d tau (like the reference), so its mean is the full gradient
         want = v.grad if k == "temperature" else v.grad / world
@@ -244,10 +298,20 @@ def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, r
             g = o["grads"][k].double()
             rel = float((g - want).norm() / want.norm().clamp_min(1e-30))
             worst = max(worst, (rel, k))
-            assert rel < rel_bar, (k, rel)
-            if cos_bar is not None:
-                cos = float((g * want).sum() / (g.norm() * want.norm()))
-                assert cos > cos_bar, (k, cos)
+            cos = float((g * want).sum() / (g.norm() * want.norm()))
+            worst_cos = min(worst_cos, (cos, k))
+            if not rel < rel_bar:
+                failures.append((k, "rel", rel))
+            if cos_bar is not None and not cos > cos_bar:
+                failures.append((k, "cos", cos))
+    if measured is not None:
+        measured.update(worst_rel=worst[0], worst_rel_param=worst[1], worst_cos=worst_cos[0], worst_cos_param=worst_cos[1], world=world)
+    assert not failures, failures[:6]
+    for k, v in sd.items():
+        if not torch.is_tensor(v) or not v.is_floating_point() or v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        if only_prefix is not None and not k.startswith(tuple(only_prefix)):
+            continue
         for o in outs[1:]:
             assert torch.equal(outs[0]["grads"][k], o["grads"][k]), k       # the all-reduced gradients are the same bits on every rank
     return worst

@@ -114,3 +114,37 @@ def test_gradsync_tower_walked_twice_per_step(tmp_path):
     port = D.free_port()
     mp.spawn(D.worker_ragged, args=(2, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", 0, 0, True, "float32", False, 2), nprocs=2, join=True)
     D.check_ragged(str(tmp_path), cfg, sizes, gradsync=True)
+
+
+def test_gradsync_fp32_wire_under_bf16_parameters_and_two_sinks(tmp_path):
+    """GradSync(reduce_dtype=float32) on a bf16 model: bf16 gradients are cast into fp32 slices, summed in fp32, and come back into `.grad`
+    in the parameters' dtype; three steps (the later ones launch from the hooks).  Two more GradSync objects of other modules are alive in
+    the same process: the grad sinks are a list, none displaces another"""
+    from oracle import clip_oracle as O
+    import torch
+    cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True)
+    port = D.free_port()
+    mp.spawn(D.worker_even, args=(2, port, dataclasses.asdict(cfg), 4, str(tmp_path), "cpu", "bfloat16", None, "gloo", 3, False, "float32", True),
+             nprocs=2, join=True)
+    D.check_even(str(tmp_path), cfg, 4, 2, dtype=torch.bfloat16, rel_bar=0.2, loss_bar=2e-3, cos_bar=0.98)
+
+
+def test_gradsync_in_place_with_two_sinks(tmp_path):
+    """same wire dtype as the parameters (fp32): every weight-gradient GEMM still writes into its bucket slice with two other sinks alive"""
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True, extra_latent_projection=True)
+    port = D.free_port()
+    mp.spawn(D.worker_even, args=(2, port, dataclasses.asdict(cfg), 8, str(tmp_path), "cpu", "float32", None, "gloo", 3, False, None, True), nprocs=2, join=True)
+    D.check_even(str(tmp_path), cfg, 8, 2)
+
+
+def test_gradsync_ranks_that_disagree_fall_back_together(tmp_path):
+    """if the ranks walk their towers differently (here: rank 1 freezes its text tower), launching buckets from the hooks pairs flat buffers of
+    different buckets (NCCL: a hang or silent corruption).  The first step's counts and completion order are compared across the ranks;
+    on disagreement every rank turns the overlap off and reduces in finish(), in index order -- the gradients stay right"""
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True)
+    port = D.free_port()
+    mp.spawn(D.worker_disagreeing_ranks, args=(2, port, dataclasses.asdict(cfg), 4, str(tmp_path)), nprocs=2, join=True)
+    # (rank 1's frozen text tower contributed zeros: the vision side of the model is what both ranks differentiated)
+    D.check_even(str(tmp_path), cfg, 4, 2, only_prefix=("visual_transformer.", "to_visual_latent", "temperature"))

@@ -91,6 +91,49 @@ def test_four_ranks_on_gpu_mid_bf16_gradsync(tmp_path):
     print("worst gradient relative error (4 ranks, bf16):", worst)
 
 
+MID = dict(dim_text=512, dim_image=512, dim_latent=512, num_text_tokens=2000, text_enc_depth=2, text_seq_len=70, text_heads=8,
+           visual_enc_depth=2, visual_image_size=128, visual_patch_size=32, visual_heads=8, decoupled_contrastive_learning=True)
+
+
+def test_rccl_world_size_one_head_and_gradsync(tmp_path):
+    """RCCL ITSELF on the one GPU of the box: a world-size-1 `nccl` process group, the rank-sharded head forced on
+    (all-gather of the latents, log-sum-exp gather, scalar all-reduces) and GradSync(overlap=True) over persistent buckets -- bf16, dim 512,
+    vision tower and weight gradients on their side streams, three steps (the later ones launch buckets from the hooks).  With one rank the
+    collectives are copies, but they run on RCCL's own stream, `Work.wait()` has real stream semantics, and every event edge GradSync /
+    GatheredViews record is exercised against the backend they were written for; NaN-poisoned allocations make a missing edge visible.
+    Result = the fp64 oracle's single-process loss and gradients (the single-process bf16 bars)."""
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig(**MID)
+    port = D.free_port()
+    mp.spawn(D.worker_even, args=(1, port, dataclasses.asdict(cfg), 16, str(tmp_path), "cuda", "bfloat16", 8, "nccl", 3, True), nprocs=1, join=True)
+    worst = D.check_even(str(tmp_path), cfg, 16, 1, dtype=torch.bfloat16, patch_keep=8, rel_bar=0.08, loss_bar=3e-4, cos_bar=0.999)
+    print("worst gradient relative error (world-size-1 nccl, bf16):", worst)
+
+
+@pytest.mark.parametrize("wire", [None, "float32"], ids=["bf16-wire", "fp32-wire"])
+def test_eight_ranks_on_gpu_mid_bf16_gradsync_wire_dtype(tmp_path, wire):
+    """the dim-512 bf16 model on EIGHT ranks: what the bucket all-reduce costs in accuracy when the wire is
+    bf16 (the running sum is rounded at every hop) against GradSync(reduce_dtype=float32).  The measured worst gradient error and cosine
+    of both go into gpurun_out/gradsync_wire_dtype.json; the bars are those of the 4-rank test for bf16 and the 2-rank ones for fp32."""
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig(**MID)
+    port = D.free_port()
+    mp.spawn(D.worker_even, args=(8, port, dataclasses.asdict(cfg), 4, str(tmp_path), "cuda", "bfloat16", 8, "gloo", 2, False, wire), nprocs=8, join=True)
+    bars = dict(rel_bar=0.08, loss_bar=3e-4, cos_bar=0.999) if wire else dict(rel_bar=0.12, loss_bar=3e-4, cos_bar=0.99)
+    measured = {}
+    try:
+        worst = D.check_even(str(tmp_path), cfg, 4, 8, dtype=torch.bfloat16, patch_keep=8, measured=measured, **bars)
+    finally:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "gradsync_wire_dtype.json")
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[wire or "bfloat16"] = measured
+        with open(path, "w") as f:
+            json.dump(rec, f, indent=1)
+    print("worst gradient relative error (8 ranks, bf16 model, wire", wire or "bfloat16", "):", worst)
+
+
 def test_rccl_two_ranks_one_device_probe(tmp_path):
     """RCCL (`nccl` backend) with both ranks on cuda:0: recorded, not required -- the single-GPU box cannot give each rank its own
     device; the driver's multi-GPU scaling run is where RCCL itself executes"""

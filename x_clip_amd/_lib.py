@@ -26,6 +26,7 @@ _SIGNATURES = {
     "xclip_abi_version": (c_int, []),
     "xclip_last_error": (c_char_p, []),
     "xclip_build_info": (c_char_p, []),
+    "xclip_clock_sample": (c_int, [P, L, P]),
     "xclip_layernorm_fwd": (c_int, [P, L, P, P, P, L, L, P, P, L, L, F, I, I, P]),
     "xclip_layernorm_bwd_workspace_bytes": (c_int64, [L, L]),
     "xclip_layernorm_bwd": (c_int, [P, P, L, P, P, P, P, P, L, P, P, L, L, L, I, I, P]),
@@ -77,7 +78,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 def _bind(path: str):

@@ -459,6 +459,13 @@ class CLIP(nn.Module):
         bs = b // k
         on_gpu = dev.type == "cuda"                              # (CPU = the test build: the slices simply run one after the other)
         main = torch.cuda.current_stream(dev) if on_gpu else None
+        # narrow heads in a no-grad pass reuse padded copies of the projection weights (Transformer._pad_cache): they are built HERE, on
+        # the main stream and in front of the fork event, so that a side-stream slice that hits the cache never reads them before the
+        # padding kernels have run (the cache is filled by whichever slice calls stack_params first -- slice 0, after the fork)
+        tt = getattr(self.text_transformer, "transformer", None)
+        if on_gpu and tt is not None and hasattr(tt, "stack_params") and not (torch.is_grad_enabled() and not freeze):
+            with torch.no_grad():
+                tt.stack_params()
         # the fork point: everything the inputs depend on has been issued to `main` by now.  Recorded BEFORE slice 0 is issued, so the
         # side streams wait for the inputs only -- not for slice 0's kernels (a wait_stream(main) after slice 0 had been issued put every
         # later slice behind the whole of slice 0 and serialised the forward)

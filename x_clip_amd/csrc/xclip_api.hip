@@ -582,6 +582,12 @@ int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale,
     return check_launch(__func__);
 }
 
+int xclip_clock_sample(uint64_t* out2, int64_t ticks_10ns, void* stream) {
+    XC_REQUIRE(out2 != nullptr && ticks_10ns > 0 && ticks_10ns <= 100000, "out2 must hold two uint64; 0 < ticks <= 100000 (1 ms)");
+    hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out2, (long)ticks_10ns);
+    return check_launch(__func__);
+}
+
 namespace {
 inline int dwconv_bwd_blocks(int64_t batch, int64_t h, int64_t C, int dtype) {
     const int64_t items = batch * h * h * (C / vec_of(dtype));

@@ -144,7 +144,7 @@ class GradSync:
 
     Parameters are grouped into buckets (one per large top-level sub-module: vision tower, text tower; the rest together); each bucket
     owns one flat buffer allocated once, in which every parameter has a fixed, 128-byte aligned slice.  The backward's weight-gradient
-    GEMMs write straight into those slices (`claim`, reached through x_clip_amd.functional's grad sink; autograd then adopts the slice as
+    GEMMs write straight into those slices (`claim`, reached through x_clip_amd.functional's grad sinks; autograd then adopts the slice as
     `.grad` without a copy), gradients produced elsewhere (gains, embeddings, biases: a few % of the bytes) are copied into their slices
     when the bucket is launched -- no per-step `torch.cat` of the whole gradient.  When the last gradient of a bucket has been
     accumulated the bucket is all-reduced asynchronously on the process group's stream (RCCL over xGMI on MI355X) while autograd keeps
@@ -153,21 +153,35 @@ class GradSync:
     When is a bucket complete?  A parameter's post-accumulate hook fires once per backward pass THROUGH it, and a tower can be walked more
     than once per step (the MLM side loss encodes the masked text with the same tower, SimSiam runs the vision tower four more times,
     `image_micro_batches` slices it) -- so "every parameter has fired once" is not "the bucket is final".  The first step therefore
-    reduces every bucket in `finish()` and records how many firings each bucket saw; from the second step on a bucket is launched from
-    the hook that brings its count to that number (`overlap=False` keeps every launch in `finish()`: for graphs that change from step to
-    step).  A firing that arrives after its bucket was launched means the graph grew since the last step: that is an error, not a
-    silently wrong gradient.
+    reduces every bucket in `finish()` and records how many firings each bucket saw and in which order the buckets completed; from the
+    second step on a bucket becomes READY at the hook that brings its count to that number (`overlap=False` keeps every launch in
+    `finish()`: for graphs that change from step to step).  A firing that arrives after its bucket was launched means the graph grew
+    since the last step: that is an error, not a silently wrong gradient.
+
+    Collectives are issued in ONE order on every rank.  What was learned in the first step (firing counts, completion order) is compared
+    across the ranks once, at the end of that step (one small all-gather and host read); ranks that disagree -- data-dependent side
+    losses, a rank that skipped a tower -- fall back together to launching every bucket in `finish()` in index order.  After that the
+    order is frozen: a ready bucket is launched only once all buckets before it in that order have been, so two ranks can never pair
+    flat buffers of different buckets (under NCCL / RCCL a hang or silent corruption), whatever their hooks do later.
 
     Stream ordering is explicit, not inherited: the towers' backward nodes run on different HIP streams (the vision tower on its side
     stream, weight gradients on theirs), so every post-accumulate hook records an event on the stream its gradient was accumulated on and
     the launching stream waits for all events of the bucket before the collective is enqueued (gloo would hide a missing edge here --
     its GPU collectives are host-staged and synchronous -- NCCL / RCCL would not).  Buckets always have the same byte size on every rank
-    (a parameter without a gradient contributes zeros), so ranks cannot disagree about a collective's size."""
+    (a parameter without a gradient contributes zeros), so ranks cannot disagree about a collective's size.
 
-    def __init__(self, module: torch.nn.Module, group=None, overlap: bool = True):
+    `reduce_dtype=torch.float32`: the flat buffers (and the wire) are fp32 whatever the parameters' dtype -- bf16 gradients are cast into
+    their slices at launch, summed in fp32, and cast back into `.grad` in `finish()`.  A bf16 all-reduce rounds the running sum at every
+    hop; over 8 ranks the cancelling column-sum gradients (biases, gains) lose a digit (tests/test_distributed_gpu.py measures both).
+    Costs twice the bytes on the wire and two casting passes; the weight-gradient GEMMs then no longer write in place.
+
+    Unsupported: gradient accumulation over several backward passes without a `finish()` between them (a bucket is reduced once per step)."""
+
+    def __init__(self, module: torch.nn.Module, group=None, overlap: bool = True, reduce_dtype: Optional[torch.dtype] = None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.overlap = overlap
+        self.reduce_dtype = reduce_dtype
         self.buckets = []
         seen = set()                                         # a tower shared with a side-loss wrapper (mlm.transformer, visual_ssl.net)
                                                              # is listed under both children: reduce every parameter once
@@ -189,26 +203,34 @@ class GradSync:
         # one flat buffer per (bucket, dtype, device): offsets are fixed for the life of the object
         self.flats = []                                      # per bucket: list of flat tensors
         self._slot = {}                                      # id(param) -> (bucket, flat index, offset in elements)
-        self._by_ptr = {}                                    # param.data_ptr() -> param (the grad sink is asked by weight storage)
         for bi, ps in enumerate(self.buckets):
             groups = {}
             for p in ps:
-                groups.setdefault((p.dtype, p.device), []).append(p)
+                groups.setdefault((reduce_dtype or p.dtype, p.device), []).append(p)
             flats = []
             for (dtype, device), gps in groups.items():
-                step = max(1, _ALIGN // gps[0].element_size())
+                step = max(1, _ALIGN // torch.empty((), dtype=dtype).element_size())
                 off = 0
                 for p in gps:
                     self._slot[id(p)] = (bi, len(flats), off)
-                    self._by_ptr[p.data_ptr()] = p
                     off += (p.numel() + step - 1) // step * step
                 flats.append(torch.zeros(off, dtype=dtype, device=device))
             self.flats.append(flats)
-        self._count = [0] * len(self.buckets)
-        self._seen = [0] * len(self.buckets)
-        self._expected = [None] * len(self.buckets)          # hook firings per step that complete a bucket (learned in the first step)
+        self._by_ptr = {}                                    # weight storage address -> param (the grad sink is asked by weight storage)
+        self._index_params()
+        nb = len(self.buckets)
+        self._count = [0] * nb
+        self._seen = [0] * nb
+        self._expected = [None] * nb                         # hook firings per step that complete a bucket (learned in the first step)
+        self._order = list(range(nb))                        # the one order collectives are issued in (frozen after the first step)
+        self._agreed = False                                 # the first step's counts / order have been compared across the ranks
+        self._ready = set()                                  # complete, waiting for the buckets before them in `_order`
+        self._next = 0                                       # position in `_order` of the next bucket to launch
+        self._fire_seq = 0
+        self._last_fire = [0] * nb                           # sequence number of a bucket's latest hook firing in this step
         self._events = [[] for _ in self.buckets]
         self._claimed = set()
+        self._cast_back = []                                 # (param, slice view) whose .grad has another dtype than the flat buffer
         self._step_open = False
         self.stats = {"in_place": 0, "copied": 0, "unused": 0}     # of the last step: gradients written straight into their slice / copied / absent
         self._works = []
@@ -217,7 +239,10 @@ class GradSync:
             for p in ps:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
         from . import functional as XF
-        XF.set_grad_sink(self)
+        XF.add_grad_sink(self)
+
+    def _index_params(self):
+        self._by_ptr = {p.data_ptr(): p for ps in self.buckets for p in ps}
 
     # ---- the slices ----
     def _view(self, p: Tensor) -> Tensor:
@@ -227,10 +252,21 @@ class GradSync:
 
     def claim(self, weight: Tensor, shape, dtype) -> Optional[Tensor]:
         """grad sink protocol: the buffer a backward kernel should write the gradient of the parameter stored at `weight` into, or None
-        (unknown tensor, shape / dtype mismatch, the parameter already holds a gradient -- accumulation across backward calls or a tower
-        that runs twice in one step -- in which cases autograd's own accumulation into the slice applies)"""
-        p = self._by_ptr.get(weight.data_ptr())
-        if p is None or tuple(p.shape) != tuple(shape) or p.dtype != dtype or p.grad is not None or id(p) in self._claimed:
+        (unknown tensor, shape / dtype mismatch, an fp32 wire under bf16 parameters, the parameter already holds a gradient --
+        accumulation across backward calls or a tower that runs twice in one step -- in which cases autograd's own accumulation applies)"""
+        ptr = weight.data_ptr()
+        p = self._by_ptr.get(ptr)
+        if p is None or p.data_ptr() != ptr:
+            # the map is keyed by storage address: after model.to(...) / a .data swap the addresses are stale (and an old address may
+            # since belong to another tensor) -- rebuild from the live parameters and look again
+            self._index_params()
+            p = self._by_ptr.get(ptr)
+            if p is None:
+                return None
+        if tuple(p.shape) != tuple(shape) or p.dtype != dtype or p.grad is not None or id(p) in self._claimed:
+            return None
+        bi, fi, _ = self._slot[id(p)]
+        if self.flats[bi][fi].dtype != dtype or self.flats[bi][fi].device != weight.device:
             return None
         self._claimed.add(id(p))
         return self._view(p)
@@ -245,9 +281,19 @@ class GradSync:
                                    "autograd graph walks this tower more often than in the previous step.  Use GradSync(model, overlap=False) "
                                    "for graphs that change between steps.")
             self._count[bi] += 1
-            if self.overlap and self._expected[bi] is not None and self._count[bi] == self._expected[bi]:
-                self._launch(bi)
+            self._fire_seq += 1
+            self._last_fire[bi] = self._fire_seq
+            if self.overlap and self._agreed and self._expected[bi] is not None and self._count[bi] == self._expected[bi]:
+                self._ready.add(bi)
+                self._drain_ready()
         return hook
+
+    def _drain_ready(self):
+        while self._next < len(self._order) and self._order[self._next] in self._ready:
+            bi = self._order[self._next]
+            self._ready.discard(bi)
+            self._launch(bi)
+            self._next += 1
 
     def _launch(self, bi):
         ps = self.buckets[bi]
@@ -265,8 +311,11 @@ class GradSync:
                     v.zero_()                                # unused this step: zeros on the wire, .grad stays None
                     self.stats["unused"] += 1
                 elif p.grad.data_ptr() != v.data_ptr():
-                    v.copy_(p.grad)
-                    p.grad = v
+                    v.copy_(p.grad)                          # (casts when the wire is fp32 and the gradient bf16)
+                    if v.dtype == p.grad.dtype:
+                        p.grad = v
+                    else:
+                        self._cast_back.append((p, v))
                     self.stats["copied"] += 1
                 else:
                     self.stats["in_place"] += 1
@@ -275,20 +324,56 @@ class GradSync:
         self._seen[bi] = self._count[bi]
         self._count[bi] = -1                                 # launched
 
+    def _agree(self):
+        """once, after the first step: do all ranks hold the same firing counts and completion order?  (one all-gather + host read)"""
+        nb = len(self.buckets)
+        order = sorted(range(nb), key=lambda b: (self._last_fire[b] == 0, self._last_fire[b], b))     # never fired: last, by index
+        mine = torch.tensor([(-1 if e is None else e) for e in self._expected] + order, dtype=torch.int64, device=self.flats[0][0].device)
+        every = torch.empty(self.world, 2 * nb, dtype=torch.int64, device=mine.device)
+        _gather_into(every, mine, self.group, async_op=False)
+        same = bool((every == every[0]).all().item())
+        if same:
+            self._order = order
+        else:
+            import warnings
+            warnings.warn("x_clip_amd GradSync: the ranks walked their towers differently in the first step (firing counts / completion "
+                          "order differ) -- gradient buckets will be all-reduced after the backward, in index order, without overlap")
+            self.overlap = False
+            self._order = list(range(nb))
+        self._agreed = True
+
     def finish(self):
-        """call after loss.backward(): buckets whose hook count never completed (unused parameters) are flushed too"""
-        for bi in range(len(self.buckets)):
-            if self._count[bi] > 0:
+        """call after loss.backward(): buckets that did not complete from a hook (first step, overlap off, unused parameters) are flushed
+        here, in the frozen order"""
+        first = not self._agreed
+        for bi in self._order[self._next:] if self._agreed else range(len(self.buckets)):
+            if self._count[bi] > 0 or (self._count[bi] == 0 and self._agreed and (self._expected[bi] or 0) > 0):
+                # (a bucket that fired in the agreed first step but not now -- a tower frozen later -- still goes on the wire as zeros:
+                #  the peers will launch theirs)
                 self._launch(bi)
+        for bi in range(len(self.buckets)):
             if self._count[bi] < 0:
-                self._expected[bi] = self._seen[bi]          # what completed this bucket in this step completes it in the next
+                if first:
+                    self._expected[bi] = self._seen[bi]      # what completed this bucket in the first step completes it from now on
+            elif first:
+                self._expected[bi] = 0                       # never fired (frozen tower): nothing to reduce, on any rank (checked by _agree)
             self._count[bi] = 0
         for work, flat in self._works:
             if work is not None:
                 work.wait()                                  # orders the current stream behind the collective
             flat.mul_(1.0 / self.world)
+        with torch.no_grad():
+            for p, v in self._cast_back:                     # fp32 wire: the mean goes back into the parameter's own gradient dtype
+                p.grad.copy_(v)
+        if first:
+            self._agree()
         self._works = []
+        self._cast_back = []
         self._claimed.clear()
+        self._ready.clear()
+        self._next = 0
+        self._fire_seq = 0
+        self._last_fire = [0] * len(self.buckets)
         self._step_open = False
 
     def remove(self):
@@ -296,5 +381,4 @@ class GradSync:
             h.remove()
         self._handles = []
         from . import functional as XF
-        if XF.grad_sink() is self:
-            XF.set_grad_sink(None)
+        XF.remove_grad_sink(self)

@@ -40,21 +40,31 @@ _wgrad_streams = {}
 # Optional destination for parameter gradients (x_clip_amd.distributed.GradSync registers itself): an object whose
 # `claim(weight, shape, dtype)` returns the buffer the gradient of the parameter stored at `weight` should be written into -- a slice of
 # a persistent flat all-reduce bucket -- or None.  The backward then produces that gradient in place instead of into a fresh tensor.
-_grad_sink = None
+# Several sinks may be registered (one GradSync per model): each is asked in turn, the first that knows the weight answers.
+_grad_sinks: list = []
 
 
-def set_grad_sink(sink) -> None:
-    global _grad_sink
-    _grad_sink = sink
+def add_grad_sink(sink) -> None:
+    if sink not in _grad_sinks:
+        _grad_sinks.append(sink)
 
 
-def grad_sink():
-    return _grad_sink
+def remove_grad_sink(sink) -> None:
+    if sink in _grad_sinks:
+        _grad_sinks.remove(sink)
+
+
+def grad_sinks():
+    return tuple(_grad_sinks)
 
 
 def _grad_out(weight: Optional[Tensor], shape, dtype, device) -> Tensor:
-    out = _grad_sink.claim(weight, shape, dtype) if (_grad_sink is not None and weight is not None) else None
-    return out if out is not None else torch.empty(*shape, dtype=dtype, device=device)
+    if weight is not None:
+        for sink in _grad_sinks:
+            out = sink.claim(weight, shape, dtype)
+            if out is not None:
+                return out
+    return torch.empty(*shape, dtype=dtype, device=device)
 
 
 class _SideGemm:

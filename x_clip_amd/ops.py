@@ -100,9 +100,13 @@ def layernorm_fwd(x: Tensor, g: Tensor, res: Optional[Tensor] = None, geglu: boo
         assert res.numel() == rows * dim and res.dtype == x.dtype
     assert g.dtype == x.dtype and g.numel() == dim
     L = _lib.lib()
+    probe = _probe(x)
+    ev0 = probe.begin(x) if probe is not None else None
     _lib.check(L.xclip_layernorm_fwd(x.data_ptr(), width, _c(g).data_ptr(), _ptr(res), y.data_ptr(), ldy, out_group,
                                      mean.data_ptr(), rstd.data_ptr(), rows, dim, ln_eps(x.dtype), int(geglu), dtype_code(x),
                                      _stream(x)), "xclip_layernorm_fwd")
+    if probe is not None:      # reads the row (+ the residual), writes the normalised row
+        probe.end(x, ev0, "layernorm", 0.0, rows * (width + dim + (dim if res is not None else 0)) * x.element_size(), "ln_geglu_fwd" if geglu else "ln_fwd")
     return y, mean, rstd
 
 
@@ -122,9 +126,13 @@ def layernorm_bwd(dy: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, 
         assert dres.numel() == rows * dim and dres.dtype == x.dtype
     L = _lib.lib()
     ws = workspace(x.device, L.xclip_layernorm_bwd_workspace_bytes(rows, dim))
+    probe = _probe(x)
+    ev0 = probe.begin(x) if probe is not None else None
     _lib.check(L.xclip_layernorm_bwd(dy.data_ptr(), x.data_ptr(), width, _c(g).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                      _ptr(dres), dx.data_ptr(), width, dg.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
                                      rows, dim, int(geglu), dtype_code(x), _stream(x)), "xclip_layernorm_bwd")
+    if probe is not None:      # reads dy, x (+ dres), writes dx
+        probe.end(x, ev0, "layernorm", 0.0, rows * (dim + 2 * width + (dim if dres is not None else 0)) * x.element_size(), "ln_geglu_bwd" if geglu else "ln_bwd")
     return dx, dg
 
 
@@ -359,37 +367,80 @@ def cast_from_f32(src: Tensor, dtype, scale: float = 1.0) -> Tensor:
 GEMM_GENERATION = "gemm5b"   # (b: whole-line epilogue stores through LDS)
 
 
-class GemmProbe:
-    """Optional live measurement of the GEMM launches (bench.py's `roofline` leg): while active, every xclip_gemm call
-    is bracketed by HIP events on the stream it is launched on; `summary()` returns (launches, flops, seconds)."""
-    active: Optional["GemmProbe"] = None
+class KernelProbe:
+    """Optional live measurement of the kernel families that make up a step (bench.py's `roofline` leg): while active, every
+    xclip_gemm / attention / LayerNorm-family call is bracketed by HIP events on the stream it is launched on, and after every
+    `clock_every`-th probed launch a one-wave clock sample (xclip_clock_sample, ~10 us) is queued on the same stream.
+    `summary(family)` returns (launches, flops, seconds) with `algorithmic_bytes` set; `clock_mhz()` the sampled shader clocks."""
+    active: Optional["KernelProbe"] = None
 
-    def __init__(self):
-        self.records = []
+    def __init__(self, clock_every: int = 0, clock_slots: int = 512):
+        self.records = []                 # (family, flops, ev0, ev1, algorithmic bytes, key)
+        self.clock_every = clock_every
+        self.clock_slots = clock_slots
+        self._clock = None
+        self._clock_n = 0
 
     def __enter__(self):
-        GemmProbe.active = self
+        KernelProbe.active = self
         return self
 
     def __exit__(self, *exc):
-        GemmProbe.active = None
+        KernelProbe.active = None
 
-    def summary(self):
+    # -- recording (called by the wrappers below) --
+    def begin(self, t: Tensor):
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(t.device))
+        return ev0
+
+    def end(self, t: Tensor, ev0, family: str, flops: float, nbytes: float, key=None):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream(t.device)
+        ev1.record(st)
+        self.records.append((family, flops, ev0, ev1, nbytes, key))
+        if self.clock_every and len(self.records) % self.clock_every == 0 and self._clock_n < self.clock_slots:
+            if self._clock is None:
+                self._clock = torch.zeros(self.clock_slots, 2, dtype=torch.int64, device=t.device)
+            _lib.check(_lib.lib().xclip_clock_sample(self._clock[self._clock_n].data_ptr(), 1000, st.cuda_stream), "xclip_clock_sample")
+            self._clock_n += 1
+
+    # -- results --
+    def summary(self, family: str = "gemm"):
         torch.cuda.synchronize()
-        flops = sum(r[0] for r in self.records)
-        secs = sum(r[1].elapsed_time(r[2]) for r in self.records) * 1e-3
-        self.algorithmic_bytes = sum(r[3] for r in self.records)
-        return len(self.records), flops, secs
+        recs = [r for r in self.records if r[0] == family]
+        flops = sum(r[1] for r in recs)
+        secs = sum(r[2].elapsed_time(r[3]) for r in recs) * 1e-3
+        self.algorithmic_bytes = sum(r[4] for r in recs)
+        return len(recs), flops, secs
 
     def by_shape(self):
-        """{(M, N, K, layout, has_residual): [launches, milliseconds]} over the recorded launches"""
+        """{(M, N, K, layout, has_residual): [launches, milliseconds]} over the recorded GEMM launches"""
         torch.cuda.synchronize()
         out = {}
         for r in self.records:
-            e = out.setdefault(r[4], [0, 0.0])
+            if r[0] != "gemm":
+                continue
+            e = out.setdefault(r[5], [0, 0.0])
             e[0] += 1
-            e[1] += r[1].elapsed_time(r[2])
+            e[1] += r[2].elapsed_time(r[3])
         return out
+
+    def clock_mhz(self):
+        """sorted shader-clock samples in MHz (cycles per 10 ns tick x 100); empty when no sample was taken"""
+        if self._clock is None or self._clock_n == 0:
+            return []
+        torch.cuda.synchronize()
+        c = self._clock[:self._clock_n].cpu()
+        return sorted(float(cy) / max(float(tk), 1.0) * 100.0 for cy, tk in c.tolist() if tk > 0)
+
+
+GemmProbe = KernelProbe            # (round 1-3 name)
+
+
+def _probe(t: Tensor):
+    p = KernelProbe.active
+    return p if (p is not None and t.is_cuda) else None
 
 
 def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False, alpha: float = 1.0,
@@ -414,20 +465,17 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
     plain = bias is None and residual is None and addrows is None
     wbytes = L.xclip_gemm_workspace_bytes(M, N, K, code) if plain else 0
     ws = workspace(a.device, wbytes)
-    probe = GemmProbe.active if a.is_cuda else None
-    if probe is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(torch.cuda.current_stream(a.device))
+    probe = _probe(a)
+    ev0 = probe.begin(a) if probe is not None else None
     _lib.check(L.xclip_gemm(int(a_kmajor), int(b_kmajor), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
                             out.stride(0), M, N, K, alpha, _ptr(bias), _ptr(residual),
                             0 if residual is None else residual.stride(0), _ptr(addrows), _ptr(rowidx),
                             0 if addrows is None else addrows.stride(0), _ptr(ws), 0 if ws is None else ws.numel(), code,
                             _stream(a)), "xclip_gemm")
     if probe is not None:
-        ev1.record(torch.cuda.current_stream(a.device))
         esz = a.element_size()
-        probe.records.append((2.0 * M * N * K, ev0, ev1, (M * K + N * K + M * N) * esz + (M * N * esz if residual is not None else 0),
-                              (M, N, K, ("T" if a_kmajor else "N") + ("N" if b_kmajor else "T"), residual is not None)))
+        probe.end(a, ev0, "gemm", 2.0 * M * N * K, (M * K + N * K + M * N) * esz + (M * N * esz if residual is not None else 0),
+                  (M, N, K, ("T" if a_kmajor else "N") + ("N" if b_kmajor else "T"), residual is not None))
     return out
 
 
@@ -445,9 +493,13 @@ def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float,
     if mask is not None:
         assert mask.dtype == torch.bool and tuple(mask.shape) == (b, n)
         mask = _c(mask)
+    probe = _probe(qkv)
+    ev0 = probe.begin(qkv) if probe is not None else None
     _lib.check(_lib.lib().xclip_attention_fwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), lse.data_ptr(), b, n, heads, head_dim, scale,
                                               int(causal), float(dropout_p), int(dropout_seed) & _U64, dtype_code(qkv), _stream(qkv)),
                "xclip_attention_fwd")
+    if probe is not None:      # S = Q K^T and O = P V: 2 x 2 n^2 hd per head (causal: the same count -- the skipped half is the kernel's gain); q, k, v in, o out
+        probe.end(qkv, ev0, "attention", 4.0 * b * heads * n * n * head_dim, 4 * b * n * heads * head_dim * qkv.element_size() + 4 * b * heads * n, "attn_fwd")
     return out, lse
 
 
@@ -458,9 +510,13 @@ def attention_bwd(qkv: Tensor, mask: Optional[Tensor], out: Tensor, dout: Tensor
     b, n, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(b, heads, n, dtype=torch.float32, device=qkv.device)
+    probe = _probe(qkv)
+    ev0 = probe.begin(qkv) if probe is not None else None
     _lib.check(_lib.lib().xclip_attention_bwd(qkv.data_ptr(), _ptr(mask), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
                                               delta.data_ptr(), dqkv.data_ptr(), b, n, heads, head_dim, scale, int(causal), float(dropout_p),
                                               int(dropout_seed) & _U64, dtype_code(qkv), _stream(qkv)), "xclip_attention_bwd")
+    if probe is not None:      # dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q (algorithmic: 4 products; the S recompute is the implementation's); q, k, v, o, dO in, dq, dk, dv out
+        probe.end(qkv, ev0, "attention", 8.0 * b * heads * n * n * head_dim, 8 * b * n * heads * head_dim * qkv.element_size() + 8 * b * heads * n, "attn_bwd")
     return dqkv
 
 
@@ -706,9 +762,13 @@ def layernorm_chain_fwd(p: Tensor, g1: Tensor, res: Tensor, g2: Tensor):
     assert res.shape == p.shape and res.dtype == p.dtype and g1.numel() == dim and g2.numel() == dim
     x1, h2 = torch.empty_like(p), torch.empty_like(p)
     st = [torch.empty(rows, dtype=torch.float32, device=p.device) for _ in range(4)]
+    probe = _probe(p)
+    ev0 = probe.begin(p) if probe is not None else None
     _lib.check(_lib.lib().xclip_layernorm_chain_fwd(p.data_ptr(), _c(g1).data_ptr(), res.data_ptr(), x1.data_ptr(), st[0].data_ptr(),
                                                     st[1].data_ptr(), _c(g2).data_ptr(), h2.data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
                                                     rows, dim, ln_eps(p.dtype), dtype_code(p), _stream(p)), "xclip_layernorm_chain_fwd")
+    if probe is not None:      # reads p, res; writes x1, h2
+        probe.end(p, ev0, "layernorm", 0.0, 4 * rows * dim * p.element_size(), "ln_chain_fwd")
     return x1, st[0], st[1], h2, st[2], st[3]
 
 
@@ -724,10 +784,14 @@ def layernorm_chain_bwd(dh2: Tensor, x1: Tensor, g2: Tensor, mean2: Tensor, rstd
     L = _lib.lib()
     wbytes = L.xclip_layernorm_chain_bwd_workspace_bytes(rows, dim)
     ws = workspace(x1.device, wbytes)
+    probe = _probe(x1)
+    ev0 = probe.begin(x1) if probe is not None else None
     _lib.check(L.xclip_layernorm_chain_bwd(dh2.data_ptr(), x1.data_ptr(), _c(g2).data_ptr(), mean2.data_ptr(), rstd2.data_ptr(),
                                            dres.data_ptr(), dx1.data_ptr(), p.data_ptr(), _c(g1).data_ptr(), mean1.data_ptr(),
                                            rstd1.data_ptr(), dp.data_ptr(), dg2.data_ptr(), dg1.data_ptr(), ws.data_ptr(), wbytes, rows, dim,
                                            dtype_code(x1), _stream(x1)), "xclip_layernorm_chain_bwd")
+    if probe is not None:      # reads dh2, x1, dres, p; writes dx1, dp
+        probe.end(x1, ev0, "layernorm", 0.0, 6 * rows * dim * x1.element_size(), "ln_chain_bwd")
     return dx1, dp
 
 
