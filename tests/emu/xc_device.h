@@ -262,6 +262,12 @@ inline int xc_num_cus() {
     return v;
 }
 
+// split-K policies plan for an MI355X whatever the emulated grid (hw/xc_device.h: the device's own count)
+inline int xc_policy_cus() {
+    static const int v = [] { const char* e = getenv("XCLIP_EMU_CUS"); return e != nullptr && atoi(e) > 0 ? atoi(e) : 256; }();
+    return v;
+}
+
 namespace xc {
 
 typedef uint16_t bf16_t;

@@ -40,6 +40,19 @@ def test_cfg1_vs_oracle(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_high_temperature_vs_oracle(dtype):
+    """exp(tau) = 200 end to end ON THE GPU (the NaN this pins was GPU-visible for two rounds and its end-to-end
+    test ran on the emulator only) -- the reference multiplies by exp(tau) without a clamp (x_clip.py:574,736) and exponentiates
+    without subtracting a maximum (:826); the product's log-sum-exp forms and one-exponential gradient must not depend on that.
+    CLS head on the toy and the dim-512 model (the latter through the ring-loop kernels of simloss5.h), FILIP + DCL on the toy."""
+    import dataclasses
+    loose = dict(bf16_cos=0.97, bf16_rel=0.3, bf16_loss=5e-2)   # (bf16 logits of magnitude 100: the loss bar is absolute)
+    C.case_vs_oracle(DEV, dtype, O.CFG1, 5, temperature=5.3, **loose)
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True, use_all_token_embeds=True), 5, temperature=5.3, **loose)
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, decoupled_contrastive_learning=True), 264, temperature=5.3, label=f"mid b=264 exp(tau)=200 [{'fp32' if dtype == torch.float32 else 'bf16'}]", **loose)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_mid_vs_oracle(dtype):
     C.case_vs_oracle(DEV, dtype, MID, 24)
 

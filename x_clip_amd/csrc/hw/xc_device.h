@@ -37,6 +37,10 @@ inline int xc_num_cus() {
     return n;
 }
 
+// the CU count work-SPLITTING policies plan for (split-K slice counts): the device's.  (The emulator twin answers 256 here while running
+// its persistent grids on 3 "CUs": the CPU suite then takes the MI355X's split decisions and exercises the same slabs.)
+inline int xc_policy_cus() { return xc_num_cus(); }
+
 namespace xc {
 
 typedef uint16_t bf16_t;                                            // raw bfloat16 bits

@@ -253,7 +253,7 @@ inline bool use_gemm2(int64_t M, int64_t N, int64_t K, int dtype) {
 }
 int gemm2_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + G2_BM - 1) / G2_BM) * ((N + G2_BN - 1) / G2_BN);
-    int64_t s = 256 / tiles;
+    int64_t s = xc_policy_cus() / tiles;                      // one 8-wave work-group per CU: enough K slices to fill the part that runs it
     const int64_t maxs = K / (4 * G2_BK);
     if (s > maxs) s = maxs;
     if (s > 64) s = 64;
@@ -264,7 +264,7 @@ int gemm2_splits(int64_t M, int64_t N, int64_t K) {
 int gemm_splits(int64_t M, int64_t N, int64_t K, int dtype) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int bk = 8 * vec_of(dtype);
-    int64_t s = 512 / tiles;
+    int64_t s = 2 * xc_policy_cus() / tiles;                    // two 4-wave work-groups per CU
     const int64_t maxs = K / (4 * bk);
     if (s > maxs) s = maxs;
     if (s > 64) s = 64;
