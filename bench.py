@@ -243,7 +243,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    probe = None if args.no_probe else ops.KernelProbe(clock_every=16)
+    probe = None if args.no_probe else ops.KernelProbe()
     fence()
     tele0 = gpu_telemetry(local_rank)
     ms0 = torch.cuda.memory_stats(dev)
@@ -364,10 +364,17 @@ def main():
         out["roofline"]["families"] = fam
         out["roofline"]["families_ms_per_step"] = round(sum(v["ms_per_step"] for v in fam.values()), 3)
         out["roofline"]["probe_pass_ms_per_step"] = round(probe_elapsed / max(args.steps, 1) * 1e3, 3)
-        clk = probe.clock_mhz()
-        # shader cycles per 10 ns tick, sampled by a one-wave kernel queued after every 16th probed launch of the probe pass
+        # The shader clock UNDER the load: two more steps in which a one-wave sampler is started on a side stream in front of every 8th GEMM
+        # launch and counts shader cycles (s_memtime) over 200 us of the constant 100 MHz counter while that GEMM -- and whatever follows it --
+        # runs on the other CUs.  (Sampled BETWEEN kernels the part reads 2.4 GHz: the power management lets go within microseconds; round 4's
+        # first measurement, profiles/r04_a_bench.log.)  The sampler's CU cannot take a GEMM work-group meanwhile, so these two steps are not timed.
+        with ops.KernelProbe(under_load_every=8, record=False) as cprobe:
+            for _ in range(2):
+                step()
+        fence()
+        clk = cprobe.clock_mhz()
         out["clock_mhz"] = ({"min": round(clk[0]), "median": round(clk[len(clk) // 2]), "max": round(clk[-1]), "samples": len(clk),
-                             "measured": "xclip_clock_sample (s_memtime over 10 us of s_memrealtime) between the kernels of the probe pass"}
+                             "measured": "xclip_clock_sample: shader cycles over 200 us windows that start with every 8th GEMM launch of two extra steps (one wave on a side stream beside the running kernels)"}
                             if clk else None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

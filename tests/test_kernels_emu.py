@@ -334,6 +334,35 @@ def test_gemm6_gemm7_experimental_kernels():
         assert out.returncode == 0 and "gemm6 ok" in out.stdout, (gen, out.stderr[-2000:])
 
 
+def test_gemm_row_tail_as_split_k():
+    """xclip_api.hip gemm2_tail_cut: a persistent launch whose last round would fill only a few CUs cuts its rows at the last whole round and
+    runs the row tail as a split-K problem (fp32 slabs + the reduction, which also applies alpha and the skip term).  The policy plans for
+    the device's CU count, so the emulator is told it has 4 (its own interpreter: the count is read once): 1280 rows = 5 row tiles x 2
+    column tiles = 2 rounds + 2 tiles -> 4 row tiles in the main launch, 1 as slabs; NT / NN, with and without a skip term, in place"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from x_clip_amd import _lib, ops\n"
+        "from emu.build_emu import build\n"
+        "_lib._use_library_for_tests(build())\n"
+        "torch.manual_seed(0)\n"
+        "L = _lib.lib()\n"
+        "assert L.xclip_gemm_workspace_bytes(1280, 512, 1536, 1) == 2 * 256 * 512 * 4        # the tail: 2 tiles x 2 K slices fill the 4 CUs\n"
+        "assert L.xclip_gemm_workspace_bytes(1280, 512, 512, 1) == 0                         # short K: a tile is not worth cutting\n"
+        "for (M, N, K, bk, res, inplace) in [(1280, 512, 1536, False, False, False), (1280, 512, 2048, False, True, False), (1280, 512, 2048, True, True, True), (1416, 256, 1024, True, False, False)]:\n"
+        "    a = torch.randn(M, K).bfloat16(); b = (torch.randn(K, N) if bk else torch.randn(N, K)).bfloat16()\n"
+        "    r = torch.randn(M, N).bfloat16() if res else None\n"
+        "    want = 0.5 * (a.float() @ (b.float() if bk else b.float().t())) + (r.float() if res else 0)\n"
+        "    out = r.clone() if inplace else None\n"
+        "    got = ops.gemm(a, b, M, N, K, b_kmajor=bk, alpha=0.5, residual=(out if inplace else r), out=out).float()\n"
+        "    assert float((got - want.bfloat16().float()).abs().max()) <= float(want.abs().max()) * 2.0 ** -7, (M, N, K)   # one bf16 ulp at the scale\n"
+        "print('tail ok')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XCLIP_EMU_CUS="4"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "tail ok" in out.stdout, out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2), (4, 70, 3, 65, 64, 1),
                                                   (9, 32, 9, 32, 64, 1), (7, 40, 8, 33, 64, 1), (3, 256, 6, 32, 64, 1)])
 def test_filip_fused(bx, nt, by, ni, d, chunks):

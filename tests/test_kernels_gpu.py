@@ -68,7 +68,10 @@ def test_gemm_layouts(dtype, layout, M, N, K_):
 
 @pytest.mark.parametrize("layout,M,N,K_,res", [("nt", 263168, 1536, 512, False), ("nn", 263168, 512, 1536, False), ("nt", 131584, 512, 512, False),
                                                ("tn", 1536, 512, 263168, False), ("nt", 263168, 512, 2048, True), ("tn", 512, 2048, 263168, False),
-                                               ("nt", 65536, 4096, 512, False)])
+                                               ("nt", 65536, 4096, 512, False),
+                                               # round 4: the row tail as a split-K problem (xclip_api.hip gemm2_tail_cut) -- text rows 1028 row tiles,
+                                               # vision rows 132: FF1 input gradient, FF2 forward + skip through the reduction's residual term
+                                               ("nn", 263168, 512, 4096, False), ("nn", 33792, 512, 4096, False), ("nt", 33792, 512, 2048, True)])
 def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_, res):
     """text-tower shapes at full size, every CU streaming (the regime the counted DMA waits and the stores left in flight across the
     tile boundary have to be right in -- the emulator lands every DMA piece at once and cannot see an early read, nor a missing wait

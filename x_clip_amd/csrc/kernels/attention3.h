@@ -139,6 +139,23 @@ XC_DEV void a3_stagger(int ticks_10ns, int first_round) {
         for (int spin = 0; spin < 4 * ticks_10ns && realtime_10ns() < until; ++spin) nap();
     }
 }
+// key validity bytes of a head into LDS: at most two positions per thread in the shapes these kernels take (npad <= 288; the forward
+// runs 2 npad threads, the backward 256), both loads unconditional (index clamped) and in flight together.  Written as
+// `Ms[k] = (k < n) && (mask == nullptr || mask[k])` every position was a branch around its own load and a full drain of the memory
+// counter -- which also counts the operand images requested just before (tools/isa_scan.py, round 3: five such pairs in the backward).
+XC_DEV void a3_key_validity(unsigned char* Ms, const unsigned char* mask, long row0, int n, int npad) {
+    const int k0 = threadIdx.x, k1 = threadIdx.x + blockDim.x;
+    unsigned char m0 = 1, m1 = 1;
+    if (mask != nullptr) {                                     // (uniform)
+        m0 = mask[row0 + (k0 < n ? k0 : n - 1)];
+        m1 = mask[row0 + (k1 < n ? k1 : n - 1)];
+    }
+    if (k0 < npad) Ms[k0] = (k0 < n) && m0 != 0;
+    if (k1 < npad) Ms[k1] = (k1 < n) && m1 != 0;
+    for (int k = k1 + blockDim.x; k < npad; k += blockDim.x)   // (never in the shapes above)
+        Ms[k] = (k < n) && (mask == nullptr || mask[row0 + k] != 0);
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------------
 // (at most 128 VGPRs: two 8-wave work-groups of ~78 KB LDS share a CU)
 template <bool CAUSAL>
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
     float* lse_out = p.lse + ((long)bi * p.heads + hh) * n;
     a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
     a3_dma_image(Vs, Vb, ldq, n, npad, wave, nwaves, lane);
-    for (int k = tid; k < npad; k += blockDim.x) Ms[k] = (k < n) && (p.mask == nullptr || p.mask[(long)bi * n + k] != 0);
+    a3_key_validity(Ms, p.mask, (long)bi * n, n, npad);
     const bool coop = a3_coop_tail(n);
     const int tail0 = (n >> 5) << 5, ntail = n & 31;
     const int q0 = wave * 32;
@@ -440,7 +457,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
     bf16_t* dV = dK + (long)p.heads * ATT_DH;
     a3_dma_image(R0, Kb, ldq, n, npad, wave, nwaves, lane);
     a3_dma_image(R1, Vb, ldq, n, npad, wave, nwaves, lane);
-    for (int k = tid; k < npad; k += blockDim.x) Ms[k] = (k < n) && (p.mask == nullptr || p.mask[(long)bi * n + k] != 0);
+    a3_key_validity(Ms, p.mask, (long)bi * n, n, npad);
     const bool coop = a3_coop_tail(n);
     const int tail0 = (n >> 5) << 5, ntail = n & 31;
     const int nblk = a3_waves(n);                              // 32-row blocks owned by single waves (without a cooperative tail)
@@ -450,6 +467,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
     for (int blk = wave; blk < nsub; blk += nwaves) {
         const int row_ = blk * 32 + c31;
         const int rl = row_ < n ? row_ : n - 1;
+        const float lse_r = p.lse[((long)bi * p.heads + hh) * n + rl];      // (unconditional, with the row's O / dO chunks: one round trip)
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
         acc += shfl_xor(acc, 32);
         if (h == 0) {
             Ds[row_] = row_ < n ? acc : 0.f;
-            Ls[row_] = row_ < n ? p.lse[((long)bi * p.heads + hh) * n + rl] * 1.4426950408889634f : 0.f;
+            Ls[row_] = row_ < n ? lse_r * 1.4426950408889634f : 0.f;
         }
     }
     wait_vmem();

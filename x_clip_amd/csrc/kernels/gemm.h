@@ -236,10 +236,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
-// Sum split-K slabs, scale, convert:  C[m, n] = alpha * sum_s partial[s][m][n]
+// Sum split-K slabs, scale, convert:  C[m, n] = alpha * sum_s partial[s][m][n] (+ residual[m, n]: the skip term of a product whose row
+// tail was split over K, xclip_api.hip gemm2_tail; residual may alias C)
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, T* __restrict__ C, long ldc,
-                                                            int M, int N, int splits, float alpha) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, T* C, long ldc,
+                                                            int M, int N, int splits, float alpha, const T* residual = nullptr, long ldr = 0) {
     const long total = (long)M * (N / 4);
     for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
         const long m = id / (N / 4);
@@ -251,8 +252,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[q] += t[q];
         }
+        if (residual != nullptr) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) C[m * ldc + n + q] = from_f32<T>(s[q] * alpha);
+            for (int q = 0; q < 4; ++q) s[q] = s[q] * alpha + to_f32(residual[m * ldr + n + q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) C[m * ldc + n + q] = from_f32<T>(s[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) C[m * ldc + n + q] = from_f32<T>(s[q] * alpha);
+        }
     }
 }
 

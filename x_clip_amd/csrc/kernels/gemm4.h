@@ -14,6 +14,7 @@
 // branches but its own back-edge.  The epilogue is compiled per MODE (what the caller's optional terms are) with a straight-line
 // interior-tile path: 64 conversions, 32 v_permlane32_swap, 16 descriptor stores with immediate offsets.
 #pragma once
+#include <type_traits>
 #include "gemm3.h"
 
 namespace xc {
@@ -232,6 +233,16 @@ template <class E> struct g5_loose8<E, decltype((void)E::LOOSE8)> { static const
 template <class E, class = void> struct g5_defer_frags { static constexpr bool value = false; };
 template <class E> struct g5_defer_frags<E, decltype((void)E::DEFER_FRAGS)> { static constexpr bool value = E::DEFER_FRAGS; };
 
+// the held groups of a split tile boundary (g5_run): a function template of its own so that epilogues without line stores are never asked
+// for store_line_groups
+template <bool ON, int NG, class Epilogue>
+XC_DEV void g5_store_held(const Epilogue& epi, const u32x4 (&held)[NG][4], int i0, int m0, int n0, bool stream) {
+    if constexpr (ON) {
+        if (stream) epi.template store_line_groups<true, NG>(held, i0, m0, n0);
+        else epi.template store_line_groups<false, NG>(held, i0, m0, n0);
+    }
+}
+
 template <bool A_KMAJOR, bool B_KMAJOR, class Epilogue, int ABL = 0>
 XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int tid = threadIdx.x;
@@ -345,6 +356,17 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     int tile_no = 0;
     bool a_early = false;                                     // the next step's A pieces have been issued at the tile boundary
     int in_flight = 0;                                        // stores per lane the previous tile's epilogue left behind (16 or 0)
+    // SPLIT (measurement: XCLIP_GEMM5_ABL & 4096).  A tile's 16 line stores are older than the B pieces the next tile's first step requests
+    // and the memory counter retires in order: the second step's wait for those pieces is a wait for all 128 KiB of stores, 1.75 K steps
+    // after every CU of the chip released its tile at the same moment.  Here only the first 8 stores leave at the boundary; the other 8
+    // (32 registers, carried through the next tile's first K step) are issued BEHIND that step's B pieces, so the second step's wait leaves
+    // them in flight and the third step's takes them: the burst is halved and has one more K step to drain.
+    constexpr int HG = (ABL & 4096) ? 2 : ((ABL & 8192) ? 1 : 0);   // 32-row groups held back: rows 64 .. 127 (spills 31 registers) / rows 96 .. 127
+    constexpr bool SPLIT = HG != 0;
+    constexpr int HS = 4 * HG;                                // ... = that many stores per lane
+    u32x4 held[HG ? HG : 1][4];
+    bool pending = false, late8 = false;
+    int hm0 = 0, hn0 = 0;
     int step = 0, sa3 = 0;                                    // running K-step counter (B stage = step & 1) and A stage = step % 3
     for (int id = blockIdx.x; id < ntiles; id += stride) {
         int m0, n0;
@@ -352,14 +374,17 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
         f32x16 acc[4][2];                                     // (first k-block of the tile runs with C = 0)
 
         if ((ABL & 2048) && (tile_no == 2 || tile_no == 3)) stamp[tile_no == 2 ? 0 : 10] = shader_cycles();
-        for (int t = 0; t < nt; ++t, ++step) {
+        // one K step; FIRST = the tile's first (compiled on its own: C = 0 in its first k-block, the boundary's counted waits, the held
+        // half of the previous tile's stores -- none of that is in the loop over the other steps)
+        auto kstep = [&](const int t, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const int sa_next = sa3 == 2 ? 0 : sa3 + 1;       // A stage of step s + 1
             const int sa_free = sa3 == 0 ? 2 : sa3 - 1;       // A stage of step s + 2 == the one step s - 1 used
             const unsigned char* As = ldsA + sa3 * G2_OPER_BYTES;
             const unsigned char* Bs = ldsB + (step & 1) * G2_OPER_BYTES;
             unsigned char* const a_dst = ldsA + sa_free * G2_OPER_BYTES;
             unsigned char* const b_dst = ldsB + (step & 1) * G2_OPER_BYTES;
-            const bool early = a_early && t == 0;
+            const bool early = FIRST && a_early;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1;
@@ -370,9 +395,12 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     // (first step of a tile behind an interior bf16 tile: its 16 whole-line stores are YOUNGER than A(s + 1), B(s + 1)
                     //  -- the counter retires in issue order -- and may stay in flight for one more K step)
                     if (!(ABL & 32)) {
-                        if (!(ABL & 1024) && t == 0 && in_flight == 16) XC_WAIT_VMEM_LE(20);
-                        else if (g5_loose8<Epilogue>::value && t == 0 && in_flight == 8) XC_WAIT_VMEM_LE(12);
+                        if (!(ABL & 1024) && FIRST && in_flight == 16) XC_WAIT_VMEM_LE(20);
+                        else if (g5_loose8<Epilogue>::value && FIRST && in_flight == 8) XC_WAIT_VMEM_LE(12);
+                        else if (SPLIT && FIRST && in_flight == 16 - HS) { if (HG == 2) XC_WAIT_VMEM_LE(12); else XC_WAIT_VMEM_LE(16); }
+                        else if (SPLIT && !FIRST && late8) { if (HG == 2) XC_WAIT_VMEM_LE(12); else XC_WAIT_VMEM_LE(8); }   // the held stores were issued behind B(s + 1): still in flight
                         else XC_WAIT_VMEM_LE(4);
+                        if (SPLIT && !FIRST) late8 = false;
                     }
                     if (!(ABL & 16)) barrier_nodrain();          // ... for every wave; and nobody reads A stage sa3 / B stage step & 1 any more
                     if (!(ABL & 8) && !(g5_defer_frags<Epilogue>::value && t == nt - 1))
@@ -381,7 +409,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                 }
                 sched_fence();
                 if (ABL & 1) {
-                    if (kk == 0 && t == 0) {
+                    if (kk == 0 && FIRST) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -396,7 +424,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                         if (kk == 3) { sched_fence(); piece_b(i, b_dst); sched_fence(); }
                     }
                 } else
-                if (kk == 0 && t == 0) {                         // first k-block of the tile: C = 0
+                if (kk == 0 && FIRST) {                          // first k-block of the tile: C = 0
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -412,6 +440,11 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
                     if (kk == 0) { sched_fence(); piece_a(i, a_dst); sched_fence(); }
                     if (kk == 3) { sched_fence(); piece_b(i, b_dst); sched_fence(); }
                 }
+                if (SPLIT && FIRST && kk == 3 && pending) {          // (uniform) the previous tile's held line stores, behind this step's B pieces
+                    g5_store_held<SPLIT, HG ? HG : 1>(epi, held, 4 - HG, hm0, hn0, p.stream_out != 0);
+                    pending = false;
+                    late8 = true;
+                }
                 if (kk == 0 && !early) next_a();
                 if (kk == 3) next_b();
                 sched_fence();
@@ -420,8 +453,11 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             }
             sa3 = sa_next;
             if ((ABL & 2048) && tile_no == 2 && t < 8) stamp[1 + t] = shader_cycles();
-            if ((ABL & 2048) && tile_no == 3 && t == 0) stamp[11] = shader_cycles();
-        }
+            if ((ABL & 2048) && tile_no == 3 && FIRST) stamp[11] = shader_cycles();
+            ++step;
+        };
+        kstep(0, std::true_type{});
+        for (int t = 1; t < nt; ++t) kstep(t, std::false_type{});
         if ((ABL & 2048) && tile_no == 2) reg_keep(acc[3][1]);
         ++tile_no;
         if (ABL & 4) {
@@ -440,9 +476,25 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             for (int q = 0; q < 4; ++q) piece_a(q, freed);
             next_a();
             a_early = true;
-            if (p.stream_out) epi.template store_lines<true>(o, m0, n0);
-            else epi.template store_lines<false>(o, m0, n0);
-            in_flight = 16;
+            bool split_now = false;
+            if constexpr (SPLIT) split_now = nt >= 3 && id + stride < ntiles;   // (a next tile exists: its first step issues the second half)
+            if constexpr (SPLIT) if (split_now) {
+                u32x4 (&first)[4 - HG][4] = reinterpret_cast<u32x4 (&)[4 - HG][4]>(o[0]);
+                g5_store_held<SPLIT, 4 - HG>(epi, first, 0, m0, n0, p.stream_out != 0);
+#pragma unroll
+                for (int i = 0; i < HG; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) held[i][k] = o[4 - HG + i][k];
+                pending = true;
+                hm0 = m0;
+                hn0 = n0;
+                in_flight = 16 - HS;
+            }
+            if (!split_now) {
+                if (p.stream_out) epi.template store_lines<true>(o, m0, n0);
+                else epi.template store_lines<false>(o, m0, n0);
+                in_flight = 16;
+            }
         } else {
             // (residual / slab tiles take the same 4 KiB slice for their whole-line forms; ragged tiles and the general terms ignore it)
             in_flight = epi.with_scratch(acc, m0, n0, ldsA + (sa3 == 0 ? 2 : sa3 - 1) * G2_OPER_BYTES + mine);
@@ -453,6 +505,7 @@ XC_DEV void g5_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
             lds_wait<0>(a[0], b[0]);
         }
     }
+    if (SPLIT && pending) g5_store_held<SPLIT, HG ? HG : 1>(epi, held, 4 - HG, hm0, hn0, p.stream_out != 0);   // (cannot happen: the split needs a next tile)
     XC_WAIT_VMEM_LE(0);                                       // trailing (redundant) pieces must land before the LDS is released
     epi.finish();
     if ((ABL & 2048) && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {   // one row of 12 stamps per wave
@@ -588,6 +641,22 @@ struct G4GemmEpilogue {
             for (int k = 0; k < 4; ++k) {
                 if (NT) buf_st16_nt<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[i][k]);
                 else buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[i][k]);
+            }
+    }
+    // NG of the four 32-row groups (groups i0 ... i0 + NG - 1) of store_lines: g5_run's split boundary
+    template <bool NT, int NG>
+    XC_DEV void store_line_groups(const u32x4 (&o)[NG][4], int i0, int m0, int n0) const {
+        const int lane = threadIdx.x & 63;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const BufRsrc rc = make_rsrc(p.C + (long)m0 * p.ldc + n0, 255u * (uint32_t)p.ldc * 2u + 512u);
+        const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.ldc + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
+        const uint32_t s8 = (uint32_t)p.ldc * 16u;
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (NT) buf_st16_nt<0>(rc, vc, s8 * (uint32_t)(4 * (i0 + i) + k), o[i][k]);
+                else buf_st16<0>(rc, vc, s8 * (uint32_t)(4 * (i0 + i) + k), o[i][k]);
             }
     }
     // interior tile, bf16 output with a residual term, residual loads AND stores as whole 128-byte lines.  (History: the general
@@ -743,6 +812,7 @@ struct G4ProbeEpilogue {
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char*) const { return (*this)(acc, m0, n0); }
     XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4], int = 0, int = 0) const {}
     template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
+    template <bool NT, int NG> XC_DEV void store_line_groups(const u32x4 (&)[NG][4], int, int, int) const {}
 };
 
 template <bool A_KMAJOR, bool B_KMAJOR, int MODE, int ABL = 0>

@@ -88,12 +88,12 @@ struct Sim5FastGradEpilogue {
     // The accumulators of a full tile become G in place.  Per logit: G = exp(s - R) (a' + c') with s = acc * scale,
     // a' = gs a exp(R - lse_q), c' = gs c exp(R - lse_k) -- ONE exponential per logit, in the base-2 domain: one fma + a bare v_exp_f32;
     // then an add, an fma, and an fma for sum G o acc (d tau = that sum x scale / gs, applied once per wave).
-    // The reference point R is the midpoint of the wave block's lse values (its 128 rows' when a != 0, its 64 columns' when c != 0; one
-    // interleaved max / min butterfly per tile): exp(R - lse) and exp(s - R) then stay inside fp32 as long as those values lie within
-    // ~120 of each other.  (History: R = scale -- valid since |cos| <= 1 -- overflowed exp(scale - lse) at exp(tau) = 200 with small
+    // The reference point R is one of the wave block's own lse values (its first row's, or its first column's when a = 0): exp(R - lse)
+    // and exp(s - R) then stay inside fp32 as long as every lse of the block (its 128 rows' when a != 0, its 64 columns' when c != 0)
+    // lies within 60 of it.  (History: R = scale -- valid since |cos| <= 1 -- overflowed exp(scale - lse) at exp(tau) = 200 with small
     // cosines; R = the block's first row's lse failed as soon as the lse values themselves spread: exp(tau) = 200 with a few perfectly
     // matched pairs among unrelated ones puts matched rows at ~200 and the others at ~40, and 0 x inf = NaN filled 65519 of 65536
-    // entries of the ADVICE r3 reproducer.)  When the spread is larger than that -- no single reference point can bridge it -- the
+    // entries of the ADVICE r3 reproducer.)  When some lse lies farther away than that (a wave vote) the
     // SAME loop nest runs its exact form (`exact`, wave-uniform): G = gs a exp(s - lse_q) + gs c exp(s - lse_k), two exponentials per
     // logit, as the other side of a branch around each row's four logits of a column quad, the per-row / per-column registers holding
     // the lse values themselves instead of the factors.  (As a second copy of the loop nest -- to_g<EXACT> -- the kernel spilled 59
@@ -118,20 +118,18 @@ struct Sim5FastGradEpilogue {
 #pragma unroll
         for (int i = 0; i < 4; ++i) lq[i] = p.lse_q[m0 + wm * 128 + i * 32 + (lane & 31)];
         const float lk1 = p.lse_k[n0 + wn * 64 + lane];
+        // the reference point: one of the block's own lse values (its first row's, or its first column's when a = 0) -- a uniform load;
+        // whether every other lse of the block lies within 60 of it is ONE vote (no cross-lane reduction: a min / max butterfly in front
+        // of every tile's arithmetic cost 27 us of 170 at 4096 x 32768, profiles/r04_a_sim_g_after_exact_path.log)
+        const float Rq = p.lse_q[m0 + wm * 128], Rk = p.lse_k[n0 + wn * 64];
         u32x4 t = ld16(kcol);
-        float hi = -3.0e38f, lo = 3.0e38f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            hi = (a != 0.f) ? fmaxf(hi, lq[i]) : hi;
-            lo = (a != 0.f) ? fminf(lo, lq[i]) : lo;
-        }
-        hi = (c != 0.f) ? fmaxf(hi, lk1) : hi;
-        lo = (c != 0.f) ? fminf(lo, lk1) : lo;
-        wave_max_min(hi, lo);
-        // (wave-uniform by construction; gfx950 has no scalar float arithmetic, so every derived value is brought back into an SGPR by hand)
         auto sgpr = [](float v) { return u2f((uint32_t)uniform((int)f2u(v))); };
-        const bool exact = uniform((hi - lo) > 120.f ? 1 : 0) != 0;
-        const float R = sgpr(0.5f * (hi + lo));
+        const float R = sgpr((a != 0.f) ? Rq : Rk);
+        bool far = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) far = far || (a != 0.f && !(fabsf(lq[i] - R) <= 60.f));
+        far = far || (c != 0.f && !(fabsf(lk1 - R) <= 60.f));
+        const bool exact = wave_any(far);                            // (uniform)
         const float scale2 = sgpr(scale * LOG2E), R2 = sgpr(R * LOG2E);
         const float cx = sgpr((c != 0.f) ? gs * c : 0.f);
         const bool on_diag = !sim5_off_diagonal(p, m0, n0);          // (uniform)

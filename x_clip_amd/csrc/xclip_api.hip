@@ -260,6 +260,26 @@ int gemm2_splits(int64_t M, int64_t N, int64_t K) {
     return s < 2 ? 1 : (int)s;
 }
 
+// ---- the row tail of a persistent GEMM ------------------------------------------------------------------------------------------------
+// One work-group per CU walks tiles_m x tiles_n tiles: the launch takes ceil(tiles / CUs) rounds of one tile time each, and a last round
+// that fills a few CUs costs as much as a full one.  The text tower's rows are batch x 257 (the CLS token): 263,168 rows = 1028 row tiles,
+// x 2 column tiles (every N = 512 product: out-projection, FF2, the QKV / FF1 input gradients) = 2056 tiles = 8 rounds + 8 tiles -- a NINTH
+// round for 3 % of a round's work, 12 % of the launch (115 us of the FF1 input gradient's 940); the vision tower's 33,792 rows are
+// 132 row tiles: 264 tiles = TWO rounds for 1.03.  So the rows are cut at the last whole round: the main launch takes `main_rows`, and the
+// few row tiles behind it become a split-K problem of their own that fills the part for a few K steps -- fp32 slabs + the reduction
+// (which also adds the skip term of an FF2 forward).  Worth it when a tile is long (>= 16 K steps) and the tail small (<= half a round).
+// -> rows of the main launch (a multiple of the tile), 0 = no cut
+int64_t gemm2_tail_cut(int64_t M, int64_t N, int64_t K) {
+    const int64_t cus = xc_policy_cus();
+    const int64_t tm = (M + G2_BM - 1) / G2_BM, tn = (N + G2_BN - 1) / G2_BN, tiles = tm * tn;
+    const int64_t rounds = tiles / cus;
+    if (rounds < 1 || tiles % cus == 0 || K / G2_BK < 16 || M % 8 != 0) return 0;
+    const int64_t tm_main = rounds * cus / tn;                 // the most row tiles `rounds` rounds can hold
+    const int64_t tail_tiles = tiles - tm_main * tn;
+    if (tm_main < 1 || tail_tiles * 2 > cus || M - tm_main * G2_BM < 128) return 0;      // (a tail the 256 x 256 kernels would not take)
+    return tm_main * G2_BM;
+}
+
 // split-K policy shared by xclip_gemm and xclip_gemm_workspace_bytes: fill ~512 work-groups, keep >= 4 K steps each
 int gemm_splits(int64_t M, int64_t N, int64_t K, int dtype) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
@@ -710,7 +730,55 @@ int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, in
     return check_launch(__func__);
 }
 
+// the 256 x 256 bf16 kernels behind xclip_gemm.  reduce = false: a split-K problem leaves its fp32 slabs in `workspace` for the caller
+// (*splits_out of them; alpha not applied).
+static int gemm2_run(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                     int64_t K, float alpha, const void* bias, const void* residual, int64_t ldr, const void* addrows, const int32_t* rowidx,
+                     int64_t ld_add, void* workspace, int64_t workspace_bytes, hipStream_t st, bool reduce, int* splits_out) {
+    const bool plain = (bias == nullptr && residual == nullptr && addrows == nullptr);
+    Gemm2Params q;
+    q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = (bf16_t*)C; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
+    q.M = (int)M; q.N = (int)N; q.K = (int)K; q.alpha = alpha;
+    q.bias = (const bf16_t*)bias; q.residual = (const bf16_t*)residual; q.ldr = ldr;
+    q.addrows = (const bf16_t*)addrows; q.rowidx = rowidx; q.ld_add = ld_add;
+    q.tiles_m = (int)((M + G2_BM - 1) / G2_BM); q.tiles_n = (int)((N + G2_BN - 1) / G2_BN);
+    // an output that cannot stay in the 8 x 4 MiB of L2 anyway is streamed past it: the A / B panels the sibling tiles share then
+    // survive a round's 32 MiB of output (XCLIP_GEMM_NT=0 / 1 forces the policy, for measurement)
+    static const int nt_env = measure_env("XCLIP_GEMM_NT", -1);
+    q.stream_out = nt_env >= 0 ? nt_env : (M * N * 2 > (int64_t)(48 << 20) ? 1 : 0);
+    // more than 8 N tiles (FF1: 16): banded tile order for the ring kernel (XCLIP_GEMM_BAND=<tiles per band>, 0 = off, for measurement)
+    static const int band_env = measure_env("XCLIP_GEMM_BAND", -1);
+    // FF1 forward in the step: 1227 -> 1155 us (profiles/r02_run22_gemm_banded_order.log); the widest band of 4..8 tiles that divides
+    // the N tiles, none if there is none (9 tiles) or the operand fits anyway (<= 8 tiles)
+    q.band_n = 0;
+    if (band_env != 0 && q.tiles_n > 8)
+        for (int b = band_env > 0 ? band_env : 8; b >= 4 && q.band_n == 0; --b)
+            if (q.tiles_n % b == 0) q.band_n = b;
+    int splits = gemm2_splits(M, N, K);
+    if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
+    q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);
+    // rounding the slice up can leave the last slices EMPTY (96 K steps over 17 slices -> 6 per slice, 16 slices cover them): a slice
+    // without work returns without touching its slab and the reduction would add whatever the workspace held before
+    splits = (int)((K + q.k_per_split - 1) / q.k_per_split);
+    q.partial = splits > 1 ? (float*)workspace : nullptr;
+    if (!a_kmajor && !b_kmajor) launch_gemm2<false, false>(q, splits, st);
+    else if (!a_kmajor && b_kmajor) launch_gemm2<false, true>(q, splits, st);
+    else launch_gemm2<true, true>(q, splits, st);
+    if (splits_out != nullptr) *splits_out = splits;
+    if (splits > 1 && reduce) {
+        int64_t blocks = (M * (N / 4) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace,
+                           (bf16_t*)C, (long)ldc, (int)M, (int)N, splits, alpha);
+    }
+    return check_launch(__func__);
+}
+
 int64_t xclip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype) {
+    if (use_gemm2(M, N, K, dtype)) {
+        const int64_t cut = gemm2_tail_cut(M, N, K);           // (normal-A layouts only; the k-major-A caller just gets a little more than it needs)
+        if (cut > 0) return (int64_t)gemm2_splits(M - cut, N, K) * (M - cut) * N * 4;
+    }
     const int s = use_gemm2(M, N, K, dtype) ? gemm2_splits(M, N, K) : gemm_splits(M, N, K, dtype);
     return s > 1 ? (int64_t)s * M * N * 4 : 0;
 }
@@ -738,41 +806,33 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
     hipStream_t st = (hipStream_t)stream;
     const bool plain = (bias == nullptr && residual == nullptr && addrows == nullptr);
     if (use_gemm2(M, N, K, dtype)) {
-        Gemm2Params q;
-        q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = (bf16_t*)C; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
-        q.M = (int)M; q.N = (int)N; q.K = (int)K; q.alpha = alpha;
-        q.bias = (const bf16_t*)bias; q.residual = (const bf16_t*)residual; q.ldr = ldr;
-        q.addrows = (const bf16_t*)addrows; q.rowidx = rowidx; q.ld_add = ld_add;
-        q.tiles_m = (int)((M + G2_BM - 1) / G2_BM); q.tiles_n = (int)((N + G2_BN - 1) / G2_BN);
-        // an output that cannot stay in the 8 x 4 MiB of L2 anyway is streamed past it: the A / B panels the sibling tiles share then
-        // survive a round's 32 MiB of output (XCLIP_GEMM_NT=0 / 1 forces the policy, for measurement)
-        static const int nt_env = measure_env("XCLIP_GEMM_NT", -1);
-        q.stream_out = nt_env >= 0 ? nt_env : (M * N * 2 > (int64_t)(48 << 20) ? 1 : 0);
-        // more than 8 N tiles (FF1: 16): banded tile order for the ring kernel (XCLIP_GEMM_BAND=<tiles per band>, 0 = off, for measurement)
-        static const int band_env = measure_env("XCLIP_GEMM_BAND", -1);
-        // FF1 forward in the step: 1227 -> 1155 us (profiles/r02_run22_gemm_banded_order.log); the widest band of 4..8 tiles that divides
-        // the N tiles, none if there is none (9 tiles) or the operand fits anyway (<= 8 tiles)
-        q.band_n = 0;
-        if (band_env != 0 && q.tiles_n > 8)
-            for (int b = band_env > 0 ? band_env : 8; b >= 4 && q.band_n == 0; --b)
-                if (q.tiles_n % b == 0) q.band_n = b;
-        int splits = gemm2_splits(M, N, K);
-        if (splits > 1 && (!plain || workspace == nullptr || workspace_bytes < (int64_t)splits * M * N * 4)) splits = 1;
-        q.k_per_split = (int)((((K / G2_BK) + splits - 1) / splits) * G2_BK);
-        // rounding the slice up can leave the last slices EMPTY (96 K steps over 17 slices -> 6 per slice, 16 slices cover them): a slice
-        // without work returns without touching its slab and the reduction would add whatever the workspace held before
-        splits = (int)((K + q.k_per_split - 1) / q.k_per_split);
-        q.partial = splits > 1 ? (float*)workspace : nullptr;
-        if (!a_kmajor && !b_kmajor) launch_gemm2<false, false>(q, splits, st);
-        else if (!a_kmajor && b_kmajor) launch_gemm2<false, true>(q, splits, st);
-        else launch_gemm2<true, true>(q, splits, st);
-        if (splits > 1) {
-            int64_t blocks = (M * (N / 4) + 255) / 256;
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace,
-                               (bf16_t*)C, (long)ldc, (int)M, (int)N, splits, alpha);
+        // the row tail as a split-K problem of its own (gemm2_tail_cut): the main rows, then the tail's slabs, then the reduction that also
+        // applies alpha and the skip term
+        const int64_t cut = (!a_kmajor && bias == nullptr && addrows == nullptr && workspace != nullptr) ? gemm2_tail_cut(M, N, K) : 0;
+        const int64_t mt = M - cut;
+        if (cut > 0 && gemm2_splits(mt, N, K) > 1 && workspace_bytes >= (int64_t)gemm2_splits(mt, N, K) * mt * N * 4) {
+            int rc = gemm2_run(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, cut, N, K, alpha, nullptr, residual, ldr, nullptr, nullptr, 0, nullptr, 0, st,
+                               true, nullptr);
+            if (rc != 0) return rc;
+            const char* At = (const char*)A + cut * lda * 2;     // (bf16: use_gemm2)
+            char* Ct = (char*)C + cut * ldc * 2;
+            const char* Rt = residual != nullptr ? (const char*)residual + cut * ldr * 2 : nullptr;
+            int tsplits = 1;
+            rc = gemm2_run(a_kmajor, b_kmajor, At, lda, B, ldb, Ct, ldc, mt, N, K, alpha, nullptr, nullptr, 0, nullptr, nullptr, 0, workspace,
+                           workspace_bytes, st, false, &tsplits);
+            if (rc != 0) return rc;
+            if (tsplits > 1) {
+                int64_t blocks = (mt * (N / 4) + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace, (bf16_t*)Ct,
+                                   (long)ldc, (int)mt, (int)N, tsplits, alpha, (const bf16_t*)Rt, (long)ldr);
+            } else if (Rt != nullptr) {
+                return xcapi::fail(__func__, "internal: tail GEMM did not split");
+            }
+            return check_launch(__func__);
         }
-        return check_launch(__func__);
+        return gemm2_run(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, M, N, K, alpha, bias, residual, ldr, addrows, rowidx, ld_add, workspace,
+                         workspace_bytes, st, true, nullptr);
     }
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;

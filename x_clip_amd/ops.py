@@ -374,12 +374,19 @@ class KernelProbe:
     `summary(family)` returns (launches, flops, seconds) with `algorithmic_bytes` set; `clock_mhz()` the sampled shader clocks."""
     active: Optional["KernelProbe"] = None
 
-    def __init__(self, clock_every: int = 0, clock_slots: int = 512):
+    def __init__(self, clock_every: int = 0, clock_slots: int = 512, under_load_every: int = 0, record: bool = True):
         self.records = []                 # (family, flops, ev0, ev1, algorithmic bytes, key)
         self.clock_every = clock_every
         self.clock_slots = clock_slots
+        # under_load_every = n: in front of every n-th GEMM launch a one-wave sampler is started on a SIDE stream and counts shader cycles
+        # for 200 us -- while the GEMM runs on the other 255 CUs (the sampler's CU cannot take a GEMM work-group meanwhile: such a pass
+        # reads the clock the part sustains under the load, its kernel times are not to be quoted)
+        self.under_load_every = under_load_every
+        self.record = record
         self._clock = None
         self._clock_n = 0
+        self._seen = 0
+        self._side = None
 
     def __enter__(self):
         KernelProbe.active = self
@@ -389,21 +396,38 @@ class KernelProbe:
         KernelProbe.active = None
 
     # -- recording (called by the wrappers below) --
-    def begin(self, t: Tensor):
+    def _sample(self, t: Tensor, stream, ticks: int):
+        if self._clock is None:
+            self._clock = torch.zeros(self.clock_slots, 2, dtype=torch.int64, device=t.device)
+        if self._clock_n < self.clock_slots:
+            _lib.check(_lib.lib().xclip_clock_sample(self._clock[self._clock_n].data_ptr(), ticks, stream.cuda_stream), "xclip_clock_sample")
+            self._clock_n += 1
+
+    def begin(self, t: Tensor, family: str = ""):
+        if self.under_load_every and family == "gemm":
+            self._seen += 1
+            if self._seen % self.under_load_every == 0:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=t.device)
+                    self._clock = torch.zeros(self.clock_slots, 2, dtype=torch.int64, device=t.device)
+                # the sampler starts when the launching stream gets HERE (the host runs many kernels ahead of the device)
+                self._side.wait_event(torch.cuda.current_stream(t.device).record_event())
+                self._sample(t, self._side, 20000)
+        if not self.record:
+            return None
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(t.device))
         return ev0
 
     def end(self, t: Tensor, ev0, family: str, flops: float, nbytes: float, key=None):
+        if not self.record:
+            return
         ev1 = torch.cuda.Event(enable_timing=True)
         st = torch.cuda.current_stream(t.device)
         ev1.record(st)
         self.records.append((family, flops, ev0, ev1, nbytes, key))
-        if self.clock_every and len(self.records) % self.clock_every == 0 and self._clock_n < self.clock_slots:
-            if self._clock is None:
-                self._clock = torch.zeros(self.clock_slots, 2, dtype=torch.int64, device=t.device)
-            _lib.check(_lib.lib().xclip_clock_sample(self._clock[self._clock_n].data_ptr(), 1000, st.cuda_stream), "xclip_clock_sample")
-            self._clock_n += 1
+        if self.clock_every and len(self.records) % self.clock_every == 0:
+            self._sample(t, st, 1000)
 
     # -- results --
     def summary(self, family: str = "gemm"):
@@ -462,11 +486,11 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
         assert addrows.stride(1) == 1 and addrows.shape[1] == N
     L = _lib.lib()
     code = dtype_code(a)
-    plain = bias is None and residual is None and addrows is None
-    wbytes = L.xclip_gemm_workspace_bytes(M, N, K, code) if plain else 0
+    # split-K slabs: plain products, and the row tail of a long-K product with or without a skip term (xclip_api.hip gemm2_tail_cut)
+    wbytes = L.xclip_gemm_workspace_bytes(M, N, K, code) if (bias is None and addrows is None) else 0
     ws = workspace(a.device, wbytes)
     probe = _probe(a)
-    ev0 = probe.begin(a) if probe is not None else None
+    ev0 = probe.begin(a, "gemm") if probe is not None else None
     _lib.check(L.xclip_gemm(int(a_kmajor), int(b_kmajor), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
                             out.stride(0), M, N, K, alpha, _ptr(bias), _ptr(residual),
                             0 if residual is None else residual.stride(0), _ptr(addrows), _ptr(rowidx),
