@@ -344,6 +344,12 @@ inline void wave_max_min(float& hi, float& lo) {
     }
 }
 
+inline float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    auto lo = [](uint32_t v) { uint32_t u = v << 16; float f; memcpy(&f, &u, 4); return f; };
+    auto hi = [](uint32_t v) { uint32_t u = v & 0xffff0000u; float f; memcpy(&f, &u, 4); return f; };
+    return c + lo(a) * lo(b) + hi(a) * hi(b);
+}
+
 inline f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
     struct Dep { float a[8], b[8]; } mine;                // (converted once per lane, not once per product)
     for (int k = 0; k < 8; ++k) { mine.a[k] = bf2f((bf16_t)a[k]); mine.b[k] = bf2f((bf16_t)b[k]); }

@@ -268,7 +268,7 @@ def _attention_ref(qkv64, mask, heads, scale, causal=False, hd=64, drop=None):
     return (p @ v).permute(0, 2, 1, 3).reshape(b, n, heads * hd)
 
 
-def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64, drop=None):
+def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64, drop=None, mask_override=None):
     """hd = features per head slot: 64, or 128 (wide heads, reference Attention(dim_head > 64), x_clip.py:201-212); drop = (p, seed):
     attention dropout (x_clip.py:212,241) with the product's own stateless keep-mask"""
     qkv = rnd((batch, n, 3 * heads * hd), dtype, 22)
@@ -282,6 +282,8 @@ def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64, dro
                 mask[bi, n - k:] = False
             if n > 3:
                 mask[bi, 2] = bi % 2 == 0           # a hole in the middle as well
+    if mask_override is not None:
+        mask = mask_override
     scale = hd ** -0.5
     dk = {} if drop is None else dict(dropout_p=drop[0], dropout_seed=drop[1])
     out, lse = ops.attention_fwd(qkv.to(dev), None if mask is None else mask.to(dev), heads, scale, causal, hd, **dk)
@@ -292,6 +294,19 @@ def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64, dro
     close(out, r, dtype, "attn out" + tag, ulps=2.0, unit="scale")
     dqkv = ops.attention_bwd(qkv.to(dev), None if mask is None else mask.to(dev), out, dout.to(dev), lse, heads, scale, causal, hd, **dk)
     close(dqkv, q64.grad, dtype, "attn dqkv" + tag, mult=3.0, ulps=2.0, unit="scale")
+
+
+def case_attention_single_tail(dev, dtype, n=257, heads=2):
+    """n = 32 q + 1 (the text encoder's CLS + 256 tokens): the tail row enters the head-resident kernels as the INITIAL value of their
+    accumulators (attention3.h a3_tail_dot / a3_tail_outer), not as a 33rd MFMA block.  Four samples: no mask at all; a hole in the middle
+    with the tail key valid; the tail key itself padded; everything but the first three keys padded (the tail query then sees three keys)"""
+    mask = torch.ones(4, n, dtype=torch.bool)
+    mask[1, 40] = False
+    mask[2, n - 1] = False
+    mask[2, 7] = False
+    mask[3, 3:] = False
+    case_attention(dev, dtype, 4, n, heads, True, mask_override=mask)
+    case_attention(dev, dtype, 1, n, heads, False)
 
 
 def case_attention_spike(dev, dtype):

@@ -20,7 +20,9 @@ HOT = {
     "gemm5_kernel<false, true, 0, 0>": (0, 0), "gemm5_kernel<false, false, 0, 0>": (0, 0),      # forward NT / dgrad NN, interior path only
     "sim5_lse_kernel": (0, 0),                                                                  # no load at all in a tile's epilogue
     "filip5_kernel": (0, 0),
-    "attn3_fwd_kernel<false>": (1, 0), "attn3_bwd_kernel<false>": (5, 0), "attn3_bwd_kernel<true>": (5, 0),
+    # (round 4: the two key-validity bytes of a thread are requested together and waited for once -- the scan counts both loads of that one
+    #  round trip, plus the loop for shapes the kernels never get; the backward's 5 branch-guarded loads of round 3 are gone)
+    "attn3_fwd_kernel<false>": (3, 0), "attn3_bwd_kernel<false>": (6, 0), "attn3_bwd_kernel<true>": (6, 0),
     "ln_geglu_bwd_kernel<bf16, 2, 2>": (0, 0), "ln_fwd_kernel<bf16, 4, true>": (4, 0), "ln_fwd_kernel<bf16, 1, false>": (2, 0),
     "ln_bwd_kernel<bf16, 1, false>": (3, 0), "ln_chain_fwd_kernel<bf16, 1>": (2, 0), "ln_chain_bwd_kernel<bf16, 1>": (1, 0),
     "splitk_reduce_kernel<bf16>": (0, 0),

@@ -97,6 +97,12 @@ def test_attention_causal_long_bf16(n):
     K.case_attention(DEV, torch.bfloat16, 1, n, 1, True, causal=True)
 
 
+def test_attention_single_tail_row():
+    """257 = 8 x 32 + 1 tokens, not causal: the tail key / query as the accumulators' initial values (no 33rd block), with and without masks"""
+    K.case_attention_single_tail(DEV, torch.bfloat16)
+    K.case_attention_single_tail(DEV, torch.bfloat16, n=129, heads=1)
+
+
 def test_attention_rescale_spike():
     K.case_attention_spike(DEV, torch.float32)
 

@@ -136,6 +136,13 @@ def test_attention_wide_heads(dtype, n, heads, masked, causal):
     K.case_attention(DEV, dtype, 3, n, heads, masked, causal=causal, hd=128)
 
 
+def test_attention_single_tail_row():
+    """257 = 8 x 32 + 1 tokens, not causal: the tail key / query as the accumulators' initial values (no 33rd block), with and without masks"""
+    K.case_attention_single_tail(DEV, torch.bfloat16)
+    K.case_attention_single_tail(DEV, torch.bfloat16, n=129, heads=3)
+    K.case_attention_single_tail(DEV, torch.bfloat16, n=257, heads=8)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 def test_attention_rescale_spike(dtype):
     K.case_attention_spike(DEV, dtype)

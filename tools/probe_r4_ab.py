@@ -1,0 +1,64 @@
+"""Round-4 A/B probes on one box, measurement build (the switches are read once per process: run once per setting):
+    python tools/probe_r4_ab.py attn      XCLIP_ATTN_ABL=4 -> the 257th token as a 33rd block (round-3 form); unset -> as the accumulators' initial value
+    python tools/probe_r4_ab.py gemm      XCLIP_GEMM_TAIL=0 -> uncut persistent launches; unset -> the row tail as a split-K problem
+Prints one line per shape; the text / vision shapes of BASELINE configs[1] (b = 1024)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from x_clip_amd import _lib, ops
+_lib.use_measurement_build()
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+
+
+def timeit(fn, iters=20, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):                                   # three rounds: median of the round means
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) / iters)
+    return sorted(ts)[1]
+
+
+def warm_clock():
+    a, b = torch.randn(263168, 512, device=dev, dtype=bf), torch.randn(1536, 512, device=dev, dtype=bf)
+    for _ in range(150):
+        ops.gemm(a, b, 263168, 1536, 512)
+    torch.cuda.synchronize()
+
+
+tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("XCLIP_")) or "default"
+what = sys.argv[1] if len(sys.argv) > 1 else "attn"
+warm_clock()
+if what == "attn":
+    for (b, n, h, masked) in [(1024, 257, 8, True), (1024, 257, 8, False), (1024, 256, 8, True), (1024, 33, 8, False), (1024, 129, 8, True)]:
+        qkv = torch.randn(b, n, 3 * h * 64, device=dev, dtype=bf)
+        mask = torch.ones(b, n, dtype=torch.bool, device=dev) if masked else None
+        t = timeit(lambda: ops.attention_fwd(qkv, mask, h, 0.125))
+        out, lse = ops.attention_fwd(qkv, mask, h, 0.125)
+        do = torch.randn_like(out)
+        tb = timeit(lambda: ops.attention_bwd(qkv, mask, out, do, lse, h, 0.125))
+        fl = 4.0 * b * h * n * n * 64
+        print(f"[{tag}] attention b={b} n={n} h={h} mask={int(masked)}: fwd {t*1e3:7.1f} us ({fl/t/1e9:6.1f} TF/s)   bwd {tb*1e3:7.1f} us ({2*fl/tb/1e9:6.1f} TF/s algorithmic)", flush=True)
+else:
+    Mt, Mv = 1024 * 257, 1024 * 33
+    for (name, M, N, K, bk, res) in [("ff1 dgrad text", Mt, 512, 4096, True, False), ("ff2 fwd+skip text", Mt, 512, 2048, False, True),
+                                     ("qkv dgrad text", Mt, 512, 1536, True, False), ("out fwd text", Mt, 512, 512, False, False),
+                                     ("ff1 dgrad vision", Mv, 512, 4096, True, False), ("ff2 fwd+skip vision", Mv, 512, 2048, False, True),
+                                     ("qkv dgrad vision", Mv, 512, 1536, True, False), ("qkv fwd vision", Mv, 1536, 512, False, False),
+                                     ("ff1 fwd vision", Mv, 4096, 512, False, False)]:
+        a = torch.randn(M, K, device=dev, dtype=bf)
+        b = torch.randn((K, N) if bk else (N, K), device=dev, dtype=bf)
+        r = torch.randn(M, N, device=dev, dtype=bf) if res else None
+        out = torch.empty(M, N, device=dev, dtype=bf)
+        t = timeit(lambda: ops.gemm(a, b, M, N, K, b_kmajor=bk, residual=r, out=out))
+        tiles = ((M + 255) // 256) * (N // 256)
+        print(f"[{tag}] {name:22s} M={M:7d} N={N:5d} K={K:5d}: {t*1e3:8.1f} us  {2.0*M*N*K/t/1e9:7.1f} TF/s   ({tiles} tiles = {tiles/256:.2f} rounds)", flush=True)

@@ -124,6 +124,13 @@ XC_DEV f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// c + a.lo * b.lo + a.hi * b.hi of two packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16): dot products of single rows that are not
+// worth an MFMA block (the 257th token of the text encoder in attention3.h)
+XC_DEV float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
 // ---- LDS DMA and transpose read (gfx950) -----------------------------------------------------------------
 // glds16: every lane copies 16 bytes from its own global address to LDS at lds_wave_base + 16 * lane
 // (global_load_lds_dwordx4: the destination is wave-uniform base + lane * 16, the source is per lane; no VGPR

@@ -139,6 +139,43 @@ XC_DEV void a3_stagger(int ticks_10ns, int first_round) {
         for (int spin = 0; spin < 4 * ticks_10ns && realtime_10ns() < until; ++spin) nap();
     }
 }
+// ---- a single tail row (n = 32 q + 1: the text encoder's 257 = CLS + 256 tokens) without a 33rd MFMA block ------------------------------
+// As the LAST sub-tile of every sweep the tail row costs a whole masked 32 x 32 step -- 8 to 16 MFMAs and ~110 vector instructions for one
+// useful row or column of 32 (n = 257 ran 23 % longer than n = 256).  A lane owns a query (or key) of its wave's block, so the one score
+// it has against the tail row is a 64-long dot product of two rows it can reach directly: its own row fragments (registers) and the tail
+// row of the resident image (LDS, the same address in every lane of a half-wave: a broadcast read) -- 16 v_dot2c_f32_bf16 and one
+// exchange between the half-waves.  Processed FIRST, the tail row's contribution is the INITIAL value of the accumulators (forward: the
+// probability of the first key seen is exactly 1, so m = s, l = 1, O = v_tail; backward: dQ = dS k_tail, dK = dS q_tail, dV = P dO_tail)
+// instead of zeros, and the sweeps run over the full sub-tiles only.
+// score of the lane's row (fragments f: 8 features per k-block for its half h) against row `row` of sub-tile `t` of an image
+XC_DEV float a3_tail_dot(const unsigned char* img, int t, int row, const u32x4 (&f)[4], int lane) {
+    const int h = lane >> 5;
+    float acc = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const u32x4 g = ld16(img + t * 4096 + (row * 128 + a2_slot(row, kb * 2 + h) * 16));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc = dot2_bf16(f[kb][w], g[w], acc);
+    }
+    return acc + shfl_xor(acc, 32);
+}
+// acc[db][r] = mul * X[row][d = 32 db + mfma_row(r, lane)]: row `row` of sub-tile t of an image in the transposed accumulator layout
+XC_DEV void a3_tail_outer(const unsigned char* img, int t, int row, float mul, int lane, f32x16 (&acc)[2]) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x2 v = *reinterpret_cast<const u32x2*>(img + t * 4096 + (row * 128 + a2_slot(row, 4 * db + g) * 16 + 8 * h));
+            acc[db][4 * g + 0] = mul * u2f(v[0] << 16);
+            acc[db][4 * g + 1] = mul * u2f(v[0] & 0xffff0000u);
+            acc[db][4 * g + 2] = mul * u2f(v[1] << 16);
+            acc[db][4 * g + 3] = mul * u2f(v[1] & 0xffff0000u);
+        }
+}
+// (abl & 4, measurement build: the round-3 form -- the tail row as the last sub-tile of every sweep)
+XC_HOST_DEV bool a3_single_tail(int n, int abl = 0) { return a3_coop_tail(n) && (n & 31) == 1 && !(abl & 4); }
+
 // key validity bytes of a head into LDS: at most two positions per thread in the shapes these kernels take (npad <= 288; the forward
 // runs 2 npad threads, the backward 256), both loads unconditional (index clamped) and in flight together.  Written as
 // `Ms[k] = (k < n) && (mask == nullptr || mask[k])` every position was a branch around its own load and a full drain of the memory
@@ -217,7 +254,16 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m = ATT_NEG, l = 0.f;
-    for (int t = 0; t < nsub; ++t) a3_fwd_step_auto<CAUSAL>(Ks, Vs, Ms, t, qf, scale2, lane, q0, o, m, l);
+    int tend = nsub;
+    if (a3_single_tail(n, p.chunks)) {                         // (uniform) the 257th key first: it initialises (m, l, O) -- see a3_tail_dot
+        tend = nsub - 1;
+        if (!CAUSAL && Ms[tail0] != 0) {                       // (causal: the last key is hidden from every query of a full block)
+            m = a3_tail_dot(Ks, tend, 0, qf, lane) * scale2;
+            l = 1.f;
+            a3_tail_outer(Vs, tend, 0, 1.f, lane, o);
+        }
+    }
+    for (int t = 0; t < tend; ++t) a3_fwd_step_auto<CAUSAL>(Ks, Vs, Ms, t, qf, scale2, lane, q0, o, m, l);
     sync();                                                    // every wave is done with the K / V images (and the tail partials are in)
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     a2_store_rows(lds + wave * 32 * 144, o, inv, out, (long)p.heads * ATT_DH, q0, n, lane);
@@ -429,7 +475,7 @@ XC_DEV void a3_row_frags(const bf16_t* X, long ldx, int r, int lane, u32x4 (&f)[
 // rows from global), so the second pair is DMA'd over the first between the phases and a head needs ~80 KB of LDS instead
 // of 160: TWO work-groups of four waves per CU (each wave takes every fourth 32-row block), one computing while the other
 // waits for HBM.  (The one-work-group-per-CU version measured load + store skeleton 405 us, phase A 225, phase B 395, total
-// 1060 = their sum at n = 256.)  p.chunks is a measurement switch here (XCLIP_ATTN_ABL: 1 = skip phase A, 2 = skip phase B).
+// 1060 = their sum at n = 256.)  p.chunks is a measurement switch here (XCLIP_ATTN_ABL: 1 = skip phase A, 2 = skip phase B, 4 = the tail row as a 33rd block).
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
     XC_LDS_DYNAMIC(lds);
@@ -514,7 +560,15 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g0[db][r] = 0.f;
             const float lse_q = Ls[row], delta_q = Ds[row];
-            const int tend = CAUSAL ? (rb + 1 < nsub ? rb + 1 : nsub) : nsub;      // key sub-tiles above the diagonal contribute nothing
+            int tend = CAUSAL ? (rb + 1 < nsub ? rb + 1 : nsub) : nsub;            // key sub-tiles above the diagonal contribute nothing
+            if (a3_single_tail(n, p.chunks) && !CAUSAL) {                           // (uniform) the 257th key: dQ starts at dS k_tail
+                tend = nsub - 1;
+                if (Ms[tail0] != 0) {
+                    const float pt = fast_exp2(a3_tail_dot(R0, tend, 0, f0, lane) * scale2 - lse_q);
+                    const float ds = pt * (a3_tail_dot(R1, tend, 0, f1, lane) - delta_q);        // dS / scale
+                    a3_tail_outer(R0, tend, 0, ds, lane, g0);
+                }
+            }
             a3_bwd_dq_sweep<CAUSAL>(R0, R1, Ms, 0, tend, 1, plain_bits, f0, f1, lse_q, delta_q, scale2, lane, row, g0);
             a3_store_rows_direct(g0, dQ, ldq, rb * 32, n, lane, p.scale);
         }
@@ -545,8 +599,17 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { g0[db][r] = 0.f; g1[db][r] = 0.f; }
             const bool keys_plain = wave_all(kvalid);                              // (uniform: no padding among this block's keys)
+            int qend = nsub;
+            if (a3_single_tail(n, p.chunks)) {                                     // (uniform) the 257th query: dK / dV start at its contribution
+                qend = nsub - 1;                                                   // (causal: the last query sees every key)
+                const float st = a3_tail_dot(R0, qend, 0, f0, lane);               // (every lane: the dot product ends in a cross-lane exchange)
+                const float pt = kvalid ? fast_exp2(st * scale2 - Ls[tail0]) : 0.f;
+                const float ds = pt * (a3_tail_dot(R1, qend, 0, f1, lane) - Ds[tail0]);          // dS / scale
+                a3_tail_outer(R0, qend, 0, ds, lane, g0);
+                a3_tail_outer(R1, qend, 0, pt, lane, g1);
+            }
             // (query sub-tiles below the diagonal see none of these keys)
-            a3_bwd_dkv_sweep<CAUSAL>(R0, R1, Ls, Ds, CAUSAL ? rb : 0, nsub, 1, n, keys_plain, f0, f1, kvalid, scale2, lane, row, g0, g1);
+            a3_bwd_dkv_sweep<CAUSAL>(R0, R1, Ls, Ds, CAUSAL ? rb : 0, qend, 1, n, keys_plain, f0, f1, kvalid, scale2, lane, row, g0, g1);
             a3_store_rows_direct(g0, dK, ldq, rb * 32, n, lane, p.scale);
             a3_store_rows_direct(g1, dV, ldq, rb * 32, n, lane);
         }

@@ -270,6 +270,8 @@ int gemm2_splits(int64_t M, int64_t N, int64_t K) {
 // (which also adds the skip term of an FF2 forward).  Worth it when a tile is long (>= 16 K steps) and the tail small (<= half a round).
 // -> rows of the main launch (a multiple of the tile), 0 = no cut
 int64_t gemm2_tail_cut(int64_t M, int64_t N, int64_t K) {
+    static const int on = measure_env("XCLIP_GEMM_TAIL", 1);   // (measurement build: 0 = the uncut launch, for the A/B)
+    if (!on) return 0;
     const int64_t cus = xc_policy_cus();
     const int64_t tm = (M + G2_BM - 1) / G2_BM, tn = (N + G2_BN - 1) / G2_BN, tiles = tm * tn;
     const int64_t rounds = tiles / cus;

@@ -90,6 +90,8 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
         static const int stag = measure_env("XCLIP_ATTN_STAGGER_FWD", -1);
         const int half_head = (int)(1300.0 * (double)n * (double)n / (257.0 * 257.0));
         p.stagger_10ns = (attn3_fwd_lds_bytes((int)n) <= 80 * 1024 && batch * heads >= 1024) ? (stag >= 0 ? stag : half_head) : 0;
+        static const int abl_f = measure_env("XCLIP_ATTN_ABL", 0);  // measurement build only: 4 = the tail row as a 33rd block (round-3 form)
+        p.chunks = abl_f;
         if (causal) {
             XC_ALLOW_LDS(attn3_fwd_kernel<true>, 160 * 1024);
             hipLaunchKernelGGL(attn3_fwd_kernel<true>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn3_fwd_lds_bytes((int)n), st, p);
