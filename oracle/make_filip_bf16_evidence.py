@@ -1,0 +1,76 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  What the REFERENCE's own bf16 run of the fine-grained (FILIP) head differs by from its fp32 run.
+
+The product's bf16 FILIP tests hold parameter gradients to 16 % relative error / cosine 0.985 against the fp64 oracle -- far looser than
+the 8 % / 0.999 of every CLS-head case -- with the argument that bf16 token scores tie differently in the max over image / text tokens
+(x_clip.py:805-811), "as the reference's own bf16 run would".  VERDICT r3 (weak #3) asked for that claim as evidence: this script runs the
+unmodified reference (imported from /root/reference, CPU) on the configuration of tests/test_clip_gpu.py::test_filip_mid_vs_oracle --
+dim 512, depth 2 / 2, 70 text tokens, 16 patches, batch 24 -- once in fp32 and once with `.to(bfloat16)` parameters and inputs, from the same
+(bf16-representable) weights, and records per parameter the relative error and cosine of the bf16 gradient against the fp32 one.
+
+    python oracle/make_filip_bf16_evidence.py      # rewrites tests/golden/filip_ref_bf16_vs_fp32.json
+
+tests/test_oracle_golden.py::test_filip_bf16_bars_are_the_references_own checks that the product's bars are not looser than 1.5 x what
+the reference itself shows (and that the CLS head of the same model is an order of magnitude tighter -- the looseness is FILIP's).
+"""
+import dataclasses
+import json
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle.clip_oracle import ClipConfig, make_inputs, make_state_dict  # noqa: E402
+from oracle.make_golden import import_reference  # noqa: E402
+
+MID = ClipConfig(dim_text=512, dim_image=512, dim_latent=512, num_text_tokens=2000, text_enc_depth=2, text_seq_len=70,
+                 text_heads=8, visual_enc_depth=2, visual_image_size=128, visual_patch_size=32, visual_heads=8)
+
+
+def run(x_clip, cfg, dtype, batch, seed):
+    sd = make_state_dict(cfg, seed, torch.float32)
+    sd = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in sd.items()}     # bf16-representable in both runs
+    text, image, _, _ = make_inputs(cfg, batch, seed + 1)
+    image = image.to(torch.bfloat16).float()
+    model = x_clip.CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)
+    model.load_state_dict(sd)
+    model = model.to(dtype).train()
+    loss = model(text, image.to(dtype), return_loss=True)
+    loss.backward()
+    return float(loss.detach().float()), {k: p.grad.detach().double() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def compare(x_clip, cfg, batch, seed):
+    l32, g32 = run(x_clip, cfg, torch.float32, batch, seed)
+    l16, g16 = run(x_clip, cfg, torch.bfloat16, batch, seed)
+    rows = {}
+    for k, a in g32.items():
+        b = g16[k]
+        if float(a.abs().max()) == 0.0:
+            continue
+        rows[k] = {"rel": float((b - a).norm() / a.norm()), "cos": float((a * b).sum() / (a.norm() * b.norm()))}
+    worst_rel = max(rows.items(), key=lambda kv: kv[1]["rel"])
+    worst_cos = min(rows.items(), key=lambda kv: kv[1]["cos"])
+    return {"loss_fp32": l32, "loss_bf16": l16, "worst_rel": worst_rel[1]["rel"], "worst_rel_param": worst_rel[0],
+            "worst_cos": worst_cos[1]["cos"], "worst_cos_param": worst_cos[0], "params": len(rows)}
+
+
+def main():
+    x_clip = import_reference()
+    torch.manual_seed(0)
+    out = {"what": "reference x_clip.CLIP, CPU: gradients of a bf16 run against the fp32 run of the same bf16-representable weights and inputs",
+           "config": "dim 512, depth 2 / 2, 70 text tokens, 16 patches (tests/test_clip_gpu.py MID), batch 24, seed 7",
+           "torch": torch.__version__}
+    out["filip"] = compare(x_clip, dataclasses.replace(MID, use_all_token_embeds=True), 24, 7)
+    out["cls"] = compare(x_clip, MID, 24, 7)
+    path = os.path.join(ROOT, "tests", "golden", "filip_ref_bf16_vs_fp32.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

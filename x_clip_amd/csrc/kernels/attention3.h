@@ -237,7 +237,16 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
         float m = ATT_NEG, l = 0.f;
-        for (int t = wave; t < nsub; t += nwaves) a3_fwd_step_auto<CAUSAL>(Ks, Vs, Ms, t, qf, scale2, lane, tail0, o, m, l);
+        int tcoop = nsub;
+        if (a3_single_tail(n, p.chunks)) {                     // (uniform) the tail query against the tail key: no sub-tile of its own --
+            tcoop = nsub - 1;                                  // the last wave's partial starts from it (wave 0 used to walk TWO sub-tiles)
+            if (wave == nwaves - 1 && Ms[tail0] != 0) {
+                m = a3_tail_dot(Ks, tcoop, 0, qf, lane) * scale2;
+                l = 1.f;
+                a3_tail_outer(Vs, tcoop, 0, 1.f, lane, o);
+            }
+        }
+        for (int t = wave; t < tcoop; t += nwaves) a3_fwd_step_auto<CAUSAL>(Ks, Vs, Ms, t, qf, scale2, lane, tail0, o, m, l);
         if (c31 < ntail) {
             float* rec = Ts + ((long)wave * A3_TAIL_MAX + c31) * A3_TAIL_REC;
             if (h == 0) { rec[0] = m; rec[1] = l; }
@@ -547,7 +556,13 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g0[db][r] = 0.f;
             const float lq = Ls[tail0 + c31], dl = Ds[tail0 + c31];
-            a3_bwd_dq_sweep<CAUSAL>(R0, R1, Ms, wave, nsub, nwaves, plain_bits, f0, f1, lq, dl, scale2, lane, tail0 + c31, g0);
+            int tcoop = nsub;
+            if (a3_single_tail(n, p.chunks)) {                 // (uniform) tail query x tail key: the last wave's partial starts from it
+                tcoop = nsub - 1;
+                const float st = a3_tail_dot(R0, tcoop, 0, f0, lane), dt_ = a3_tail_dot(R1, tcoop, 0, f1, lane);
+                if (wave == nwaves - 1 && Ms[tail0] != 0) a3_tail_outer(R0, tcoop, 0, fast_exp2(st * scale2 - lq) * (dt_ - dl), lane, g0);
+            }
+            a3_bwd_dq_sweep<CAUSAL>(R0, R1, Ms, wave, tcoop, nwaves, plain_bits, f0, f1, lq, dl, scale2, lane, tail0 + c31, g0);
             if (c31 < ntail) a3_put_col(Tp + ((long)wave * A3_TAIL_MAX + c31) * 128, g0, lane);
         }
         for (int rb = wave; rb < nblk; rb += nwaves) {
@@ -622,7 +637,17 @@ __global__ __launch_bounds__(256) void attn3_bwd_kernel(AttnParams p) {
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { g0[db][r] = 0.f; g1[db][r] = 0.f; }
-            a3_bwd_dkv_sweep<CAUSAL>(R0, R1, Ls, Ds, wave, nsub, nwaves, n, false, f0, f1, tvalid, scale2, lane, tail0 + c31, g0, g1);
+            int tcoop = nsub;
+            if (a3_single_tail(n, p.chunks)) {                 // (uniform) tail key x tail query: the last wave's partial starts from it
+                tcoop = nsub - 1;
+                const float st = a3_tail_dot(R0, tcoop, 0, f0, lane), dt_ = a3_tail_dot(R1, tcoop, 0, f1, lane);
+                if (wave == nwaves - 1) {
+                    const float pt = tvalid ? fast_exp2(st * scale2 - Ls[tail0]) : 0.f;
+                    a3_tail_outer(R0, tcoop, 0, pt * (dt_ - Ds[tail0]), lane, g0);
+                    a3_tail_outer(R1, tcoop, 0, pt, lane, g1);
+                }
+            }
+            a3_bwd_dkv_sweep<CAUSAL>(R0, R1, Ls, Ds, wave, tcoop, nwaves, n, false, f0, f1, tvalid, scale2, lane, tail0 + c31, g0, g1);
             if (c31 < ntail) {
                 float* rec = Tp + ((long)wave * A3_TAIL_MAX + c31) * 128;
                 a3_put_col(rec, g0, lane);

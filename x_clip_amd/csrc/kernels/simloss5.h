@@ -135,14 +135,21 @@ struct Sim5FastGradEpilogue {
         const bool on_diag = !sim5_off_diagonal(p, m0, n0);          // (uniform)
         float dt = 0.f;
         const float ax = sgpr((a != 0.f) ? gs * a : 0.f);
-        float rowv[4];                                               // the row's factor gs a exp(R - lse_q) -- exact form: its reference point lse_q, base 2
+        // the exact form rides on the fast one: a small block in front of each column quad (uniform branch, rare) computes the quad's 16
+        // values of G with two exponentials each and REPLACES the accumulators by raw' = log2(G) / scale2 -- the fast arithmetic below,
+        // run with R = 0 and the factors (1, 0), then reproduces G = exp2(raw' scale2) (zero for the clamped log of 0).  The hot path is
+        // the round-3 code plus that branch: as the other side of an if / else around the quad's logits the kernel spilled 41 registers,
+        // around each row's four logits it lost the overlap of the exponentials (G 170 -> 206 us, profiles/r04_b_sim_g.log).
+        const float R2f = exact ? 0.f : R2;                           // (uniform)
+        float rowv[4];                                               // the row's factor gs a exp(R - lse_q) -- exact form: 1
+        float lq2[4];                                                // (exact form only: the row's lse_q, base 2)
         int dl[4];                                                   // the row's diagonal column, relative to the lane's first column
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = m0 + wm * 128 + i * 32 + (lane & 31);
             const float f = (a != 0.f) ? ax * fast_exp(R - lq[i]) : 0.f;
-            // (a = 0 in the exact form: exp2(-huge) = 0, not 0 x exp2(junk))
-            rowv[i] = exact ? ((a != 0.f) ? lq[i] * LOG2E : 3.0e38f) : f;
+            rowv[i] = exact ? 1.f : f;
+            lq2[i] = (a != 0.f) ? lq[i] * LOG2E : 3.0e38f;            // (a = 0: exp2(-huge) = 0, not 0 x exp2(junk))
             dl[i] = gm + p.diag_off - (n0 + wn * 64 + 4 * h);
         }
 #pragma unroll
@@ -151,12 +158,11 @@ struct Sim5FastGradEpilogue {
             for (int q = 0; q < 4; ++q) {
                 u32x4 tn = t;
                 if (j * 4 + q < 7) tn = ld16(kcol + (j * 4 + q + 1 < 4 ? 0 : 32) + 8 * ((j * 4 + q + 1) & 3));   // the next quad's four lse_k
-                float ek[4];                                         // gs c exp(R - lse_k) of the quad's four columns -- exact form: lse_k, base 2
+                float ek[4];                                         // gs c exp(R - lse_k) of the quad's four columns -- exact form: 0
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float lk = u2f(t[k]);
-                    const float f = (c != 0.f) ? cx * fast_exp(R - lk) : 0.f;
-                    ek[k] = exact ? ((c != 0.f) ? lk * LOG2E : 3.0e38f) : f;
+                    const float f = (c != 0.f) ? cx * fast_exp(R - u2f(t[k])) : 0.f;
+                    ek[k] = exact ? 0.f : f;
                 }
                 float rawd[4] = {0.f, 0.f, 0.f, 0.f};                // the row's positive logit (unscaled), if it lies in this quad
                 if (on_diag) {
@@ -171,27 +177,30 @@ struct Sim5FastGradEpilogue {
                             if (p.dcl) acc[i][j][4 * q + k] = sel ? -1.0e30f : acc[i][j][4 * q + k];
                         }
                 }
+                if (exact) {                                         // (uniform; rare)
+                    const float inv2 = 1.0f / scale2;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (exact) {                                     // (uniform; rare) two exponentials per logit, each with its own lse
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float raw = acc[i][j][4 * q + k];
                             const float s2 = raw * scale2;
-                            const float g = ax * fast_exp2(s2 - rowv[i]) + cx * fast_exp2(s2 - ek[k]);
-                            dt += g * raw;
-                            acc[i][j][4 * q + k] = g;
+                            const float lk2 = (c != 0.f) ? u2f(t[k]) * LOG2E : 3.0e38f;
+                            const float g = ax * fast_exp2(s2 - lq2[i]) + cx * fast_exp2(s2 - lk2);
+                            const float rp = fmaxf(__builtin_log2f(g) * inv2, -1.0e30f);             // raw': exp2(raw' scale2) = g
+                            dt += g * raw - fast_exp2(rp * scale2) * rp;                             // (what the loop below adds is taken out)
+                            acc[i][j][4 * q + k] = rp;
                         }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float raw = acc[i][j][4 * q + k];
-                            const float g = fast_exp2(raw * scale2 - R2) * (rowv[i] + ek[k]);
-                            dt += g * raw;
-                            acc[i][j][4 * q + k] = g;
-                        }
-                    }
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float raw = acc[i][j][4 * q + k];
+                        const float g = fast_exp2(raw * scale2 - R2f) * (rowv[i] + ek[k]);
+                        dt += g * raw;
+                        acc[i][j][4 * q + k] = g;
+                    }
                 if (on_diag) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
