@@ -162,7 +162,7 @@ void launch_gemm4(const Gemm2Params& p, dim3 pgrid, bool ring3, hipStream_t st) 
         static const int abl = measure_env("XCLIP_GEMM5_ABL", 0);
         if (ring3 && abl) {
 #define XC_ABL5(N) case N: XC_ALLOW_LDS((gemm5_kernel<false, false, G4_PLAIN, N>), G5_LDS_BYTES); hipLaunchKernelGGL((gemm5_kernel<false, false, G4_PLAIN, N>), pgrid, dim3(G2_THREADS), G5_LDS_BYTES, st, p); return;
-            switch (abl) { XC_ABL5(1) XC_ABL5(2) XC_ABL5(4) XC_ABL5(8) XC_ABL5(9) XC_ABL5(10) XC_ABL5(11) XC_ABL5(14) XC_ABL5(16) XC_ABL5(32) XC_ABL5(48) XC_ABL5(12) XC_ABL5(6) XC_ABL5(26) XC_ABL5(58) XC_ABL5(64) XC_ABL5(74) XC_ABL5(128) XC_ABL5(256) XC_ABL5(512) XC_ABL5(1024) XC_ABL5(2560) XC_ABL5(4096) XC_ABL5(526) XC_ABL5(522) default: break; }
+            switch (abl) { XC_ABL5(1) XC_ABL5(2) XC_ABL5(4) XC_ABL5(8) XC_ABL5(9) XC_ABL5(10) XC_ABL5(11) XC_ABL5(14) XC_ABL5(16) XC_ABL5(32) XC_ABL5(48) XC_ABL5(12) XC_ABL5(6) XC_ABL5(26) XC_ABL5(58) XC_ABL5(64) XC_ABL5(74) XC_ABL5(128) XC_ABL5(256) XC_ABL5(512) XC_ABL5(1024) XC_ABL5(2560) XC_ABL5(4096) XC_ABL5(8192) XC_ABL5(526) XC_ABL5(522) default: break; }
 #undef XC_ABL5
         }
     }
