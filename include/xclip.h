@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 16
+#define XCLIP_ABI_VERSION 17
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -229,9 +229,10 @@ int xclip_dwconv4s2_bwd(const void* dy, const void* x, const void* w, void* dx, 
                         int64_t batch, int64_t h, int64_t C, int dtype, void* stream);
 /* Rotary position embedding (RotaryEmbedding / apply_rotary_pos_emb, x_clip.py:155-176; applied to q, k and v, :221-223), in
  * place on rows of `slots` head slots of `slot_width` (64 or 128) features (the packed qkv activation: slots = 3 * heads).  Token
- * position = row % n; in every slot the first 32 features are rotated pairwise (j, j + 16) by pos * inv_freq[j]; inv_freq: 16 device fp32 values, the
- * module's `inv_freq` buffer 10000^(-2 j / 32).  inverse != 0 applies the transposed rotation = the backward of the forward call. */
-int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, int64_t slot_width, const float* inv_freq, int inverse,
+ * position = row % n; in every slot the first `rot` = min(dim_head, 32) features (x_clip.py:311; even, 2 .. 32) are rotated pairwise
+ * (j, j + rot / 2) by pos * inv_freq[j]; inv_freq: rot / 2 device fp32 values, the module's `inv_freq` buffer 10000^(-2 j / rot).
+ * inverse != 0 applies the transposed rotation = the backward of the forward call. */
+int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, int64_t slot_width, int64_t rot, const float* inv_freq, int inverse,
                  int dtype, void* stream);
 /* Similarity regularisation (x_clip.py:773-784): D[r,c] = A[r,c] - C[r,c] for two materialised similarity blocks (text-text and
  * image-image, [rows, cols] in the model dtype, row strides lda / ldc), 0 where c == r + diag_off (the global diagonal);

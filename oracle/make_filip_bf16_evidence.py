@@ -8,7 +8,7 @@ unmodified reference (imported from /root/reference, CPU) on the configuration o
 dim 512, depth 2 / 2, 70 text tokens, 16 patches, batch 24 -- once in fp32 and once with `.to(bfloat16)` parameters and inputs, from the same
 (bf16-representable) weights, and records per parameter the relative error and cosine of the bf16 gradient against the fp32 one.
 
-    python oracle/make_filip_bf16_evidence.py      # rewrites tests/golden/filip_ref_bf16_vs_fp32.json
+    python oracle/make_filip_bf16_evidence.py      # rewrites tests/golden/evidence/filip_ref_bf16_vs_fp32.json
 
 tests/test_oracle_golden.py::test_filip_bf16_bars_are_the_references_own checks that the product's bars are not looser than 1.5 x what
 the reference itself shows (and that the CLS head of the same model is an order of magnitude tighter -- the looseness is FILIP's).
@@ -66,7 +66,7 @@ def main():
            "torch": torch.__version__}
     out["filip"] = compare(x_clip, dataclasses.replace(MID, use_all_token_embeds=True), 24, 7)
     out["cls"] = compare(x_clip, MID, 24, 7)
-    path = os.path.join(ROOT, "tests", "golden", "filip_ref_bf16_vs_fp32.json")
+    path = os.path.join(ROOT, "tests", "golden", "evidence", "filip_ref_bf16_vs_fp32.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

@@ -86,6 +86,9 @@ CASES = {
     "cfg1_simclr": (dict(use_visual_ssl=True, visual_ssl_type="simclr", image_ssl_loss_weight=0.2, ssl_projection_size=32, simclr_temperature=0.5), 4, 0, 0, 0.0),
     "cfg1_rotary": (dict(text_rotary_pos_emb=True), 4, 0, 0, 0.0),
     "cfg1_rotary_dcl_multiview": (dict(text_rotary_pos_emb=True, decoupled_contrastive_learning=True), 4, 1, 0, 0.0),
+    # heads narrower than 32: the reference rotates min(dim_head, 32) features (x_clip.py:311) -- 24 (12 pairs: not a whole 16-byte chunk) and 16
+    "cfg1_rotary_narrow24": (dict(text_rotary_pos_emb=True, text_dim_head=24), 4, 0, 0, 0.0),
+    "cfg1_rotary_narrow16_dcl": (dict(text_rotary_pos_emb=True, text_dim_head=16, text_heads=2, decoupled_contrastive_learning=True), 4, 0, 0, 0.0),
     "cfg1_simreg_extra": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.1), 4, 0, 0, 0.0),
     "cfg1_simreg_extra_dcl": (dict(extra_latent_projection=True, sim_reg_loss_weight=0.5, decoupled_contrastive_learning=True), 6, 0, 0, 0.0),
     "p16_heads2": (dict(dim_text=48, dim_image=80, dim_latent=40, text_heads=2, text_dim_head=32,

@@ -301,7 +301,7 @@ def case_attention_single_tail(dev, dtype, n=257, heads=2):
     accumulators (attention3.h a3_tail_dot / a3_tail_outer), not as a 33rd MFMA block.  Four samples: no mask at all; a hole in the middle
     with the tail key valid; the tail key itself padded; everything but the first three keys padded (the tail query then sees three keys)"""
     mask = torch.ones(4, n, dtype=torch.bool)
-    mask[1, 40] = False
+    mask[1, min(40, n // 2)] = False
     mask[2, n - 1] = False
     mask[2, 7] = False
     mask[3, 3:] = False

@@ -30,7 +30,7 @@ def emulator_library():
 # cfg1_simsiam, cfg1_simclr (4096-wide projector: minutes on the emulator), cfg1_causal) are exercised on the GPU only
 # (cfg1_filip_dcl and cfg1_simsiam_mlm_dcl run in test_no_kernel_reads_unwritten_memory below, with poisoned allocations)
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_patchdrop",
-                                  "cfg1_simreg_extra_dcl", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm_dcl_multiview", "cfg1_causal_dcl_multiview", "cfg1_wide_heads", "cfg1_wide_heads_rotary_dcl"])
+                                  "cfg1_simreg_extra_dcl", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm_dcl_multiview", "cfg1_causal_dcl_multiview", "cfg1_wide_heads", "cfg1_wide_heads_rotary_dcl", "cfg1_rotary_narrow24", "cfg1_rotary_narrow16_dcl"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 

@@ -28,7 +28,7 @@ def hip_library():
 
 
 @pytest.mark.parametrize("name", ["cfg1_infonce", "cfg1_dcl", "cfg1_extra_dcl", "cfg1_multiview", "cfg1_multiview_m3n1",
-                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm", "cfg1_mlm_dcl_multiview", "cfg1_simsiam", "cfg1_simsiam_mlm_dcl", "cfg1_simclr", "cfg1_causal", "cfg1_causal_dcl_multiview", "cfg1_wide_heads", "cfg1_wide_heads_rotary_dcl"])
+                                  "cfg1_patchdrop", "cfg1_filip", "cfg1_filip_dcl", "cfg1_simreg_extra", "cfg1_simreg_extra_dcl", "cfg1_rotary", "cfg1_rotary_dcl_multiview", "cfg1_filip_downsample", "cfg1_filip_downsample_extra_dcl", "cfg1_mlm", "cfg1_mlm_dcl_multiview", "cfg1_simsiam", "cfg1_simsiam_mlm_dcl", "cfg1_simclr", "cfg1_causal", "cfg1_causal_dcl_multiview", "cfg1_wide_heads", "cfg1_wide_heads_rotary_dcl", "cfg1_rotary_narrow24", "cfg1_rotary_narrow16_dcl"])
 def test_clip_matches_reference_fixture(name):
     C.case_golden(DEV, name)
 

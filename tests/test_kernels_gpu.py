@@ -139,6 +139,7 @@ def test_attention_wide_heads(dtype, n, heads, masked, causal):
 def test_attention_single_tail_row():
     """257 = 8 x 32 + 1 tokens, not causal: the tail key / query as the accumulators' initial values (no 33rd block), with and without masks"""
     K.case_attention_single_tail(DEV, torch.bfloat16)
+    K.case_attention_single_tail(DEV, torch.bfloat16, n=33, heads=2)          # the vision tower's 32 kept patches + CLS: ONE wave per head
     K.case_attention_single_tail(DEV, torch.bfloat16, n=129, heads=3)
     K.case_attention_single_tail(DEV, torch.bfloat16, n=257, heads=8)
 

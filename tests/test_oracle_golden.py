@@ -111,3 +111,18 @@ def test_distributed_fixture_identity(name):
         if n is None:          # unused *_extra projections
             continue
         assert abs(float(sd[k].grad.norm()) - n) <= 2e-4 * n + 1e-7, k
+
+
+def test_filip_bf16_bars_are_the_references_own():
+    """the product's bf16 FILIP tests hold gradients to 16 % / cosine 0.985 against the fp64 oracle (every CLS case: 8 % /
+    0.999) "as the reference's own bf16 run would" differ.  tests/golden/evidence/filip_ref_bf16_vs_fp32.json (oracle/make_filip_bf16_evidence.py)
+    is that run: the unmodified reference in bf16 against itself in fp32, same bf16-representable weights and inputs, the configuration of
+    tests/test_clip_gpu.py::test_filip_mid_vs_oracle.  The reference differs from ITSELF by far more than the product is allowed to differ
+    from the exact model (its LayerNorm statistics, softmax sums and loss are bf16 arithmetic too; the product's are fp32)."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "evidence", "filip_ref_bf16_vs_fp32.json")) as f:
+        ev = json.load(f)
+    product_rel_bar, product_cos_bar = 0.16, 0.985           # tests/test_clip_gpu.py::test_filip_mid_vs_oracle[bf16]
+    assert ev["filip"]["worst_rel"] > product_rel_bar and ev["filip"]["worst_cos"] < product_cos_bar, ev["filip"]
+    # and the looseness is FILIP's: the CLS head of the same model in the same bf16 reference run is about twice as tight
+    assert ev["cls"]["worst_rel"] < 0.6 * ev["filip"]["worst_rel"], ev

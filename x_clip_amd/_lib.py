@@ -56,7 +56,7 @@ _SIGNATURES = {
     "xclip_rowlse": (c_int, [P, L, L, L, L, I, F, P, P, P]),
     "xclip_rowgrad": (c_int, [P, L, P, L, L, L, I, F, P, P, L, P, P]),
     "xclip_simreg_diff": (c_int, [P, L, P, L, P, L, L, L, L, P, I, P]),
-    "xclip_rotary": (c_int, [P, L, L, L, L, L, P, I, I, P]),
+    "xclip_rotary": (c_int, [P, L, L, L, L, L, L, P, I, I, P]),
     "xclip_layernorm_chain_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, L, F, I, P]),
     "xclip_layernorm_chain_bwd_workspace_bytes": (c_int64, [L, L]),
     "xclip_layernorm_chain_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, L, I, P]),
@@ -78,7 +78,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 def _bind(path: str):

@@ -148,12 +148,14 @@ class Transformer(nn.Module):
     def forward(self, x, rotary_pos_emb=None, mask=None):
         rotary = None
         if exists(rotary_pos_emb):
-            # the reference takes the [n, 32] angle table RotaryEmbedding.forward returns (x_clip.py:166,274); the kernels regenerate
-            # the angles from 16 frequencies, which are the table's row for position 1 -- provided the table IS position x frequency
+            # the reference takes the [n, rot] angle table RotaryEmbedding.forward returns (rot = min(dim_head, 32), x_clip.py:166,274,311); the
+            # kernels regenerate the angles from rot / 2 frequencies, which are the table's row for position 1 -- provided the table IS
+            # position x frequency
             t = rotary_pos_emb.float()
-            if t.dim() != 2 or t.shape[1] != 32 or t.shape[0] < max(2, x.shape[1]):
-                raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): a [n, 32] angle table covering the sequence")
-            rotary = t[1, :16].contiguous()
+            rot = t.shape[1] if t.dim() == 2 else 0
+            if t.dim() != 2 or rot % 2 != 0 or not 2 <= rot <= min(32, self.dim_head) or t.shape[0] < max(2, x.shape[1]):
+                raise NotImplementedError("Transformer.forward(rotary_pos_emb=table): a [n, min(dim_head, 32)] angle table covering the sequence")
+            rotary = t[1, :rot // 2].contiguous()
             # the check reads the table on the host (a sync): once per table -- the same tensor, unmodified, is not checked again
             key = (rotary_pos_emb.data_ptr(), rotary_pos_emb._version, tuple(rotary_pos_emb.shape), rotary_pos_emb.dtype)
             if self._rotary_ok != key:
@@ -167,16 +169,16 @@ class Transformer(nn.Module):
 
 class RotaryEmbedding(nn.Module):
     """reference RotaryEmbedding (x_clip.py:155-166): holds the `inv_freq` buffer (state_dict key parity).  The kernels
-    (xclip_rotary) regenerate the same 10000^(-2j/dim) frequencies; dim is min(dim_head, 32) = 32 on this path."""
+    (xclip_rotary) regenerate the same 10000^(-2j/dim) frequencies; dim = min(dim_head, 32) (x_clip.py:311), even."""
 
     def __init__(self, dim):
         super().__init__()
-        if dim != 32:
-            raise NotImplementedError("rotary embedding: the kernels rotate the first 32 features of 64-wide heads")
+        if dim % 2 != 0 or not 2 <= dim <= 32:
+            raise NotImplementedError("rotary embedding: an even number of 2 .. 32 rotated features per head (min(dim_head, 32))")
         self.register_buffer('inv_freq', 1. / (10000 ** (torch.arange(0, dim, 2).float() / dim)))
 
     def frequencies(self, device) -> Tensor:
-        """the 16 fp32 frequencies the kernels take.  A model cast with .to(bfloat16) also rounds the buffer (the reference then
+        """the dim / 2 fp32 frequencies the kernels take.  A model cast with .to(bfloat16) also rounds the buffer (the reference then
         computes its angle table from the rounded values); the frequencies are regenerated in fp32 in that case."""
         f = self.inv_freq
         if f.dtype != torch.float32:
@@ -197,8 +199,8 @@ class TextTransformer(nn.Module):
         if causal and rotary_pos_emb:
             raise NotImplementedError("causal + rotary text encoder: the reference builds its angle table for n + 1 positions (x_clip.py:330) "
                                       "but a causal encoder has n (no CLS token), so its own forward fails with a shape error")
-        if rotary_pos_emb and dim_head < 32:
-            raise NotImplementedError("rotary embedding with dim_head < 32 (the kernel rotates the first 32 dimensions of a head)")
+        if rotary_pos_emb and dim_head % 2 != 0:
+            raise NotImplementedError("rotary embedding needs an even dim_head (the reference's rotate_half splits the rotated features in two)")
         self.token_emb = nn.Embedding(num_tokens, dim)
         self.abs_pos_emb = nn.Embedding(max_seq_len, dim) if not rotary_pos_emb else None      # x_clip.py:311-312
         self.rotary_pos_emb = RotaryEmbedding(min(dim_head, 32)) if rotary_pos_emb else None

@@ -382,6 +382,27 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* __restrict__ X, long ld,
     }
 }
 
+// the same rotation for rot < 32 features per head (heads narrower than 32: the reference rotates min(dim_head, 32), x_clip.py:311): pairs
+// (j, j + rot / 2), one lane per pair, element accesses -- rot / 2 is not a whole 16-byte chunk in general (dim_head 24: 12 pairs)
+template <typename T>
+__global__ __launch_bounds__(256) void rotary_pairs_kernel(T* __restrict__ X, long ld, long rows, int n, int slots, int slot_width, int half,
+                                                           const float* __restrict__ inv_freq, float sign) {
+    const long items = rows * slots * half;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(it % half);
+        const long rs = it / half;
+        const int slot = (int)(rs % slots);
+        const long row = rs / slots;
+        T* p = X + row * ld + slot * slot_width + j;
+        float sn, cs;
+        sincosf((float)(row % n) * inv_freq[j], &sn, &cs);
+        sn *= sign;
+        const float x1 = to_f32(p[0]), x2 = to_f32(p[half]);
+        p[0] = from_f32<T>(x1 * cs - x2 * sn);
+        p[half] = from_f32<T>(x2 * cs + x1 * sn);
+    }
+}
+
 // ---- feed-forward dropout (reference nn.Dropout between the inner LayerNorm and the second Linear, x_clip.py:193-194) -------------
 // y[i] = x[i] * keep(i) / (1 - p) over a contiguous [n] tensor, keep from drop_hash(seed, i) (common.h).  The same launch on the
 // gradient is the backward.  In place is fine.  One 16-byte chunk per lane.

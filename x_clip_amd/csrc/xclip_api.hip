@@ -713,10 +713,11 @@ int xclip_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int
     return check_launch(__func__);
 }
 
-int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, int64_t slot_width, const float* inv_freq, int inverse,
+int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, int64_t slot_width, int64_t rot, const float* inv_freq, int inverse,
                  int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
     XC_REQUIRE(slot_width == 64 || slot_width == 128, "head slots are 64 or 128 wide");
+    XC_REQUIRE(rot >= 2 && rot <= 32 && rot % 2 == 0, "rot = min(dim_head, 32) rotated features per head: even, 2 .. 32");
     XC_REQUIRE(rows >= 0 && n > 0 && slots > 0 && ld >= slots * slot_width && ld % vec_of(dtype) == 0, "bad shape");
     XC_REQUIRE(x && aligned16(x) && inv_freq, "null or misaligned pointer");
     if (rows == 0) return 0;
@@ -725,6 +726,15 @@ int xclip_rotary(void* x, int64_t ld, int64_t rows, int64_t n, int64_t slots, in
     if (blocks > 8192) blocks = 8192;
     dim3 grid((unsigned)blocks), block(256);
     const float sign = inverse ? -1.0f : 1.0f;
+    if (rot != 32) {                                             // narrow heads: element pairs
+        int64_t pb = (rows * slots * (rot / 2) + 255) / 256;
+        if (pb > 8192) pb = 8192;
+        if (dtype == XCLIP_BF16)
+            hipLaunchKernelGGL((rotary_pairs_kernel<bf16_t>), dim3((unsigned)pb), block, 0, (hipStream_t)stream, (bf16_t*)x, (long)ld, (long)rows, (int)n, (int)slots, (int)slot_width, (int)(rot / 2), inv_freq, sign);
+        else
+            hipLaunchKernelGGL((rotary_pairs_kernel<float>), dim3((unsigned)pb), block, 0, (hipStream_t)stream, (float*)x, (long)ld, (long)rows, (int)n, (int)slots, (int)slot_width, (int)(rot / 2), inv_freq, sign);
+        return check_launch(__func__);
+    }
     if (dtype == XCLIP_BF16)
         hipLaunchKernelGGL((rotary_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)x, (long)ld, (long)rows, (int)n, (int)slots, (int)slot_width, inv_freq, sign);
     else

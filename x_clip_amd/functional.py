@@ -121,7 +121,7 @@ class StackSpec:
     heads: int
     dim_head: int = 64
     checkpoint: bool = False
-    rotary: Optional[Tensor] = None         # rotary embedding on q, k, v: the inv_freq buffer (16 fp32), x_clip.py:155-176,221-223
+    rotary: Optional[Tensor] = None         # rotary embedding on q, k, v: the inv_freq buffer (min(dim_head, 32) / 2 fp32), x_clip.py:155-176,221-223,311
     causal: bool = False                    # causal attention (the autoregressive text encoder), x_clip.py:231-234
     attn_dropout: float = 0.0               # dropout on the softmax probabilities (x_clip.py:212,241); 0 outside training
     ff_dropout: float = 0.0                 # dropout between the inner LayerNorm and the second Linear (x_clip.py:193-194)
@@ -133,8 +133,6 @@ class StackSpec:
         # padded output columns are zero and meet zero weights); only the scale dim_head^-0.5 is the head's own.
         if not 1 <= self.dim_head <= 128:
             raise NotImplementedError("x_clip_amd attention kernels hold heads of up to 128 dimensions (the reference default is 64)")
-        if self.rotary is not None and self.dim_head < 32:
-            raise NotImplementedError("rotary embedding with dim_head < 32 (the kernel rotates the first 32 dimensions of a head)")
         if not (0.0 <= self.attn_dropout < 1.0 and 0.0 <= self.ff_dropout < 1.0):
             raise ValueError("dropout probabilities must lie in [0, 1)")
 

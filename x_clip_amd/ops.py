@@ -709,13 +709,13 @@ def simreg_diff(A: Tensor, C: Tensor, diag_off: int, sumsq_accum: Tensor) -> Ten
 
 def rotary_(x: Tensor, n: int, inv_freq: Tensor, inverse: bool = False, head_dim: int = 64) -> Tensor:
     """in-place rotary position embedding on x [rows, slots * head_dim] (packed q | k | v head slots of 64 or 128 features), position =
-    row % n, angles pos * inv_freq[j] on the first 32 features of every slot (x_clip.py:155-176, 221-223); inverse=True is the backward
-    of the forward call"""
+    row % n, angles pos * inv_freq[j] on the first rot = 2 * len(inv_freq) = min(dim_head, 32) features of every slot, pairs (j, j + rot / 2)
+    (x_clip.py:155-176, 221-223, 311); inverse=True is the backward of the forward call"""
     _dev_check(x, inv_freq)
     assert x.dim() == 2 and x.stride(1) == 1 and head_dim in (64, 128) and x.shape[1] % head_dim == 0
-    assert inv_freq.dtype == torch.float32 and inv_freq.numel() == 16 and inv_freq.is_contiguous()
-    _lib.check(_lib.lib().xclip_rotary(x.data_ptr(), x.stride(0), x.shape[0], n, x.shape[1] // head_dim, head_dim, inv_freq.data_ptr(),
-                                       int(inverse), dtype_code(x), _stream(x)), "xclip_rotary")
+    assert inv_freq.dtype == torch.float32 and 1 <= inv_freq.numel() <= 16 and inv_freq.is_contiguous()
+    _lib.check(_lib.lib().xclip_rotary(x.data_ptr(), x.stride(0), x.shape[0], n, x.shape[1] // head_dim, head_dim, 2 * inv_freq.numel(),
+                                       inv_freq.data_ptr(), int(inverse), dtype_code(x), _stream(x)), "xclip_rotary")
     return x
 
 
