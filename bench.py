@@ -332,7 +332,9 @@ def main():
             with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as f:
                 tj = json.load(f)
             if tj.get("kernel_generation") == ops.GEMM_GENERATION and tj.get("workload_tag", "default-infonce-b1024") == workload_tag:
-                traffic, traffic_src = round(tj["bytes_per_launch"]), tj.get("source")
+                # per xclip_gemm call as this probe counts them (a call whose row tail is cut is three kernel launches)
+                traffic = round(tj["bytes_per_step"] / max(launches // max(args.steps, 1), 1)) if tj.get("bytes_per_step") else round(tj["bytes_per_launch"])
+                traffic_src = tj.get("source")
         except Exception:
             pass
         out["roofline"] = {"kernel": "xclip_gemm (gemm5_kernel<bf16> NT/NN + gemm4_kernel<bf16> TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad",

@@ -30,7 +30,7 @@ HOT = {
 # G of the contrastive head: round 4's exact two-exponential form for wave blocks whose lse values spread beyond one reference point
 #  sits beside the fast form -- the compiler parks 9 loop-invariant values in scratch during the prologue; what is held is that the
 # K loop has no scratch traffic and a tile's epilogue at most one reload (kernel: spilled registers, scratch instructions behind the first MFMA)
-PROLOGUE_SPILLS_ONLY = {"sim5_grad_fast_kernel<true>": (16, 2), "sim5_grad_fast_kernel<false>": (16, 2)}
+PROLOGUE_SPILLS_ONLY = {"sim5_grad_fast_kernel<true, 0>": (16, 2), "sim5_grad_fast_kernel<false, 0>": (16, 2)}
 # kernels whose ragged-tile path legitimately holds serialized loads (row gathers, residual rows): spills only
 NO_SPILL = ["gemm4_kernel<true, true, 1>", "gemm5_kernel<false, false, 3, 0>", "gemm5_kernel<false, true, 3, 0>", "filip_route_kernel<bf16>"]
 

@@ -43,7 +43,7 @@ for TASK in "$@"; do
         rm -rf /tmp/pmc_$c; timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-probe --no-overlap > /dev/null 2>&1
       done
       F=$(find /tmp/pmc_FETCH_SIZE -name "p_counter_collection.csv" | head -1); W=$(find /tmp/pmc_WRITE_SIZE -name "p_counter_collection.csv" | head -1)
-      (echo "# HBM-side traffic per kernel, bench.py --steps 1 --warmup 1 --no-overlap (b=1024): rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes"; python $R/tools/pmc_traffic.py $F $W $R/gpurun_out/${TAG}_gemm_traffic.json gemm) > $R/gpurun_out/${TAG}_hbm_traffic_pmc.txt 2>&1
+      (echo "# HBM-side traffic per kernel, bench.py --steps 1 --warmup 1 --no-overlap (b=1024): rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes"; python $R/tools/pmc_traffic.py $F $W $R/gpurun_out/${TAG}_gemm_traffic.json gemm 4) > $R/gpurun_out/${TAG}_hbm_traffic_pmc.txt 2>&1
       tail -3 $R/gpurun_out/${TAG}_hbm_traffic_pmc.txt;;
     py)
       ( timeout 900 python tools/$REST ) > gpurun_out/${TAG}${SUF}.log 2>&1; grep -v amdgpu gpurun_out/${TAG}${SUF}.log | tail -40 | cut -c1-230;;

@@ -2,7 +2,7 @@
 """HBM-side traffic per kernel family from two rocprofv3 PMC passes of the same command (CSV output):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d F -o p -- <cmd>
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d W -o p -- <cmd>
-    python tools/pmc_traffic.py F/p_counter_collection.csv W/p_counter_collection.csv [gemm_traffic.json [kernel family, default gemm3]]
+    python tools/pmc_traffic.py F/p_counter_collection.csv W/p_counter_collection.csv [gemm_traffic.json [kernel family, default gemm3 [steps of <cmd>]]]
 FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts the 128-byte requests of wide coalesced reads as 64 B -> x2
 (MI355X_MICROARCH.md, HBM section).  Infinity-Cache hits are part of FETCH_SIZE (fabric traffic: an upper bound on HBM reads)."""
 import csv
@@ -46,13 +46,16 @@ def main():
     n = sum(r[1] for r in g)
     per = sum(r[5] * r[1] for r in g) / max(n, 1)
     print(f"# {fam} family: {n} launches, {per:.1f} MB per launch (reads x2 + writes)")
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # steps the traced command ran (bench.py: 2 pre-warm + warm-up + timed)
+    if steps:
+        print(f"# {fam} family: {per * n / steps / 1e3:.2f} GB per step over {steps} steps ({n // steps} kernel launches per step: one xclip_gemm call is 1 - 3 of them)")
     if len(sys.argv) > 3:
         with open(sys.argv[3], "w") as f:
             import os
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             from x_clip_amd.ops import GEMM_GENERATION
             json.dump({"kernel_family": fam + "*_kernel", "kernel_generation": GEMM_GENERATION, "workload_tag": os.environ.get("XCLIP_WORKLOAD_TAG", "default-infonce-b1024"),
-                       "bytes_per_launch": per * 1e6, "launches": n,
+                       "bytes_per_launch": per * 1e6, "launches": n, "steps": steps, "bytes_per_step": (per * 1e6 * n / steps) if steps else None,
                        "source": "tools/pmc_traffic.py over rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (FETCH_SIZE x2 gfx950 correction)"}, f, indent=1)
 
 

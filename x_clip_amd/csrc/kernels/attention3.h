@@ -37,7 +37,7 @@ XC_DEV void a3_dma_image(unsigned char* img, const bf16_t* X, long ldx, int n, i
 // 0.69 ms).  Instead the q full tiles get one wave each and the tail rows are processed COOPERATIVELY: wave w evaluates the
 // tail queries against key sub-tiles w, w + nwaves, ...; the partial (max, sum, O) triples meet in a small LDS scratch.
 constexpr int A3_TAIL_MAX = 2;
-XC_HOST_DEV bool a3_coop_tail(int n) { return (n & 31) != 0 && (n & 31) <= A3_TAIL_MAX && n >= 33; }
+XC_HOST_DEV bool a3_coop_tail(int n) { return (n & 31) != 0 && (n & 31) <= A3_TAIL_MAX && n >= 64; }
 XC_HOST_DEV int a3_waves(int n) { return a3_coop_tail(n) ? n / 32 : (n + 31) / 32; }
 constexpr int A3_TAIL_REC = 66;                                // floats per (wave, tail row): m, l, O[64]
 

@@ -45,7 +45,8 @@ XC_DEV bool sim5_off_diagonal(const SimParams& p, int m0, int n0) { return m0 + 
 
 // (STREAM -- non-temporal stores for a G the L2s cannot hold anyway -- is a template parameter: as a run-time branch around the 16
 //  stores it cost this kernel 102 spilled registers)
-template <bool STREAM>
+// (VAR: measurement build only, XCLIP_SIMG -- 1 = without DEFER_FRAGS, 2 = without the spread vote / exact form (round-3 arithmetic), 3 = both)
+template <bool STREAM, int VAR = 0>
 struct Sim5FastGradEpilogue {
     const SimParams& p;
     const Gemm2Params& gp;       // C = G, ldc = ldg, alpha = 1: what the line stores address
@@ -54,7 +55,7 @@ struct Sim5FastGradEpilogue {
     // the epilogue works on all 128 accumulators at once beside ~50 registers of its own: it takes the 24 the loop would hold for the next
     // tile's first fragments (gemm4.h g5_defer_frags) -- without them every further term of the arithmetic tipped the kernel into
     // 30 - 250 spilled registers (tests/test_isa_guard.py)
-    static constexpr bool DEFER_FRAGS = true;
+    static constexpr bool DEFER_FRAGS = !(VAR & 1);
     XC_DEV void finish() {
         const float dt = wave_sum(dt_acc) * (scale / (p.g_times_scale ? scale : 1.0f));
         if ((threadIdx.x & 63) == 0 && p.dtau != nullptr) atomic_add(p.dtau, dt);
@@ -129,7 +130,7 @@ struct Sim5FastGradEpilogue {
 #pragma unroll
         for (int i = 0; i < 4; ++i) far = far || (a != 0.f && !(fabsf(lq[i] - R) <= 60.f));
         far = far || (c != 0.f && !(fabsf(lk1 - R) <= 60.f));
-        const bool exact = wave_any(far);                            // (uniform)
+        const bool exact = (VAR & 2) ? false : wave_any(far);        // (uniform)
         const float scale2 = sgpr(scale * LOG2E), R2 = sgpr(R * LOG2E);
         const float cx = sgpr((c != 0.f) ? gs * c : 0.f);
         const bool on_diag = !sim5_off_diagonal(p, m0, n0);          // (uniform)
@@ -243,14 +244,14 @@ struct Sim5EdgeTiles {
     }
 };
 
-template <bool STREAM>
+template <bool STREAM, int VAR = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_fast_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);
     Gemm2Params g = sim3_gemm_params(p);
     g.C = reinterpret_cast<bf16_t*>(p.G);
     g.ldc = p.ldg;
     g.stream_out = STREAM;
-    g5_run<false, false, Sim5FastGradEpilogue<STREAM>>(g, lds, Sim5FastGradEpilogue<STREAM>{p, g, sim_scale(p), p.gmul != nullptr ? *p.gmul : 1.0f});
+    g5_run<false, false, Sim5FastGradEpilogue<STREAM, VAR>>(g, lds, Sim5FastGradEpilogue<STREAM, VAR>{p, g, sim_scale(p), p.gmul != nullptr ? *p.gmul : 1.0f});
 }
 __global__ __launch_bounds__(G2_THREADS, 2) void sim5_grad_edge_kernel(SimParams p) {
     XC_LDS_DYNAMIC(lds);

@@ -1089,6 +1089,14 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
 #else
         const bool skip_fast = false, skip_edge = false;
 #endif
+#ifdef XCLIP_MEASURE
+        static const int simg = measure_env("XCLIP_SIMG", 0);      // A/B of this round's additions to the G kernel (simloss5.h VAR), streamed form only
+        if (!skip_fast && simg >= 1 && simg <= 3 && nq * ldg * 2 > (48LL << 20)) {
+#define XC_SIMG(V) case V: XC_ALLOW_LDS((sim5_grad_fast_kernel<true, V>), G5_LDS_BYTES); hipLaunchKernelGGL((sim5_grad_fast_kernel<true, V>), sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p); break;
+            switch (simg) { XC_SIMG(1) XC_SIMG(2) XC_SIMG(3) }
+#undef XC_SIMG
+        } else
+#endif
         if (skip_fast) {
         } else if (nq * ldg * 2 > (48LL << 20)) {                   // G larger than the L2s can hold anyway: streamed stores
             XC_ALLOW_LDS(sim5_grad_fast_kernel<true>, G5_LDS_BYTES);
