@@ -141,6 +141,9 @@ struct Sim5FastGradEpilogue {
         // run with R = 0 and the factors (1, 0), then reproduces G = exp2(raw' scale2) (zero for the clamped log of 0).  The hot path is
         // the round-3 code plus that branch: as the other side of an if / else around the quad's logits the kernel spilled 41 registers,
         // around each row's four logits it lost the overlap of the exponentials (G 170 -> 206 us, profiles/r04_b_sim_g.log).
+        // What robustness costs, same box (profiles/r04_d_sim_g_variants.log, 4096 x 32768 x 512): 181.7 us without the vote and this block
+        // (XCLIP_SIMG=2), 196.2 us with them (one vote + ONE copy of the loop nest per tile: 269 spilled registers); without DEFER_FRAGS the
+        // spills sit in the tile loop: 220.8 us.  Round 3's 170 us form returned NaN for every wave block whose lse values spread beyond 88.
         const float R2f = exact ? 0.f : R2;                           // (uniform)
         float rowv[4];                                               // the row's factor gs a exp(R - lse_q) -- exact form: 1
         float lq2[4];                                                // (exact form only: the row's lse_q, base 2)
