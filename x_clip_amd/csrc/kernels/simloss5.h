@@ -94,11 +94,10 @@ struct Sim5FastGradEpilogue {
     // lies within 60 of it.  (History: R = scale -- valid since |cos| <= 1 -- overflowed exp(scale - lse) at exp(tau) = 200 with small
     // cosines; R = the block's first row's lse failed as soon as the lse values themselves spread: exp(tau) = 200 with a few perfectly
     // matched pairs among unrelated ones puts matched rows at ~200 and the others at ~40, and 0 x inf = NaN filled 65519 of 65536
-    // entries of the ADVICE r3 reproducer.)  When some lse lies farther away than that (a wave vote) the
-    // SAME loop nest runs its exact form (`exact`, wave-uniform): G = gs a exp(s - lse_q) + gs c exp(s - lse_k), two exponentials per
-    // logit, as the other side of a branch around each row's four logits of a column quad, the per-row / per-column registers holding
-    // the lse values themselves instead of the factors.  (As a second copy of the loop nest -- to_g<EXACT> -- the kernel spilled 59
-    // registers; with the exact form's terms in registers of their own beside the fast form's, 46.)
+    // entries of the ADVICE r3 reproducer.)  When some lse lies farther away than that (a wave vote) the tile takes the EXACT form
+    // G = gs a exp(s - lse_q) + gs c exp(s - lse_k), two exponentials per logit whose arguments are <= 0 wherever the term matters -- as a
+    // small block in front of each column quad's arithmetic (see `exact` below; how it got there: a second copy of the loop nest spilled
+    // 59 - 269 registers, an if / else around the quad's logits 41, around each row's four logits it cost the overlap of the exponentials).
     // A tile that holds a piece of the positive diagonal (uniform test; O(tiles_m) tiles) corrects that logit per column
     // quad, in two small blocks around the quad's arithmetic: G = (dcl ? 0 : the above) - gs e.  (As a second copy of the whole loop for
     // those tiles the function spilled 255 registers; as a per-logit select in the one loop it would tax every tile.)
