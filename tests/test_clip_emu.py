@@ -58,13 +58,17 @@ def test_high_temperature_vs_oracle(dtype):
 
 def test_narrow_heads_vs_oracle():
     """dim_head below the kernels' 64 (x_clip.py:201-211 accepts any): heads run zero-padded, the scale stays dim_head^-0.5, and the
-    gradients of the real to_qkv / to_out weights come back through the padding; rotary with 32-wide heads rotates the whole head"""
+    gradients of the real to_qkv / to_out weights come back through the padding; rotary with 32-wide heads rotates the whole head,
+    with narrower ones all of their features"""
     import dataclasses
     C.case_vs_oracle(DEV, torch.float32, dataclasses.replace(O.CFG1, text_dim_head=32, visual_dim_head=24, text_rotary_pos_emb=True), 4)
     with pytest.raises(NotImplementedError):
         C.build_clip(dataclasses.replace(O.CFG1, text_dim_head=160), {}, DEV, torch.float32)
+    # rotary heads narrower than 32 (round 4): min(dim_head, 32) rotated features (x_clip.py:311) -- 16 and 24 (12 pairs: not a 16-byte chunk)
+    C.case_vs_oracle(DEV, torch.float32, dataclasses.replace(O.CFG1, text_dim_head=16, text_rotary_pos_emb=True), 4)
+    C.case_vs_oracle(DEV, torch.bfloat16, dataclasses.replace(O.CFG1, text_dim_head=24, text_rotary_pos_emb=True), 4, bf16_loss=1.4e-3)
     with pytest.raises(NotImplementedError):
-        C.build_clip(dataclasses.replace(O.CFG1, text_dim_head=16, text_rotary_pos_emb=True), {}, DEV, torch.float32)
+        C.build_clip(dataclasses.replace(O.CFG1, text_dim_head=15, text_rotary_pos_emb=True), {}, DEV, torch.float32)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])

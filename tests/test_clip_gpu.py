@@ -107,6 +107,8 @@ def test_mid_narrow_heads_vs_oracle(dtype):
     """text_dim_head = 32 (rotary: the whole head is rotated), visual_dim_head = 48: zero-padded to the kernels' 64-wide heads"""
     import dataclasses
     C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, text_dim_head=32, visual_dim_head=48, text_rotary_pos_emb=True), 16)
+    # rotary heads narrower than 32 (round 4): min(dim_head, 32) = 24 rotated features -- 12 pairs, the element-pair kernel
+    C.case_vs_oracle(DEV, dtype, dataclasses.replace(MID, text_dim_head=24, text_heads=16, visual_dim_head=48, text_rotary_pos_emb=True), 16)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
