@@ -1,6 +1,7 @@
 """Round-4 A/B probes on one box, measurement build (the switches are read once per process: run once per setting):
     python tools/probe_r4_ab.py attn      XCLIP_ATTN_ABL=4 -> the 257th token as a 33rd block (round-3 form); unset -> as the accumulators' initial value
     python tools/probe_r4_ab.py gemm      XCLIP_GEMM_TAIL=0 -> uncut persistent launches; unset -> the row tail as a split-K problem
+    python tools/probe_r4_ab.py wide      heads of 80 / 96 / 128 features (128-wide head slots, the tiled kernels of attention.h) beside the 64-wide head-resident ones
 Prints one line per shape; the text / vision shapes of BASELINE configs[1] (b = 1024)."""
 import os
 import sys
@@ -48,6 +49,19 @@ if what == "attn":
         tb = timeit(lambda: ops.attention_bwd(qkv, mask, out, do, lse, h, 0.125))
         fl = 4.0 * b * h * n * n * 64
         print(f"[{tag}] attention b={b} n={n} h={h} mask={int(masked)}: fwd {t*1e3:7.1f} us ({fl/t/1e9:6.1f} TF/s)   bwd {tb*1e3:7.1f} us ({2*fl/tb/1e9:6.1f} TF/s algorithmic)", flush=True)
+elif what == "wide":
+    # the same model width (512 = heads x dim_head) at n = 257: 8 x 64 (head-resident attention3.h), then 128-wide head slots (attention.h,
+    # two 64-wide halves per head; a narrower head is zero-padded to its slot by the host, so 80 / 96 cost what 128 costs per head)
+    for (h, slot, label) in [(8, 64, "8 heads x 64"), (6, 128, "6 heads x 80 (slot 128)"), (5, 128, "5 heads x 96 (slot 128)"), (4, 128, "4 heads x 128")]:
+        b, n = 1024, 257
+        qkv = torch.randn(b, n, 3 * h * slot, device=dev, dtype=bf)
+        mask = torch.ones(b, n, dtype=torch.bool, device=dev)
+        sc = (slot if slot == 64 else {6: 80, 5: 96, 4: 128}[h]) ** -0.5
+        t = timeit(lambda: ops.attention_fwd(qkv, mask, h, sc, head_dim=slot), iters=10, warm=3)
+        out, lse = ops.attention_fwd(qkv, mask, h, sc, head_dim=slot)
+        do = torch.randn_like(out)
+        tb = timeit(lambda: ops.attention_bwd(qkv, mask, out, do, lse, h, sc, head_dim=slot), iters=10, warm=3)
+        print(f"[{tag}] attention b={b} n={n} {label:26s}: fwd {t*1e3:8.1f} us   bwd {tb*1e3:8.1f} us   (per head: fwd {t*1e6/(b*h):6.3f} ns x1e3, bwd {tb*1e6/(b*h):6.3f})", flush=True)
 else:
     Mt, Mv = 1024 * 257, 1024 * 33
     for (name, M, N, K, bk, res) in [("ff1 dgrad text", Mt, 512, 4096, True, False), ("ff2 fwd+skip text", Mt, 512, 2048, False, True),
