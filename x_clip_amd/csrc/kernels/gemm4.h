@@ -666,6 +666,7 @@ struct G4GemmEpilogue {
     // residual lines (requested one group ahead) go into the wave's LDS slice in line order and come back in the accumulator layout
     // (8 bytes per 32 x 32 quad), the sum is formed in fp32 and rounded once, and the packed result takes the way of store_lines.
     // In place (residual == C) is fine: a group's lines are loaded before they are stored, by the same lanes.
+    template <bool NT = false>
     XC_DEV void store_full_res_lds(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
         const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
@@ -707,7 +708,10 @@ struct G4GemmEpilogue {
             for (int k = 0; k < 4; ++k) o[k] = *reinterpret_cast<const u32x4*>(line + k * 1024);
             lds_fence();                                                            // (the next group's residual overwrites the slice)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) buf_st16<0>(rc, vc, c8 * (uint32_t)(4 * i + k), o[k]);
+            for (int k = 0; k < 4; ++k) {
+                if (NT) buf_st16_nt<0>(rc, vc, c8 * (uint32_t)(4 * i + k), o[k]);     // (an output the L2s cannot hold anyway: g5_run stream_out)
+                else buf_st16<0>(rc, vc, c8 * (uint32_t)(4 * i + k), o[k]);
+            }
         }
     }
     // interior tile, fp32 split-K slab, every store 8 rows x 128 contiguous bytes (as store_lines; the weight-gradient GEMMs are one
@@ -752,7 +756,10 @@ struct G4GemmEpilogue {
             return 32;
         }
         if (MODE == G4_RES && full) {
-            store_full_res_lds(acc, m0, n0, scratch);
+            // (round 4: the FF2 + skip output -- 270 MB at the text tower's shape -- left through ordinary stores although the plain
+            //  epilogue streams such outputs; the LayerNorm that reads it next then waits for the dirty lines' write-back)
+            if (p.stream_out) store_full_res_lds<true>(acc, m0, n0, scratch);
+            else store_full_res_lds<false>(acc, m0, n0, scratch);
             return 0;                                            // (loads and stores mixed: the next wait drains them)
         }
         return (*this)(acc, m0, n0);
