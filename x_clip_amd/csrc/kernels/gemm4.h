@@ -756,10 +756,10 @@ struct G4GemmEpilogue {
             return 32;
         }
         if (MODE == G4_RES && full) {
-            // (round 4: the FF2 + skip output -- 270 MB at the text tower's shape -- left through ordinary stores although the plain
-            //  epilogue streams such outputs; the LayerNorm that reads it next then waits for the dirty lines' write-back)
-            if (p.stream_out) store_full_res_lds<true>(acc, m0, n0, scratch);
-            else store_full_res_lds<false>(acc, m0, n0, scratch);
+            // (round 4, measured and not kept: non-temporal stores here as in the plain epilogue -- FF2 + skip 496.5 -> 503.2 us alone,
+            //  262 -> 270 us average in the step, and the LayerNorm that reads the output next did not gain: 63.6 -> 64.0 us;
+            //  profiles/r04_f_ab_gemm_nt0.log, r04_f_kernel_stats.txt against r04_c_kernel_stats.txt)
+            store_full_res_lds<false>(acc, m0, n0, scratch);
             return 0;                                            // (loads and stores mixed: the next wait drains them)
         }
         return (*this)(acc, m0, n0);
