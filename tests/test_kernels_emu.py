@@ -85,7 +85,7 @@ def test_attention_causal(dtype, n, masked):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
-@pytest.mark.parametrize("n,masked,causal", [(33, False, False), (70, True, False), (97, True, True), (130, False, True)])
+@pytest.mark.parametrize("n,masked,causal", [(33, False, False), (70, True, False), (97, True, True), (130, False, True), (257, True, False), (258, False, True)])
 def test_attention_wide_heads(dtype, n, masked, causal):
     """128-feature head slots (reference Attention accepts any dim_head, x_clip.py:201-212): two 64-wide halves per head"""
     K.case_attention(DEV, dtype, 2, n, 2, masked, causal=causal, hd=128)

@@ -8,6 +8,7 @@
 #include "kernels/attention.h"
 #include "kernels/attention2.h"
 #include "kernels/attention3.h"
+#include "kernels/attention4.h"
 
 using namespace xc;
 using namespace xcapi;
@@ -74,7 +75,20 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
     p.drop_thresh = drop_thresh(dropout_p); p.drop_scale = 1.0f / (1.0f - dropout_p); p.drop_seed = dropout_seed;
     const bool tiled_only = p.drop_thresh != 0;               // dropout lives in the tiled kernels (attention.h)
     hipStream_t st = (hipStream_t)stream;
-    if (head_dim == 128) {                                     // wide heads: the tiled kernels with two 64-wide halves per head
+    if (head_dim == 128 && dtype == XCLIP_BF16 && n <= A3_MAX_N && !tiled_only) {   // wide heads, head-resident (attention4.h)
+        XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
+        const int nwq = a4_fwd_waves((int)n);
+        XC_REQUIRE(attn4_fwd_lds_bytes((int)n) <= 160 * 1024, "internal: wide-head forward LDS");
+        if (causal) {
+            XC_ALLOW_LDS(attn4_fwd_kernel<true>, 160 * 1024);
+            hipLaunchKernelGGL(attn4_fwd_kernel<true>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn4_fwd_lds_bytes((int)n), st, p);
+        } else {
+            XC_ALLOW_LDS(attn4_fwd_kernel<false>, 160 * 1024);
+            hipLaunchKernelGGL(attn4_fwd_kernel<false>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn4_fwd_lds_bytes((int)n), st, p);
+        }
+        return check_launch(__func__);
+    }
+    if (head_dim == 128) {                                     // wide heads, long sequences / fp32 / dropout: the tiled kernels with two 64-wide halves per head
         const int nw = attn_waves(n);
 #define W(T) switch (nw) { case 1: launch_attn_fwd<T, 1, 2>(p, st); break; case 2: launch_attn_fwd<T, 2, 2>(p, st); break; \
                            case 3: launch_attn_fwd<T, 3, 2>(p, st); break; default: launch_attn_fwd<T, 4, 2>(p, st); break; }
@@ -131,7 +145,19 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     p.drop_thresh = drop_thresh(dropout_p); p.drop_scale = 1.0f / (1.0f - dropout_p); p.drop_seed = dropout_seed;
     const bool tiled_only = p.drop_thresh != 0;               // dropout lives in the tiled kernels (attention.h)
     hipStream_t st = (hipStream_t)stream;
-    if (head_dim == 128) {                                     // wide heads: delta pass + the tiled dQ / dK, dV kernels on two halves
+    if (head_dim == 128 && dtype == XCLIP_BF16 && n <= A3_MAX_N && !tiled_only) {   // wide heads, head-resident (attention4.h; computes delta itself)
+        XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
+        const int nwq = a3_bwd_waves((int)n);
+        if (causal) {
+            XC_ALLOW_LDS(attn4_bwd_kernel<true>, 160 * 1024);
+            hipLaunchKernelGGL(attn4_bwd_kernel<true>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn4_bwd_lds_bytes((int)n), st, p);
+        } else {
+            XC_ALLOW_LDS(attn4_bwd_kernel<false>, 160 * 1024);
+            hipLaunchKernelGGL(attn4_bwd_kernel<false>, dim3((unsigned)(batch * heads)), dim3(nwq * 64), attn4_bwd_lds_bytes((int)n), st, p);
+        }
+        return check_launch(__func__);
+    }
+    if (head_dim == 128) {                                     // wide heads, long sequences / fp32 / dropout: delta pass + the tiled dQ / dK, dV kernels on two halves
         XC_REQUIRE(delta_ws != nullptr, "wide heads need the [batch, heads, n] fp32 delta workspace");
         dim3 wgrid((unsigned)((batch * n + 3) / 4)), wblock(256);
         if (dtype == XCLIP_BF16)
