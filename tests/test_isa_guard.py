@@ -31,6 +31,9 @@ HOT = {
 #  sits beside the fast form -- the compiler parks 9 loop-invariant values in scratch during the prologue; what is held is that the
 # K loop has no scratch traffic and a tile's epilogue at most one reload (kernel: spilled registers, scratch instructions behind the first MFMA)
 PROLOGUE_SPILLS_ONLY = {"sim5_grad_fast_kernel<true, 0>": (16, 2), "sim5_grad_fast_kernel<false, 0>": (16, 2)}
+# wide-head attention (attention4.h, round 4): the backward lives in 340 of its wave's 512 registers without spilling; the forward (eight waves,
+# 256 registers) parks ~20 values of its two step variants
+WIDE_HEADS = {"attn4_bwd_kernel<false>": 0, "attn4_bwd_kernel<true>": 0, "attn4_fwd_kernel<false>": 24, "attn4_fwd_kernel<true>": 24}
 # kernels whose ragged-tile path legitimately holds serialized loads (row gathers, residual rows): spills only
 NO_SPILL = ["gemm4_kernel<true, true, 1>", "gemm5_kernel<false, false, 3, 0>", "gemm5_kernel<false, true, 3, 0>", "filip_route_kernel<bf16>"]
 
@@ -58,6 +61,10 @@ def test_hot_kernels_do_not_spill_or_stall(isa):
         if s["vspill"] > vs or s["hot_scratch"] > hot or s["serial"] > 1 or s["atomics"] > 1:
             bad.append(f"{k}: {s['vspill']} spilled vector registers (<= {vs}), {s['hot_scratch']} scratch instructions behind the first MFMA (<= {hot}), "
                        f"{s['serial']} load + drain pairs, {s['atomics']} atomics")
+    for k, vs in WIDE_HEADS.items():
+        assert k in isa, f"{k}: not in the library any more -- update tests/test_isa_guard.py"
+        if isa[k]["vspill"] > vs or isa[k]["atomics"]:
+            bad.append(f"{k}: {isa[k]['vspill']} spilled vector registers (<= {vs}), {isa[k]['atomics']} atomics")
     for k in NO_SPILL:
         assert k in isa, f"{k}: not in the library any more -- update tests/test_isa_guard.py"
         if isa[k]["vspill"] or isa[k]["scratch"]:
