@@ -366,6 +366,12 @@ def cast_from_f32(src: Tensor, dtype, scale: float = 1.0) -> Tensor:
 # profiles/gemm_traffic.json) are tagged with it and ignored by bench.py when they belong to an older kernel
 GEMM_GENERATION = "gemm5b"   # (b: whole-line epilogue stores through LDS)
 
+# True: forward / input-gradient products never get a split-K workspace, so the library cannot cut the row tail of a persistent launch off as
+# a split-K problem (xclip_api.hip gemm2_tail_cut).  Which rows form that tail depends on the batch size; without the cut a sample's
+# activations are BIT-identical whatever else shares its batch (tests/test_clip_gpu.py::test_full_size_properties_bf16), at the price of the
+# last partial round of tiles (vision tower N = 512 products +12 ... +18 %, text +1 ... +2 %).  Weight gradients keep their split-K slabs.
+BATCH_INVARIANT_GEMM = False
+
 
 class KernelProbe:
     """Optional live measurement of the kernel families that make up a step (bench.py's `roofline` leg): while active, every
@@ -487,7 +493,7 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
     L = _lib.lib()
     code = dtype_code(a)
     # split-K slabs: plain products, and the row tail of a long-K product with or without a skip term (xclip_api.hip gemm2_tail_cut)
-    wbytes = L.xclip_gemm_workspace_bytes(M, N, K, code) if (bias is None and addrows is None) else 0
+    wbytes = L.xclip_gemm_workspace_bytes(M, N, K, code) if (bias is None and addrows is None and not (BATCH_INVARIANT_GEMM and not a_kmajor)) else 0
     ws = workspace(a.device, wbytes)
     probe = _probe(a)
     ev0 = probe.begin(a, "gemm") if probe is not None else None
