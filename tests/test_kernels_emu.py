@@ -341,6 +341,20 @@ def test_gemm6_gemm7_experimental_kernels():
         assert out.returncode == 0 and "gemm6 ok" in out.stdout, (gen, out.stderr[-2000:])
 
 
+def test_gemm_split_k_whole_slices_per_xcd():
+    """weight-gradient (TN) split-K launches whose slices come in whole groups of 8 run on a 1-D grid on which an XCD holds whole K slices
+    (gemm2.h g2_where: the work-groups that read the same K range share an L2); the others keep the (tile, slice) grid.  16 slices x 2 tiles,
+    8 x 8, 16 x 4 (1-D) and 10 slices x 12 tiles (2-D) against an fp32 product"""
+    from x_clip_amd import ops
+    torch.manual_seed(0)
+    for (M, N, K, slices) in [(512, 256, 4096, 16), (1024, 512, 2048, 8), (512, 512, 4096, 16), (1536, 512, 2624, 10)]:
+        a, b = torch.randn(K, M).bfloat16(), torch.randn(K, N).bfloat16()
+        assert _lib.lib().xclip_gemm_workspace_bytes(M, N, K, 1) == slices * M * N * 4
+        got = ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True).float()
+        want = a.float().t() @ b.float()
+        assert float((got - want.bfloat16().float()).abs().max()) <= float(want.abs().max()) * 2.0 ** -7, (M, N, K)
+
+
 def test_gemm_row_tail_as_split_k():
     """xclip_api.hip gemm2_tail_cut: a persistent launch whose last round would fill only a few CUs cuts its rows at the last whole round and
     runs the row tail as a split-K problem (fp32 slabs + the reduction, which also applies alpha and the skip term).  The policy plans for

@@ -1,6 +1,7 @@
 """Round-4 A/B probes on one box, measurement build (the switches are read once per process: run once per setting):
     python tools/probe_r4_ab.py attn      XCLIP_ATTN_ABL=4 -> the 257th token as a 33rd block (round-3 form); unset -> as the accumulators' initial value
     python tools/probe_r4_ab.py gemm      XCLIP_GEMM_TAIL=0 -> uncut persistent launches; unset -> the row tail as a split-K problem
+    python tools/probe_r4_ab.py wgrad     XCLIP_GEMM_SPLIT2D=1 -> split-K weight gradients on the (tile, slice) grid; unset -> 1-D grid, an XCD holds whole K slices
     python tools/probe_r4_ab.py wide      heads of 80 / 96 / 128 features (128-wide head slots, the tiled kernels of attention.h) beside the 64-wide head-resident ones
 Prints one line per shape; the text / vision shapes of BASELINE configs[1] (b = 1024)."""
 import os
@@ -49,6 +50,16 @@ if what == "attn":
         tb = timeit(lambda: ops.attention_bwd(qkv, mask, out, do, lse, h, 0.125))
         fl = 4.0 * b * h * n * n * 64
         print(f"[{tag}] attention b={b} n={n} h={h} mask={int(masked)}: fwd {t*1e3:7.1f} us ({fl/t/1e9:6.1f} TF/s)   bwd {tb*1e3:7.1f} us ({2*fl/tb/1e9:6.1f} TF/s algorithmic)", flush=True)
+elif what == "wgrad":
+    Mt, Mv = 1024 * 257, 1024 * 33
+    for (name, M, N, K) in [("ff1 wgrad text", 4096, 512, Mt), ("ff2 wgrad text", 512, 2048, Mt), ("qkv wgrad text", 1536, 512, Mt), ("out wgrad text", 512, 512, Mt),
+                            ("ff1 wgrad vision", 4096, 512, Mv), ("ff2 wgrad vision", 512, 2048, Mv), ("qkv wgrad vision", 1536, 512, Mv), ("out wgrad vision", 512, 512, Mv),
+                            ("patch embed wgrad", 512, 3072, 32768)]:
+        a = torch.randn(K, M, device=dev, dtype=bf)
+        b = torch.randn(K, N, device=dev, dtype=bf)
+        out = torch.empty(M, N, device=dev, dtype=bf)
+        t = timeit(lambda: ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, out=out))
+        print(f"[{tag}] {name:20s} M={M:5d} N={N:5d} K={K:7d}: {t*1e3:8.1f} us  {2.0*M*N*K/t/1e9:7.1f} TF/s", flush=True)
 elif what == "wide":
     # the same model width (512 = heads x dim_head) at n = 257: 8 x 64 (head-resident attention3.h), then 128-wide head slots (attention.h,
     # two 64-wide halves per head; a narrower head is zero-padded to its slot by the host, so 80 / 96 cost what 128 costs per head)

@@ -115,7 +115,30 @@ struct Gemm2Params {
     int tiles_m, tiles_n;
     int band_n;                // ring kernel: N tiles per band of the tile order (0 = plain n-fastest order; gemm4.h g5_run)
     int stream_out;            // interior bf16 tiles leave with non-temporal stores (an output larger than the L2s: gemm4.h store_lines)
+    int split_lin = 0;         // > 0: split-K launch on a 1-D grid, = the number of K slices (g2_where); 0: blockIdx.x = tile, blockIdx.y = slice
 };
+
+// Which (tile, K slice) a work-group of a split-K launch computes.  On the 2-D grid (tile, slice) the hardware's round-robin placement
+// (linear id mod 8 = XCD) scatters the tiles of ONE slice -- the work-groups that read the same K range of both operands -- over all eight
+// L2s: a weight-gradient launch (32 tiles x 8 slices: 16 + 2 operand panels per slice) found half of its panel reads in L2 where 72 % are
+// shared.  The 1-D form gives XCD x the slices x, x + 8, ... whole: work-group `lin` sits on XCD lin & 7 and is the (lin >> 3)-th of that XCD's
+// (slice, tile) pairs, tile fastest.  The grid is 8 * tiles * ceil(slices / 8) work-groups; the ones whose slice does not exist leave at once.
+XC_DEV bool g2_where(const Gemm2Params& p, int ntiles, int& tile0, int& slice, int& stride) {
+    if (p.split_lin > 0) {
+        const int lin = blockIdx.x, j = lin >> 3;
+        slice = (lin & 7) + 8 * (j / ntiles);
+        tile0 = j % ntiles;
+        stride = ntiles;                                       // (one tile per work-group)
+        return slice < p.split_lin;
+    }
+    tile0 = blockIdx.x;
+    slice = blockIdx.y;
+    stride = gridDim.x;
+    return (int)blockIdx.x < ntiles;
+}
+XC_DEV int g2_slice(const Gemm2Params& p, int ntiles) {
+    return p.split_lin > 0 ? (int)(blockIdx.x & 7) + 8 * ((int)(blockIdx.x >> 3) / ntiles) : (int)blockIdx.y;
+}
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm2_kernel(Gemm2Params p) {

@@ -235,7 +235,7 @@ struct G3GemmEpilogue {
             for (int j = 0; j < 2; ++j) {
                 const int nb = n0 + wn * 64 + j * 32;
                 if (p.partial != nullptr) {
-                    float* slab = p.partial + ((long)blockIdx.y * p.M + gmc) * p.N;
+                    float* slab = p.partial + ((long)g2_slice(p, p.tiles_m * p.tiles_n) * p.M + gmc) * p.N;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int gn = nb + 4 * h + 8 * q;

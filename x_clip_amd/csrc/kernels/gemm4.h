@@ -78,14 +78,15 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     const int wave = uniform(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int kbeg = blockIdx.y * p.k_per_split;
+    int tile0, slice, stride;
+    const bool mine = g2_where(p, ntiles, tile0, slice, stride);
+    const int kbeg = slice * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
     const int nt = (kend - kbeg) / G2_BK;
-    const int stride = gridDim.x;
-    if ((int)blockIdx.x >= ntiles || nt <= 0) return;            // (uniform over the work-group)
+    if (!mine || nt <= 0) return;                                // (uniform over the work-group)
 
     auto tile_origin = [&](int id, int& m0, int& n0) {
-        const int tile = xcd_remap(id, ntiles);
+        const int tile = p.split_lin > 0 ? id : xcd_remap(id, ntiles);      // (1-D split launches place their work-groups themselves)
         m0 = (tile / p.tiles_n) * G2_BM;
         n0 = (tile % p.tiles_n) * G2_BN;
     };
@@ -96,7 +97,7 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     unsigned char* const my0 = lds + wave * 4096;                               // this wave's first piece inside an operand image
 
     // the DMA iterator: tile `did`, K step `dt`; runs up to two steps ahead of the MFMAs, across tile boundaries
-    int did = blockIdx.x, dt = 0, dm = 0, dn = 0;
+    int did = tile0, dt = 0, dm = 0, dn = 0;
     tile_origin(did, dm, dn);
     G4Operand<A_KMAJOR> oa;
     G4Operand<B_KMAJOR> ob;
@@ -141,7 +142,7 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     lds_wait<0>(a[0], b[0]);
 
     int step = 0;                                             // running K-step counter: LDS stage = step & 1
-    for (int id = blockIdx.x; id < ntiles; id += stride) {
+    for (int id = tile0; id < ntiles; id += stride) {
         int m0, n0;
         tile_origin(id, m0, n0);
         // acc[i][j] holds the TRANSPOSED 32 x 32 block (MFMA operands swapped): register r of lane l is
@@ -720,7 +721,7 @@ struct G4GemmEpilogue {
     XC_DEV void store_full_slab_lds(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
         const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
-        const float* slab = p.partial + ((long)blockIdx.y * p.M + m0) * p.N + n0;
+        const float* slab = p.partial + ((long)g2_slice(p, p.tiles_m * p.tiles_n) * p.M + m0) * p.N + n0;
         const BufRsrc rc = make_rsrc(slab, 255u * (uint32_t)p.N * 4u + 1024u);
         const uint32_t vc = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)p.N + (uint32_t)(wn * 64 + 4 * (lane & 7))) * 4u;
         const uint32_t s8 = (uint32_t)p.N * 32u;                                    // 8 rows * N * 4 bytes

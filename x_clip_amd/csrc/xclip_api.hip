@@ -205,6 +205,19 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
     const bool small_ld = p.lda < (1L << 22) && p.ldb < (1L << 22) && p.ldc < (1L << 22) && (long)p.N < (1L << 21);
     if (gen != 3 && small_ld) {
         const bool ring3 = gen == 5 || ((gen == 0 || gen >= 6) && !AK);   // (6, 7: gemm6.h / gemm7.h for the shapes they take, the default otherwise)
+        // split-K on the two-stage loop (the weight gradients): a 1-D grid whose work-groups place themselves so that an XCD holds whole
+        // K slices (gemm2.h g2_where); XCLIP_GEMM_SPLIT2D=1 (measurement build) keeps the (tile, slice) grid for the A/B
+        static const int split2d = measure_env("XCLIP_GEMM_SPLIT2D", 0);
+        // (only where it balances: whole groups of 8 slices and no more work-groups on an XCD than it has CUs -- the QKV gradient's 12 tiles x 21
+        //  slices and the patch embedding's 24 x 10 put 36 / 48 work-groups on some XCDs and ran 52 % / 49 % SLOWER, profiles/r04_h_ab_wgrad_*.log)
+        if (splits > 1 && !ring3 && !split2d && splits % 8 == 0 && gx * (splits / 8) <= xc_policy_cus() / 8) {
+            Gemm2Params q = p;
+            q.split_lin = splits;
+            const dim3 lgrid((unsigned)(8 * gx * ((splits + 7) / 8)), 1);
+            if (q.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(q, lgrid, ring3, st);
+            else launch_gemm4<AK, BK_, G4_PLAIN>(q, lgrid, ring3, st);
+            return;
+        }
         const bool terms = p.bias != nullptr || p.residual != nullptr || p.addrows != nullptr;
 #ifdef XCLIP_MEASURE
         // experiment (XCLIP_GEMM=7): four waves of 128 x 128 per tile, one per SIMD (measure/gemm7.h)
