@@ -342,9 +342,9 @@ def test_gemm6_gemm7_experimental_kernels():
 
 
 def test_gemm_split_k_whole_slices_per_xcd():
-    """weight-gradient (TN) split-K launches whose slices come in whole groups of 8 run on a 1-D grid on which an XCD holds whole K slices
-    (gemm2.h g2_where: the work-groups that read the same K range share an L2); the others keep the (tile, slice) grid.  16 slices x 2 tiles,
-    8 x 8, 16 x 4 (1-D) and 10 slices x 12 tiles (2-D) against an fp32 product"""
+    """weight-gradient (TN) split-K launches run on a 1-D grid whose work-groups place themselves: the (slice, tile) pairs slice-major, one
+    contiguous eighth per XCD (gemm2.h g2_where: the work-groups that read the same K range share an L2).  16 slices x 2 tiles, 8 x 8, 16 x 4
+    (whole slices per XCD) and 10 slices x 12 tiles (slices shared by two XCDs, 120 pairs = 15 per XCD) against an fp32 product"""
     from x_clip_amd import ops
     torch.manual_seed(0)
     for (M, N, K, slices) in [(512, 256, 4096, 16), (1024, 512, 2048, 8), (512, 512, 4096, 16), (1536, 512, 2624, 10)]:

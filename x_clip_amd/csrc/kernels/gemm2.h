@@ -121,15 +121,22 @@ struct Gemm2Params {
 // Which (tile, K slice) a work-group of a split-K launch computes.  On the 2-D grid (tile, slice) the hardware's round-robin placement
 // (linear id mod 8 = XCD) scatters the tiles of ONE slice -- the work-groups that read the same K range of both operands -- over all eight
 // L2s: a weight-gradient launch (32 tiles x 8 slices: 16 + 2 operand panels per slice) found half of its panel reads in L2 where 72 % are
-// shared.  The 1-D form gives XCD x the slices x, x + 8, ... whole: work-group `lin` sits on XCD lin & 7 and is the (lin >> 3)-th of that XCD's
-// (slice, tile) pairs, tile fastest.  The grid is 8 * tiles * ceil(slices / 8) work-groups; the ones whose slice does not exist leave at once.
+// shared.  The 1-D form lists the (slice, tile) pairs slice-major and gives every XCD one contiguous eighth of the list: work-group `lin`
+// sits on XCD lin & 7 and is that XCD's (lin >> 3)-th pair.  With 8 | slices an XCD holds whole slices; otherwise (the QKV gradient's 21
+// slices of 12 tiles) at most two XCDs share a slice.  The grid is 8 * ceil(pairs / 8) work-groups; the few without a pair leave at once.
+XC_DEV void g2_pair(const Gemm2Params& p, int ntiles, int& tile, int& slice, bool& valid) {
+    const int total = ntiles * p.split_lin, chunk = (total + 7) >> 3;
+    const int lin = blockIdx.x, j = lin >> 3, w = (lin & 7) * chunk + j;
+    valid = j < chunk && w < total;
+    slice = w / ntiles;
+    tile = w - slice * ntiles;
+}
 XC_DEV bool g2_where(const Gemm2Params& p, int ntiles, int& tile0, int& slice, int& stride) {
     if (p.split_lin > 0) {
-        const int lin = blockIdx.x, j = lin >> 3;
-        slice = (lin & 7) + 8 * (j / ntiles);
-        tile0 = j % ntiles;
+        bool valid;
+        g2_pair(p, ntiles, tile0, slice, valid);
         stride = ntiles;                                       // (one tile per work-group)
-        return slice < p.split_lin;
+        return valid;
     }
     tile0 = blockIdx.x;
     slice = blockIdx.y;
@@ -137,7 +144,13 @@ XC_DEV bool g2_where(const Gemm2Params& p, int ntiles, int& tile0, int& slice, i
     return (int)blockIdx.x < ntiles;
 }
 XC_DEV int g2_slice(const Gemm2Params& p, int ntiles) {
-    return p.split_lin > 0 ? (int)(blockIdx.x & 7) + 8 * ((int)(blockIdx.x >> 3) / ntiles) : (int)blockIdx.y;
+    if (p.split_lin > 0) {
+        int tile, slice;
+        bool valid;
+        g2_pair(p, ntiles, tile, slice, valid);
+        return slice;
+    }
+    return (int)blockIdx.y;
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR>

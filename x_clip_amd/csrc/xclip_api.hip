@@ -208,12 +208,10 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
         // split-K on the two-stage loop (the weight gradients): a 1-D grid whose work-groups place themselves so that an XCD holds whole
         // K slices (gemm2.h g2_where); XCLIP_GEMM_SPLIT2D=1 (measurement build) keeps the (tile, slice) grid for the A/B
         static const int split2d = measure_env("XCLIP_GEMM_SPLIT2D", 0);
-        // (only where it balances: whole groups of 8 slices and no more work-groups on an XCD than it has CUs -- the QKV gradient's 12 tiles x 21
-        //  slices and the patch embedding's 24 x 10 put 36 / 48 work-groups on some XCDs and ran 52 % / 49 % SLOWER, profiles/r04_h_ab_wgrad_*.log)
-        if (splits > 1 && !ring3 && !split2d && splits % 8 == 0 && gx * (splits / 8) <= xc_policy_cus() / 8) {
+        if (splits > 1 && !ring3 && !split2d) {
             Gemm2Params q = p;
             q.split_lin = splits;
-            const dim3 lgrid((unsigned)(8 * gx * ((splits + 7) / 8)), 1);
+            const dim3 lgrid((unsigned)(8 * ((gx * splits + 7) / 8)), 1);
             if (q.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(q, lgrid, ring3, st);
             else launch_gemm4<AK, BK_, G4_PLAIN>(q, lgrid, ring3, st);
             return;
