@@ -176,6 +176,10 @@ def main():
             dist.init_process_group(backend)
 
     from x_clip_amd import CLIP, functional, losses, ops
+    measure_build = os.environ.get("XCLIP_BENCH_MEASURE_BUILD") == "1"   # own A/B inside the step: libxclip_hip_measure.so and its XCLIP_* switches
+    if measure_build:
+        from x_clip_amd import _lib
+        _lib.use_measurement_build()
     if os.environ.get("XCLIP_FILIP_FUSED") == "0":           # own A/B: the chunked FILIP forward (materialised similarities + reduction passes)
         losses.FILIP_FUSED = False
     if os.environ.get("XCLIP_FILIP_CHUNK_MB"):                 # own A/B: size of the backward's routing-matrix chunks
@@ -303,6 +307,8 @@ def main():
         "allocator": {"device_mallocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
                       "peak_reserved_gb": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 2)},
     }
+    if measure_build:     # not a product line: the measurement build with whatever XCLIP_* switches were set
+        out["build"] = {"library": "libxclip_hip_measure.so", "switches": {k: v for k, v in os.environ.items() if k.startswith("XCLIP_")}}
     if probe is not None:
         # Per-launch GEMM durations: HIP events around every xclip_gemm launch, on the stream it is launched on, over K more
         # steps of the same workload right after the timed region.  That pass runs on a single stream: in the timed region
@@ -364,6 +370,17 @@ def main():
             fam["layernorm"] = {"bound": "hbm", "achieved": round(b_ln / s_ln / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                 "frac": round(b_ln / s_ln / HBM_PEAK, 4), "algorithmic_gb_per_step": round(b_ln / max(args.steps, 1) / 1e9, 3),
                                 "ms_per_step": round(s_ln / max(args.steps, 1) * 1e3, 3), "launches_per_step": n_ln // max(args.steps, 1)}
+        # the contrastive head's two similarity kernels (S = I T^T with the log-sum-exp epilogue; S again with the G epilogue): one
+        # 2 nq nk d product each, against the MFMA peak and -- G writes nq x nk -- the HBM floor, per kernel
+        for key, name in (("sim_fwd", "head_forward"), ("sim_grad", "head_G")):
+            recs = [r for r in probe.records if r[0] == "head" and r[5] == key]
+            if recs:
+                s_h = sum(r[2].elapsed_time(r[3]) for r in recs) * 1e-3
+                f_h, b_h = sum(r[1] for r in recs), sum(r[4] for r in recs)
+                fam[name] = {"bound": "mfma", "achieved": round(f_h / s_h / 1e12, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                             "frac": round(f_h / s_h / MFMA_PEAK_BF16, 4), "hbm_frac": round(b_h / s_h / HBM_PEAK, 4),
+                             "avg_launch_us": round(s_h / len(recs) * 1e6, 2),
+                             "ms_per_step": round(s_h / max(args.steps, 1) * 1e3, 3), "launches_per_step": len(recs) // max(args.steps, 1)}
         out["roofline"]["families"] = fam
         out["roofline"]["families_ms_per_step"] = round(sum(v["ms_per_step"] for v in fam.values()), 3)
         out["roofline"]["probe_pass_ms_per_step"] = round(probe_elapsed / max(args.steps, 1) * 1e3, 3)

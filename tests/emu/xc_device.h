@@ -422,6 +422,8 @@ inline void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
 }
 template <int IMM>
 inline void buf_st16_nt(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) { buf_st16<IMM>(r, voff, soff, v); }
+inline u32x4 ld16_nt(const void* p) { u32x4 v; memcpy(&v, p, 16); return v; }
+inline void st16_nt(void* p, u32x4 v) { memcpy(p, &v, 16); }
 inline void wait_vmem() {}
 // transpose read: lane c of a 16-lane group, slot j <- element (c & 3) at the address supplied by lane 4j + (c >> 2)
 inline s16x4 lds_read_tr16(const void* p) {

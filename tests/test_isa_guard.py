@@ -23,8 +23,9 @@ HOT = {
     # (round 4: the two key-validity bytes of a thread are requested together and waited for once -- the scan counts both loads of that one
     #  round trip, plus the loop for shapes the kernels never get; the backward's 5 branch-guarded loads of round 3 are gone)
     "attn3_fwd_kernel<false>": (3, 0), "attn3_bwd_kernel<false>": (6, 0), "attn3_bwd_kernel<true>": (6, 0),
-    "ln_geglu_bwd_kernel<bf16, 2, 2>": (0, 0), "ln_fwd_kernel<bf16, 4, true>": (4, 0), "ln_fwd_kernel<bf16, 1, false>": (2, 0),
-    "ln_bwd_kernel<bf16, 1, false>": (3, 0), "ln_chain_fwd_kernel<bf16, 1>": (2, 0), "ln_chain_bwd_kernel<bf16, 1>": (1, 0),
+    # (last template argument: the non-temporal hint on the streamed rows, xclip_api.hip ROWS_NT)
+    "ln_geglu_bwd_kernel<bf16, 2, 2, true>": (0, 0), "ln_fwd_kernel<bf16, 4, true, true>": (4, 0), "ln_fwd_kernel<bf16, 1, false, true>": (2, 0),
+    "ln_bwd_kernel<bf16, 1, false, true>": (3, 0), "ln_chain_fwd_kernel<bf16, 1, false>": (2, 0), "ln_chain_bwd_kernel<bf16, 1, true>": (1, 0),
     "splitk_reduce_kernel<bf16>": (0, 0),
 }
 # G of the contrastive head: round 4's exact two-exponential form for wave blocks whose lse values spread beyond one reference point

@@ -184,6 +184,9 @@ template <int IMM>
 XC_DEV void buf_st16_nt(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4 nt\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
 }
+// plain 16-byte global accesses with the non-temporal hint (streamed once: first use is last use)
+XC_DEV u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+XC_DEV void st16_nt(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
 XC_DEV void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // lds_read_tr16 (ds_read_b64_tr_b16): within each 16-lane group, lane c (slot j) receives the 16-bit element
 // at addr[lane 4j + (c >> 2) of the group] + (c & 3): a 4 x 16 block whose rows are addressed by the lanes is

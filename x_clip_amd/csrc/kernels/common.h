@@ -61,13 +61,14 @@ XC_DEV u32x4 pack(const float (&f)[8], bf16_t*) {
     return r;
 }
 
-template <typename T>
+// NT: the access carries the non-temporal hint (rows streamed once through a kernel: first use is last use)
+template <typename T, bool NT = false>
 XC_DEV void load_vec(const T* p, float (&f)[Elem<T>::VEC]) {
-    unpack(ld16(p), f, (T*)nullptr);
+    unpack(NT ? ld16_nt(p) : ld16(p), f, (T*)nullptr);
 }
-template <typename T>
+template <typename T, bool NT = false>
 XC_DEV void store_vec(T* p, const float (&f)[Elem<T>::VEC]) {
-    st16(p, pack(f, (T*)nullptr));
+    if (NT) st16_nt(p, pack(f, (T*)nullptr)); else st16(p, pack(f, (T*)nullptr));
 }
 
 XC_DEV float to_f32(float v) { return v; }

@@ -18,7 +18,7 @@ namespace xc {
 // ---- row <-> registers --------------------------------------------------------------------------------
 // Loads row `xr` (width D); with GEGLU the source row is [value(D) | gate(D)] and the loaded value is
 // value * gelu(gate) (u/gt return the raw halves for the backward).
-template <typename T, int MAXC, bool GEGLU>
+template <typename T, int MAXC, bool GEGLU, bool NT = false>
 XC_DEV void load_row(const T* xr, int D, int lane, float (&v)[MAXC][Elem<T>::VEC]) {
     constexpr int VEC = Elem<T>::VEC;
     const int nch = D / VEC;
@@ -26,10 +26,10 @@ XC_DEV void load_row(const T* xr, int D, int lane, float (&v)[MAXC][Elem<T>::VEC
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
-            load_vec<T>(xr + c * VEC, v[i]);
+            load_vec<T, NT>(xr + c * VEC, v[i]);
             if (GEGLU) {
                 float gt[VEC];
-                load_vec<T>(xr + D + c * VEC, gt);
+                load_vec<T, NT>(xr + D + c * VEC, gt);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) v[i][j] *= gelu_erf(gt[j]);
             }
@@ -65,7 +65,7 @@ XC_DEV void row_stats(const float (&v)[MAXC][Elem<T>::VEC], int D, int lane, flo
 }
 
 // ---- LayerNorm forward:  y = (x - mean) * rstd * g (+ res) ---------------------------------------------
-template <typename T, int MAXC, bool GEGLU>
+template <typename T, int MAXC, bool GEGLU, bool NT = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ g,
                                                      const T* __restrict__ res, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
     // the vision encoder output, x_clip.py:389-390), so the final LayerNorm writes straight into [b, 1+n, D]
     const long yrow = y_grp > 0 ? row + row / y_grp + 1 : row;
     float v[MAXC][VEC];
-    load_row<T, MAXC, GEGLU>(x + row * ldx, D, lane, v);
+    load_row<T, MAXC, GEGLU, NT>(x + row * ldx, D, lane, v);
     float mean, var;
     row_stats<T, MAXC>(v, D, lane, mean, var);
     const float rstd = fast_rsqrt(var + eps);
@@ -93,11 +93,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
             for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * gv[j];
             if (res != nullptr) {
                 float rv[VEC];
-                load_vec<T>(res + row * (long)D + c * VEC, rv);
+                load_vec<T, NT>(res + row * (long)D + c * VEC, rv);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] += rv[j];
             }
-            store_vec<T>(y + yrow * ldy + c * VEC, o);
+            store_vec<T, NT>(y + yrow * ldy + c * VEC, o);
         }
     }
     if (lane == 0) {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const T* __restrict__ 
 // to_out LayerNorm + skip) is immediately followed by h2 = LN(x1) g2 (the feed-forward PreNorm).  Both are row-wise over the same
 // rows, so one kernel reads p and res once and writes x1, h2 and both pairs of statistics: the second LayerNorm no longer
 // re-reads x1.  The second one sees x1 exactly as stored (rounded to T), so results are those of the two separate calls.
-template <typename T, int MAXC>
+template <typename T, int MAXC, bool NT = false>
 __global__ __launch_bounds__(256) void ln_chain_fwd_kernel(const T* __restrict__ p, const T* __restrict__ g1, const T* __restrict__ res,
                                                            T* __restrict__ x1, float* __restrict__ mean1, float* __restrict__ rstd1,
                                                            const T* __restrict__ g2, T* __restrict__ h2, float* __restrict__ mean2,
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void ln_chain_fwd_kernel(const T* __restrict__
     if (row >= rows) return;
     const int nch = D / VEC;
     float v[MAXC][VEC], rv[MAXC][VEC];
-    load_row<T, MAXC, false>(p + row * (long)D, D, lane, v);
-    load_row<T, MAXC, false>(res + row * (long)D, D, lane, rv);    // (both rows requested before the first reduction)
+    load_row<T, MAXC, false, NT>(p + row * (long)D, D, lane, v);
+    load_row<T, MAXC, false, NT>(res + row * (long)D, D, lane, rv);    // (both rows requested before the first reduction)
     float mean, var;
     row_stats<T, MAXC>(v, D, lane, mean, var);
     const float rstd = fast_rsqrt(var + eps);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void ln_chain_fwd_kernel(const T* __restrict__
             load_vec<T>(g1 + c * VEC, gv);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v[i][j] = to_f32(from_f32<T>((v[i][j] - mean) * rstd * gv[j] + rv[i][j]));   // x1 as stored
-            store_vec<T>(x1 + row * (long)D + c * VEC, v[i]);
+            store_vec<T, NT>(x1 + row * (long)D + c * VEC, v[i]);
         }
     }
     float m2, var2;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void ln_chain_fwd_kernel(const T* __restrict__
             load_vec<T>(g2 + c * VEC, gv);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - m2) * r2 * gv[j];
-            store_vec<T>(h2 + row * (long)D + c * VEC, o);
+            store_vec<T, NT>(h2 + row * (long)D + c * VEC, o);
         }
     }
     if (lane == 0) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void ln_chain_fwd_kernel(const T* __restrict__
 
 // backward of the same pair: dx1 = LN2'(dh2) + dres (the gradient of x1: still written, the next residual junction adds it), then
 // dp = LN1'(dx1) from the registers.  dg2 / dg1 partial rows per work-group as in ln_bwd_kernel: partial [gridDim.x, 2 D].
-template <typename T, int MAXC>
+template <typename T, int MAXC, bool NT = false>
 __global__ __launch_bounds__(256) void ln_chain_bwd_kernel(const T* __restrict__ dh2, const T* __restrict__ x1, const T* __restrict__ g2,
                                                            const float* __restrict__ mean2, const float* __restrict__ rstd2,
                                                            const T* __restrict__ dres, T* __restrict__ dx1, const T* __restrict__ p,
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256) void ln_chain_bwd_kernel(const T* __restrict__
         for (int i = 0; i < MAXC; ++i) {                           // all four rows requested before the first reduction
             const int c = lane + 64 * i;
             if (c < nch) {
-                load_vec<T>(dres + row * (long)D + c * VEC, rv[i]);
-                load_vec<T>(p + row * (long)D + c * VEC, pv[i]);
+                load_vec<T, NT>(dres + row * (long)D + c * VEC, rv[i]);
+                load_vec<T, NT>(p + row * (long)D + c * VEC, pv[i]);
             }
         }
 #pragma unroll
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(256) void ln_chain_bwd_kernel(const T* __restrict__
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { xh[i][j] = 0.f; dy[i][j] = 0.f; }
             if (c < nch) {
-                load_vec<T>(x1 + row * (long)D + c * VEC, xh[i]);
-                load_vec<T>(dh2 + row * (long)D + c * VEC, dy[i]);
+                load_vec<T, NT>(x1 + row * (long)D + c * VEC, xh[i]);
+                load_vec<T, NT>(dh2 + row * (long)D + c * VEC, dy[i]);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     xh[i][j] = (xh[i][j] - m2) * r2;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void ln_chain_bwd_kernel(const T* __restrict__
                     s1 += dyg;
                     s2 += dyg * ph;
                 }
-                store_vec<T>(dx1 + row * (long)D + c * VEC, dy[i]);
+                store_vec<T, NT>(dx1 + row * (long)D + c * VEC, dy[i]);
             }
         }
         c1 = wave_sum(s1) / (float)D;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void ln_chain_bwd_kernel(const T* __restrict__
                 float o[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] = r1 * (dy[i][j] * g1v[i][j] - c1 - xh[i][j] * c2);
-                store_vec<T>(dp + row * (long)D + c * VEC, o);
+                store_vec<T, NT>(dp + row * (long)D + c * VEC, o);
             }
         }
     }
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void ln_chain_bwd_kernel(const T* __restrict__
 // [rows, 2D] gradient of the FF1 output.  Waves walk the rows grid-stride and keep their dg partials in
 // registers; one LDS fold + one row of per-work-group partial sums at the end.  `dres` (optional, [rows, D]) is
 // added to dx: the pre-norm residual blocks x + f(LN(x)) hand their skip-path gradient straight to this kernel.
-template <typename T, int MAXC, bool GEGLU>
+template <typename T, int MAXC, bool GEGLU, bool NT = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long ldx,
                                                      const T* __restrict__ g, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const T* __restrict__ dres,
@@ -358,13 +358,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
         const float mean = mean_in[row], rstd = rstd_in[row];
         float xh[MAXC][VEC], dyv[MAXC][VEC];
-        load_row<T, MAXC, GEGLU>(x + row * ldx, D, lane, xh);
+        load_row<T, MAXC, GEGLU, NT>(x + row * ldx, D, lane, xh);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
-                load_vec<T>(dy + row * (long)D + c * VEC, dyv[i]);
+                load_vec<T, NT>(dy + row * (long)D + c * VEC, dyv[i]);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     xh[i][j] = (xh[i][j] - mean) * rstd;
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 for (int j = 0; j < VEC; ++j) da[j] = rstd * (dyv[i][j] - c1 - xh[i][j] * c2);
                 if (GEGLU) {
                     float u[VEC], t[VEC], du[VEC], dt[VEC];
-                    load_vec<T>(x + row * ldx + c * VEC, u);
-                    load_vec<T>(x + row * ldx + D + c * VEC, t);
+                    load_vec<T, NT>(x + row * ldx + c * VEC, u);
+                    load_vec<T, NT>(x + row * ldx + D + c * VEC, t);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
                         float cdf, pdf;
@@ -395,16 +395,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                         du[j] = da[j] * (t[j] * cdf);                          // d/du [u gelu(t)]
                         dt[j] = da[j] * u[j] * (cdf + t[j] * pdf);             // d/dt [u gelu(t)]
                     }
-                    store_vec<T>(dx + row * lddx + c * VEC, du);
-                    store_vec<T>(dx + row * lddx + D + c * VEC, dt);
+                    store_vec<T, NT>(dx + row * lddx + c * VEC, du);
+                    store_vec<T, NT>(dx + row * lddx + D + c * VEC, dt);
                 } else {
                     if (dres != nullptr) {                         // gradient arriving over the residual branch
                         float rv[VEC];
-                        load_vec<T>(dres + row * (long)D + c * VEC, rv);
+                        load_vec<T, NT>(dres + row * (long)D + c * VEC, rv);
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) da[j] += rv[j];
                     }
-                    store_vec<T>(dx + row * lddx + c * VEC, da);
+                    store_vec<T, NT>(dx + row * lddx + c * VEC, da);
                 }
             }
         }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // floats per lane) until the row's two reductions are known; gamma sits in LDS.  One exp + one rcp per element.
 // SPLIT waves share a row (each MAXC chunks per lane of its D / SPLIT columns) so that wide rows stay under 168 VGPRs
 // (three waves per SIMD); their two partial sums meet in LDS, double-buffered so one barrier per row suffices.
-template <typename T, int MAXC, int SPLIT>
+template <typename T, int MAXC, int SPLIT, bool NT = false>
 __global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long ldx,
                                                            const T* __restrict__ g, const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, T* __restrict__ dx, long lddx,
@@ -477,9 +477,9 @@ __global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const T* __restrict__
             const int c = lane + 64 * i;
             if (c < nch) {
                 float u[VEC], t[VEC], gv[VEC];
-                load_vec<T>(x + rr * ldx + (c0 + c) * VEC, u);
-                load_vec<T>(x + rr * ldx + D + (c0 + c) * VEC, t);
-                load_vec<T>(dy + rr * (long)D + (c0 + c) * VEC, dyg[i]);
+                load_vec<T, NT>(x + rr * ldx + (c0 + c) * VEC, u);
+                load_vec<T, NT>(x + rr * ldx + D + (c0 + c) * VEC, t);
+                load_vec<T, NT>(dy + rr * (long)D + (c0 + c) * VEC, dyg[i]);
                 load_vec<T>(gs + (c0 + c) * VEC, gv);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -519,8 +519,8 @@ __global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const T* __restrict__
                         du[j] = da * ge[i][j];
                         dt[j] = da * udge[i][j];
                     }
-                    store_vec<T>(dx + row * lddx + (c0 + c) * VEC, du);
-                    store_vec<T>(dx + row * lddx + D + (c0 + c) * VEC, dt);
+                    store_vec<T, NT>(dx + row * lddx + (c0 + c) * VEC, du);
+                    store_vec<T, NT>(dx + row * lddx + D + (c0 + c) * VEC, dt);
                 }
             }
         }

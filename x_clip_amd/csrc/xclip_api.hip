@@ -51,6 +51,13 @@ inline int chunks_per_lane(int64_t dim, int vec) {
     return c;
 }
 
+// Non-temporal row accesses, per kernel (bit 1 GEGLU-LayerNorm backward, 2 GEGLU-LayerNorm forward, 4 LayerNorm forward, 8 LayerNorm backward,
+// 16 chained forward, 32 chained backward).  Inside the step (profiles/r04_m_kernel_stats_nt{0,63}.txt): GEGLU forward -8 %, GEGLU backward -2 %,
+// plain forward / backward / chained backward -1 ... -2 %, chained forward +1 % -- the hint stays off there.  XCLIP_ROWS_NT (measurement build)
+// overrides the mask.
+constexpr int ROWS_NT = 1 | 2 | 4 | 8 | 32;
+inline bool rows_nt_flipped(int bit) { return ((measure_env("XCLIP_ROWS_NT", ROWS_NT) ^ ROWS_NT) & bit) != 0; }
+
 template <typename T, int MAXC>
 void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, void* y, int64_t ldy, int y_grp, float* mean,
                    float* rstd, int rows, int dim, float eps, int geglu, hipStream_t st) {
@@ -71,11 +78,26 @@ void launch_ln_fwd(const void* x, int64_t ldx, const void* g, const void* res, v
         }
     }
 #endif
+    constexpr bool NTG = (ROWS_NT & 2) != 0, NTP = (ROWS_NT & 4) != 0;
+#ifdef XCLIP_MEASURE
+    if constexpr (sizeof(T) == 2 && MAXC <= 4) {
+        if (geglu && rows_nt_flipped(2)) {
+            hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, true, !NTG>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res,
+                               (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
+            return;
+        }
+        if (!geglu && rows_nt_flipped(4)) {
+            hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, false, !NTP>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res,
+                               (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
+            return;
+        }
+    }
+#endif
     if (geglu)
-        hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, true>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res,
+        hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, true, NTG>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g, (const T*)res,
                            (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
     else
-        hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, false>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g,
+        hipLaunchKernelGGL((ln_fwd_kernel<T, MAXC, false, NTP>), grid, block, 0, st, (const T*)x, (long)ldx, (const T*)g,
                            (const T*)res, (T*)y, mean, rstd, rows, dim, eps, (long)ldy, y_grp);
 }
 constexpr int LN_BWD_MAX_BLOCKS = 4096;          // MI355X, 263k x 512 rows: 1024 work-groups 180 us, 2048: 189, 4096: 163, 8192: 165
@@ -83,37 +105,64 @@ inline int ln_bwd_blocks(int64_t rows) {
     const int64_t b = (rows + 3) / 4;
     return (int)(b > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : b);
 }
+// the GEGLU variant: 80 VGPRs and 20 KB of LDS per work-group = six resident work-groups per CU; the grid is a whole number of such
+// rounds (never more than ln_bwd_blocks(rows): the workspace is sized by that)
+inline int ln_geglu_bwd_blocks(int64_t rows) {
+    const int64_t b = (rows + 1) / 2, cap = ln_bwd_blocks(rows);
+    const int per_round = 6 * xc_policy_cus();
+    int64_t want = (int64_t)measure_env("XCLIP_LNG_BLOCKS", 2 * per_round);
+    if (want > cap) want = cap;
+    return (int)(b < want ? (b < 1 ? 1 : b) : want);
+}
 
 template <typename T, int MAXC>
-void launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
-                   const void* dres, void* dx, int64_t lddx, float* dg, int rows, int dim, int geglu, hipStream_t st) {
+int launch_ln_bwd(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
+                  const void* dres, void* dx, int64_t lddx, float* dg, int rows, int dim, int geglu, hipStream_t st) {
     const int blocks = ln_bwd_blocks(rows);
     dim3 grid(blocks), block(256);
     const size_t lds = (size_t)3 * dim * sizeof(float);
+    constexpr bool NTG = (ROWS_NT & 1) != 0, NTP = (ROWS_NT & 8) != 0;
+#define XC_LNB(KERNEL, GRID, LDS) do { XC_ALLOW_LDS((KERNEL), LDS); hipLaunchKernelGGL((KERNEL), GRID, block, LDS, st, (const T*)dy, (const T*)x, (long)ldx, (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim); } while (0)
+#define XC_LNB_RES(KERNEL, GRID, LDS) do { XC_ALLOW_LDS((KERNEL), LDS); hipLaunchKernelGGL((KERNEL), GRID, block, LDS, st, (const T*)dy, (const T*)x, (long)ldx, (const T*)g, mean, rstd, (const T*)dres, (T*)dx, (long)lddx, dg, rows, dim); } while (0)
     if (geglu) {
         // rows wider than 3 chunks per lane are shared by two waves (register budget: three waves per SIMD)
         constexpr int SPLIT = (MAXC >= 4 && MAXC % 2 == 0) ? 2 : 1;
         constexpr int C = MAXC / SPLIT;
-        const size_t lds2 = ((size_t)4 * dim + 16) * sizeof(float) + (size_t)dim * sizeof(T);
-        if (SPLIT == 2 && (dim / Elem<T>::VEC) % 2 == 0) {
-            XC_ALLOW_LDS((ln_geglu_bwd_kernel<T, C, SPLIT>), lds2);
-            hipLaunchKernelGGL((ln_geglu_bwd_kernel<T, C, SPLIT>), grid, block, lds2, st, (const T*)dy, (const T*)x, (long)ldx,
-                               (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+        const bool split = SPLIT == 2 && (dim / Elem<T>::VEC) % 2 == 0;
+        // four waves' dg partials of their column part + the row sums + gamma
+        const size_t lds2 = ((size_t)4 * (dim / (split ? 2 : 1)) + 16) * sizeof(float) + (size_t)dim * sizeof(T)
+                            + (measure_env("XCLIP_LNG_LDSPAD", 0) && split ? (size_t)2 * dim * sizeof(float) : 0);   // what rounds 1-3 requested
+        dim3 ggrid(ln_geglu_bwd_blocks(rows));
+        if (split) {
+#ifdef XCLIP_MEASURE
+            if (rows_nt_flipped(1)) {
+                XC_LNB((ln_geglu_bwd_kernel<T, C, SPLIT, !NTG>), ggrid, lds2);
+                return (int)ggrid.x;
+            }
+#endif
+            XC_LNB((ln_geglu_bwd_kernel<T, C, SPLIT, NTG>), ggrid, lds2);
+            return (int)ggrid.x;
         } else if (MAXC <= 4) {
             constexpr int C1 = MAXC <= 4 ? MAXC : 1;
-            XC_ALLOW_LDS((ln_geglu_bwd_kernel<T, C1, 1>), lds2);
-            hipLaunchKernelGGL((ln_geglu_bwd_kernel<T, C1, 1>), grid, block, lds2, st, (const T*)dy, (const T*)x, (long)ldx,
-                               (const T*)g, mean, rstd, (T*)dx, (long)lddx, dg, rows, dim);
+            XC_LNB((ln_geglu_bwd_kernel<T, C1, 1, NTG>), ggrid, lds2);
+            return (int)ggrid.x;
         } else {                                               // very wide rows with an odd chunk count: the generic two-pass kernel
-            XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, true>), lds);
-            hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, true>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
-                               (const T*)g, mean, rstd, (const T*)dres, (T*)dx, (long)lddx, dg, rows, dim);
+            XC_LNB_RES((ln_bwd_kernel<T, MAXC, true, NTG>), grid, lds);
         }
     } else {
-        XC_ALLOW_LDS((ln_bwd_kernel<T, MAXC, false>), lds);
-        hipLaunchKernelGGL((ln_bwd_kernel<T, MAXC, false>), grid, block, lds, st, (const T*)dy, (const T*)x, (long)ldx,
-                           (const T*)g, mean, rstd, (const T*)dres, (T*)dx, (long)lddx, dg, rows, dim);
+#ifdef XCLIP_MEASURE
+        if constexpr (sizeof(T) == 2 && MAXC <= 2) {
+            if (rows_nt_flipped(8)) {
+                XC_LNB_RES((ln_bwd_kernel<T, MAXC, false, !NTP>), grid, lds);
+                return blocks;
+            }
+        }
+#endif
+        XC_LNB_RES((ln_bwd_kernel<T, MAXC, false, NTP>), grid, lds);
     }
+#undef XC_LNB
+#undef XC_LNB_RES
+    return blocks;
 }
 
 // dispatch on (dtype, chunks per lane); F is a macro taking (T, MAXC)
@@ -347,10 +396,10 @@ int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* 
     if (rows == 0) return 0;
     const int cpl = chunks_per_lane(dim, vec);
     float* partial = (float*)workspace;
-#define F(T, C) launch_ln_bwd<T, C>(dy, x, ldx, g, mean, rstd, dres, dx, lddx, partial, (int)rows, (int)dim, geglu, (hipStream_t)stream)
+    int nblk = 0;                                              // rows of dg partials the kernel wrote
+#define F(T, C) nblk = launch_ln_bwd<T, C>(dy, x, ldx, g, mean, rstd, dres, dx, lddx, partial, (int)rows, (int)dim, geglu, (hipStream_t)stream)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
-    const int nblk = ln_bwd_blocks(rows);
     int slices = nblk / 64;
     if (slices < 1) slices = 1;
     hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices), dim3(256), 1024, (hipStream_t)stream,
@@ -368,7 +417,14 @@ int xclip_layernorm_chain_fwd(const void* p, const void* g1, const void* res, vo
     if (rows == 0) return 0;
     const int cpl = chunks_per_lane(dim, vec);
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define F(T, C) hipLaunchKernelGGL((ln_chain_fwd_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)p, (const T*)g1, (const T*)res, (T*)x1, mean1, rstd1, (const T*)g2, (T*)h2, mean2, rstd2, (int)rows, (int)dim, eps)
+    constexpr bool NTC = (ROWS_NT & 16) != 0;
+#ifdef XCLIP_MEASURE
+    if (dtype == XCLIP_BF16 && cpl == 1 && rows_nt_flipped(16)) {
+        hipLaunchKernelGGL((ln_chain_fwd_kernel<bf16_t, 1, !NTC>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)g1, (const bf16_t*)res, (bf16_t*)x1, mean1, rstd1, (const bf16_t*)g2, (bf16_t*)h2, mean2, rstd2, (int)rows, (int)dim, eps);
+        return check_launch(__func__);
+    }
+#endif
+#define F(T, C) hipLaunchKernelGGL((ln_chain_fwd_kernel<T, C, NTC>), grid, block, 0, (hipStream_t)stream, (const T*)p, (const T*)g1, (const T*)res, (T*)x1, mean1, rstd1, (const T*)g2, (T*)h2, mean2, rstd2, (int)rows, (int)dim, eps)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
     return check_launch(__func__);
@@ -392,7 +448,14 @@ int xclip_layernorm_chain_bwd(const void* dh2, const void* x1, const void* g2, c
     dim3 grid((unsigned)nblk), block(256);
     float* partial = (float*)workspace;
     const size_t lds = (size_t)6 * dim * sizeof(float);
-#define F(T, C) do { XC_ALLOW_LDS((ln_chain_bwd_kernel<T, C>), lds); hipLaunchKernelGGL((ln_chain_bwd_kernel<T, C>), grid, block, lds, (hipStream_t)stream, (const T*)dh2, (const T*)x1, (const T*)g2, mean2, rstd2, (const T*)dres, (T*)dx1, (const T*)p, (const T*)g1, mean1, rstd1, (T*)dp, partial, (int)rows, (int)dim); } while (0)
+    constexpr bool NTC = (ROWS_NT & 32) != 0;
+#ifdef XCLIP_MEASURE
+    if (dtype == XCLIP_BF16 && cpl == 1 && rows_nt_flipped(32)) {
+        XC_ALLOW_LDS((ln_chain_bwd_kernel<bf16_t, 1, !NTC>), lds);
+        hipLaunchKernelGGL((ln_chain_bwd_kernel<bf16_t, 1, !NTC>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)dh2, (const bf16_t*)x1, (const bf16_t*)g2, mean2, rstd2, (const bf16_t*)dres, (bf16_t*)dx1, (const bf16_t*)p, (const bf16_t*)g1, mean1, rstd1, (bf16_t*)dp, partial, (int)rows, (int)dim);
+    } else
+#endif
+#define F(T, C) do { XC_ALLOW_LDS((ln_chain_bwd_kernel<T, C, NTC>), lds); hipLaunchKernelGGL((ln_chain_bwd_kernel<T, C, NTC>), grid, block, lds, (hipStream_t)stream, (const T*)dh2, (const T*)x1, (const T*)g2, mean2, rstd2, (const T*)dres, (T*)dx1, (const T*)p, (const T*)g1, mean1, rstd1, (T*)dp, partial, (int)rows, (int)dim); } while (0)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
     int slices = nblk / 64;

@@ -375,7 +375,7 @@ BATCH_INVARIANT_GEMM = False
 
 class KernelProbe:
     """Optional live measurement of the kernel families that make up a step (bench.py's `roofline` leg): while active, every
-    xclip_gemm / attention / LayerNorm-family call is bracketed by HIP events on the stream it is launched on, and after every
+    xclip_gemm / attention / LayerNorm-family / contrastive-head (similarity forward and G) call is bracketed by HIP events on the stream it is launched on, and after every
     `clock_every`-th probed launch a one-wave clock sample (xclip_clock_sample, ~10 us) is queued on the same stream.
     `summary(family)` returns (launches, flops, seconds) with `algorithmic_bytes` set; `clock_mhz()` the sampled shader clocks."""
     active: Optional["KernelProbe"] = None
@@ -593,8 +593,12 @@ def simloss_chunked_fwd(q: Tensor, k_chunks, scale: float, diag_off: int, dcl: b
         kc = _c(kc)
         nk = kc.shape[0]
         assert kc.shape[1] == d and kc.dtype == q.dtype
+        probe = _probe(q)
+        ev0 = probe.begin(q) if probe is not None else None
         _lib.check(L.xclip_simloss_partial(q.data_ptr(), kc.data_ptr(), nq, nk, d, sc, lsp, diag_off - col0, int(dcl), ws.data_ptr(),
                                            slot0, slots, pos.data_ptr(), dtype_code(q), _stream(q)), "xclip_simloss_partial")
+        if probe is not None:      # S = q k^T once; both latent sets in, two fp32 partials per (row, 64-column slot) out
+            probe.end(q, ev0, "head", 2.0 * nq * nk * d, (nq + nk) * d * q.element_size() + 8 * nq * ((nk + 63) // 64), "sim_fwd")
         slot0 += (nk + 63) // 64
     _lib.check(L.xclip_simloss_combine(ws.data_ptr(), nq, slots, pos.data_ptr(), lse.data_ptr(), _ptr(loss_accum), coef, _stream(q)),
                "xclip_simloss_combine")
@@ -622,9 +626,13 @@ def simloss_grad(q: Tensor, k: Tensor, scale: float, diag_off: int, dcl: bool, a
     if gmul is not None:
         assert gmul.dtype == torch.float32 and gmul.numel() == 1
     sc, lsp = _scale_args(scale, log_scale)
+    probe = _probe(q)
+    ev0 = probe.begin(q) if probe is not None else None
     _lib.check(_lib.lib().xclip_simloss_grad(q.data_ptr(), k.data_ptr(), nq, nk, d, sc, lsp, diag_off, int(dcl), a, c, e, _ptr(gmul),
                                              int(times_scale), lse_q.data_ptr(), lse_k.data_ptr(), G.data_ptr(), G.stride(0),
                                              _ptr(dtau_accum), dtype_code(q), _stream(q)), "xclip_simloss_grad")
+    if probe is not None:          # S recomputed once; both latent sets and the two lse vectors in, G out
+        probe.end(q, ev0, "head", 2.0 * nq * nk * d, (nq + nk) * (d * q.element_size() + 4) + nq * ldg * q.element_size(), "sim_grad")
     return G
 
 
