@@ -4,7 +4,8 @@
 // Layout: one wave64 per row, the whole row held in registers (lane owns the 16-byte chunks
 // c = lane + 64*i), every global access a coalesced 16-byte transaction, all reductions are wave
 // shuffles -- no LDS in the forward kernels.  Algorithmic HBM traffic: forward 2 x rows x D x e
-// (+ residual read), backward 3 x rows x D x e.
+// (+ residual read), backward 3 x rows x D x e.  A row is read once and written once: the streamed accesses carry the
+// non-temporal hint where the launcher's template argument NT says so (xclip_api.hip ROWS_NT: measured per kernel).
 //
 // Semantics follow the reference LayerNorm (x_clip.py:112-121: biased variance, gain only, the caller
 // passes eps = 1e-5 for fp32 and 1e-3 otherwise), GEGLU (x_clip.py:180-183: value = first half, gate =
