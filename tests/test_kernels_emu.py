@@ -384,6 +384,27 @@ def test_gemm_row_tail_as_split_k():
     assert out.returncode == 0 and "tail ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_geglu_layernorm_bwd_grid_smaller_than_its_workspace():
+    """xclip_api.hip ln_geglu_bwd_blocks: the GEGLU-LayerNorm backward runs two rounds of six work-groups per CU, fewer than the rows of dg
+    partials its workspace is sized for; a one-CU emulator (12 work-groups) walks 203 rows in nine passes with a dead slot in the last one,
+    and the fold must read exactly the partial rows that were written"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from x_clip_amd import _lib\n"
+        "from emu.build_emu import build\n"
+        "_lib._use_library_for_tests(build())\n"
+        "import kernel_cases as K\n"
+        "for dtype in K.DTYPES:\n"
+        "    K.case_layernorm(torch.device('cpu'), dtype, 203, 2048, True, False)\n"
+        "    K.case_layernorm(torch.device('cpu'), dtype, 50, 1024, True, False)\n"
+        "print('grid ok')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XCLIP_EMU_CUS="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "grid ok" in out.stdout, out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("bx,nt,by,ni,d,chunks", [(5, 77, 4, 98, 64, 1), (4, 64, 7, 64, 128, 1), (3, 130, 3, 200, 64, 2), (4, 70, 3, 65, 64, 1),
                                                   (9, 32, 9, 32, 64, 1), (7, 40, 8, 33, 64, 1), (3, 256, 6, 32, 64, 1)])
 def test_filip_fused(bx, nt, by, ni, d, chunks):

@@ -25,7 +25,8 @@ def hip_library():
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 @pytest.mark.parametrize("rows,dim,geglu,res", [(5, 64, False, False), (1031, 512, False, True), (517, 2048, True, False),
-                                                (66, 4096, True, False), (7, 1544, True, False), (130, 768, False, False), (9000, 512, False, False)])
+                                                (66, 4096, True, False), (7, 1544, True, False), (130, 768, False, False), (9000, 512, False, False),
+                                                (13001, 2048, True, False)])     # (GEGLU backward: 3072 work-groups of the 3251 the workspace is sized for, 2 - 3 passes each)
 def test_layernorm(dtype, rows, dim, geglu, res):
     K.case_layernorm(DEV, dtype, rows, dim, geglu, res)
 
