@@ -265,8 +265,30 @@ DIST_CASES = (("dist2_infonce", dict()), ("dist2_dcl", dict(decoupled_contrastiv
               ("dist2_simreg_extra", dict(extra_latent_projection=True, sim_reg_loss_weight=0.5)))
 
 
+def live(spec_json: str, out_path: str):
+    """python oracle/make_golden.py --live '<json>' <out.json>: ONE reference run on a configuration given on the command line
+    ({"config": ClipConfig overrides, "batch", "n_aug_text", "n_aug_image", "patch_dropout", "param_seed", "input_seed"}), written as a
+    fixture record to <out.json> -- tests/test_live_reference.py compares the product with the reference on configurations no committed
+    fixture holds, in the container where /root/reference exists"""
+    global PARAM_SEED
+    spec = json.loads(spec_json)
+    cfg = ClipConfig(**{**CFG1.ctor_kwargs(), **spec.get("config", {})})
+    PARAM_SEED = int(spec.get("param_seed", PARAM_SEED))
+    x_clip = import_reference()
+    out = run_reference(x_clip, cfg, int(spec["batch"]), int(spec.get("n_aug_text", 0)), int(spec.get("n_aug_image", 0)),
+                        float(spec.get("patch_dropout", 0.0)), input_seed=int(spec.get("input_seed", INPUT_SEED)))
+    rec = dict(case="live", config=cfg.ctor_kwargs(), batch=int(spec["batch"]), n_aug_text=int(spec.get("n_aug_text", 0)),
+               n_aug_image=int(spec.get("n_aug_image", 0)), visual_patch_dropout=float(spec.get("patch_dropout", 0.0)),
+               param_seed=PARAM_SEED, input_seed=int(spec.get("input_seed", INPUT_SEED)), **out)
+    with open(out_path, "w") as f:
+        json.dump(rec, f)
+    print(f"live: loss={out['loss']:.9f} dtau={out['dtau']:+.9f}")
+
+
 def main():
     """python oracle/make_golden.py [case ...]   (no arguments: every case)"""
+    if len(sys.argv) == 4 and sys.argv[1] == "--live":
+        return live(sys.argv[2], sys.argv[3])
     only = set(sys.argv[1:])
     os.makedirs(GOLDEN, exist_ok=True)
     x_clip = import_reference()

@@ -92,9 +92,9 @@ def run_product(model, text, image, aug_t, aug_i, dev, dtype, keep=None, mlm=Non
     return loss
 
 
-def case_golden(dev, name, dtype=torch.float32):
-    """product vs. the reference's own numbers (fixture), fp32"""
-    rec = load_golden(name)
+def case_golden(dev, name, dtype=torch.float32, rec=None):
+    """product vs. the reference's own numbers (fixture; `rec`: a record produced on the spot, tests/test_live_reference.py), fp32"""
+    rec = load_golden(name) if rec is None else rec
     cfg = O.ClipConfig(**rec["config"])
     sd = O.make_state_dict(cfg, rec["param_seed"], torch.float32)
     text, image, aug_t, aug_i = O.make_inputs(cfg, rec["batch"], rec["input_seed"], rec["n_aug_text"], rec["n_aug_image"])
