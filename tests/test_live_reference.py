@@ -48,6 +48,13 @@ SPECS = {
     # wide heads (96 / 80) + patch dropout + three text views against one image view
     "wide_heads_patchdrop_m3n1": dict(config=dict(text_dim_head=96, text_heads=2, visual_dim_head=80, visual_heads=2, multiview_loss_weight=0.25),
                                       batch=3, n_aug_text=2, n_aug_image=0, patch_dropout=0.5, param_seed=105, input_seed=206),
+    # the MLM side loss through a text tower of width 96 (three 32-wide heads), DCL, odd batch; the draw of masked positions is the reference's own
+    "mlm_dcl_odd_width": dict(config=dict(use_mlm=True, dim_text=96, text_heads=3, text_dim_head=32, decoupled_contrastive_learning=True),
+                              batch=5, param_seed=109, input_seed=210),
+    # autoregressive text encoder (causal attention, EOS pooling) with CLOOB projections and one augmented text view
+    "causal_extra_m2n1": dict(config=dict(text_causal_mask=True, text_has_cls_token=False, text_eos_id=3, extra_latent_projection=True,
+                                          text_dim_head=48, text_heads=2),
+                              batch=4, n_aug_text=1, n_aug_image=0, param_seed=111, input_seed=212),
 }
 
 
