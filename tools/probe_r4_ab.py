@@ -2,6 +2,7 @@
     python tools/probe_r4_ab.py attn      XCLIP_ATTN_ABL=4 -> the 257th token as a 33rd block (round-3 form); unset -> as the accumulators' initial value
     python tools/probe_r4_ab.py gemm      XCLIP_GEMM_TAIL=0 -> uncut persistent launches; unset -> the row tail as a split-K problem
     python tools/probe_r4_ab.py wgrad     XCLIP_GEMM_SPLIT2D=1 -> split-K weight gradients on the (tile, slice) grid; unset -> 1-D grid, an XCD holds whole K slices
+    python tools/probe_r4_ab.py scatter   XCLIP_SCATTER_STAGED=0 -> the token-embedding gradient flushes a run with strided atomics; unset -> through the wave's LDS row
     python tools/probe_r4_ab.py wide      heads of 80 / 96 / 128 features (128-wide head slots, the tiled kernels of attention.h) beside the 64-wide head-resident ones
 Prints one line per shape; the text / vision shapes of BASELINE configs[1] (b = 1024)."""
 import os
@@ -50,6 +51,20 @@ if what == "attn":
         tb = timeit(lambda: ops.attention_bwd(qkv, mask, out, do, lse, h, 0.125))
         fl = 4.0 * b * h * n * n * 64
         print(f"[{tag}] attention b={b} n={n} h={h} mask={int(masked)}: fwd {t*1e3:7.1f} us ({fl/t/1e9:6.1f} TF/s)   bwd {tb*1e3:7.1f} us ({2*fl/tb/1e9:6.1f} TF/s algorithmic)", flush=True)
+elif what == "scatter":
+    for (b, n, vocab, zipf) in [(1024, 256, 10000, False), (1024, 256, 49408, False), (1024, 256, 49408, True)]:
+        g = torch.Generator(device="cpu").manual_seed(0)
+        if zipf:                                                 # frequencies ~ 1 / rank, like natural text
+            w = 1.0 / torch.arange(1, vocab + 1, dtype=torch.float64)
+            tok = torch.multinomial(w / w.sum(), b * n, replacement=True, generator=g).view(b, n)
+        else:
+            tok = torch.randint(0, vocab, (b, n), generator=g)
+        tok = tok.to(dev)
+        st = torch.sort(tok.flatten())
+        dout = torch.randn(b * (n + 1), 512, device=dev, dtype=bf)
+        dE = torch.zeros(vocab, 512, dtype=torch.float32, device=dev)
+        t = timeit(lambda: ops.scatter_add_sorted(dout, st.values, st.indices, dE, n_in=n, n_out=n + 1, row_off=1))
+        print(f"[{tag}] scatter_add_sorted {b} x {n} tokens, vocabulary {vocab}{' (zipf)' if zipf else ' (uniform)'}: {t*1e3:7.1f} us ({b * n * 1024 / t / 1e6:6.0f} GB/s of rows)", flush=True)
 elif what == "wgrad":
     Mt, Mv = 1024 * 257, 1024 * 33
     for (name, M, N, K) in [("ff1 wgrad text", 4096, 512, Mt), ("ff2 wgrad text", 512, 2048, Mt), ("qkv wgrad text", 1536, 512, Mt), ("out wgrad text", 512, 512, Mt),

@@ -286,12 +286,18 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const T* __restri
 // One wave per `chunk` consecutive sorted entries: equal ids are summed in registers and flushed with one fp32
 // atomic per column when the id changes -- a vocabulary row hit k times costs ~1 flush instead of k, which is what made
 // the unsorted scatter (one atomic per element) the slowest non-GEMM kernel of the step.
+// The flush goes through the wave's D floats of LDS (`staged`: the launcher grants 4 x D x 4 bytes) so that one atomic instruction covers 64
+// CONSECUTIVE floats of the table row: a lane accumulates the 16-byte chunks it loaded (VEC consecutive columns), and flushing those directly
+// makes every atomic instruction touch 64 different 32-byte sectors -- with ids drawn uniformly (a run is ~26 entries at 262 k tokens over
+// 10 k ids) the kernel was bound by that: 13 M sector atomics per launch.
 template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void scatter_add_sorted_kernel(const T* __restrict__ src, long lds_, const long long* __restrict__ ids,
                                                                  const long long* __restrict__ perm, float* __restrict__ table,
                                                                  long count, int D, int n_in, int n_out, int row_off, int chunk,
-                                                                 long long table_rows) {
+                                                                 long long table_rows, int staged) {
     constexpr int VEC = Elem<T>::VEC;
+    XC_LDS_DYNAMIC(lds);
+    float* const stage = reinterpret_cast<float*>(lds) + (long)wave_id() * D;
     const int lane = lane_id();
     const int nch = D / VEC;
     const long e0 = ((long)blockIdx.x * 4 + wave_id()) * chunk;
@@ -308,15 +314,29 @@ __global__ __launch_bounds__(256) void scatter_add_sorted_kernel(const T* __rest
         if (id != cur) {                                   // wave-uniform: flush the finished run
             float* trow = table + (long)cur * D;
             const bool in_table = cur >= 0 && cur < table_rows;  // an id without a row is dropped, never written out of bounds
+            if (staged) {
 #pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const int c = lane + 64 * i;
-                if (c < nch)
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < nch)
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        if (in_table) atomic_add(trow + c * VEC + k, acc[i][k]);
-                        acc[i][k] = 0.f;
-                    }
+                        for (int k = 0; k < VEC; ++k) { stage[c * VEC + k] = acc[i][k]; acc[i][k] = 0.f; }
+                }
+                lds_fence();                               // (wave-private hand-off: the lanes read what other lanes stored)
+                if (in_table)
+                    for (int j = lane; j < D; j += 64) atomic_add(trow + j, stage[j]);
+                lds_fence();                               // (... before the next flush overwrites it)
+            } else {
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < nch)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            if (in_table) atomic_add(trow + c * VEC + k, acc[i][k]);
+                            acc[i][k] = 0.f;
+                        }
+                }
             }
             cur = id;
         }

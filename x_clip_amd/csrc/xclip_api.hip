@@ -659,7 +659,10 @@ int xclip_scatter_add_sorted(const void* src, int64_t lds, const int64_t* sorted
     if (chunk < 16) chunk = 16;
     const int64_t waves = (count + chunk - 1) / chunk;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-#define F(T, C) hipLaunchKernelGGL((scatter_add_sorted_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)src, (long)lds, (const long long*)sorted_ids, (const long long*)perm, table_accum, (long)count, (int)dim, (int)n_in, (int)n_out, (int)row_off, (int)chunk, (long long)table_rows)
+    // the flush is staged through LDS (one wave's row of fp32: coalesced atomics) where four rows fit the default 64 KiB
+    const size_t stage_bytes = (size_t)4 * dim * sizeof(float) <= 64 * 1024 ? (size_t)4 * dim * sizeof(float) : 0;
+    const int staged = measure_env("XCLIP_SCATTER_STAGED", 1) && stage_bytes > 0;
+#define F(T, C) hipLaunchKernelGGL((scatter_add_sorted_kernel<T, C>), grid, block, staged ? stage_bytes : 0, (hipStream_t)stream, (const T*)src, (long)lds, (const long long*)sorted_ids, (const long long*)perm, table_accum, (long)count, (int)dim, (int)n_in, (int)n_out, (int)row_off, (int)chunk, (long long)table_rows, staged)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
     return check_launch(__func__);
