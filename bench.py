@@ -51,16 +51,20 @@ def gpu_telemetry(index=0):
     return out
 
 
-def model_flops_per_pair(model, n_text_tokens, n_img_tokens, n_patches_embedded):
+def model_flops_per_pair(model, n_text_tokens, n_img_tokens, n_patches_embedded, text_rows_pruned=False):
     """algorithmic forward FLOPs per (text, image) pair of the work this implementation executes (SURVEY.md 8(d));
-    fwd + bwd = 3x.  Patch embedding is counted on the patches actually embedded (kept patches only)."""
-    def tower(t, n):
+    fwd + bwd = 3x.  Patch embedding is counted on the patches actually embedded (kept patches only); with the text tower asked for its
+    CLS row only (CLIP.prune_unused_rows) the last text layer's to_out and feed-forward products are counted on that one row."""
+    def tower(t, n, pooled=False):
         D, I = t.dim, t.heads * t.dim_head
         per_tok = 2 * D * 3 * I + 2 * I * D + 2 * D * 8 * D + 2 * 4 * D * D
-        return t.depth * (n * per_tok + 4 * n * n * I)
+        f = t.depth * (n * per_tok + 4 * n * n * I)
+        if pooled and t.depth >= 1:
+            f -= (n - 1) * (2 * I * D + 2 * D * 8 * D + 2 * 4 * D * D)
+        return f
     tt, vt = model.text_transformer.transformer, model.visual_transformer.transformer
     patch_dim = model.visual_transformer.to_tokens[1].weight.shape[1]
-    f = tower(tt, n_text_tokens) + tower(vt, n_img_tokens)
+    f = tower(tt, n_text_tokens, text_rows_pruned) + tower(vt, n_img_tokens)
     f += 2 * n_patches_embedded * patch_dim * vt.dim + 2 * vt.dim * vt.dim
     f += 2 * tt.dim * model.dim_latent + 2 * vt.dim * model.dim_latent
     return f
@@ -141,6 +145,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side streams for the vision tower / weight gradients "
                     "(use this for rocprofv3 kernel-trace runs whose per-kernel averages should be of kernels running alone)")
     ap.add_argument("--dcl", action="store_true")
+    ap.add_argument("--dense-last-layer", action="store_true", help="CLIP.prune_unused_rows = False: the text tower's last layer runs every token row, "
+                    "as the reference computes it (default: only the CLS row the head reads; same loss, same gradients)")
     ap.add_argument("--text-slices", type=int, default=1, help="CLIP.text_micro_batches: slices of the text batch on separate streams")
     ap.add_argument("--image-slices", type=int, default=None, help="CLIP.image_micro_batches: sequential slices of the image batch through the "
                     "vision tower (bounds the recompute transient; default 2 for --config vitl, else 1)")
@@ -203,6 +209,10 @@ def main():
     model = CLIP(decoupled_contrastive_learning=args.dcl, **extra).to(torch.bfloat16).to(dev)
     model.train()
     model.assume_equal_batch = True
+    model.prune_unused_rows = not args.dense_last_layer
+    # (does the text tower run pooled in this configuration?  CLS head, own TextTransformer, no dropout: clip.py forward / functional.can_pool)
+    text_pooled = (model.prune_unused_rows and not args.filip and not args.causal
+                   and functional.can_pool(model.text_transformer.transformer.spec()))
     sync = GradSync(model) if world > 1 else None
 
     b = args.batch
@@ -274,7 +284,7 @@ def main():
     vt = model.visual_transformer
     n_keep = max(1, int(vt.num_patches * (1 - vt.patch_dropout.prob)))
     views = 2 if args.config == "vitl" else 1                # a pair with one augmented text + image = two passes of each tower
-    fwd_flops = views * model_flops_per_pair(model, model.text_seq_len + 1, n_keep, n_keep)
+    fwd_flops = views * model_flops_per_pair(model, model.text_seq_len + 1, n_keep, n_keep, text_rows_pruned=text_pooled)
     pairs = b * world * args.steps
     value = pairs / elapsed
     plain_default = args.config == "default" and not (args.filip or args.simsiam or args.causal)
@@ -296,6 +306,10 @@ def main():
                                "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ("" if not args.simsiam else " + SimSiam side loss") +
                                ("" if not args.causal else ", causal text encoder") + ", fwd+bwd",
                    "workload_tag": workload_tag, "local_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
+                   # the CLS head reads one row of the text encoding: the last text layer's row-wise part (to_out, feed-forward, norm_out) runs on
+                   # that row only -- same loss, same gradient of every parameter as the dense layer (tests: pruned_rows_equal_dense, the reference
+                   # fixtures); `dense_last_layer` below times the same step with every row computed
+                   "text_last_layer_rows": "cls-only" if text_pooled else "all",
                    "gflop_per_pair_fwd_bwd": round(3 * fwd_flops / 1e9, 3)},
         "model_mfma_frac": round(value * 3 * fwd_flops / (world * MFMA_PEAK_BF16), 4),
         "loss": round(loss_val, 5),
@@ -396,6 +410,25 @@ def main():
         out["clock_mhz"] = ({"min": round(clk[0]), "median": round(clk[len(clk) // 2]), "max": round(clk[-1]), "samples": len(clk),
                              "measured": "xclip_clock_sample: shader cycles over 200 us windows that start with every 8th GEMM launch of two extra steps (one wave on a side stream beside the running kernels)"}
                             if clk else None)
+    if text_pooled:
+        # the same step with the reference's dense last text layer (every token row through to_out / feed-forward / norm_out), for the record
+        model.prune_unused_rows = False
+        for _ in range(2):
+            step()
+        fence()
+        td = time.perf_counter()
+        nd = max(2, min(5, args.steps))
+        for _ in range(nd):
+            step()
+        fence()
+        dense_s = time.perf_counter() - td
+        if world > 1:
+            t = torch.tensor([dense_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dense_s = float(t.item())
+        model.prune_unused_rows = True
+        out["dense_last_layer"] = {"ms_per_step": round(dense_s / nd * 1e3, 3), "value": round(b * world * nd / dense_s, 2), "steps": nd,
+                                   "note": "CLIP.prune_unused_rows = False (bench.py --dense-last-layer): identical loss and gradients"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

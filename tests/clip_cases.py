@@ -347,3 +347,62 @@ def case_live_rows(dev, cfg: O.ClipConfig, b, live, dtype=torch.bfloat16, seed=4
         #  gain of the fifth text layer at b = 1024 against 8 rows)
         assert rs < (1e-4 if fp32 else 3e-2), (k, rs)
     REPORT[f"{label} vs the product's own {len(live)}-row step (rel only)"] = {"loss_err": 0.0, "worst_rel": self_rel, "worst_cos": (1.0, "")}
+
+
+def case_pruned_rows_equal_dense(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, checkpoint=False, micro=1, freeze_text=False, seed=31):
+    """CLIP.prune_unused_rows (the text tower asked for its CLS row only: the last layer's row-wise part on B rows, functional.stack_forward
+    `pool_row`) against the dense last layer the reference computes: the same loss and the same gradient of every parameter (per-row
+    arithmetic is identical; the only difference is how many rows a launch holds: fp32 1e-6 of the gradient's norm, bf16 a few ulps of the
+    weight-gradient sums)"""
+    sd = O.make_state_dict(cfg, seed, torch.float32)
+    text, image, aug_t, _ = O.make_inputs(cfg, batch, seed + 1, n_aug_text, 0)
+    from x_clip_amd import functional as XF
+    res, calls = [], []
+    real = XF._layer_forward_pooled
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    for prune in (True, False):
+        calls.clear()
+        XF._layer_forward_pooled = counted
+        try:
+            res.append(_pruned_run(cfg, sd, dev, dtype, checkpoint, prune, micro, text, image, aug_t, freeze_text))
+        finally:
+            XF._layer_forward_pooled = real
+        # one pooled last layer per slice of the text pass (augmented views ride in the same batch), + its re-run under checkpointing
+        # (unless the tower is frozen: no backward)
+        want = micro * (2 if (checkpoint and not freeze_text) else 1) if prune else 0
+        assert len(calls) == want, (prune, len(calls), want)
+    _pruned_compare(res, dtype, freeze_text)
+
+
+def _pruned_run(cfg, sd, dev, dtype, checkpoint, prune, micro, text, image, aug_t, freeze_text):
+    if True:
+        model = build_clip(cfg, sd, dev, dtype, checkpoint_during_training=checkpoint)
+        model.prune_unused_rows = prune
+        model.text_micro_batches = micro
+        model._micro_batch_min_rows = 1
+        kw = dict(aug_text=[a.to(dev) for a in aug_t]) if aug_t else {}
+        loss = model(text.to(dev), image.to(dtype).to(dev), return_loss=True, freeze_text_encoder=freeze_text, **kw)
+        loss.backward()
+        return float(loss.detach()), {k: (None if p.grad is None else p.grad.detach().double().cpu()) for k, p in model.named_parameters()}
+
+
+def _pruned_compare(res, dtype, freeze_text):
+    (l1, g1), (l0, g0) = res
+    tol = 1e-6 if dtype == torch.float32 else 2e-3
+    assert abs(l1 - l0) <= tol * max(1.0, abs(l0)), (l1, l0)
+    assert set(g1) == set(g0)
+    touched = 0
+    for k in g0:
+        if g0[k] is None:
+            assert g1[k] is None or float(g1[k].abs().max()) == 0.0, k
+            continue
+        assert g1[k] is not None, k
+        nrm = float(g0[k].norm())
+        err = float((g1[k] - g0[k]).norm())
+        assert err <= (2e-6 if dtype == torch.float32 else 2e-2) * nrm + 1e-12, (k, err, nrm)
+        touched += 1
+    assert touched > 0 or freeze_text

@@ -382,3 +382,15 @@ def test_transformer_dropout_vs_oracle(dtype):
     with torch.no_grad():
         ye = net(x, mask=mask)
     assert float((ye.double() - plain).abs().max()) < (1e-4 if fp32 else 6e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_pruned_text_rows_equal_dense_last_layer(dtype):
+    """the CLS head reads one row of the text encoding: the tower's last layer runs its row-wise part on that row alone (CLIP.prune_unused_rows);
+    plain, DCL + CLOOB projections with an augmented text view under activation checkpointing, two text slices, rotary, frozen text tower"""
+    import dataclasses
+    C.case_pruned_rows_equal_dense(DEV, dtype, O.CFG1, 5)
+    C.case_pruned_rows_equal_dense(DEV, dtype, dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True, extra_latent_projection=True), 4, n_aug_text=1,
+                                   checkpoint=True)
+    C.case_pruned_rows_equal_dense(DEV, dtype, dataclasses.replace(O.CFG1, text_rotary_pos_emb=True), 6, micro=2)
+    C.case_pruned_rows_equal_dense(DEV, dtype, O.CFG1, 4, freeze_text=True)

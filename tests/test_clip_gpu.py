@@ -57,6 +57,18 @@ def test_mid_vs_oracle(dtype):
     C.case_vs_oracle(DEV, dtype, MID, 24)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_pruned_text_rows_equal_dense_last_layer(dtype):
+    """CLIP.prune_unused_rows (the text tower's last layer runs its row-wise part on the CLS rows only) against the dense last layer: same loss,
+    same gradient of every parameter; mid-size model at b = 40 (+ an augmented text view under checkpointing, + two text slices), and the
+    default architecture at b = 24 (the shapes bench.py runs: 257 positions, 8 heads)"""
+    C.case_pruned_rows_equal_dense(DEV, dtype, MID, 40)
+    C.case_pruned_rows_equal_dense(DEV, dtype, dataclasses.replace(MID, decoupled_contrastive_learning=True, extra_latent_projection=True), 16, n_aug_text=1,
+                                   checkpoint=True)
+    C.case_pruned_rows_equal_dense(DEV, dtype, dataclasses.replace(MID, text_rotary_pos_emb=True), 32, micro=2)
+    C.case_pruned_rows_equal_dense(DEV, dtype, O.ClipConfig(num_text_tokens=3000), 24)
+
+
 # ---- the HEADLINE architecture (what bench.py times: O.ClipConfig() defaults = depth 6 / 6, text length 256 -> 257 positions, 64
 # patches of which 32 are kept) against the fp64 oracle, every parameter gradient in full ---------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])

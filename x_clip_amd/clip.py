@@ -207,11 +207,13 @@ class TextTransformer(nn.Module):
         self.cls_token = nn.Parameter(torch.randn(dim)) if not causal else None            # x_clip.py:314
         self.transformer = Transformer(dim, dim_head=dim_head, causal=causal, **kwargs)
 
-    def forward(self, x, mask=None):
+    def forward(self, x, mask=None, *, pool_row: Optional[int] = None):
+        """pool_row = r (not a reference keyword): the caller will read row r of every sample's encoding and nothing else -- the result is
+        then [b, dim], and the last layer's row-wise part (to_out, feed-forward, norm_out) runs on those rows alone (functional.stack_forward)"""
         t = self.transformer
         pos = self.abs_pos_emb.weight if exists(self.abs_pos_emb) else None
         return XF.text_encode(x, mask, self.token_emb.weight, pos, self.cls_token, t.stack_params(),
-                              t.spec(rotary=self.rotary_pos_emb.frequencies(x.device) if exists(self.rotary_pos_emb) else None))
+                              t.spec(rotary=self.rotary_pos_emb.frequencies(x.device) if exists(self.rotary_pos_emb) else None), pool_row=pool_row)
 
 
 class PatchDropout(nn.Module):
@@ -259,12 +261,13 @@ class VisionTransformer(nn.Module):
                                 self.pos_emb.weight, self.to_cls_tokens[1].weight, t.stack_params(), t.spec())
 
 
-def model_forward_with_context(*, fn, args, freeze):
+def model_forward_with_context(*, fn, args, freeze, kwargs=None):
     """x_clip.py:394-408: a frozen encoder runs without a graph and its output is detached"""
+    kwargs = kwargs or {}
     if not freeze:
-        return fn(*args)
+        return fn(*args, **kwargs)
     with torch.no_grad():
-        enc = fn(*args)
+        enc = fn(*args, **kwargs)
     return enc.detach()
 
 
@@ -421,6 +424,9 @@ class CLIP(nn.Module):
         self.assume_equal_batch = False           # set True to skip the per-step batch-size exchange between ranks
 
         self.overlap_towers = True                 # issue the vision tower on a side stream next to the text tower (GPU only)
+        # the CLS head reads one row of the text encoding (x_clip.py:708): ask the tower for that row only (forward(): `pool_row`).  Off = the
+        # dense last layer, as the reference computes it (same loss and gradients either way)
+        self.prune_unused_rows = True
         # >1: the text batch runs through the text tower in that many slices, each on its own HIP stream.  The tower alternates
         # MFMA-bound GEMMs with HBM-bound row kernels; with two slices in flight one slice's LayerNorm / GEGLU kernels (no LDS, few
         # registers: they fit on a CU beside a persistent GEMM work-group) run under the other slice's GEMMs.  Encoders are row
@@ -453,11 +459,11 @@ class CLIP(nn.Module):
             self._streams[(device, which)] = st
         return st
 
-    def _encode_text(self, text_args, freeze):
+    def _encode_text(self, text_args, freeze, kwargs=None):
         """-> list of encodings, one per slice of the batch (a single entry unless text_micro_batches > 1 applies)"""
         k, dev, b = int(self.text_micro_batches), text_args[0].device, text_args[0].shape[0]
         if k <= 1 or b % k != 0 or b // k < self._micro_batch_min_rows:
-            return [model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze)]
+            return [model_forward_with_context(fn=self.text_transformer, args=text_args, freeze=freeze, kwargs=kwargs)]
         bs = b // k
         on_gpu = dev.type == "cuda"                              # (CPU = the test build: the slices simply run one after the other)
         main = torch.cuda.current_stream(dev) if on_gpu else None
@@ -476,12 +482,12 @@ class CLIP(nn.Module):
         for i in range(k):
             args_i = tuple(a[i * bs: (i + 1) * bs] for a in text_args)
             if i == 0 or not on_gpu:
-                outs.append(model_forward_with_context(fn=self.text_transformer, args=args_i, freeze=freeze))
+                outs.append(model_forward_with_context(fn=self.text_transformer, args=args_i, freeze=freeze, kwargs=kwargs))
                 continue
             st = self._side_stream(dev, which=i)
             st.wait_event(fork)
             with torch.cuda.stream(st):
-                outs.append(model_forward_with_context(fn=self.text_transformer, args=args_i, freeze=freeze))
+                outs.append(model_forward_with_context(fn=self.text_transformer, args=args_i, freeze=freeze, kwargs=kwargs))
         for i in range(1, k if on_gpu else 1):
             main.wait_stream(self._side_stream(dev, which=i))
             outs[i].record_stream(main)
@@ -554,6 +560,13 @@ class CLIP(nn.Module):
         text_args = (text,)
         if not self.text_encode_without_mask:
             text_args = (*text_args, text_mask)
+        # x_clip.py:708: the CLS path reads `enc_text[:, 0]` and nothing else -- the text tower is then asked for that row only and runs the
+        # row-wise part of its last layer on it (functional.stack_forward `pool_row`; same loss, same gradients: the other rows of that part
+        # are dead in the forward and their gradient is exactly zero in the backward).  `prune_unused_rows = False` keeps the dense last layer.
+        text_kwargs = None
+        if (self.prune_unused_rows and isinstance(self.text_transformer, TextTransformer) and self.text_has_cls_token
+                and not self.text_causal_mask and not self.use_all_token_embeds and not return_encodings):
+            text_kwargs = dict(pool_row=0)
 
         # The two towers are independent until the head.  On a GPU the vision tower is issued on a side HIP stream (autograd
         # replays its backward there too), so its small kernels fill the gaps the text tower's leaves; the head waits for both.
@@ -563,11 +576,11 @@ class CLIP(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 enc_image = self._encode_image(image, freeze_image_encoder)
-            enc_text_parts = self._encode_text(text_args, freeze_text_encoder)
+            enc_text_parts = self._encode_text(text_args, freeze_text_encoder, text_kwargs)
             main.wait_stream(side)
             enc_image.record_stream(main)
         else:
-            enc_text_parts = self._encode_text(text_args, freeze_text_encoder)
+            enc_text_parts = self._encode_text(text_args, freeze_text_encoder, text_kwargs)
             enc_image = self._encode_image(image, freeze_image_encoder)
         # (the CLS path below only needs row 0 of every sample: the slices are joined after that selection, not before)
         cls_only = (len(enc_text_parts) > 1 and not self.text_causal_mask and not return_encodings and not self.use_all_token_embeds

@@ -219,11 +219,89 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     return dx, [d_qkv, d_out, d_ff1, d_ff2]
 
 
+# ---- the LAST layer when only one token row per sample leaves the stack (the CLS row: x_clip.py:708 `enc_text[:, 0]`) -----------------
+# Everything behind the attention is row-wise (to_out + its LayerNorm + skip, the feed-forward block, norm_out), so the rows nobody reads
+# are dead in the forward, and in the backward their gradient is exactly zero: the loss reaches the layer through the pooled row alone.
+# The pooled variants run that part on B rows instead of B n (the last text layer of the default CLIP: 1,024 rows instead of 263,168 --
+# four large GEMMs and five row-kernel passes in the forward, five GEMMs and their weight gradients in the backward); the attention itself,
+# to_qkv and the first LayerNorm stay dense (every key / value row feeds the pooled query).  Same arithmetic per row, same results.
+def _pool_view(t2d: Tensor, B: int, n: int, row: int) -> Tensor:
+    """rows b n + row of a contiguous [B n, W] tensor as a [B, W] view (row stride n W)"""
+    Wd = t2d.shape[1]
+    return t2d.view(B, n * Wd)[:, row * Wd:(row + 1) * Wd]
+
+
+def _layer_forward_pooled(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor], rotary: Optional[Tensor],
+                          causal: bool, scale: float, hs: int, row: int):
+    g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
+    M, D = x.shape
+    inner = heads * hs
+    h, m1, r1 = ops.layernorm_fwd(x, g_attn)
+    qkv = ops.gemm(h, w_qkv, M, 3 * inner, D)
+    if rotary is not None:
+        ops.rotary_(qkv, n, rotary, head_dim=hs)
+    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, scale, causal, hs, 0.0, 0)
+    xc = torch.empty(B, D, dtype=x.dtype, device=x.device)
+    ops.copy_rows(_pool_view(x, B, n, row), xc)                                        # the skip connection's pooled rows
+    p = ops.gemm(_pool_view(o.view(M, inner), B, n, row), w_out, B, D, inner)          # from here on: B rows
+    x1, m2, r2, h2, m3, r3 = ops.layernorm_chain_fwd(p, g_out, xc, g_ff)
+    u = ops.gemm(h2, w_ff1, B, w_ff1.shape[0], D)
+    a, m4, r4 = ops.layernorm_fwd(u, g_inner, geglu=True)
+    x2 = ops.gemm(a, w_ff2, B, D, a.shape[1], residual=x1)
+    return x2, (x, h, m1, r1, qkv, o, lse, p, m2, r2, x1, h2, m3, r3, u, a, m4, r4)
+
+
+def _layer_backward_pooled(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
+                           gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm", rotary: Optional[Tensor], causal: bool,
+                           scale: float, hs: int, row: int):
+    """dx2 [B, D]: gradient w.r.t. the pooled rows of the layer output -> (gradient w.r.t. the layer input [B n, D], weight gradients)"""
+    g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
+    dg_attn, dg_out, dg_ff, dg_inner = gain_acc
+    x, h, m1, r1, qkv, o, lse, p, m2, r2, x1, h2, m3, r3, u, a, m4, r4 = saved
+    M, D = x.shape
+    inner = heads * hs
+    F2 = w_ff1.shape[0]
+    Fh = F2 // 2
+    da = ops.gemm(dx2, w_ff2, B, Fh, D, b_kmajor=True)
+    d_ff2 = sg.wgrad(dx2, a, D, Fh, B, w_ff2) if need_w[3] else None
+    du, _ = ops.layernorm_bwd(da, u, g_inner, m4, r4, geglu=True, dg=dg_inner)
+    dh2 = ops.gemm(du, w_ff1, B, D, F2, b_kmajor=True)
+    d_ff1 = sg.wgrad(du, h2, F2, D, B, w_ff1) if need_w[2] else None
+    dx1, dp = ops.layernorm_chain_bwd(dh2, x1, g_ff, m3, r3, dx2, p, g_out, m2, r2, dg_ff, dg_out)
+    oc = _pool_view(o.view(M, inner), B, n, row)
+    d_out = sg.wgrad(dp, oc, D, inner, B, w_out) if need_w[1] else None
+    # the attention sees a gradient on the pooled query rows only (dK / dV of every row come from those queries)
+    do = torch.zeros(M, inner, dtype=dp.dtype, device=dp.device)
+    ops.gemm(dp, w_out, B, inner, D, b_kmajor=True, out=_pool_view(do, B, n, row))
+    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, scale, causal, hs, 0.0, 0)
+    del do
+    if rotary is not None:
+        ops.rotary_(dqkv.view(M, 3 * inner), n, rotary, inverse=True, head_dim=hs)
+    dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
+    d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M, w_qkv) if need_w[0] else None
+    del dqkv
+    dx, _ = ops.layernorm_bwd(dh, x, g_attn, m1, r1, dg=dg_attn)
+    # the skip connection carries a gradient on the pooled rows only
+    dxr = _pool_view(dx, B, n, row)
+    t = torch.empty(B, D, dtype=dx.dtype, device=dx.device)
+    ops.copy_rows(dxr, t)
+    ops.copy_rows(ops.add_rows(t, dx1), dxr)
+    return dx, [d_qkv, d_out, d_ff1, d_ff2]
+
+
 # ---- the whole stack: norm_in -> depth x (attention, feed-forward) -> norm_out ------------------------------------------
+def can_pool(spec: StackSpec) -> bool:
+    """may the last layer run on one row per sample (`pool_row`)?  Dropout masks are indexed by the element's position in the dense
+    activation (the oracle rebuilds them from it), so a stack with dropout keeps the dense last layer"""
+    return spec.depth >= 1 and spec.attn_dropout == 0.0 and spec.ff_dropout == 0.0
+
+
 def stack_forward(x0: Tensor, B: int, n: int, spec: StackSpec, params: Sequence[Tensor], mask: Optional[Tensor],
-                  out: Optional[Tensor] = None, out_group: int = 0, keep_tape: bool = True):
-    """x0 [B*n, D] -> norm_out(...) [B*n, D] (or written into `out`, see ops.layernorm_fwd) and the backward tape."""
+                  out: Optional[Tensor] = None, out_group: int = 0, keep_tape: bool = True, pool_row: Optional[int] = None):
+    """x0 [B*n, D] -> norm_out(...) [B*n, D] (or written into `out`, see ops.layernorm_fwd) and the backward tape.
+    pool_row = r: only token row r of every sample is wanted -> [B, D] (the last layer's row-wise part runs on those rows alone)"""
     assert len(params) == 2 + LAYER_PARAMS * spec.depth
+    assert pool_row is None or (can_pool(spec) and out is None and 0 <= pool_row < n)
     g_in, g_out = params[0], params[-1]
     x, m_in, r_in = ops.layernorm_fwd(x0, g_in)
     layers = []
@@ -232,20 +310,23 @@ def stack_forward(x0: Tensor, B: int, n: int, spec: StackSpec, params: Sequence[
     seed0 = _draw_seed() if (spec.attn_dropout > 0.0 or spec.ff_dropout > 0.0) else 0
     for l in range(spec.depth):
         W = params[1 + LAYER_PARAMS * l: 1 + LAYER_PARAMS * (l + 1)]
-        x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
-                                       (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
+        if pool_row is not None and l == spec.depth - 1:
+            x_next, saved = _layer_forward_pooled(x, B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot, pool_row)
+        else:
+            x_next, saved = _layer_forward(x, B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
+                                           (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
         if keep_tape:
             layers.append((saved[0],) if spec.checkpoint else saved)
         x = x_next
     y, m_out, r_out = ops.layernorm_fwd(x, g_out, out=out, out_group=out_group)
-    tape = (x0, m_in, r_in, layers, x, m_out, r_out, seed0) if keep_tape else None
+    tape = (x0, m_in, r_in, layers, x, m_out, r_out, seed0, pool_row) if keep_tape else None
     return y, tape
 
 
 def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Sequence[Tensor], mask: Optional[Tensor],
                    need: Sequence[bool]):
-    """dy [B*n, D] contiguous -> (dx0, grads aligned with `params` (None where not needed))"""
-    x0, m_in, r_in, layers, x_last, m_out, r_out, seed0 = tape
+    """dy [B*n, D] contiguous ([B, D] for a pooled forward) -> (dx0, grads aligned with `params` (None where not needed))"""
+    x0, m_in, r_in, layers, x_last, m_out, r_out, seed0, pool_row = tape
     gains = [params[0]] + [params[1 + LAYER_PARAMS * l + k] for l in range(spec.depth) for k in (0, 3, 4, 6)] + [params[-1]]
     gg = _GainGrads(gains)
     grads: List[Optional[Tensor]] = [None] * len(params)
@@ -255,12 +336,20 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
         base = 1 + LAYER_PARAMS * l
         W = params[base: base + LAYER_PARAMS]
         saved = layers[l]
+        pooled = pool_row is not None and l == spec.depth - 1
         if spec.checkpoint:                      # re-run the layer forward from its saved input
-            _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
-                                      (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
+            if pooled:
+                _, saved = _layer_forward_pooled(saved[0], B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot, pool_row)
+            else:
+                _, saved = _layer_forward(saved[0], B, n, W, spec.heads, mask, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
+                                          (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
         need_w = [need[base + 1], need[base + 2], need[base + 5], need[base + 7]]
-        dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
-                                     (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
+        if pooled:
+            dx, dws = _layer_backward_pooled(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal,
+                                             spec.dim_head ** -0.5, spec.head_slot, pool_row)
+        else:
+            dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
+                                      (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
         layers[l] = None                         # release this layer's activations
         sg.layer_done()
         grads[base + 1], grads[base + 2], grads[base + 5], grads[base + 7] = dws
@@ -325,8 +414,8 @@ def transformer(x: Tensor, params: Sequence[Tensor], spec: StackSpec, mask: Opti
 # ---- text encoder ---------------------------------------------------------------------------------------------------------
 class _TextEncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, spec: StackSpec, tokens: Tensor, mask: Optional[Tensor], grad_mode: bool, E: Tensor, P: Optional[Tensor],
-                cls: Optional[Tensor], *stack: Tensor):
+    def forward(ctx, spec: StackSpec, tokens: Tensor, mask: Optional[Tensor], grad_mode: bool, pool_row: Optional[int], E: Tensor,
+                P: Optional[Tensor], cls: Optional[Tensor], *stack: Tensor):
         B, n = tokens.shape
         npos = n + (1 if cls is not None else 0)
         D = E.shape[1]
@@ -339,19 +428,22 @@ class _TextEncodeFn(torch.autograd.Function):
         if mask is not None:                                            # F.pad(mask, (1, 0), True)    :334
             kmask = mask if cls is None else torch.cat([mask.new_ones(B, 1), mask], dim=1)
             kmask = kmask.contiguous()
-        y, tape = stack_forward(x0.view(B * npos, D), B, npos, spec, stack, kmask, keep_tape=keep)
+        y, tape = stack_forward(x0.view(B * npos, D), B, npos, spec, stack, kmask, keep_tape=keep, pool_row=pool_row)
         ctx.save_for_backward(*stack)
         ctx.spec, ctx.kmask, ctx.tape = spec, kmask, tape
         ctx.tokens, ctx.meta = tokens, (B, n, npos, D, E.shape[0], P is not None, cls is not None, E.dtype)
-        ctx.pos_rows = ctx_pos_rows
-        return y.view(B, npos, D)
+        ctx.pos_rows, ctx.pool_row = ctx_pos_rows, pool_row
+        return y.view(B, npos, D) if pool_row is None else y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         B, n, npos, D, vocab, has_pos, has_cls, dtype = ctx.meta
-        need = ctx.needs_input_grad[1:]                                  # (indices below: without the grad_mode slot)
-        dy = _contig_grad(dy, (B, npos, D), dtype, ctx.tokens.device).view(B * npos, D)
+        need = ctx.needs_input_grad[2:]                                  # (indices below: without the grad_mode and pool_row slots)
+        if ctx.pool_row is None:
+            dy = _contig_grad(dy, (B, npos, D), dtype, ctx.tokens.device).view(B * npos, D)
+        else:
+            dy = _contig_grad(dy, (B, D), dtype, ctx.tokens.device)
         dx0, sgrads = stack_backward(dy, _take_tape(ctx), B, npos, ctx.spec, ctx.saved_tensors, ctx.kmask, need[6:])
         dE = dP = dcls = None
         if need[3] or need[4] or need[5]:
@@ -365,19 +457,22 @@ class _TextEncodeFn(torch.autograd.Function):
                 full[:dP.shape[0]].copy_(dP)
                 dP = full
             dcls = ops.cast_from_f32(acls, dtype) if (need[5] and has_cls) else None
-        return (None, None, None, None, dE, dP, dcls, *sgrads)
+        return (None, None, None, None, None, dE, dP, dcls, *sgrads)
 
 
 def text_encode(tokens: Tensor, mask: Optional[Tensor], E: Tensor, P: Optional[Tensor], cls: Optional[Tensor],
-                stack: Sequence[Tensor], spec: StackSpec) -> Tensor:
-    """TextTransformer.forward (x_clip.py:317-338): int64 tokens [b, n] (+ bool key mask [b, n]) -> [b, n+1, D]."""
+                stack: Sequence[Tensor], spec: StackSpec, pool_row: Optional[int] = None) -> Tensor:
+    """TextTransformer.forward (x_clip.py:317-338): int64 tokens [b, n] (+ bool key mask [b, n]) -> [b, n+1, D];
+    pool_row = r (the caller reads `[:, r]` and nothing else): -> [b, D], that row of every sample (stack_forward)."""
     if tokens.dtype != torch.int64:
         raise TypeError(f"text tokens must be int64, got {tokens.dtype}")
     if P is not None and tokens.shape[1] > P.shape[0]:
         raise IndexError(f"text length {tokens.shape[1]} exceeds max_seq_len {P.shape[0]}")
     if mask is not None and mask.dtype != torch.bool:
         mask = mask.bool()
-    return _TextEncodeFn.apply(spec, tokens, mask, torch.is_grad_enabled(), E, P, cls, *stack)
+    if pool_row is not None and not can_pool(spec):                   # (dropout: dense last layer, then the row)
+        return select_row(_TextEncodeFn.apply(spec, tokens, mask, torch.is_grad_enabled(), None, E, P, cls, *stack), pool_row)
+    return _TextEncodeFn.apply(spec, tokens, mask, torch.is_grad_enabled(), pool_row, E, P, cls, *stack)
 
 
 # ---- vision encoder -----------------------------------------------------------------------------------------------------------
