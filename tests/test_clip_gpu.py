@@ -1,6 +1,7 @@
 """MI355X end-to-end parity of the product `x_clip_amd.CLIP` through libxclip_hip.so: reference golden fixtures, the fp64
 oracle at small and medium shapes (fp32 and bf16), and size-independent properties at the full BASELINE configs[1]
 shape (local batch 1024, bf16)."""
+import dataclasses
 import math
 import os
 import sys
