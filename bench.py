@@ -412,6 +412,9 @@ def main():
                             if clk else None)
     if text_pooled:
         # the same step with the reference's dense last text layer (every token row through to_out / feed-forward / norm_out), for the record
+        # (side streams as in the timed region: the probe pass above switched them off)
+        if not args.no_overlap:
+            set_overlap(True, args.overlap)
         model.prune_unused_rows = False
         for _ in range(2):
             step()
