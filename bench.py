@@ -54,13 +54,14 @@ def gpu_telemetry(index=0):
 def model_flops_per_pair(model, n_text_tokens, n_img_tokens, n_patches_embedded, text_rows_pruned=False):
     """algorithmic forward FLOPs per (text, image) pair of the work this implementation executes (SURVEY.md 8(d));
     fwd + bwd = 3x.  Patch embedding is counted on the patches actually embedded (kept patches only); with the text tower asked for its
-    CLS row only (CLIP.prune_unused_rows) the last text layer's to_out and feed-forward products are counted on that one row."""
+    CLS row only (CLIP.prune_unused_rows) the last text layer's query projection, attention, to_out and feed-forward are counted on that one row
+    (its key / value projections on every row)."""
     def tower(t, n, pooled=False):
         D, I = t.dim, t.heads * t.dim_head
         per_tok = 2 * D * 3 * I + 2 * I * D + 2 * D * 8 * D + 2 * 4 * D * D
         f = t.depth * (n * per_tok + 4 * n * n * I)
-        if pooled and t.depth >= 1:
-            f -= (n - 1) * (2 * I * D + 2 * D * 8 * D + 2 * 4 * D * D)
+        if pooled and t.depth >= 1:                            # last layer: to_q, the attention, to_out and the feed-forward on ONE row
+            f -= (n - 1) * (2 * D * I + 2 * I * D + 2 * D * 8 * D + 2 * 4 * D * D) + 4 * (n * n - n) * I
         return f
     tt, vt = model.text_transformer.transformer, model.visual_transformer.transformer
     patch_dim = model.visual_transformer.to_tokens[1].weight.shape[1]

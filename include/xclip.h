@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 17
+#define XCLIP_ABI_VERSION 18
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -145,6 +145,17 @@ int xclip_attention_fwd(const void* qkv, const uint8_t* mask, void* out, float* 
 int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
                         float* delta_ws, void* dqkv, int64_t batch, int64_t n, int64_t heads, int64_t head_dim, float scale, int causal,
                         float dropout_p, uint64_t dropout_seed, int dtype, void* stream);
+/* The same attention for ONE query row per (sample, head) -- the last layer of a tower whose caller reads a single token row (the CLS head,
+ * x_clip.py:708 `enc_text[:, 0]`; Attention.forward x_clip.py:213-245 restricted to that query):
+ * q [batch, heads, head_dim] = to_qkv's first third applied to the pooled rows; kv [batch, n, 2, heads, head_dim] = its other two thirds
+ * for every row; mask as above; keys [0, visible_keys) are visible (n, or the pooled row's index + 1 under a causal mask).
+ * out [batch, heads, head_dim]; lse [batch, heads] fp32 (natural log of the scaled scores' sum), saved for the backward.
+ * Backward: dq [batch, heads, head_dim] and dkv [batch, n, 2, heads, head_dim], fully overwritten (hidden keys: zeros). */
+int xclip_attention_pool_fwd(const void* q, const void* kv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n,
+                             int64_t heads, int64_t head_dim, float scale, int64_t visible_keys, int dtype, void* stream);
+int xclip_attention_pool_bwd(const void* q, const void* kv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
+                             void* dq, void* dkv, int64_t batch, int64_t n, int64_t heads, int64_t head_dim, float scale,
+                             int64_t visible_keys, int dtype, void* stream);
 /* Feed-forward dropout (nn.Dropout between the inner LayerNorm and the second Linear, x_clip.py:193-194): y[i] = x[i] keep(i) / (1 - p)
  * over n contiguous elements (n a multiple of the 16-byte chunk), keep(i) iff drop_hash(seed, i) >= p 2^32.  The same call on the
  * gradient is the backward; y == x is allowed. */

@@ -352,8 +352,7 @@ def case_live_rows(dev, cfg: O.ClipConfig, b, live, dtype=torch.bfloat16, seed=4
 def case_pruned_rows_equal_dense(dev, dtype, cfg: O.ClipConfig, batch, n_aug_text=0, checkpoint=False, micro=1, freeze_text=False, seed=31):
     """CLIP.prune_unused_rows (the text tower asked for its CLS row only: the last layer's row-wise part on B rows, functional.stack_forward
     `pool_row`) against the dense last layer the reference computes: the same loss and the same gradient of every parameter (per-row
-    arithmetic is identical; the only difference is how many rows a launch holds: fp32 1e-5 of the gradient's norm, bf16 a few ulps of the
-    weight-gradient sums)"""
+    arithmetic is identical; the only difference is how many rows a launch holds: fp32 1e-5 of the gradient's norm, bf16 4 %)"""
     sd = O.make_state_dict(cfg, seed, torch.float32)
     text, image, aug_t, _ = O.make_inputs(cfg, batch, seed + 1, n_aug_text, 0)
     from x_clip_amd import functional as XF
@@ -404,6 +403,9 @@ def _pruned_compare(res, dtype, freeze_text):
         nrm = float(g0[k].norm())
         err = float((g1[k] - g0[k]).norm())
         # (fp32: two runs of the SAME configuration already differ by ~2e-6 in gradients that are summed with atomics -- the position tables)
-        assert err <= (1e-5 if dtype == torch.float32 else 2e-2) * nrm + 1e-12, (k, err, nrm)
+        # (bf16: the pooled attention keeps its probabilities in fp32 where the dense kernels round them to bf16 for the MFMA: the text latents
+        #  move by a bf16 ulp and every gradient behind the head with them -- 2.3 % on a cancelling bias sum of the dim-64 toy model; the
+        #  oracle bars of the same models are 8 %)
+        assert err <= (1e-5 if dtype == torch.float32 else 4e-2) * nrm + 1e-12, (k, err, nrm)
         touched += 1
     assert touched > 0 or freeze_text

@@ -296,6 +296,42 @@ def case_attention(dev, dtype, batch, n, heads, masked, causal=False, hd=64, dro
     close(dqkv, q64.grad, dtype, "attn dqkv" + tag, mult=3.0, ulps=2.0, unit="scale")
 
 
+def case_attention_pool(dev, dtype, batch, n, heads, masked, hd=64, row=0, causal=False):
+    """ONE query row per (sample, head) (attention_pool.h; the last text layer under the CLS head): against the fp64 attention of the dense
+    packed qkv restricted to that query row -- output, and the gradients of the pooled query and of every key / value row"""
+    qkv = rnd((batch, n, 3 * heads * hd), dtype, 28)
+    dout = rnd((batch, heads * hd), dtype, 29)
+    mask = None
+    if masked:
+        mask = torch.ones(batch, n, dtype=torch.bool)
+        for bi in range(batch):
+            k = (bi * 5 + 2) % max(1, n // 2)
+            if k:
+                mask[bi, n - k:] = False
+            if n > 3 and row != 2:
+                mask[bi, 2] = bi % 2 == 0
+        mask[:, row] = True
+    scale = hd ** -0.5
+    inner = heads * hd
+    q = qkv[:, row, :inner].contiguous()
+    kv = qkv[:, :, inner:].contiguous()
+    m_dev = None if mask is None else mask.to(dev)
+    vis = row + 1 if causal else None
+    out, lse = ops.attention_pool_fwd(q.to(dev), kv.to(dev), m_dev, heads, scale, hd, vis)
+    q64 = ref64(qkv).requires_grad_(True)
+    r = _attention_ref(q64, mask, heads, scale, causal, hd, None)[:, row]
+    r.backward(ref64(dout))
+    tag = f" pooled row {row}" + ("" if hd == 64 else f" (head slot {hd})")
+    close(out, r, dtype, "attn out" + tag, ulps=2.0, unit="scale")
+    dq, dkv = ops.attention_pool_bwd(q.to(dev), kv.to(dev), m_dev, out, dout.to(dev), lse, heads, scale, hd, vis)
+    g = q64.grad
+    close(dq, g[:, row, :inner], dtype, "attn dq" + tag, mult=3.0, ulps=2.0, unit="scale")
+    close(dkv, g[:, :, inner:], dtype, "attn dkv" + tag, mult=3.0, ulps=2.0, unit="scale")
+    off = g[:, :, :inner].clone()
+    off[:, row] = 0
+    assert float(off.abs().max()) == 0.0                       # (the reference's dQ is zero off the pooled row)
+
+
 def case_attention_single_tail(dev, dtype, n=257, heads=2):
     """n = 32 q + 1 (the text encoder's CLS + 256 tokens): the tail row enters the head-resident kernels as the INITIAL value of their
     accumulators (attention3.h a3_tail_dot / a3_tail_outer), not as a 33rd MFMA block.  Four samples: no mask at all; a hole in the middle

@@ -427,3 +427,11 @@ def test_attention_dropout(dtype, n, masked, causal, hd):
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
 def test_dropout(dtype):
     K.case_dropout(DEV, dtype)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
+@pytest.mark.parametrize("batch,n,heads,masked,hd,row,causal", [(2, 37, 2, True, 64, 0, False), (2, 20, 1, False, 128, 0, False), (1, 70, 2, True, 64, 5, True), (3, 9, 3, True, 128, 0, False)])
+def test_attention_pool(dtype, batch, n, heads, masked, hd, row, causal):
+    """attention for one query row per (sample, head): key counts that are not multiples of the keys per wave-load (8 / 4 / 16), masks with a
+    hole and a padded tail, both head-slot widths, a pooled row in the middle under a causal mask"""
+    K.case_attention_pool(DEV, dtype, batch, n, heads, masked, hd, row, causal)

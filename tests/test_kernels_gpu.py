@@ -32,6 +32,14 @@ def test_layernorm(dtype, rows, dim, geglu, res):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
+@pytest.mark.parametrize("batch,n,heads,masked,hd,row,causal", [(4, 257, 8, True, 64, 0, False), (3, 77, 12, True, 64, 0, False), (2, 290, 3, False, 128, 0, False), (2, 1000, 2, True, 64, 5, True), (5, 33, 2, True, 128, 0, False)])
+def test_attention_pool(dtype, batch, n, heads, masked, hd, row, causal):
+    """attention for one query row per (sample, head): key counts that are not multiples of the keys per wave-load (8 / 4 / 16), masks with a
+    hole and a padded tail, both head-slot widths, a pooled row in the middle under a causal mask"""
+    K.case_attention_pool(DEV, dtype, batch, n, heads, masked, hd, row, causal)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 def test_l2norm(dtype):
     K.case_l2norm(DEV, dtype, 1027, 512)
     K.case_l2norm(DEV, dtype, 33, 64)

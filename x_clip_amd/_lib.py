@@ -47,6 +47,8 @@ _SIGNATURES = {
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),
     "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, L, F, I, F, U, I, P]),
     "xclip_attention_bwd": (c_int, [P, P, P, P, P, P, P, L, L, L, L, F, I, F, U, I, P]),
+    "xclip_attention_pool_fwd": (c_int, [P, P, P, P, P, L, L, L, L, F, L, I, P]),
+    "xclip_attention_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, L, L, L, L, F, L, I, P]),
     "xclip_dropout": (c_int, [P, P, L, F, U, I, P]),
     "xclip_filip_reduce": (c_int, [P, L, P, P, P, P, L, P, P, P, L, L, L, L, L, L, I, P]),
     "xclip_filip_fused_ok": (c_int, [L, L, L, I]),
@@ -78,7 +80,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 def _bind(path: str):

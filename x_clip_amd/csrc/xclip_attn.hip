@@ -9,6 +9,7 @@
 #include "kernels/attention2.h"
 #include "kernels/attention3.h"
 #include "kernels/attention4.h"
+#include "kernels/attention_pool.h"
 
 using namespace xc;
 using namespace xcapi;
@@ -55,6 +56,19 @@ int attn_waves(int64_t n) {
     return best;
 }
 
+// ---- one query row per (sample, head): the last layer of a tower whose caller reads a single token row (kernels/attention_pool.h) ----
+template <typename T>
+int launch_attn_pool(const AttnPoolParams& p, int64_t head_dim, bool backward, hipStream_t st) {
+    const dim3 grid((unsigned)(((int64_t)p.batch * p.heads + 3) / 4)), block(256);
+    if (head_dim == 64) {
+        if (backward) hipLaunchKernelGGL((attn_pool_bwd_kernel<T, 64>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((attn_pool_fwd_kernel<T, 64>), grid, block, 0, st, p);
+    } else {
+        if (backward) hipLaunchKernelGGL((attn_pool_bwd_kernel<T, 128>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((attn_pool_fwd_kernel<T, 128>), grid, block, 0, st, p);
+    }
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -202,6 +216,40 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
                       case 3: launch_attn2_bwd<3>(p, st); break; default: launch_attn2_bwd<4>(p, st); break; }
     } else { F(float) }
 #undef F
+    return check_launch(__func__);
+}
+
+int xclip_attention_pool_fwd(const void* q, const void* kv, const uint8_t* mask, void* out, float* lse, int64_t batch, int64_t n,
+                             int64_t heads, int64_t head_dim, float scale, int64_t visible_keys, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(batch >= 0 && n > 0 && heads > 0 && visible_keys >= 1 && visible_keys <= n, "bad shape");
+    XC_REQUIRE(head_dim == 64 || head_dim == 128, "head_dim must be 64 or 128 (narrower / in-between widths are zero-padded by the caller)");
+    XC_REQUIRE(q && kv && out && lse && aligned16(q) && aligned16(kv) && aligned16(out), "pointers must be non-null and 16-byte aligned");
+    if (batch == 0) return 0;
+    AttnPoolParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = q; p.kv = kv; p.mask = mask; p.out = out; p.lse = lse;
+    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.nvis = (int)visible_keys; p.scale = scale;
+    if (dtype == XCLIP_BF16) launch_attn_pool<bf16_t>(p, head_dim, false, (hipStream_t)stream);
+    else launch_attn_pool<float>(p, head_dim, false, (hipStream_t)stream);
+    return check_launch(__func__);
+}
+
+int xclip_attention_pool_bwd(const void* q, const void* kv, const uint8_t* mask, const void* out, const void* dout, const float* lse,
+                             void* dq, void* dkv, int64_t batch, int64_t n, int64_t heads, int64_t head_dim, float scale,
+                             int64_t visible_keys, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    XC_REQUIRE(batch >= 0 && n > 0 && heads > 0 && visible_keys >= 1 && visible_keys <= n, "bad shape");
+    XC_REQUIRE(head_dim == 64 || head_dim == 128, "head_dim must be 64 or 128 (narrower / in-between widths are zero-padded by the caller)");
+    XC_REQUIRE(q && kv && out && dout && lse && dq && dkv, "null pointer");
+    XC_REQUIRE(aligned16(q) && aligned16(kv) && aligned16(out) && aligned16(dout) && aligned16(dq) && aligned16(dkv), "pointers must be 16-byte aligned");
+    if (batch == 0) return 0;
+    AttnPoolParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = q; p.kv = kv; p.mask = mask; p.out = const_cast<void*>(out); p.lse = const_cast<float*>(lse); p.dout = dout; p.dq = dq; p.dkv = dkv;
+    p.batch = (int)batch; p.n = (int)n; p.heads = (int)heads; p.nvis = (int)visible_keys; p.scale = scale;
+    if (dtype == XCLIP_BF16) launch_attn_pool<bf16_t>(p, head_dim, true, (hipStream_t)stream);
+    else launch_attn_pool<float>(p, head_dim, true, (hipStream_t)stream);
     return check_launch(__func__);
 }
 

@@ -90,6 +90,16 @@ class _SideGemm:
         self.keep.append((dy, x))
         return out
 
+    def wgrad_into(self, dy: Tensor, x: Tensor, N1: int, N2: int, M: int, out: Tensor) -> Tensor:
+        """the same product written into a given [N1, N2] view (a row block of a weight gradient assembled from two products)"""
+        if self.side is None:
+            return ops.gemm(dy, x, N1, N2, M, a_kmajor=True, b_kmajor=True, out=out)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            ops.gemm(dy, x, N1, N2, M, a_kmajor=True, b_kmajor=True, out=out)
+        self.keep.append((dy, x))
+        return out
+
     def layer_done(self):
         if self.side is None:
             return
@@ -237,13 +247,22 @@ def _layer_forward_pooled(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads:
     M, D = x.shape
     inner = heads * hs
     h, m1, r1 = ops.layernorm_fwd(x, g_attn)
-    qkv = ops.gemm(h, w_qkv, M, 3 * inner, D)
-    if rotary is not None:
-        ops.rotary_(qkv, n, rotary, head_dim=hs)
-    o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, scale, causal, hs, 0.0, 0)
     xc = torch.empty(B, D, dtype=x.dtype, device=x.device)
     ops.copy_rows(_pool_view(x, B, n, row), xc)                                        # the skip connection's pooled rows
-    p = ops.gemm(_pool_view(o.view(M, inner), B, n, row), w_out, B, D, inner)          # from here on: B rows
+    if rotary is None:
+        # one query per head: to_qkv's first third on the pooled rows, the other two on every row, attention_pool.h (causal: the pooled
+        # row sees the keys up to itself)
+        q = ops.gemm(_pool_view(h, B, n, row), w_qkv[:inner], B, inner, D)
+        kv = ops.gemm(h, w_qkv[inner:], M, 2 * inner, D)
+        oc, lse = ops.attention_pool_fwd(q, kv.view(B, n, 2 * inner), mask, heads, scale, hs, row + 1 if causal else None)
+        qkv, o = (q, kv), oc                                                           # (the tape's qkv / o slots: the pooled forms)
+    else:
+        # (the rotary kernel walks whole packed qkv rows: the dense attention, then its pooled rows)
+        qkv = ops.gemm(h, w_qkv, M, 3 * inner, D)
+        ops.rotary_(qkv, n, rotary, head_dim=hs)
+        o, lse = ops.attention_fwd(qkv.view(B, n, 3 * inner), mask, heads, scale, causal, hs, 0.0, 0)
+        oc = _pool_view(o.view(M, inner), B, n, row)
+    p = ops.gemm(oc, w_out, B, D, inner)                                               # from here on: B rows
     x1, m2, r2, h2, m3, r3 = ops.layernorm_chain_fwd(p, g_out, xc, g_ff)
     u = ops.gemm(h2, w_ff1, B, w_ff1.shape[0], D)
     a, m4, r4 = ops.layernorm_fwd(u, g_inner, geglu=True)
@@ -268,18 +287,36 @@ def _layer_backward_pooled(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tenso
     dh2 = ops.gemm(du, w_ff1, B, D, F2, b_kmajor=True)
     d_ff1 = sg.wgrad(du, h2, F2, D, B, w_ff1) if need_w[2] else None
     dx1, dp = ops.layernorm_chain_bwd(dh2, x1, g_ff, m3, r3, dx2, p, g_out, m2, r2, dg_ff, dg_out)
-    oc = _pool_view(o.view(M, inner), B, n, row)
-    d_out = sg.wgrad(dp, oc, D, inner, B, w_out) if need_w[1] else None
-    # the attention sees a gradient on the pooled query rows only (dK / dV of every row come from those queries)
-    do = torch.zeros(M, inner, dtype=dp.dtype, device=dp.device)
-    ops.gemm(dp, w_out, B, inner, D, b_kmajor=True, out=_pool_view(do, B, n, row))
-    dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, scale, causal, hs, 0.0, 0)
-    del do
-    if rotary is not None:
+    if rotary is None:
+        q, kv = qkv
+        d_out = sg.wgrad(dp, o, D, inner, B, w_out) if need_w[1] else None
+        doc = ops.gemm(dp, w_out, B, inner, D, b_kmajor=True)
+        dq, dkv = ops.attention_pool_bwd(q, kv.view(B, n, 2 * inner), mask, o, doc, lse, heads, scale, hs, row + 1 if causal else None)
+        # d h = dkv W_kv on every row, + dq W_q on the pooled rows (added with the skip gradient below)
+        dh = ops.gemm(dkv.view(M, 2 * inner), w_qkv[inner:], M, D, 2 * inner, b_kmajor=True)
+        dhq = ops.gemm(dq, w_qkv[:inner], B, D, inner, b_kmajor=True)
+        hr = _pool_view(dh, B, n, row)
+        t = torch.empty(B, D, dtype=dh.dtype, device=dh.device)
+        ops.copy_rows(hr, t)
+        ops.copy_rows(ops.add_rows(t, dhq), hr)
+        d_qkv = None
+        if need_w[0]:                                          # both parts of the weight gradient into ONE tensor (a bucket slice, if claimed)
+            d_qkv = _grad_out(w_qkv, (3 * inner, D), dp.dtype, dp.device)
+            sg.wgrad_into(dq, _pool_view(h, B, n, row), inner, D, B, d_qkv[:inner])
+            sg.wgrad_into(dkv.view(M, 2 * inner), h, 2 * inner, D, M, d_qkv[inner:])
+        del dkv
+    else:
+        oc = _pool_view(o.view(M, inner), B, n, row)
+        d_out = sg.wgrad(dp, oc, D, inner, B, w_out) if need_w[1] else None
+        # the attention sees a gradient on the pooled query rows only (dK / dV of every row come from those queries)
+        do = torch.zeros(M, inner, dtype=dp.dtype, device=dp.device)
+        ops.gemm(dp, w_out, B, inner, D, b_kmajor=True, out=_pool_view(do, B, n, row))
+        dqkv = ops.attention_bwd(qkv.view(B, n, 3 * inner), mask, o, do.view(B, n, inner), lse, heads, scale, causal, hs, 0.0, 0)
+        del do
         ops.rotary_(dqkv.view(M, 3 * inner), n, rotary, inverse=True, head_dim=hs)
-    dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
-    d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M, w_qkv) if need_w[0] else None
-    del dqkv
+        dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
+        d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M, w_qkv) if need_w[0] else None
+        del dqkv
     dx, _ = ops.layernorm_bwd(dh, x, g_attn, m1, r1, dg=dg_attn)
     # the skip connection carries a gradient on the pooled rows only
     dxr = _pool_view(dx, B, n, row)

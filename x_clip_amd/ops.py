@@ -550,6 +550,49 @@ def attention_bwd(qkv: Tensor, mask: Optional[Tensor], out: Tensor, dout: Tensor
     return dqkv
 
 
+def attention_pool_fwd(q: Tensor, kv: Tensor, mask: Optional[Tensor], heads: int, scale: float, head_dim: int = 64,
+                       visible_keys: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    """ONE query row per (sample, head): q [b, heads*head_dim], kv [b, n, 2*heads*head_dim] (keys | values of every row), mask bool [b, n] or None
+    -> out [b, heads*head_dim], lse fp32 [b, heads].  visible_keys: keys [0, visible_keys) are seen (default n)"""
+    _dev_check(q, kv, mask)
+    q, kv = _c(q), _c(kv)
+    b, n, w = kv.shape
+    assert head_dim in (64, 128) and w == 2 * heads * head_dim and tuple(q.shape) == (b, heads * head_dim) and q.dtype == kv.dtype
+    out = torch.empty_like(q)
+    lse = torch.empty(b, heads, dtype=torch.float32, device=q.device)
+    if mask is not None:
+        assert mask.dtype == torch.bool and tuple(mask.shape) == (b, n)
+        mask = _c(mask)
+    probe = _probe(q)
+    ev0 = probe.begin(q) if probe is not None else None
+    _lib.check(_lib.lib().xclip_attention_pool_fwd(q.data_ptr(), kv.data_ptr(), _ptr(mask), out.data_ptr(), lse.data_ptr(), b, n, heads, head_dim,
+                                                   scale, n if visible_keys is None else int(visible_keys), dtype_code(q), _stream(q)),
+               "xclip_attention_pool_fwd")
+    if probe is not None:      # one query: 4 n hd per head; k, v in (+ q), o out
+        probe.end(q, ev0, "attention", 4.0 * b * heads * n * head_dim, (2 * b * n + 2 * b) * heads * head_dim * q.element_size(), "attn_pool_fwd")
+    return out, lse
+
+
+def attention_pool_bwd(q: Tensor, kv: Tensor, mask: Optional[Tensor], out: Tensor, dout: Tensor, lse: Tensor, heads: int, scale: float,
+                       head_dim: int = 64, visible_keys: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    """-> dq [b, heads*head_dim], dkv [b, n, 2*heads*head_dim] (every row written)"""
+    _dev_check(q, kv, mask, out, dout, lse)
+    q, kv, out, dout = _c(q), _c(kv), _c(out), _c(dout)
+    b, n, _ = kv.shape
+    assert lse.dtype == torch.float32 and lse.is_contiguous() and out.shape == q.shape and dout.shape == q.shape and dout.dtype == q.dtype
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    probe = _probe(q)
+    ev0 = probe.begin(q) if probe is not None else None
+    _lib.check(_lib.lib().xclip_attention_pool_bwd(q.data_ptr(), kv.data_ptr(), _ptr(None if mask is None else _c(mask)), out.data_ptr(),
+                                                   dout.data_ptr(), lse.data_ptr(), dq.data_ptr(), dkv.data_ptr(), b, n, heads, head_dim, scale,
+                                                   n if visible_keys is None else int(visible_keys), dtype_code(q), _stream(q)),
+               "xclip_attention_pool_bwd")
+    if probe is not None:      # dV = p dO, dP = dO v, dQ = dS k, dK = dS q: 8 n hd per head; k, v in, dk, dv out
+        probe.end(q, ev0, "attention", 8.0 * b * heads * n * head_dim, (4 * b * n + 4 * b) * heads * head_dim * q.element_size(), "attn_pool_bwd")
+    return dq, dkv
+
+
 def dropout(x: Tensor, p: float, seed: int, out: Optional[Tensor] = None) -> Tensor:
     """y = x * keep / (1 - p) with the keep-mask of (seed, flat element index) (csrc/kernels/common.h drop_hash; reference nn.Dropout in
     FeedForward, x_clip.py:193-194).  The same call on the gradient is the backward.  out=x works in place."""
