@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side streams for the vision tower / weight gradients "
                     "(use this for rocprofv3 kernel-trace runs whose per-kernel averages should be of kernels running alone)")
     ap.add_argument("--dcl", action="store_true")
+    ap.add_argument("--no-dense-compare", action="store_true", help="skip the extra steps that time the dense last text layer beside the line "
+                    "(rocprofv3 runs: every step of the process should be the same step)")
     ap.add_argument("--dense-last-layer", action="store_true", help="CLIP.prune_unused_rows = False: the text tower's last layer runs every token row, "
                     "as the reference computes it (default: only the CLS row the head reads; same loss, same gradients)")
     ap.add_argument("--text-slices", type=int, default=1, help="CLIP.text_micro_batches: slices of the text batch on separate streams")
@@ -411,7 +413,7 @@ def main():
         out["clock_mhz"] = ({"min": round(clk[0]), "median": round(clk[len(clk) // 2]), "max": round(clk[-1]), "samples": len(clk),
                              "measured": "xclip_clock_sample: shader cycles over 200 us windows that start with every 8th GEMM launch of two extra steps (one wave on a side stream beside the running kernels)"}
                             if clk else None)
-    if text_pooled:
+    if text_pooled and not args.no_dense_compare:
         # the same step with the reference's dense last text layer (every token row through to_out / feed-forward / norm_out), for the record
         # (side streams as in the timed region: the probe pass above switched them off)
         if not args.no_overlap:

@@ -33,17 +33,17 @@ for TASK in "$@"; do
     trace)
       [ -z "$ARG" ] && REST="--steps 5 --warmup 1"
       cd /tmp; rm -rf /tmp/kt$SUF
-      timeout 1200 rocprofv3 --kernel-trace -d /tmp/kt$SUF -o kt -- python $R/bench.py $REST --no-overlap --no-probe --no-cpu-baseline > $R/gpurun_out/${TAG}_bench${SUF}_traced.log 2>&1
+      timeout 1200 rocprofv3 --kernel-trace -d /tmp/kt$SUF -o kt -- python $R/bench.py $REST --no-overlap --no-probe --no-cpu-baseline --no-dense-compare > $R/gpurun_out/${TAG}_bench${SUF}_traced.log 2>&1
       DB=$(find /tmp/kt$SUF -name "*.db" | head -1)
-      (echo "# rocprofv3 --kernel-trace -- python bench.py $REST --no-overlap --no-probe --no-cpu-baseline   (every step of the run incl. the 2 pre-warm steps, single stream; summarised by tools/rocpd_stats.py)"; python $R/tools/rocpd_stats.py $DB 45) > $R/gpurun_out/${TAG}_kernel_stats${SUF}.txt 2>&1
+      (echo "# rocprofv3 --kernel-trace -- python bench.py $REST --no-overlap --no-probe --no-cpu-baseline --no-dense-compare   (every step of the run incl. the 2 pre-warm steps, single stream; summarised by tools/rocpd_stats.py)"; python $R/tools/rocpd_stats.py $DB 45) > $R/gpurun_out/${TAG}_kernel_stats${SUF}.txt 2>&1
       head -16 $R/gpurun_out/${TAG}_kernel_stats${SUF}.txt | cut -c1-190;;
     traffic)
       cd /tmp
       for c in FETCH_SIZE WRITE_SIZE; do
-        rm -rf /tmp/pmc_$c; timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-probe --no-overlap > /dev/null 2>&1
+        rm -rf /tmp/pmc_$c; timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-probe --no-overlap --no-dense-compare > /dev/null 2>&1
       done
       F=$(find /tmp/pmc_FETCH_SIZE -name "p_counter_collection.csv" | head -1); W=$(find /tmp/pmc_WRITE_SIZE -name "p_counter_collection.csv" | head -1)
-      (echo "# HBM-side traffic per kernel, bench.py --steps 1 --warmup 1 --no-overlap (b=1024): rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes"; python $R/tools/pmc_traffic.py $F $W $R/gpurun_out/${TAG}_gemm_traffic.json gemm 4) > $R/gpurun_out/${TAG}_hbm_traffic_pmc.txt 2>&1
+      (echo "# HBM-side traffic per kernel, bench.py --steps 1 --warmup 1 --no-overlap --no-dense-compare (b=1024): rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes"; python $R/tools/pmc_traffic.py $F $W $R/gpurun_out/${TAG}_gemm_traffic.json gemm 4) > $R/gpurun_out/${TAG}_hbm_traffic_pmc.txt 2>&1
       tail -3 $R/gpurun_out/${TAG}_hbm_traffic_pmc.txt;;
     py)
       ( timeout 900 python tools/$REST ) > gpurun_out/${TAG}${SUF}.log 2>&1; grep -v amdgpu gpurun_out/${TAG}${SUF}.log | tail -40 | cut -c1-230;;
