@@ -394,3 +394,24 @@ def test_pruned_text_rows_equal_dense_last_layer(dtype):
                                    checkpoint=True)
     C.case_pruned_rows_equal_dense(DEV, dtype, dataclasses.replace(O.CFG1, text_rotary_pos_emb=True), 6, micro=2)
     C.case_pruned_rows_equal_dense(DEV, dtype, O.CFG1, 4, freeze_text=True)
+
+
+def test_pruned_text_rows_inference_paths():
+    """the early returns (x_clip.py:697-746) with the text tower asked for its CLS row: latents and similarities under torch.no_grad() in eval mode
+    equal the dense tower's; return_encodings still hands back every row"""
+    cfg = O.CFG1
+    sd = O.make_state_dict(cfg, 41, torch.float32)
+    text, image, _, _ = O.make_inputs(cfg, 3, 42)
+    outs = []
+    for prune in (True, False):
+        model = C.build_clip(cfg, sd, DEV, torch.float32)
+        model.prune_unused_rows = prune
+        model.eval()
+        with torch.no_grad():
+            tl, il = model(text, image.float(), return_latents=True)[:2]
+            sim = model(text, image.float())
+            enc_t, enc_i = model(text, image.float(), return_encodings=True)
+        assert enc_t.shape == (3, cfg.text_seq_len + 1, cfg.dim_text) and enc_i.ndim == 3
+        outs.append((tl, il, sim, enc_t))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
