@@ -307,7 +307,9 @@ def main():
                                 "BASELINE configs[1]: default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256, " if (plain_default and not args.dcl and b == 1024) else
                                 "default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256 (own measurement, not a BASELINE configuration as run), ") +
                                "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ("" if not args.simsiam else " + SimSiam side loss") +
-                               ("" if not args.causal else ", causal text encoder") + ", fwd+bwd",
+                               ("" if not args.causal else ", causal text encoder") + ", fwd+bwd" +
+                               ("; the last text layer computes only the CLS row the head reads (identical loss and gradients; "
+                                "the dense layer is timed in `dense_last_layer`)" if text_pooled else ""),
                    "workload_tag": workload_tag, "local_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                    # the CLS head reads one row of the text encoding: the last text layer's row-wise part (to_out, feed-forward, norm_out) runs on
                    # that row only -- same loss, same gradient of every parameter as the dense layer (tests: pruned_rows_equal_dense, the reference
