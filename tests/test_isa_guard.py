@@ -36,7 +36,8 @@ PROLOGUE_SPILLS_ONLY = {"sim5_grad_fast_kernel<true, 0>": (16, 2), "sim5_grad_fa
 # 256 registers) parks ~20 values of its two step variants
 WIDE_HEADS = {"attn4_bwd_kernel<false>": 0, "attn4_bwd_kernel<true>": 0, "attn4_fwd_kernel<false>": 24, "attn4_fwd_kernel<true>": 24}
 # kernels whose ragged-tile path legitimately holds serialized loads (row gathers, residual rows): spills only
-NO_SPILL = ["gemm4_kernel<true, true, 1>", "gemm5_kernel<false, false, 3, 0>", "gemm5_kernel<false, true, 3, 0>", "filip_route_kernel<bf16>"]
+NO_SPILL = ["gemm4_kernel<true, true, 1>", "gemm5_kernel<false, false, 3, 0>", "gemm5_kernel<false, true, 3, 0>", "filip_route_kernel<bf16>",
+            "attn_pool_fwd_kernel<bf16, 64>", "attn_pool_bwd_kernel<bf16, 64>", "scatter_add_sorted_kernel<bf16, 1>"]
 
 
 @pytest.fixture(scope="module")
