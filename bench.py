@@ -352,9 +352,12 @@ def main():
         ach = flops / secs / 1e12 if secs > 0 else 0.0
         # the same figure over the products of at least 10 GFLOP (every token-sized Linear of the towers): the B-row products of the pooled
         # last text layer and the latent projections are launch-bound (20 us for 0.5 GFLOP) and say nothing about the kernel
-        big = [r for r in probe.records if r[0] == "gemm" and r[1] >= 1e10]
-        big_s = sum(r[2].elapsed_time(r[3]) for r in big) * 1e-3
-        ach_big = sum(r[1] for r in big) / big_s / 1e12 if big_s > 0 else 0.0
+        try:                                                       # (an auxiliary figure must never cost the line)
+            big = [r for r in probe.records if r[0] == "gemm" and r[1] >= 1e10]
+            big_s = sum(r[2].elapsed_time(r[3]) for r in big) * 1e-3
+            ach_big = sum(r[1] for r in big) / big_s / 1e12 if big_s > 0 else 0.0
+        except Exception:                                          # noqa: BLE001
+            ach_big = 0.0
         # HBM-side bytes per launch: PMC counters cannot be read from inside the process, so this is the figure of the committed
         # rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py -> profiles/gemm_traffic.json, which names the commit and
         # the summary file it came from); null when that file is absent or was measured for another kernel generation
