@@ -19,6 +19,8 @@ def sources():
     out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir)) if f.endswith(".h")]
     mdir = os.path.join(kdir, "measure")
     out += [os.path.join(mdir, f) for f in sorted(os.listdir(mdir)) if f.endswith(".h")]
+    adir = os.path.join(kdir, "asm")
+    out += [os.path.join(adir, f) for f in sorted(os.listdir(adir)) if f.endswith(".inc")]
     return out
 
 

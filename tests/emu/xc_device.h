@@ -467,6 +467,11 @@ inline void permlane32_swap(uint32_t& a, uint32_t& b) {
     if (l >= 32) a = other.b; else b = other.a;      // upper half of a <-> lower half of b
 }
 
+// whole-kernel asm units (csrc/hw/xc_device.h): not executable here -- XC_ASM_UNITS = false keeps the host from selecting such kernels
+constexpr bool XC_ASM_UNITS = false;
+#define XC_ASM_UNIT(TEXT, OPERANDS, CLOBBERS) abort()
+inline uint32_t lds_addr(const void*) { return 0; }        // (only feeds asm units)
+
 inline void atomic_add(float* p, float v) { *p += v; }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_exp2(float x) { return exp2f(x); }

@@ -33,11 +33,23 @@ def _sources():
     out += [os.path.join(kdir, f) for f in sorted(os.listdir(kdir)) if f.endswith(".h")]
     mdir = os.path.join(kdir, "measure")
     out += [os.path.join(mdir, f) for f in sorted(os.listdir(mdir)) if f.endswith(".h")]
+    adir = os.path.join(kdir, "asm")
+    out += [os.path.join(adir, f) for f in sorted(os.listdir(adir)) if f.endswith((".inc", ".py"))]
     return out
+
+
+def _generate():
+    """the hand-scheduled kernel bodies (csrc/kernels/asm/*_gen.py -> *_body.inc): regenerated when the generator is newer"""
+    adir = os.path.join(CSRC, "kernels", "asm")
+    for gen in sorted(f for f in os.listdir(adir) if f.endswith("_gen.py")):
+        inc = os.path.join(adir, gen.replace("_gen.py", "_body.inc"))
+        if not os.path.exists(inc) or os.path.getmtime(inc) < os.path.getmtime(os.path.join(adir, gen)):
+            subprocess.run([sys.executable, os.path.join(adir, gen)], check=True, stdout=subprocess.DEVNULL)
 
 
 def build(force: bool = False, verbose: bool = False, measure: bool = False) -> str:
     LIB = LIB_MEASURE if measure else globals()["LIB"]
+    _generate()
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in _sources()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

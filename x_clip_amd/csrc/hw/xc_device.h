@@ -259,6 +259,13 @@ XC_DEV void permlane32_swap(uint32_t& a, uint32_t& b) {
     b = r[1];
 }
 
+// ---- whole-kernel asm units (gemm8.h) -----------------------------------------------------------------------------------------------
+// A kernel body written as ONE asm statement: TEXT names every register it uses by hand, OPERANDS are its inputs (macro name expanding to the
+// "v"(..), "s"(..) list), CLOBBERS the macro name of its clobber list (which is also what makes the kernel descriptor allocate the
+// registers).  The emulator twin cannot execute such a body: there XC_ASM_UNITS is false and the host never selects these kernels.
+constexpr bool XC_ASM_UNITS = true;
+#define XC_ASM_UNIT(TEXT, OPERANDS, CLOBBERS) asm volatile(TEXT : : OPERANDS : CLOBBERS)
+
 XC_DEV void atomic_add(float* p, float v) { atomicAdd(p, v); }
 
 XC_DEV float fast_exp(float x) { return __expf(x); }

@@ -10,6 +10,7 @@
 #include "kernels/gemm2.h"
 #include "kernels/gemm3.h"
 #include "kernels/gemm4.h"
+#include "kernels/gemm8.h"
 #ifdef XCLIP_MEASURE                                             // negative-result experiments, measurement build only
 #include "kernels/measure/gemm6.h"
 #include "kernels/measure/gemm7.h"
@@ -204,6 +205,13 @@ inline int gemm_generation() {
     static const int v = [] { const int e = measure_env("XCLIP_GEMM", 0); return (e >= 2 && e <= 7) ? e : 0; }();
     return v;
 }
+// gemm8.h on / off.  Product: G8_DEFAULT.  Measurement build: XCLIP_GEMM8=0 / 1 at load, xclip_measure_gemm8() at run time (same-process A/B).
+constexpr int G8_DEFAULT = 0;
+static int g_gemm8 = -1;
+inline bool gemm8_on() {
+    if (g_gemm8 < 0) g_gemm8 = measure_env("XCLIP_GEMM8", G8_DEFAULT);
+    return XC_ASM_UNITS && g_gemm8 != 0;
+}
 template <bool AK, bool BK_, int MODE>
 void launch_gemm4(const Gemm2Params& p, dim3 pgrid, bool ring3, hipStream_t st) {
 #ifdef XCLIP_MEASURE
@@ -287,6 +295,15 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
             }
         }
 #endif
+        // the hand-scheduled ring kernel (gemm8.h) for the plain interior products it takes
+        if constexpr (!AK) {
+            if (gemm8_on() && g8_takes(p, splits, gx)) {
+#define XC_G8(NTST) do { XC_ALLOW_LDS((gemm8_kernel<BK_, NTST>), G5_LDS_BYTES); hipLaunchKernelGGL((gemm8_kernel<BK_, NTST>), dim3((unsigned)gx), dim3(G2_THREADS), G5_LDS_BYTES, st, p); } while (0)
+                if (p.stream_out) XC_G8(true); else XC_G8(false);
+#undef XC_G8
+                return;
+            }
+        }
         const bool res_only = p.residual != nullptr && p.bias == nullptr && p.addrows == nullptr && p.ldr < (1L << 22);
         if (p.partial != nullptr) launch_gemm4<AK, BK_, G4_SLAB>(p, pgrid, ring3, st);
         else if (res_only) launch_gemm4<AK, BK_, G4_RES>(p, pgrid, ring3, st);
@@ -862,6 +879,11 @@ static int gemm2_run(int a_kmajor, int b_kmajor, const void* A, int64_t lda, con
     }
     return check_launch(__func__);
 }
+
+#ifdef XCLIP_MEASURE
+// measurement build: gemm8.h on / off at run time (same-process A/B); -> the previous setting
+extern "C" int xclip_measure_gemm8(int on) { const int was = gemm8_on() ? 1 : 0; g_gemm8 = on; return was; }
+#endif
 
 int64_t xclip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype) {
     if (use_gemm2(M, N, K, dtype)) {
