@@ -17,7 +17,8 @@ bf = torch.bfloat16
 
 
 def run(a, b, M, N, K, bk, on, out=None):
-    L.xclip_measure_gemm8(1 if on else 0)
+    """on: False / 0 = g5_run, True / 1 = gemm8 as the product would pick it, 2.. = a measurement variant (gemm8_gen.py VARIANTS), 10 / 11 = variant 0 / 1"""
+    L.xclip_measure_gemm8(int(on))
     r = ops.gemm(a, b, M, N, K, False, bk, out=out)
     L.xclip_measure_gemm8(0)
     return r
@@ -78,36 +79,42 @@ def timeit_pair(f0, f1, iters=20, warm=6, rounds=4):
     return sorted(t[0])[len(t[0]) // 2], sorted(t[1])[len(t[1]) // 2]
 
 
-def time_shapes(quick):
+def time_shapes(quick, variants):
     Mt, Mv = 1024 * 257, 1024 * 33
     shapes = [("ff1 fwd text", Mt, 4096, 512, False), ("qkv fwd text", Mt, 1536, 512, False), ("out fwd text", Mt, 512, 512, False),
               ("ff2 dgrad text", Mt, 2048, 512, True), ("out dgrad text", Mt, 512, 512, True), ("ff1 dgrad text", Mt, 512, 4096, True),
               ("qkv dgrad text", Mt, 512, 1536, True), ("ff1 fwd vision", Mv, 4096, 512, False), ("qkv fwd vision", Mv, 1536, 512, False),
               ("ff2 dgrad vision", Mv, 2048, 512, True), ("ff1 dgrad vision", Mv, 512, 4096, True)]
     if quick:
-        shapes = shapes[:4]
+        shapes = [shapes[1], shapes[0], shapes[3], shapes[5]]
     a0 = torch.randn(Mt, 512, device=dev, dtype=bf)
     b0 = torch.randn(1536, 512, device=dev, dtype=bf)
     for _ in range(100):
         ops.gemm(a0, b0, Mt, 1536, 512)
     torch.cuda.synchronize()
-    tot = [0.0, 0.0]
+    tot = {}
     for (name, M, N, K, bk) in shapes:
         a = torch.randn(M, K, device=dev, dtype=bf)
         b = torch.randn((K, N) if bk else (N, K), device=dev, dtype=bf)
         o0 = torch.empty(M, N, device=dev, dtype=bf)
         o1 = torch.empty(M, N, device=dev, dtype=bf)
-        t0, t1 = timeit_pair(lambda: run(a, b, M, N, K, bk, False, out=o0), lambda: run(a, b, M, N, K, bk, True, out=o1))
-        same = bool((o0.view(torch.int16) == o1.view(torch.int16)).all())
         fl = 2.0 * M * N * K
-        tot[0] += t0; tot[1] += t1
-        print(f"{name:18s} M={M:6d} N={N:5d} K={K:5d} {'NN' if bk else 'NT'}: g5 {t0*1e3:8.1f} us {fl/t0/1e9:7.1f} TF/s | gemm8 {t1*1e3:8.1f} us {fl/t1/1e9:7.1f} TF/s "
-              f"| {100*(t0/t1-1):+5.1f} %  {'exact' if same else 'DIFFERENT'}", flush=True)
-    print(f"sum: g5 {tot[0]*1e3:.1f} us, gemm8 {tot[1]*1e3:.1f} us ({100*(tot[0]/tot[1]-1):+.1f} %)")
+        line = f"{name:18s} M={M:6d} N={N:5d} K={K:5d} {'NN' if bk else 'NT'}:"
+        for var in variants:
+            t0, t1 = timeit_pair(lambda: run(a, b, M, N, K, bk, 0, out=o0), lambda: run(a, b, M, N, K, bk, var, out=o1), iters=10, rounds=3)
+            same = bool((o0.view(torch.int16) == o1.view(torch.int16)).all())
+            tot[0] = tot.get(0, 0.0) + t0 / len(variants)
+            tot[var] = tot.get(var, 0.0) + t1
+            if var == variants[0]:
+                line += f" g5 {t0*1e3:7.1f} us {fl/t0/1e9:6.0f} TF/s |"
+            line += f" v{var} {t1*1e3:7.1f} ({100*(t0/t1-1):+5.1f} %{'' if same else ' x'}) |"
+        print(line, flush=True)
+    print("sum: " + ", ".join(f"{'g5' if k == 0 else 'v' + str(k)} {t*1e3:.1f} us" for k, t in tot.items()))
 
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "check"
     if what == "check":
         sys.exit(1 if check() else 0)
-    time_shapes(len(sys.argv) > 2 and sys.argv[2] == "quick")
+    variants = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1]
+    time_shapes(len(sys.argv) > 2 and sys.argv[2] == "quick", variants)

@@ -30,6 +30,8 @@ Operands of the asm statement (gemm8.h must pass exactly these, in this order):
     %19 tiles_m %20 band_n %21 dm %22 dn    tile-order constants (stride / 8 = dm * band_n + dn)
     %23 woff                           wave * 4096
     %24 ldsbase                        LDS address of the dynamic segment
+    %25 vwr  %26 vrd                   per-lane addresses of the whole-line exchange inside the wave's 4 KiB slice (gemm4.h pack_lines_i)
+(%7 vc is the row-per-lane store offset in the "rpl" variants and the whole-line store offset in the "lines" variants.)
 """
 import os
 
@@ -40,8 +42,9 @@ def ACC(b): return 16 * b                      # block b = 2 i + j: v[16 b .. 16
 def FA(s, i): return 128 + 24 * s + 4 * i      # fragment set s: a0..a3
 def FB(s, j): return 144 + 24 * s + 4 * j      #                 b0, b1
 def HELD(b): return 176 + 8 * b                # packed bf16 of block b (8 registers)
-TA, TB, VACUR, VBCUR, VB1CUR = 240, 241, 243, 244, 245
-NV = 246                                       # v0 .. v245 are named here; the operands live above
+TA, TB, TW, VACUR, VBCUR, VB1CUR = 240, 241, 242, 243, 244, 245
+def NV(bk): return 246 if bk else 247          # v0 .. v245 (v246) are named here; the operands (10 / 9 of them) live above
+def TXR(bk): return TB if bk else 246          # xor temporary of the exchange (k-major B leaves TB free; the other layout has one operand less)
 
 RA, RB, RC = 40, 44, 48
 A_CUR, A_NEXT, A_FREE, B_CUR, B_NEXT = 52, 53, 54, 55, 56
@@ -53,11 +56,12 @@ WOFF, NTM1 = 80, 81
 PA, PB, PC = 82, 84, 86
 ANT, BNT = 88, 90
 BSTEP, CSIZE = 92, 94
+SK1, SK2, SK3 = 95, 96, 97                     # 8 / 16 / 24 output rows in bytes
 S_LO, S_HI = 40, 99
 
 OP = dict(va0="%0", va1="%1", vb0="%2", vb1="%3", vaf="%4", vbf="%5", vbf1="%6", vc="%7", A="%8", B="%9", C="%10", lda="%11", ldb="%12",
           ldc="%13", nt="%14", mytiles="%15", tm0="%16", nb0="%17", band0="%18", tilesm="%19", bandn="%20", dm="%21", dn="%22", woff="%23",
-          ldsbase="%24")
+          ldsbase="%24", vwr="%25", vrd="%26")
 
 
 def v(r, n=1): return f"v{r}" if n == 1 else f"v[{r}:{r + n - 1}]"
@@ -65,8 +69,8 @@ def s(r, n=1): return f"s{r}" if n == 1 else f"s[{r}:{r + n - 1}]"
 
 
 class Body:
-    def __init__(self, bk, ntst, sps=2):
-        self.bk, self.ntst, self.sps = bk, ntst, sps
+    def __init__(self, bk, ntst, sps=2, stores=True, cvt=True, mode="lines", early=False):
+        self.bk, self.ntst, self.sps, self.do_stores, self.do_cvt, self.mode, self.early = bk, ntst, sps, stores, cvt, mode, early
         self.L = []
         self.nlabel = 0
 
@@ -121,21 +125,118 @@ class Body:
         self.e(f"s_cselect_b32 {s(left)}, {s(NTM1)}, {s(T2)}")
 
     def cvt_block(self, b):
+        if not self.do_cvt:
+            return
         for q in range(4):
             for h in range(2):
                 self.e(f"v_cvt_pk_bf16_f32 {v(HELD(b) + 2 * q + h)}, {v(ACC(b) + 4 * q + 2 * h)}, {v(ACC(b) + 4 * q + 2 * h + 1)}")
 
     def swap_block(self, b):
+        if not self.do_cvt:
+            return
         self.e("s_nop 1")
         for x, y in ((0, 2), (1, 3), (4, 6), (5, 7)):
             self.e(f"v_permlane32_swap_b32 {v(HELD(b) + x)}, {v(HELD(b) + y)}")
 
     def store(self, b, o):
+        if not self.do_stores:
+            self.e("s_nop 0")
+            return
         i, j = b >> 1, b & 1
         so = ["0", s(SI1), s(SI2), s(SI3)][i]
         imm = 64 * j + 32 * o
         self.e(f"buffer_store_dwordx4 {v(HELD(b) + 4 * o, 4)}, {OP['vc']}, {s(RC, 4)}, {so} offen" + (f" offset:{imm}" if imm else "") +
                (" nt" if self.ntst else ""))
+
+    # ---- whole-line form: a 32-row group through the wave's 4 KiB slice (gemm4.h pack_lines_i / store_lines) ----------------------------------
+    def group_writes(self, g, part):
+        """half `part` (0 / 1 = block j) of group g: four 8-byte writes; TW = vwr + slice base must be set"""
+        j = part
+        for q in range(4):
+            c = 4 * j + q
+            src = v(HELD(2 * g + j) + 2 * q, 2)
+            if c == 0:
+                self.e(f"ds_write_b64 {v(TW)}, {src}")
+            else:
+                self.e(f"v_xor_b32 {v(TXR(self.bk))}, {16 * c}, {v(TW)}")
+                self.e(f"ds_write_b64 {v(TXR(self.bk))}, {src}")
+
+    def group_reads(self, g):
+        self.e(f"v_add_u32 {v(TW)}, {s(T4)}, {OP['vrd']}")
+        for k in range(4):
+            self.e(f"ds_read_b128 {v(HELD(2 * g) + 4 * k, 4)}, {v(TW)}" + (f" offset:{1024 * k}" if k else ""))
+
+    def group_stores(self, g):
+        for k in range(4):
+            if not self.do_stores:
+                self.e("s_nop 0")
+                continue
+            if g == 0:
+                so = "0" if k == 0 else s(SK1 + k - 1)
+            elif k == 0:
+                so = s(SI1 + g - 1)
+            else:
+                self.e(f"s_add_u32 {s(T5)}, {s(SI1 + g - 1)}, {s(SK1 + k - 1)}")
+                so = s(T5)
+            self.e(f"buffer_store_dwordx4 {v(HELD(2 * g) + 4 * k, 4)}, {OP['vc']}, {s(RC, 4)}, {so} offen" + (" nt" if self.ntst else ""))
+
+    def step_lines(self, first, group, prev_stores, tag):
+        """lines mode.  first: C = 0 MFMAs behind the conversions; group: the 32-row group of the previous tile exchanged in kk1 (its A pieces
+        wait for that: kk2) and stored behind the B pieces of kk3; prev_stores: line stores the step before left behind its B pieces"""
+        self.c(f"---- K step ({tag}) ----")
+        for kk in range(4):
+            cur, nxt = kk & 1, (kk & 1) ^ 1
+            self.c(f"k-block {kk}")
+            if kk < 3:
+                x = 32 * (kk + 1)
+                self.e(f"v_xor_b32 {v(TA)}, {x}, {v(VACUR)}")
+                if not self.bk:
+                    self.e(f"v_xor_b32 {v(TB)}, {x}, {v(VBCUR)}")
+                    self.read_frags(nxt, TA, TB, None, kk + 1)
+                else:
+                    self.read_frags(nxt, TA, VBCUR, VB1CUR, kk + 1)
+                if kk == 0:
+                    self.e(f"s_add_u32 {s(T4)}, {s(A_FREE)}, {s(WOFF)}")
+                if kk == 1 and group is not None and self.do_cvt:
+                    self.e(f"v_add_u32 {v(TW)}, {s(T4)}, {OP['vwr']}")
+            else:
+                self.e(f"s_waitcnt vmcnt({4 + (prev_stores if self.do_stores else 0)})")
+                self.e("s_barrier")
+                self.e(f"s_mov_b32 {s(T0)}, {s(A_CUR)}")
+                self.e(f"s_mov_b32 {s(A_CUR)}, {s(A_NEXT)}")
+                self.e(f"s_mov_b32 {s(A_NEXT)}, {s(A_FREE)}")
+                self.e(f"s_mov_b32 {s(A_FREE)}, {s(T0)}")
+                self.e(f"s_mov_b32 {s(T0)}, {s(B_CUR)}")
+                self.e(f"s_mov_b32 {s(B_CUR)}, {s(B_NEXT)}")
+                self.e(f"s_mov_b32 {s(B_NEXT)}, {s(T0)}")
+                self.e(f"v_add_u32 {v(VACUR)}, {s(A_CUR)}, {OP['vaf']}")
+                self.e(f"v_add_u32 {v(VBCUR)}, {s(B_CUR)}, {OP['vbf']}")
+                if self.bk:
+                    self.e(f"v_add_u32 {v(VB1CUR)}, {s(B_CUR)}, {OP['vbf1']}")
+                self.read_frags(nxt, VACUR, VBCUR, VB1CUR, 0)
+                self.e(f"s_add_u32 {s(T3)}, {s(B_NEXT)}, {s(WOFF)}")
+            a_kk = 0 if (group is None or self.early) else 2
+            for i in range(4):
+                for j in range(2):
+                    b = 2 * i + j
+                    if first and kk == 0:
+                        self.cvt_block(b)
+                    self.mfma(b, cur, first and kk == 0)
+                if kk == a_kk:
+                    self.dma_piece("a", i, T4)
+                if kk == 3:
+                    self.dma_piece("b", i, T3)
+                if kk == 1 and group is not None and self.do_cvt:
+                    if i == 0: self.group_writes(group, 0)
+                    if i == 1: self.group_writes(group, 1)
+                    if i == 2: self.group_reads(group)
+            if kk == a_kk:
+                self.adv("a")
+            if kk == 3:
+                self.adv("b")
+                if group is not None:
+                    self.group_stores(group)
+            self.e("s_waitcnt lgkmcnt(0)")
 
     def next_bases(self):
         """first-step addresses of the `next` tile's operands -> ANT, BNT"""
@@ -216,7 +317,7 @@ class Body:
                 if kk == 0:
                     self.e(f"s_add_u32 {s(T4)}, {s(A_FREE)}, {s(WOFF)}")
             else:
-                self.e(f"s_waitcnt vmcnt({4 + len(st)})")
+                self.e(f"s_waitcnt vmcnt({4 + (len(st) if self.do_stores else 0)})")
                 self.e("s_barrier")
                 self.e(f"s_mov_b32 {s(T0)}, {s(A_CUR)}")
                 self.e(f"s_mov_b32 {s(A_CUR)}, {s(A_NEXT)}")
@@ -268,6 +369,9 @@ class Body:
         e(f"s_lshl_b32 {s(SI1)}, {OP['ldc']}, 5")
         e(f"s_lshl_b32 {s(SI2)}, {OP['ldc']}, 6")
         e(f"s_add_u32 {s(SI3)}, {s(SI2)}, {s(SI1)}")
+        e(f"s_lshl_b32 {s(SK1)}, {OP['ldc']}, 3")
+        e(f"s_lshl_b32 {s(SK2)}, {OP['ldc']}, 4")
+        e(f"s_add_u32 {s(SK3)}, {s(SK2)}, {s(SK1)}")
         e(f"s_sub_u32 {s(NTM1)}, {OP['nt']}, 1")
         e(f"s_mov_b32 {s(NXT_TM)}, {OP['tm0']}")
         e(f"s_mov_b32 {s(NXT_NB)}, {OP['nb0']}")
@@ -330,16 +434,25 @@ class Body:
         ltile, lgen, lgend = self.label("tile"), self.label("gen"), self.label("genend")
         e(f"{ltile}:")
         self.tile_start()
-        nspecial = 16 // self.sps
-        for t in range(nspecial):
-            blocks = [b for b in range(8) if (2 * b) // self.sps == t]
-            stores = [(b, o) for b in blocks for o in (0, 1)]
-            self.step(t == 0, blocks, stores, f"tile step {t}: previous tile's blocks {blocks}")
+        if self.mode == "rpl":
+            nspecial = 16 // self.sps
+            for t in range(nspecial):
+                blocks = [b for b in range(8) if (2 * b) // self.sps == t]
+                stores = [(b, o) for b in blocks for o in (0, 1)]
+                self.step(t == 0, blocks, stores, f"tile step {t}: previous tile's blocks {blocks}")
+        else:
+            nspecial = 5
+            for t in range(4):
+                self.step_lines(t == 0, t, 0 if t == 0 else 4, f"tile step {t}: previous tile's row group {t}")
+            self.step_lines(False, None, 4, "tile step 4: plain, behind a step with line stores")
         e(f"s_sub_u32 {s(GCNT)}, {OP['nt']}, {nspecial}")
         e(f"{lgen}:")
         e(f"s_cmp_eq_u32 {s(GCNT)}, 0")
         e(f"s_cbranch_scc1 {lgend}")
-        self.step(False, [], [], "plain")
+        if self.mode == "rpl":
+            self.step(False, [], [], "plain")
+        else:
+            self.step_lines(False, None, 0, "plain")
         e(f"s_sub_u32 {s(GCNT)}, {s(GCNT)}, 1")
         e(f"s_branch {lgen}")
         e(f"{lgend}:")
@@ -348,17 +461,30 @@ class Body:
         e(f"s_cbranch_scc1 {ltile}")
         self.c("drain: the last tile")
         self.c_rsrc_from_cur()
-        for b in range(8):
-            self.cvt_block(b)
-            self.swap_block(b)
-            self.store(b, 0)
-            self.store(b, 1)
+        if self.mode == "rpl":
+            for b in range(8):
+                self.cvt_block(b)
+                self.swap_block(b)
+                self.store(b, 0)
+                self.store(b, 1)
+        else:
+            for b in range(8):
+                self.cvt_block(b)
+            e(f"s_add_u32 {s(T4)}, {s(A_FREE)}, {s(WOFF)}")
+            for g in range(4):
+                if self.do_cvt:
+                    e(f"v_add_u32 {v(TW)}, {s(T4)}, {OP['vwr']}")
+                    self.group_writes(g, 0)
+                    self.group_writes(g, 1)
+                    self.group_reads(g)
+                    e("s_waitcnt lgkmcnt(0)")
+                self.group_stores(g)
         e("s_waitcnt vmcnt(0)")
         return self.L
 
 
-def clobbers():
-    return [f"v{i}" for i in range(NV)] + [f"s{i}" for i in range(S_LO, S_HI + 1)] + ["vcc", "memory"]
+def clobbers(bk):
+    return [f"v{i}" for i in range(NV(bk))] + [f"s{i}" for i in range(S_LO, S_HI + 1)] + ["vcc", "memory"]
 
 
 def c_string(lines):
@@ -371,20 +497,39 @@ def c_string(lines):
     return "\n".join(out)
 
 
+# measurement variants (gemm8.h instantiates 0 / 1 in the product, all of them in the measurement build): id -> Body options
+VARIANTS = {
+    0: dict(ntst=False),                           # product: whole-line stores through the LDS slice
+    1: dict(ntst=True),                            # product: the same, non-temporal (outputs the L2s cannot hold)
+    2: dict(ntst=True, mode="rpl", sps=2),         # row-per-lane stores, two per K step (first version: -20 ... -45 %)
+    3: dict(ntst=False, mode="rpl", sps=4),
+    4: dict(ntst=True, early=True),                # (garbage) A pieces not held back behind the exchange
+    5: dict(ntst=True, stores=False),              # (garbage) conversions and exchange, no stores
+    6: dict(ntst=True, stores=False, cvt=False),   # (garbage) the bare loop
+}
+
+
 def main():
     parts = ["// gemm8_body.inc -- GENERATED by gemm8_gen.py (hand-scheduled gfx950 body of gemm8_kernel); do not edit.",
-             "// Variants: G8_BODY_<layout>_<stores>: layout NT (B row-major [N, K]) / NN (B k-major [K, N]); stores P (plain) / S (non-temporal).", ""]
+             "// G8_BODY_<layout>_<variant>: layout NT (B row-major [N, K]) / NN (B k-major [K, N]); variants: gemm8_gen.py VARIANTS.", ""]
     for bk in (False, True):
-        for ntst in (False, True):
-            name = f"G8_BODY_{'NN' if bk else 'NT'}_{'S' if ntst else 'P'}"
-            body = Body(bk, ntst).build()
+        for var, opt in VARIANTS.items():
+            name = f"G8_BODY_{'NN' if bk else 'NT'}_{var}"
+            body = Body(bk, **opt).build()
             n_inst = sum(1 for l in body if not l.startswith(";") and not l.endswith(":"))
-            parts.append(f"// {name}: {n_inst} instructions")
+            if var >= 2:
+                parts.append("#ifdef XCLIP_MEASURE")
+            parts.append(f"// {name}: {opt}, {n_inst} instructions")
             parts.append(f"#define {name} \\")
             lines = c_string(body).split("\n")
             parts.append(" \\\n".join(lines))
+            if var >= 2:
+                parts.append("#endif")
             parts.append("")
-    parts.append("#define G8_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()))
+    parts.append("#define G8_CLOBBERS_NT " + ", ".join(f'"{c}"' for c in clobbers(False)))
+    parts.append("#define G8_CLOBBERS_NN " + ", ".join(f'"{c}"' for c in clobbers(True)))
+    parts.append("#define G8_RPL_VARIANTS(V) ((V) == 2 || (V) == 3)")
+    parts.append(f"#define G8_VARIANTS {len(VARIANTS)}")
     parts.append("")
     with open(os.path.join(HERE, "gemm8_body.inc"), "w") as f:
         f.write("\n".join(parts))

@@ -298,8 +298,11 @@ void launch_gemm2(const Gemm2Params& p, int splits, hipStream_t st) {
         // the hand-scheduled ring kernel (gemm8.h) for the plain interior products it takes
         if constexpr (!AK) {
             if (gemm8_on() && g8_takes(p, splits, gx)) {
-#define XC_G8(NTST) do { XC_ALLOW_LDS((gemm8_kernel<BK_, NTST>), G5_LDS_BYTES); hipLaunchKernelGGL((gemm8_kernel<BK_, NTST>), dim3((unsigned)gx), dim3(G2_THREADS), G5_LDS_BYTES, st, p); } while (0)
-                if (p.stream_out) XC_G8(true); else XC_G8(false);
+#define XC_G8(V) do { XC_ALLOW_LDS((gemm8_kernel<BK_, V>), G5_LDS_BYTES); hipLaunchKernelGGL((gemm8_kernel<BK_, V>), dim3((unsigned)gx), dim3(G2_THREADS), G5_LDS_BYTES, st, p); } while (0)
+#ifdef XCLIP_MEASURE
+                switch (g_gemm8) { case 2: XC_G8(2); return; case 3: XC_G8(3); return; case 4: XC_G8(4); return; case 5: XC_G8(5); return; case 6: XC_G8(6); return; case 10: XC_G8(0); return; case 11: XC_G8(1); return; default: break; }
+#endif
+                if (p.stream_out) XC_G8(1); else XC_G8(0);
 #undef XC_G8
                 return;
             }
