@@ -57,6 +57,7 @@ PA, PB, PC = 82, 84, 86
 ANT, BNT = 88, 90
 BSTEP, CSIZE = 92, 94
 SK1, SK2, SK3 = 95, 96, 97                     # 8 / 16 / 24 output rows in bytes
+PREV2 = 98                                     # (spread stores) the step before a tile's first left two line stores behind its B pieces
 S_LO, S_HI = 40, 99
 
 OP = dict(va0="%0", va1="%1", vb0="%2", vb1="%3", vaf="%4", vbf="%5", vbf1="%6", vc="%7", A="%8", B="%9", C="%10", lda="%11", ldb="%12",
@@ -69,8 +70,9 @@ def s(r, n=1): return f"s{r}" if n == 1 else f"s[{r}:{r + n - 1}]"
 
 
 class Body:
-    def __init__(self, bk, ntst, sps=2, stores=True, cvt=True, mode="lines", early=False):
+    def __init__(self, bk, ntst, sps=2, stores=True, cvt=True, mode="lines", early=False, spread=False):
         self.bk, self.ntst, self.sps, self.do_stores, self.do_cvt, self.mode, self.early = bk, ntst, sps, stores, cvt, mode, early
+        self.spread = spread
         self.L = []
         self.nlabel = 0
 
@@ -166,8 +168,8 @@ class Body:
         for k in range(4):
             self.e(f"ds_read_b128 {v(HELD(2 * g) + 4 * k, 4)}, {v(TW)}" + (f" offset:{1024 * k}" if k else ""))
 
-    def group_stores(self, g):
-        for k in range(4):
+    def group_stores(self, g, ks=(0, 1, 2, 3)):
+        for k in ks:
             if not self.do_stores:
                 self.e("s_nop 0")
                 continue
@@ -238,6 +240,158 @@ class Body:
                     self.group_stores(group)
             self.e("s_waitcnt lgkmcnt(0)")
 
+    # ---- the scheduled K step: fragment reads, DMA pieces and the exchange spread over the gaps between the MFMAs, counted lgkmcnt ----------
+    def sb_reset(self, names):
+        """LDS scoreboard at a step's entry: `names` were the last LDS operations issued, in this order (nothing is known to have completed)"""
+        self.sb_ids = {n: k for k, n in enumerate(names)}
+        self.sb_issued = len(names)
+        self.sb_done = 0
+
+    def sb_issue(self, name):
+        self.sb_ids[name] = self.sb_issued
+        self.sb_issued += 1
+
+    def sb_need(self, names, extra=""):
+        """the named LDS results must have landed (the LDS serves a wave's operations in order; lgkmcnt is a 4-bit counter)"""
+        ks = [self.sb_ids[n] for n in names if n in self.sb_ids]
+        if not ks or max(ks) < self.sb_done:
+            if extra:
+                self.e(f"s_waitcnt {extra}")
+            return
+        k = max(ks)
+        n = self.sb_issued - 1 - k
+        self.sb_done = k + 1
+        if n <= 15:
+            self.e(f"s_waitcnt {extra + ' ' if extra else ''}lgkmcnt({n})")
+        elif extra:
+            self.e(f"s_waitcnt {extra}")
+
+    def frag_ops(self, fs, va, vb, vb1, kk):
+        """[(name, instruction)] of the fragment reads of one k-block into set fs, in the order the MFMAs need them"""
+        A = [(f"a{i}", f"ds_read_b128 {v(FA(fs, i), 4)}, {v(va)}" + (f" offset:{4096 * i}" if i else "")) for i in range(4)]
+        if not self.bk:
+            B = [[("b0", f"ds_read_b128 {v(FB(fs, 0), 4)}, {v(vb)}")], [("b1", f"ds_read_b128 {v(FB(fs, 1), 4)}, {v(vb)} offset:4096")]]
+        else:
+            off = kk * 2048
+            B = [[("b0lo", f"ds_read_b64_tr_b16 {v(FB(fs, 0), 2)}, {v(vb)} offset:{off}"),
+                  ("b0", f"ds_read_b64_tr_b16 {v(FB(fs, 0) + 2, 2)}, {v(vb)} offset:{off + 512}")],
+                 [("b1lo", f"ds_read_b64_tr_b16 {v(FB(fs, 1), 2)}, {v(vb1)} offset:{off}"),
+                  ("b1", f"ds_read_b64_tr_b16 {v(FB(fs, 1) + 2, 2)}, {v(vb1)} offset:{off + 512}")]]
+        ops = B[0] + [A[0]] + B[1] + A[1:]
+        return [(f"f{fs}.{n}", ins) for n, ins in ops]
+
+    def step_sched(self, first, group, prev_stores, tag, stores=None, flag_wait=False):
+        """as step_lines, with every k-block's work placed in the gaps behind its MFMAs and waits counted per operand.  Entry state (every path
+        into a step provides it): the fragments of set 0 for k-block 0 were the last LDS operations issued, in frag_ops order."""
+        self.c(f"---- K step ({tag}) ----")
+        self.sb_reset([n for n, _ in self.frag_ops(0, 0, 0, 0, 0)])
+        exch = group is not None and self.do_cvt
+        for kk in range(4):
+            cur, nxt = kk & 1, (kk & 1) ^ 1
+            self.c(f"k-block {kk}")
+            gaps = [[] for _ in range(9)]                       # gaps[0]: in front of the first MFMA; gaps[m + 1]: behind MFMA m
+            if kk < 3:
+                x = 32 * (kk + 1)
+                gaps[0].append(("i", f"v_xor_b32 {v(TA)}, {x}, {v(VACUR)}"))
+                if not self.bk:
+                    gaps[0].append(("i", f"v_xor_b32 {v(TB)}, {x}, {v(VBCUR)}"))
+                    reads = self.frag_ops(nxt, TA, TB, None, kk + 1)
+                else:
+                    reads = self.frag_ops(nxt, TA, VBCUR, VB1CUR, kk + 1)
+                if kk == 0:
+                    gaps[0].append(("i", f"s_add_u32 {s(T4)}, {s(A_FREE)}, {s(WOFF)}"))
+            else:
+                # all of this wave's reads of the current stages are through, DMA(s + 1) has landed: for every wave behind the barrier
+                if flag_wait and self.do_stores:
+                    # (a tile's first step: what the step before it left behind its B pieces depends on the run time K)
+                    la, lb = self.label("w4"), self.label("wdone")
+                    self.e(f"s_cmp_eq_u32 {s(PREV2)}, 0")
+                    self.e(f"s_cbranch_scc1 {la}")
+                    self.sb_need(list(self.sb_ids), "vmcnt(6)")
+                    self.e(f"s_branch {lb}")
+                    self.e(f"{la}:")
+                    self.e("s_waitcnt vmcnt(4) lgkmcnt(0)")
+                    self.e(f"{lb}:")
+                else:
+                    self.sb_need(list(self.sb_ids), f"vmcnt({4 + (prev_stores if self.do_stores else 0)})")
+                self.e("s_barrier")
+                for ins in (f"s_mov_b32 {s(T0)}, {s(A_CUR)}", f"s_mov_b32 {s(A_CUR)}, {s(A_NEXT)}", f"s_mov_b32 {s(A_NEXT)}, {s(A_FREE)}",
+                            f"s_mov_b32 {s(A_FREE)}, {s(T0)}", f"s_mov_b32 {s(T0)}, {s(B_CUR)}", f"s_mov_b32 {s(B_CUR)}, {s(B_NEXT)}",
+                            f"s_mov_b32 {s(B_NEXT)}, {s(T0)}", f"v_add_u32 {v(VACUR)}, {s(A_CUR)}, {OP['vaf']}",
+                            f"v_add_u32 {v(VBCUR)}, {s(B_CUR)}, {OP['vbf']}"):
+                    gaps[0].append(("i", ins))
+                if self.bk:
+                    gaps[0].append(("i", f"v_add_u32 {v(VB1CUR)}, {s(B_CUR)}, {OP['vbf1']}"))
+                gaps[0].append(("i", f"s_add_u32 {s(T3)}, {s(B_NEXT)}, {s(WOFF)}"))
+                reads = self.frag_ops(nxt, VACUR, VBCUR, VB1CUR, 0)
+            # fragment reads: all issued by the gap behind MFMA 5 (two per gap first when there are eight)
+            spots = [1, 2, 3, 4, 5, 6] if len(reads) == 6 else [1, 1, 2, 2, 3, 4, 5, 6]
+            for (n, ins), g in zip(reads, spots):
+                gaps[g].append(("r", n, ins))
+            a_kk = 0 if (group is None or self.early) else 2
+            if kk == a_kk:
+                for i in range(4):
+                    gaps[2 * i + 2].append(("a", i))
+            if kk == 3:
+                for i in range(4):
+                    gaps[2 * i + 2].append(("b", i))
+            if kk == 1 and exch:
+                gaps[0].append(("i", f"v_add_u32 {v(TW)}, {s(T4)}, {OP['vwr']}"))
+                for c in range(8):
+                    gaps[1 + c // 2].append(("w", c))
+                gaps[5].append(("xr", None))
+                for k in range(4):
+                    gaps[5 + k].append(("x", k))
+
+            def flush(gap):
+                for it in gap:
+                    if it[0] == "i":
+                        self.e(it[1])
+                    elif it[0] == "r":
+                        self.e(it[2])
+                        self.sb_issue(it[1])
+                    elif it[0] == "a":
+                        if exch and not self.early and it[1] == 0:
+                            self.sb_need([f"x{k}" for k in range(4)])        # the slice is about to be overwritten
+                        self.dma_piece("a", it[1], T4)
+                    elif it[0] == "b":
+                        self.dma_piece("b", it[1], T3)
+                    elif it[0] == "w":
+                        c = it[1]
+                        src = v(HELD(2 * group + (c >> 2)) + 2 * (c & 3), 2)
+                        if c == 0:
+                            self.e(f"ds_write_b64 {v(TW)}, {src}")
+                        else:
+                            self.e(f"v_xor_b32 {v(TXR(self.bk))}, {16 * c}, {v(TW)}")
+                            self.e(f"ds_write_b64 {v(TXR(self.bk))}, {src}")
+                        self.sb_issue(f"w{c}")
+                    elif it[0] == "xr":
+                        self.e(f"v_add_u32 {v(TW)}, {s(T4)}, {OP['vrd']}")
+                    elif it[0] == "x":
+                        k = it[1]
+                        self.e(f"ds_read_b128 {v(HELD(2 * group) + 4 * k, 4)}, {v(TW)}" + (f" offset:{1024 * k}" if k else ""))
+                        self.sb_issue(f"x{k}")
+
+            flush(gaps[0])
+            for m in range(8):
+                i, j = m >> 1, m & 1
+                if first and kk == 0:
+                    self.cvt_block(m)
+                self.sb_need([f"f{cur}.a{i}", f"f{cur}.b{j}"])
+                self.mfma(m, cur, first and kk == 0)
+                flush(gaps[m + 1])
+            if kk == a_kk:
+                self.adv("a")
+            if kk == 3:
+                self.adv("b")
+                if stores is None and group is not None:
+                    stores = [(group, k) for k in range(4)]
+                if stores:
+                    if exch:
+                        self.sb_need([f"x{k}" for k in range(4)])
+                    for (g, k) in stores:
+                        self.group_stores(g, (k,))
+
     def next_bases(self):
         """first-step addresses of the `next` tile's operands -> ANT, BNT"""
         self.e(f"s_lshl_b32 {s(T0)}, {s(NXT_TM)}, 8")
@@ -276,6 +430,8 @@ class Body:
         self.e(f"s_mov_b32 {s(CUR_TM)}, {s(NXT_TM)}")
         self.e(f"s_mul_i32 {s(T0)}, {s(NXT_BAND)}, {OP['bandn']}")
         self.e(f"s_add_u32 {s(CUR_TN)}, {s(T0)}, {s(NXT_NB)}")
+        self.e(f"s_cmp_eq_u32 {OP['nt']}, 8")
+        self.e(f"s_cselect_b32 {s(PREV2)}, {s(HAVE_PREV)}, 0")
         self.e(f"s_mov_b32 {s(HAVE_PREV)}, 1")
         noadv, a1, a2 = self.label("noadv"), self.label("adv1"), self.label("adv2")
         self.e(f"s_cmp_gt_u32 {s(TILES_LEFT)}, 1")
@@ -440,17 +596,32 @@ class Body:
                 blocks = [b for b in range(8) if (2 * b) // self.sps == t]
                 stores = [(b, o) for b in blocks for o in (0, 1)]
                 self.step(t == 0, blocks, stores, f"tile step {t}: previous tile's blocks {blocks}")
+        elif self.spread:
+            # two line stores behind the B pieces of each of the tile's first eight steps: group g's lines 0, 1 in step g (its exchange is in
+            # that step's kk1), lines 2, 3 in step g + 4; a ninth step (if the tile has one) still counts the two stores of the eighth
+            nspecial = 8
+            for t in range(8):
+                self.step_sched(t == 0, t if t < 4 else None, 2, f"tile step {t}", stores=[(t & 3, 2 * (t >> 2)), (t & 3, 2 * (t >> 2) + 1)],
+                                flag_wait=(t == 0))
         else:
             nspecial = 5
+            st = self.step_sched if self.mode == "sched" else self.step_lines
             for t in range(4):
-                self.step_lines(t == 0, t, 0 if t == 0 else 4, f"tile step {t}: previous tile's row group {t}")
-            self.step_lines(False, None, 4, "tile step 4: plain, behind a step with line stores")
+                st(t == 0, t, 0 if t == 0 else 4, f"tile step {t}: previous tile's row group {t}")
+            st(False, None, 4, "tile step 4: plain, behind a step with line stores")
         e(f"s_sub_u32 {s(GCNT)}, {OP['nt']}, {nspecial}")
+        if self.mode == "sched" and self.spread:
+            e(f"s_cmp_eq_u32 {s(GCNT)}, 0")
+            e(f"s_cbranch_scc1 {lgend}")
+            self.step_sched(False, None, 2, "tile step 8: plain, behind a step with two line stores")
+            e(f"s_sub_u32 {s(GCNT)}, {s(GCNT)}, 1")
         e(f"{lgen}:")
         e(f"s_cmp_eq_u32 {s(GCNT)}, 0")
         e(f"s_cbranch_scc1 {lgend}")
         if self.mode == "rpl":
             self.step(False, [], [], "plain")
+        elif self.mode == "sched":
+            self.step_sched(False, None, 0, "plain")
         else:
             self.step_lines(False, None, 0, "plain")
         e(f"s_sub_u32 {s(GCNT)}, {s(GCNT)}, 1")
@@ -499,13 +670,13 @@ def c_string(lines):
 
 # measurement variants (gemm8.h instantiates 0 / 1 in the product, all of them in the measurement build): id -> Body options
 VARIANTS = {
-    0: dict(ntst=False),                           # product: whole-line stores through the LDS slice
-    1: dict(ntst=True),                            # product: the same, non-temporal (outputs the L2s cannot hold)
+    0: dict(ntst=False, mode="sched", spread=True),   # product: scheduled K step, whole-line stores through the LDS slice, two per K step
+    1: dict(ntst=True, mode="sched", spread=True),    # product: the same, non-temporal (outputs the L2s cannot hold)
     2: dict(ntst=True, mode="rpl", sps=2),         # row-per-lane stores, two per K step (first version: -20 ... -45 %)
-    3: dict(ntst=False, mode="rpl", sps=4),
-    4: dict(ntst=True, early=True),                # (garbage) A pieces not held back behind the exchange
-    5: dict(ntst=True, stores=False),              # (garbage) conversions and exchange, no stores
-    6: dict(ntst=True, stores=False, cvt=False),   # (garbage) the bare loop
+    3: dict(ntst=True, mode="lines"),              # whole-line stores, k-blocks as g5_run orders them (reads, then MFMAs, then lgkmcnt(0))
+    4: dict(ntst=True, mode="sched"),              # four line stores behind each of the first four steps
+    5: dict(ntst=True, mode="sched", spread=True, stores=False),              # (garbage) conversions and exchange, no stores
+    6: dict(ntst=True, mode="sched", spread=True, stores=False, cvt=False),   # (garbage) the bare loop
 }
 
 
@@ -528,7 +699,7 @@ def main():
             parts.append("")
     parts.append("#define G8_CLOBBERS_NT " + ", ".join(f'"{c}"' for c in clobbers(False)))
     parts.append("#define G8_CLOBBERS_NN " + ", ".join(f'"{c}"' for c in clobbers(True)))
-    parts.append("#define G8_RPL_VARIANTS(V) ((V) == 2 || (V) == 3)")
+    parts.append("#define G8_RPL_VARIANTS(V) ((V) == 2)")
     parts.append(f"#define G8_VARIANTS {len(VARIANTS)}")
     parts.append("")
     with open(os.path.join(HERE, "gemm8_body.inc"), "w") as f:
