@@ -36,7 +36,8 @@ PROLOGUE_SPILLS_ONLY = {"sim5_grad_fast_kernel<true, 0>": (16, 2), "sim5_grad_fa
 # 256 registers) parks ~20 values of its two step variants
 WIDE_HEADS = {"attn4_bwd_kernel<false>": 0, "attn4_bwd_kernel<true>": 0, "attn4_fwd_kernel<false>": 24, "attn4_fwd_kernel<true>": 24}
 # kernels whose ragged-tile path legitimately holds serialized loads (row gathers, residual rows): spills only
-NO_SPILL = ["gemm4_kernel<true, true, 1>", "gemm5_kernel<false, false, 3, 0>", "gemm5_kernel<false, true, 3, 0>", "filip_route_kernel<bf16>",
+NO_SPILL = ["gemm8_kernel<false, 0>", "gemm8_kernel<false, 1>", "gemm8_kernel<true, 0>", "gemm8_kernel<true, 1>",   # (asm units: the compiler's part around them)
+            "gemm4_kernel<true, true, 1>", "gemm5_kernel<false, false, 3, 0>", "gemm5_kernel<false, true, 3, 0>", "filip_route_kernel<bf16>",
             "attn_pool_fwd_kernel<bf16, 64>", "attn_pool_bwd_kernel<bf16, 64>", "scatter_add_sorted_kernel<bf16, 1>"]
 
 
@@ -72,3 +73,22 @@ def test_hot_kernels_do_not_spill_or_stall(isa):
         if isa[k]["vspill"] or isa[k]["scratch"]:
             bad.append(f"{k}: {isa[k]['vspill']} spilled vector registers, {isa[k]['scratch']} scratch instructions")
     assert not bad, "\n".join(bad)
+
+
+def test_generated_asm_bodies_are_in_sync():
+    """csrc/kernels/asm/*_body.inc is what its generator writes today (the .inc is committed so that the asm can be read in the repository)"""
+    import subprocess
+    adir = os.path.join(ROOT, "x_clip_amd", "csrc", "kernels", "asm")
+    for gen in sorted(f for f in os.listdir(adir) if f.endswith("_gen.py")):
+        inc = os.path.join(adir, gen.replace("_gen.py", "_body.inc"))
+        before = open(inc).read()
+        subprocess.run([sys.executable, os.path.join(adir, gen)], check=True, stdout=subprocess.DEVNULL)
+        after = open(inc).read()
+        assert before == after, f"{inc} was stale: regenerated -- commit it"
+
+
+def test_asm_units_name_only_their_own_registers(isa):
+    """a whole-kernel asm unit (gemm8.h) lives in the registers it names; the compiler's part must not spill around it and the kernel must fit two
+    waves per SIMD (256 registers)"""
+    for k in [n for n in isa if n.startswith("gemm8_kernel")]:
+        assert isa[k]["vspill"] == 0 and isa[k]["scratch"] == 0, (k, isa[k])

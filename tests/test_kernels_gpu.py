@@ -80,12 +80,16 @@ def test_gemm_layouts(dtype, layout, M, N, K_):
                                                ("nt", 65536, 4096, 512, False),
                                                # round 4: the row tail as a split-K problem (xclip_api.hip gemm2_tail_cut) -- text rows 1028 row tiles,
                                                # vision rows 132: FF1 input gradient, FF2 forward + skip through the reduction's residual term
-                                               ("nn", 263168, 512, 4096, False), ("nn", 33792, 512, 4096, False), ("nt", 33792, 512, 2048, True)])
+                                               ("nn", 263168, 512, 4096, False), ("nn", 33792, 512, 4096, False), ("nt", 33792, 512, 2048, True),
+                                               # round 5: gemm8.h (the asm unit) takes every plain interior NT / NN product with >= 8 K steps: the
+                                               # FF2 input gradient (k-major B at K = 512: all eight steps carry the previous tile's stores)
+                                               ("nn", 263168, 2048, 512, False), ("nt", 33792, 1536, 512, False)])
 def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_, res):
     """text-tower shapes at full size, every CU streaming (the regime the counted DMA waits and the stores left in flight across the
     tile boundary have to be right in -- the emulator lands every DMA piece at once and cannot see an early read, nor a missing wait
     state in front of an asm store): every output element against an fp32-accumulated reference product of the same bf16 operands,
-    and ten launches bit-identical.  Covers every interior-tile epilogue of gemm4.h: plain whole-line stores (nt / nn), the fp32
+    and ten launches bit-identical.  The plain NT / NN products run on gemm8.h's hand-scheduled body (held line stores under the next tile's
+    MFMAs: no emulator twin, this test and tools/probe_gemm8.py are its gate).  Covers every interior-tile epilogue of gemm4.h: plain whole-line stores (nt / nn), the fp32
     split-K slab (tn), the residual form (res: FF2 + skip), and the streamed (> 48 MiB) + banded (16 N tiles) FF1 output."""
     from x_clip_amd import ops
     a_k, b_k = layout == "tn", layout in ("nn", "tn")

@@ -70,9 +70,9 @@ def s(r, n=1): return f"s{r}" if n == 1 else f"s[{r}:{r + n - 1}]"
 
 
 class Body:
-    def __init__(self, bk, ntst, sps=2, stores=True, cvt=True, mode="lines", early=False, spread=False):
+    def __init__(self, bk, ntst, sps=2, stores=True, cvt=True, mode="lines", early=False, spread=False, st_kk=3):
         self.bk, self.ntst, self.sps, self.do_stores, self.do_cvt, self.mode, self.early = bk, ntst, sps, stores, cvt, mode, early
-        self.spread = spread
+        self.spread, self.st_kk = spread, st_kk
         self.L = []
         self.nlabel = 0
 
@@ -302,7 +302,9 @@ class Body:
                     gaps[0].append(("i", f"s_add_u32 {s(T4)}, {s(A_FREE)}, {s(WOFF)}"))
             else:
                 # all of this wave's reads of the current stages are through, DMA(s + 1) has landed: for every wave behind the barrier
-                if flag_wait and self.do_stores:
+                if self.st_kk == 2:
+                    self.sb_need(list(self.sb_ids), f"vmcnt({4 + (len(stores) if (stores and self.do_stores) else 0)})")
+                elif flag_wait and self.do_stores:
                     # (a tile's first step: what the step before it left behind its B pieces depends on the run time K)
                     la, lb = self.label("w4"), self.label("wdone")
                     self.e(f"s_cmp_eq_u32 {s(PREV2)}, 0")
@@ -343,6 +345,10 @@ class Body:
                 for k in range(4):
                     gaps[5 + k].append(("x", k))
 
+            if kk == 2 and stores and self.st_kk == 2:
+                for n, (g, k) in enumerate(stores):
+                    gaps[5 + 3 * n if len(stores) == 2 else 2 * n + 2].append(("s", g, k))
+
             def flush(gap):
                 for it in gap:
                     if it[0] == "i":
@@ -365,6 +371,10 @@ class Body:
                             self.e(f"v_xor_b32 {v(TXR(self.bk))}, {16 * c}, {v(TW)}")
                             self.e(f"ds_write_b64 {v(TXR(self.bk))}, {src}")
                         self.sb_issue(f"w{c}")
+                    elif it[0] == "s":
+                        if exch:
+                            self.sb_need([f"x{k}" for k in range(4)])
+                        self.group_stores(it[1], (it[2],))
                     elif it[0] == "xr":
                         self.e(f"v_add_u32 {v(TW)}, {s(T4)}, {OP['vrd']}")
                     elif it[0] == "x":
@@ -386,7 +396,7 @@ class Body:
                 self.adv("b")
                 if stores is None and group is not None:
                     stores = [(group, k) for k in range(4)]
-                if stores:
+                if stores and self.st_kk == 3:
                     if exch:
                         self.sb_need([f"x{k}" for k in range(4)])
                     for (g, k) in stores:
@@ -674,7 +684,7 @@ VARIANTS = {
     1: dict(ntst=True, mode="sched", spread=True),    # product: the same, non-temporal (outputs the L2s cannot hold)
     2: dict(ntst=True, mode="rpl", sps=2),         # row-per-lane stores, two per K step (first version: -20 ... -45 %)
     3: dict(ntst=True, mode="lines"),              # whole-line stores, k-blocks as g5_run orders them (reads, then MFMAs, then lgkmcnt(0))
-    4: dict(ntst=True, mode="sched"),              # four line stores behind each of the first four steps
+    4: dict(ntst=True, mode="sched", spread=True, st_kk=2),   # the two line stores of a step in its kk2 (between the A and the B pieces)
     5: dict(ntst=True, mode="sched", spread=True, stores=False),              # (garbage) conversions and exchange, no stores
     6: dict(ntst=True, mode="sched", spread=True, stores=False, cvt=False),   # (garbage) the bare loop
 }

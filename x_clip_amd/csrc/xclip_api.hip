@@ -206,7 +206,7 @@ inline int gemm_generation() {
     return v;
 }
 // gemm8.h on / off.  Product: G8_DEFAULT.  Measurement build: XCLIP_GEMM8=0 / 1 at load, xclip_measure_gemm8() at run time (same-process A/B).
-constexpr int G8_DEFAULT = 0;
+constexpr int G8_DEFAULT = 1;
 static int g_gemm8 = -1;
 inline bool gemm8_on() {
     if (g_gemm8 < 0) g_gemm8 = measure_env("XCLIP_GEMM8", G8_DEFAULT);
