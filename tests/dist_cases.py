@@ -163,6 +163,8 @@ def worker_disagreeing_ranks(rank, world, port, cfg_kwargs, batch, tmp, kind="cp
             sync.finish()
     assert sync._agreed and sync.overlap is False, (sync._agreed, sync.overlap, sync._expected, rank)
     assert any("walked their towers differently" in str(w.message) for w in caught)
+    # which buckets go on the wire may not depend on what this rank fired -- every rank issued every bucket in all three steps
+    assert sync.launched == 3 * len(sync.buckets), (rank, sync.launched, len(sync.buckets))
     grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
     torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.destroy_process_group()

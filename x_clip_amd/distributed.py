@@ -224,6 +224,7 @@ class GradSync:
         self._expected = [None] * nb                         # hook firings per step that complete a bucket (learned in the first step)
         self._order = list(range(nb))                        # the one order collectives are issued in (frozen after the first step)
         self._agreed = False                                 # the first step's counts / order have been compared across the ranks
+        self._launch_all = not overlap                       # finish() reduces every bucket whatever fired (overlap off, or the ranks disagreed)
         self._ready = set()                                  # complete, waiting for the buckets before them in `_order`
         self._next = 0                                       # position in `_order` of the next bucket to launch
         self._fire_seq = 0
@@ -234,6 +235,7 @@ class GradSync:
         self._step_open = False
         self.stats = {"in_place": 0, "copied": 0, "unused": 0}     # of the last step: gradients written straight into their slice / copied / absent
         self._works = []
+        self.launched = 0                                    # bucket all-reduces issued so far (tests: must be equal on every rank)
         self._handles = []
         for bi, ps in enumerate(self.buckets):
             for p in ps:
@@ -323,6 +325,7 @@ class GradSync:
             self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
         self._seen[bi] = self._count[bi]
         self._count[bi] = -1                                 # launched
+        self.launched += 1
 
     def _agree(self):
         """once, after the first step: do all ranks hold the same firing counts and completion order?  (one all-gather + host read)"""
@@ -339,6 +342,7 @@ class GradSync:
             warnings.warn("x_clip_amd GradSync: the ranks walked their towers differently in the first step (firing counts / completion "
                           "order differ) -- gradient buckets will be all-reduced after the backward, in index order, without overlap")
             self.overlap = False
+            self._launch_all = True                          # from now on every finish() reduces every bucket, in index order
             self._order = list(range(nb))
         self._agreed = True
 
@@ -346,11 +350,23 @@ class GradSync:
         """call after loss.backward(): buckets that did not complete from a hook (first step, overlap off, unused parameters) are flushed
         here, in the frozen order"""
         first = not self._agreed
-        for bi in self._order[self._next:] if self._agreed else range(len(self.buckets)):
-            if self._count[bi] > 0 or (self._count[bi] == 0 and self._agreed and (self._expected[bi] or 0) > 0):
-                # (a bucket that fired in the agreed first step but not now -- a tower frozen later -- still goes on the wire as zeros:
-                #  the peers will launch theirs)
-                self._launch(bi)
+        # Which buckets go on the wire must not depend on what THIS rank's backward happened to fire (ADVICE r4): a collective one rank
+        # launches and another does not pairs with the peer's next collective -- a hang or silent corruption under RCCL.
+        #   * first step (nothing agreed yet) and the fallback after a disagreement (`_launch_all`): EVERY bucket, in index order, zeros
+        #     for parameters without a gradient;
+        #   * afterwards: exactly the buckets of the agreed first step (`_expected` > 0 -- identical on every rank, checked by _agree), in
+        #     the agreed order, fired here or not (a tower frozen later still sends zeros: the peers launch theirs).
+        if first or self._launch_all:
+            todo = [bi for bi in range(len(self.buckets)) if self._count[bi] >= 0]
+        else:
+            todo = [bi for bi in self._order[self._next:] if self._count[bi] >= 0 and (self._expected[bi] or 0) > 0]
+            stray = [bi for bi in range(len(self.buckets)) if self._count[bi] > 0 and (self._expected[bi] or 0) == 0]
+            if stray:
+                raise RuntimeError(f"x_clip_amd GradSync: gradients arrived for bucket(s) {stray} that no rank reduced in the first step (a tower "
+                                   "unfrozen later?) -- their all-reduce cannot be launched from one rank's observation.  Build a new GradSync, "
+                                   "or use GradSync(model, overlap=False).")
+        for bi in todo:
+            self._launch(bi)
         for bi in range(len(self.buckets)):
             if self._count[bi] < 0:
                 if first:
