@@ -326,6 +326,39 @@ def main():
         "allocator": {"device_mallocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
                       "peak_reserved_gb": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 2)},
     }
+    if world > 1:
+        # Communication attribution: who is in the job, what the wire carries and how long the COMPUTE stream stalls for
+        # it -- an event pair on the current stream around every wait for a collective (x_clip_amd.distributed.CommProbe), over `steps` more
+        # steps of the same workload.  The prediction the first real 1 -> 8 curve is to be judged against: DESIGN.md section 4.
+        import socket
+        from x_clip_amd import distributed as xdist
+        xdist.COMM_PROBE = xdist.CommProbe()
+        for _ in range(args.steps):
+            step()
+        fence()
+        comm = xdist.COMM_PROBE.summary(args.steps)
+        xdist.COMM_PROBE = None
+        who = [None] * world
+        dist.all_gather_object(who, (socket.gethostname(), int(torch.cuda.current_device()), os.getpid()))
+        worst = torch.tensor([comm.get(k, {}).get("exposed_ms_per_step", 0.0) for k in ("latents_gather", "lse_gather", "scalar_allreduce", "gradsync_exposed")],
+                             dtype=torch.float64, device=dev)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)         # (the slowest rank's stall: that is what the step pays)
+        out["comm"] = {
+            "backend": dist.get_backend(), "pg_world_size": dist.get_world_size(), "ranks": [{"host": h, "device": d, "pid": p} for (h, d, p) in who],
+            "distinct_devices": len({(h, d) for (h, d, _) in who}),
+            "latents_gather_ms": round(float(worst[0]), 4), "lse_gather_ms": round(float(worst[1]), 4),
+            "scalar_allreduce_ms": round(float(worst[2]), 4), "gradsync_exposed_ms": round(float(worst[3]), 4),
+            "bucket_bytes": [sum(f.numel() * f.element_size() for f in fl) for fl in sync.flats],
+            "gradsync": {"buckets": len(sync.buckets), "overlap": bool(sync.overlap), "launched_from_hooks_agreed": bool(sync._agreed),
+                         "wire_dtype": str(sync.flats[0][0].dtype)},
+            "rank0": comm,
+            "measured": "HIP events on the compute stream around every wait for a collective (max over ranks), " + str(args.steps) + " extra steps; "
+                        "exposed = what the step pays, 0 when the collective finished under the kernels issued meanwhile",
+        }
+        n1 = os.environ.get("XCLIP_BENCH_N1_PAIRS_PER_S")
+        if n1:
+            out["comm"]["scaling_efficiency"] = round(value / (world * float(n1)), 4)
+            out["comm"]["scaling_efficiency_note"] = "value / (n_gpus x XCLIP_BENCH_N1_PAIRS_PER_S), the caller's 1-GPU figure (weak scaling: the per-GPU batch is fixed)"
     if measure_build:     # not a product line: the measurement build with whatever XCLIP_* switches were set
         out["build"] = {"library": "libxclip_hip_measure.so", "switches": {k: v for k, v in os.environ.items() if k.startswith("XCLIP_")}}
     if probe is not None:

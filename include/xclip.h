@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 18
+#define XCLIP_ABI_VERSION 19
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -127,6 +127,16 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
                int64_t M, int64_t N, int64_t K, float alpha, const void* bias, const void* residual, int64_t ldr,
                const void* addrows, const int32_t* rowidx, int64_t ld_add, void* workspace, int64_t workspace_bytes,
                int dtype, void* stream);
+
+/* ---- the inference returns (reference CLIP.forward with return_loss = False, x_clip.py:740-746) --------------------------------
+ * xclip_gemm_batched: `batch` independent products C_z[M,N] = alpha * op(A_z) op(B_z) with xclip_gemm's operand layouts, problem z at
+ *   A + z*stride_a (elements) etc.: einsum('b t d, b i d -> b t i') of the fine-grained (FILIP) similarities (0, 0) and its two gradients
+ *   (0, 1) / (1, 1).  No optional terms.
+ * xclip_rowdot: out[r] = <a[r,:], b[r,:]> in the operands' dtype: einsum('b d, b d -> b') of the matched pairs. */
+int xclip_gemm_batched(int a_kmajor, int b_kmajor, const void* A, int64_t lda, int64_t stride_a, const void* B, int64_t ldb, int64_t stride_b,
+                       void* C, int64_t ldc, int64_t stride_c, int64_t batch, int64_t M, int64_t N, int64_t K, float alpha, int dtype,
+                       void* stream);
+int xclip_rowdot(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t rows, int64_t dim, int dtype, void* stream);
 
 /* ---- fused attention (reference Attention.forward x_clip.py:201-245; any dim_head up to 128) ----------------------
  * head_dim = the width of a head slot in memory: 64 (the reference default; the head-resident kernels) or 128 (wide heads: two

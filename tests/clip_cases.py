@@ -259,6 +259,25 @@ def case_freeze_and_early_returns(dev, cfg, batch=8):
     torch.testing.assert_close(sim.double(), want, rtol=1e-4, atol=1e-5)
     with pytest.raises(AssertionError, match="loss cannot be used if not training"):
         m(text, image, return_loss=True)
+    # the inference returns stay differentiable (the reference's einsum is): d sim / d latent through the pair / token similarity kernels
+    from x_clip_amd import functional as XF
+    g = torch.Generator().manual_seed(11)
+    for (t, i, d) in ((5, 7, 16), (9, 12, 24)):
+        a = torch.randn(3, t, d, generator=g).to(dev).requires_grad_(True)
+        b = torch.randn(3, i, d, generator=g).to(dev).requires_grad_(True)
+        w = torch.randn(3, t, i, generator=g).to(dev)
+        (XF.token_similarity(a, b) * w).sum().backward()
+        ga, gb = a.grad.clone(), b.grad.clone()
+        a.grad = b.grad = None
+        ref = torch.einsum('b t d, b i d -> b t i', a, b)
+        torch.testing.assert_close(XF.token_similarity(a, b).detach(), ref.detach(), rtol=1e-5, atol=1e-5)
+        (ref * w).sum().backward()
+        torch.testing.assert_close(ga, a.grad, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(gb, b.grad, rtol=1e-5, atol=1e-5)
+    a = torch.randn(6, 24, generator=g).to(dev).requires_grad_(True)
+    b = torch.randn(6, 24, generator=g).to(dev).requires_grad_(True)
+    XF.pair_similarity(a, b).sum().backward()
+    torch.testing.assert_close(a.grad, b.detach(), rtol=1e-6, atol=1e-6)
 
 
 def case_pluggable_encoders_head_only(dev, B=24, d=64):

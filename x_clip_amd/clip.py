@@ -628,8 +628,8 @@ class CLIP(nn.Module):
             a, b = (text_latents_extra, image_latents_extra) if self.extra_latent_projection and not text_to_image \
                 else (text_latents, image_latents)
             if self.use_all_token_embeds:
-                return torch.einsum('b t d, b i d -> b t i', a, b) * temp
-            return torch.einsum('b d, b d -> b', a, b) * temp
+                return XF.token_similarity(a, b) * temp                                    # einsum('b t d, b i d -> b t i') * temp
+            return XF.pair_similarity(a, b) * temp                                         # einsum('b d, b d -> b') * temp
 
         # ---- training loss -----------------------------------------------------------------------------------------------
         def split_views(t, m):                                                             # '(m b) ... -> m b ...'

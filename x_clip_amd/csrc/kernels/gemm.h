@@ -45,6 +45,7 @@ struct GemmParams {
     float* partial;            // split-K slabs [splits][M][N] fp32, or null
     int k_per_split;
     int tiles_m, tiles_n;
+    long batch_a = 0, batch_b = 0, batch_c = 0;   // element strides between the problems of a batched launch (blockIdx.z; xclip_gemm_batched)
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const int m0 = (tile / p.tiles_n) * GEMM_BM, n0 = (tile % p.tiles_n) * GEMM_BN;
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
-    gemm_mainloop<T, A_KMAJOR, B_KMAJOR>(reinterpret_cast<const T*>(p.A), p.lda, reinterpret_cast<const T*>(p.B), p.ldb,
-                                         p.M, p.N, m0, n0, kbeg, kend, lds);
+    gemm_mainloop<T, A_KMAJOR, B_KMAJOR>(reinterpret_cast<const T*>(p.A) + (long)blockIdx.z * p.batch_a, p.lda,
+                                         reinterpret_cast<const T*>(p.B) + (long)blockIdx.z * p.batch_b, p.ldb, p.M, p.N, m0, n0, kbeg, kend, lds);
 
     // ---- epilogue: fp32 tile in LDS -> coalesced 16-byte stores ------------------------------------------
     constexpr int CPR = 128 / VEC;                          // output chunks per tile row
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         }
         return;
     }
-    T* C = reinterpret_cast<T*>(p.C);
+    T* C = reinterpret_cast<T*>(p.C) + (long)blockIdx.z * p.batch_c;
     const T* bias = reinterpret_cast<const T*>(p.bias);
     const T* resid = reinterpret_cast<const T*>(p.residual);
     const T* addr = reinterpret_cast<const T*>(p.addrows);

@@ -622,6 +622,28 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x
     if (lane == 0) rnorm_out[row] = rn;
 }
 
+// out[r] = <a[r, :], b[r, :]>: the similarity of matched pairs, the reference's inference return einsum('b d, b d -> b') (x_clip.py:744-746)
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, T* __restrict__ out,
+                                                     int rows, int D) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = lane_id();
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= rows) return;
+    float u[MAXC][VEC], w[MAXC][VEC];
+    load_row<T, MAXC, false>(a + row * lda, D, lane, u);
+    load_row<T, MAXC, false>(b + row * ldb, D, lane, w);
+    const int nch = D / VEC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (lane + 64 * i < nch)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) q += u[i][j] * w[i][j];
+    q = wave_sum(q);
+    if (lane == 0) out[row] = from_f32<T>(q);
+}
+
 template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                          const float* __restrict__ rnorm, T* __restrict__ dx,

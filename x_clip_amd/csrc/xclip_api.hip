@@ -981,6 +981,53 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
     return check_launch(__func__);
 }
 
+int xclip_gemm_batched(int a_kmajor, int b_kmajor, const void* A, int64_t lda, int64_t stride_a, const void* B, int64_t ldb, int64_t stride_b,
+                       void* C, int64_t ldc, int64_t stride_c, int64_t batch, int64_t M, int64_t N, int64_t K, float alpha, int dtype,
+                       void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(batch >= 0 && batch <= 65535 && M >= 0 && N > 0 && K > 0, "bad shape (up to 65535 problems per launch)");
+    XC_REQUIRE(N % vec == 0 && ldc % vec == 0 && lda % vec == 0 && ldb % vec == 0 && stride_a % vec == 0 && stride_b % vec == 0 && stride_c % vec == 0,
+               "N, the leading dimensions and the batch strides must be multiples of the 16-byte chunk");
+    const int64_t Kp = (K + vec - 1) / vec * vec, Mp = (M + vec - 1) / vec * vec;
+    XC_REQUIRE(a_kmajor ? (lda >= Mp) : (lda >= Kp), "lda must cover A's contiguous dim rounded up to the 16-byte chunk");
+    XC_REQUIRE(b_kmajor ? (ldb >= N) : (ldb >= Kp), "ldb must cover B's contiguous dim rounded up to the 16-byte chunk");
+    XC_REQUIRE(!(a_kmajor && !b_kmajor), "layout (A k-major, B normal) is not used on this path");
+    XC_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "pointers must be 16-byte aligned");
+    if (M == 0 || batch == 0) return 0;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.alpha = alpha;
+    p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.addrows = nullptr; p.rowidx = nullptr; p.ld_add = 0; p.partial = nullptr;
+    p.tiles_m = (int)((M + 127) / 128); p.tiles_n = (int)((N + 127) / 128);
+    p.k_per_split = (int)((K + 8 * vec - 1) / (8 * vec) * (8 * vec));
+    p.batch_a = stride_a; p.batch_b = stride_b; p.batch_c = stride_c;
+    dim3 grid(p.tiles_m * p.tiles_n, 1, (unsigned)batch), block(GEMM_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+#define XC_GB(T, AK, BK_) do { XC_ALLOW_LDS((gemm_kernel<T, AK, BK_>), GemmCfg<T>::LDS_BYTES); hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, block, GemmCfg<T>::LDS_BYTES, st, p); } while (0)
+    if (dtype == XCLIP_BF16) {
+        if (!a_kmajor && !b_kmajor) XC_GB(bf16_t, false, false); else if (!a_kmajor) XC_GB(bf16_t, false, true); else XC_GB(bf16_t, true, true);
+    } else {
+        if (!a_kmajor && !b_kmajor) XC_GB(float, false, false); else if (!a_kmajor) XC_GB(float, false, true); else XC_GB(float, true, true);
+    }
+#undef XC_GB
+    return check_launch(__func__);
+}
+
+int xclip_rowdot(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t rows, int64_t dim, int dtype, void* stream) {
+    XC_REQUIRE(dtype_ok(dtype), "bad dtype");
+    const int vec = vec_of(dtype);
+    XC_REQUIRE(dim > 0 && dim % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= dim && ldb >= dim, "dim / leading dimensions must be multiples of the 16-byte chunk");
+    XC_REQUIRE(aligned16(a) && aligned16(b) && out, "null or misaligned pointer");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, vec);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define F(T, C) hipLaunchKernelGGL((rowdot_kernel<T, C>), grid, block, 0, (hipStream_t)stream, (const T*)a, (long)lda, (const T*)b, (long)ldb, (T*)out, (int)rows, (int)dim)
+    XC_DISPATCH_ROW(dtype, cpl, F);
+#undef F
+    return check_launch(__func__);
+}
+
 int xclip_filip_reduce(const void* S, int64_t lds, const uint8_t* mask, const float* log_temp, float* t2i, float* i2t, int64_t ldo,
                        int16_t* kmax, int16_t* tmax, float* cnt, int64_t bx, int64_t nt, int64_t yc, int64_t ni, int64_t y0,
                        int64_t ytotal, int dtype, void* stream) {

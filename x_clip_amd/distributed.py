@@ -25,6 +25,65 @@ import torch.distributed as dist
 Tensor = torch.Tensor
 
 
+class CommProbe:
+    """bench.py (world > 1): how long the COMPUTE stream stalls for each collective.  An event pair on the current stream around every point
+    where it waits for a collective (`work.wait()` orders the stream behind the process group's own stream; a blocking collective is such a
+    point as a whole): the elapsed time between the pair is what the collective cost the step -- ~0 when it finished under the kernels
+    issued meanwhile -- and the payload says what the wire carried.  On CPU tensors (gloo tests) the host clock brackets the wait instead."""
+
+    def __init__(self):
+        self.records = []                                    # (tag, ev0 | t0, ev1 | t1, payload bytes)
+
+    def span(self, tag: str, t: Tensor, nbytes: int):
+        probe = self
+
+        class _Span:
+            def __enter__(self_inner):
+                if t.is_cuda:
+                    self_inner.a = torch.cuda.Event(enable_timing=True)
+                    self_inner.a.record(torch.cuda.current_stream(t.device))
+                else:
+                    import time
+                    self_inner.a = time.perf_counter()
+
+            def __exit__(self_inner, *exc):
+                if t.is_cuda:
+                    b = torch.cuda.Event(enable_timing=True)
+                    b.record(torch.cuda.current_stream(t.device))
+                else:
+                    import time
+                    b = time.perf_counter()
+                probe.records.append((tag, self_inner.a, b, int(nbytes)))
+                return False
+        return _Span()
+
+    def summary(self, steps: int):
+        """{tag: {exposed_ms_per_step, calls_per_step, payload_bytes_per_step}} (call after a device synchronisation)"""
+        out = {}
+        for tag, a, b, nb in self.records:
+            ms = a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3
+            e = out.setdefault(tag, {"exposed_ms_per_step": 0.0, "calls_per_step": 0.0, "payload_bytes_per_step": 0})
+            e["exposed_ms_per_step"] += ms / steps
+            e["calls_per_step"] += 1.0 / steps
+            e["payload_bytes_per_step"] += nb // steps
+        for e in out.values():
+            e["exposed_ms_per_step"] = round(e["exposed_ms_per_step"], 4)
+            e["calls_per_step"] = round(e["calls_per_step"], 2)
+        return out
+
+
+COMM_PROBE: Optional[CommProbe] = None                       # set by bench.py for its communication-attribution pass
+
+
+class _NoSpan:
+    def __enter__(self): return None
+    def __exit__(self, *exc): return False
+
+
+def _span(tag: str, t: Tensor, nbytes: int):
+    return COMM_PROBE.span(tag, t, nbytes) if COMM_PROBE is not None else _NoSpan()
+
+
 def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -54,8 +113,9 @@ class GatheredViews:
     chunks(v) -> [(tensor [rows_r, d], first global row)] with the LOCAL chunk first (available immediately) and the
     peers' chunks after it; call `wait()` before touching a peer chunk."""
 
-    def __init__(self, views: Sequence[Tensor], sizes: Sequence[int], group=None):
+    def __init__(self, views: Sequence[Tensor], sizes: Sequence[int], group=None, tag: str = "latents_gather"):
         self.group = group
+        self.tag = tag
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.sizes = list(sizes)
@@ -80,9 +140,10 @@ class GatheredViews:
 
     def wait(self):
         if not self._waited:
-            for w in self._works:
-                if w is not None:
-                    w.wait()                                   # orders the current stream after the collective
+            with _span(self.tag, self.bufs[0], sum(b.numel() * b.element_size() for b in self.bufs)):
+                for w in self._works:
+                    if w is not None:
+                        w.wait()                               # orders the current stream after the collective
             self._waited = True
 
     def chunks(self, v: int) -> List[Tuple[Tensor, int]]:
@@ -94,7 +155,8 @@ class GatheredViews:
 
 
 def all_reduce_scalars(t: Tensor, group=None) -> Tensor:
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    with _span("scalar_allreduce", t, t.numel() * t.element_size()):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -374,10 +436,13 @@ class GradSync:
             elif first:
                 self._expected[bi] = 0                       # never fired (frozen tower): nothing to reduce, on any rank (checked by _agree)
             self._count[bi] = 0
-        for work, flat in self._works:
-            if work is not None:
-                work.wait()                                  # orders the current stream behind the collective
-            flat.mul_(1.0 / self.world)
+        if self._works:
+            # (everything between the end of the backward and the last averaged bucket: launches of the buckets no hook completed, the waits)
+            with _span("gradsync_exposed", self._works[0][1], sum(f.numel() * f.element_size() for _, f in self._works)):
+                for work, flat in self._works:
+                    if work is not None:
+                        work.wait()                          # orders the current stream behind the collective
+                    flat.mul_(1.0 / self.world)
         with torch.no_grad():
             for p, v in self._cast_back:                     # fp32 wire: the mean goes back into the parameter's own gradient dtype
                 p.grad.copy_(v)

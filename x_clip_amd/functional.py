@@ -682,6 +682,67 @@ def l2norm(x: Tensor) -> Tensor:
     return _L2NormFn.apply(x)
 
 
+class _PairSimilarityFn(torch.autograd.Function):
+    """einsum('b d, b d -> b'): the similarity of matched pairs, the reference's inference return (x_clip.py:744-746)"""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor):
+        ctx.save_for_backward(a, b)
+        return ops.rowdot(a, b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ds):
+        a, b = ctx.saved_tensors
+        ds = ds.unsqueeze(-1)
+        return (ds * b if ctx.needs_input_grad[0] else None), (ds * a if ctx.needs_input_grad[1] else None)
+
+
+def pair_similarity(a: Tensor, b: Tensor) -> Tensor:
+    return _PairSimilarityFn.apply(a, b)
+
+
+def _pad_dim(x: Tensor, dim: int, mult: int) -> Tensor:
+    n = x.shape[dim]
+    if n % mult == 0:
+        return x.contiguous()
+    shape = list(x.shape)
+    shape[dim] = (n + mult - 1) // mult * mult
+    out = x.new_zeros(shape)
+    out.narrow(dim, 0, n).copy_(x)
+    return out
+
+
+class _TokenSimilarityFn(torch.autograd.Function):
+    """einsum('b t d, b i d -> b t i'): every text token against every image token of the MATCHED pair -- the reference's fine-grained
+    inference return (x_clip.py:742-743).  One batched launch forward, one per gradient (xclip_gemm_batched)."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor):
+        B, t, d = a.shape
+        i = b.shape[1]
+        v = ops.vec(a.dtype)
+        assert d % v == 0, "latent width must be a multiple of the 16-byte chunk"
+        a, bp = a.contiguous(), _pad_dim(b, 1, v)               # (the product's N is a whole number of chunks: zero rows behind the image tokens)
+        ctx.save_for_backward(a, b.contiguous())
+        return ops.bmm(a, bp, t, bp.shape[1], d)[:, :, :i]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ds):
+        a, b = ctx.saved_tensors
+        B, t, d = a.shape
+        i = b.shape[1]
+        dsp = _pad_dim(ds, 2, ops.vec(a.dtype))                 # [B, t, ip], zero columns behind i
+        da = ops.bmm(dsp, b, t, d, i, False, True) if ctx.needs_input_grad[0] else None          # dS b
+        db = ops.bmm(dsp, a, i, d, t, True, True) if ctx.needs_input_grad[1] else None           # dS^T a
+        return da, db
+
+
+def token_similarity(a: Tensor, b: Tensor) -> Tensor:
+    return _TokenSimilarityFn.apply(a, b)
+
+
 class _SelectRowFn(torch.autograd.Function):
     """enc[:, index] as a contiguous [b, D] tensor (x_clip.py:708-709); the backward scatters into a zeroed buffer."""
 

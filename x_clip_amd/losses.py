@@ -114,7 +114,8 @@ class _ContrastiveFn(torch.autograd.Function):
             w1 = xdist._gather_into(lse_all, send, spec.group, async_op=True)
             xdist.all_reduce_scalars(loss, spec.group)
             if w1 is not None:
-                w1.wait()
+                with xdist._span("lse_gather", lse_all, lse_all.numel() * 4):
+                    w1.wait()
         ctx.spec, ctx.plan, ctx.groups = spec, plan, groups
         ctx.mats, ctx.gathered, ctx.lse_local, ctx.lse_all = mats, gathered, lse_local, lse_all
         ctx.tau32, ctx.geom = tau32, (m, n, b, d, B, off, sizes, rank, extra, tau.dtype)

@@ -509,6 +509,34 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
     return out
 
 
+def bmm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False, alpha: float = 1.0) -> Tensor:
+    """one launch of B independent products out[z] = alpha * op(a[z]) op(b[z]) -> [B, M, N], gemm()'s operand layouts per problem (normal
+    a[z] [M, K] / b[z] [N, K]; k-major a[z] [K, M] / b[z] [K, N]); a, b 3-D with unit inner stride, N a multiple of the 16-byte chunk.  The
+    fine-grained similarities of matched pairs and their gradients (reference inference return einsum('b t d, b i d -> b t i'), x_clip.py:742-743)"""
+    _dev_check(a, b)
+    assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.dtype == b.dtype and a.stride(2) == 1 and b.stride(2) == 1
+    assert N % vec(a.dtype) == 0
+    B = a.shape[0]
+    out = torch.empty(B, M, N, dtype=a.dtype, device=a.device)
+    for z0 in range(0, B, 65535):
+        z1 = min(B, z0 + 65535)
+        _lib.check(_lib.lib().xclip_gemm_batched(int(a_kmajor), int(b_kmajor), a[z0:].data_ptr(), a.stride(1), a.stride(0), b[z0:].data_ptr(),
+                                                 b.stride(1), b.stride(0), out[z0:].data_ptr(), N, M * N, z1 - z0, M, N, K, alpha,
+                                                 dtype_code(a), _stream(a)), "xclip_gemm_batched")
+    return out
+
+
+def rowdot(a: Tensor, b: Tensor) -> Tensor:
+    """out[r] = <a[r], b[r]> for a, b [rows, d] (einsum('b d, b d -> b'), x_clip.py:744-746)"""
+    _dev_check(a, b)
+    a, b = _c(a), _c(b)
+    assert a.shape == b.shape and a.dim() == 2 and a.dtype == b.dtype
+    out = torch.empty(a.shape[0], dtype=a.dtype, device=a.device)
+    _lib.check(_lib.lib().xclip_rowdot(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), a.shape[0], a.shape[1],
+                                       dtype_code(a), _stream(a)), "xclip_rowdot")
+    return out
+
+
 # ---- attention --------------------------------------------------------------------------------------------------------
 def attention_fwd(qkv: Tensor, mask: Optional[Tensor], heads: int, scale: float, causal: bool = False,
                   head_dim: int = 64, dropout_p: float = 0.0, dropout_seed: int = 0) -> Tuple[Tensor, Tensor]:
