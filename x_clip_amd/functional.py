@@ -249,11 +249,14 @@ def _layer_forward_pooled(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads:
     h, m1, r1 = ops.layernorm_fwd(x, g_attn)
     xc = torch.empty(B, D, dtype=x.dtype, device=x.device)
     ops.copy_rows(_pool_view(x, B, n, row), xc)                                        # the skip connection's pooled rows
-    if rotary is None:
+    if rotary is None or row == 0:
         # one query per head: to_qkv's first third on the pooled rows, the other two on every row, attention_pool.h (causal: the pooled
-        # row sees the keys up to itself)
+        # row sees the keys up to itself).  Rotary encoders: keys and values are rotated at their positions; the query at position 0 is
+        # rotated by the angle 0 -- the identity (x_clip.py:155-176,221-223)
         q = ops.gemm(_pool_view(h, B, n, row), w_qkv[:inner], B, inner, D)
         kv = ops.gemm(h, w_qkv[inner:], M, 2 * inner, D)
+        if rotary is not None:
+            ops.rotary_(kv, n, rotary, head_dim=hs)
         oc, lse = ops.attention_pool_fwd(q, kv.view(B, n, 2 * inner), mask, heads, scale, hs, row + 1 if causal else None)
         qkv, o = (q, kv), oc                                                           # (the tape's qkv / o slots: the pooled forms)
     else:
@@ -287,11 +290,13 @@ def _layer_backward_pooled(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tenso
     dh2 = ops.gemm(du, w_ff1, B, D, F2, b_kmajor=True)
     d_ff1 = sg.wgrad(du, h2, F2, D, B, w_ff1) if need_w[2] else None
     dx1, dp = ops.layernorm_chain_bwd(dh2, x1, g_ff, m3, r3, dx2, p, g_out, m2, r2, dg_ff, dg_out)
-    if rotary is None:
+    if rotary is None or row == 0:
         q, kv = qkv
         d_out = sg.wgrad(dp, o, D, inner, B, w_out) if need_w[1] else None
         doc = ops.gemm(dp, w_out, B, inner, D, b_kmajor=True)
         dq, dkv = ops.attention_pool_bwd(q, kv.view(B, n, 2 * inner), mask, o, doc, lse, heads, scale, hs, row + 1 if causal else None)
+        if rotary is not None:
+            ops.rotary_(dkv.view(M, 2 * inner), n, rotary, inverse=True, head_dim=hs)      # the saved kv is the rotated one; R^T maps its gradient back
         # d h = dkv W_kv on every row, + dq W_q on the pooled rows (added with the skip gradient below)
         dh = ops.gemm(dkv.view(M, 2 * inner), w_qkv[inner:], M, D, 2 * inner, b_kmajor=True)
         dhq = ops.gemm(dq, w_qkv[:inner], B, D, inner, b_kmajor=True)
