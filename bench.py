@@ -189,6 +189,8 @@ def main():
     if measure_build:
         from x_clip_amd import _lib
         _lib.use_measurement_build()
+    if os.environ.get("XCLIP_BENCH_FFN_FUSED") == "0":        # own A/B: the feed-forward backward as xclip_gemm + xclip_layernorm_bwd (two kernels)
+        ops.FUSE_FFN_DGRAD = False
     if os.environ.get("XCLIP_FILIP_FUSED") == "0":           # own A/B: the chunked FILIP forward (materialised similarities + reduction passes)
         losses.FILIP_FUSED = False
     if os.environ.get("XCLIP_FILIP_CHUNK_MB"):                 # own A/B: size of the backward's routing-matrix chunks
@@ -442,6 +444,16 @@ def main():
                              "frac": round(f_h / s_h / MFMA_PEAK_BF16, 4), "hbm_frac": round(b_h / s_h / HBM_PEAK, 4),
                              "avg_launch_us": round(s_h / len(recs) * 1e6, 2),
                              "ms_per_step": round(s_h / max(args.steps, 1) * 1e3, 3), "launches_per_step": len(recs) // max(args.steps, 1)}
+        # round 5: net.4's input gradient + net.2's backward as one kernel (gemm9.h): neither a plain product nor a row kernel -- its own line,
+        # with the product's flops and the bytes it has to move (dout, x1, x2, u | t in; d(u | t) out)
+        recs = [r for r in probe.records if r[0] == "fused_ffn_bwd"]
+        if recs:
+            s_f = sum(r[2].elapsed_time(r[3]) for r in recs) * 1e-3
+            f_f, b_f = sum(r[1] for r in recs), sum(r[4] for r in recs)
+            fam["fused_ffn_bwd"] = {"bound": "hbm", "achieved": round(b_f / s_f / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                    "frac": round(b_f / s_f / HBM_PEAK, 4), "mfma_frac": round(f_f / s_f / MFMA_PEAK_BF16, 4),
+                                    "avg_launch_us": round(s_f / len(recs) * 1e6, 2),
+                                    "ms_per_step": round(s_f / max(args.steps, 1) * 1e3, 3), "launches_per_step": len(recs) // max(args.steps, 1)}
         out["roofline"]["families"] = fam
         out["roofline"]["families_ms_per_step"] = round(sum(v["ms_per_step"] for v in fam.values()), 3)
         out["roofline"]["probe_pass_ms_per_step"] = round(probe_elapsed / max(args.steps, 1) * 1e3, 3)

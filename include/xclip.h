@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 19
+#define XCLIP_ABI_VERSION 20
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -137,6 +137,18 @@ int xclip_gemm_batched(int a_kmajor, int b_kmajor, const void* A, int64_t lda, i
                        void* C, int64_t ldc, int64_t stride_c, int64_t batch, int64_t M, int64_t N, int64_t K, float alpha, int dtype,
                        void* stream);
 int xclip_rowdot(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t rows, int64_t dim, int dtype, void* stream);
+
+/* ---- the feed-forward block's backward through net.4 and net.2 in one product (reference FeedForward, x_clip.py:180-199) ----------------
+ * d(u | t) [M, 2F] = the GEGLU-LayerNorm backward of dh = dout [M, D] w2 [D, F], with dh never written: the two row statistics of the
+ * LayerNorm backward follow from dout, the block's input x1 and output x2 (= x1 + h w2^T) and the vector w2 gamma (csrc/kernels/gemm9.h).
+ * x [M, 2F] = FF1's output (value | gate), mean / rstd = the forward LayerNorm's statistics, dg_accum [F] fp32 += the gain's gradient.
+ * bf16, M and F multiples of 256, D a multiple of 64 (xclip_ffn_dgrad_geglu_ok); the caller runs xclip_gemm + xclip_layernorm_bwd otherwise. */
+int xclip_ffn_dgrad_geglu_ok(int64_t M, int64_t F, int64_t D, int dtype);
+int64_t xclip_ffn_dgrad_geglu_workspace_bytes(int64_t M, int64_t F, int64_t D);
+int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t ldw, const void* x, int64_t ldx, const void* gamma,
+                          const float* mean, const float* rstd, const void* x2, int64_t ld2, const void* x1, int64_t ld1, void* dx,
+                          int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes, int64_t M, int64_t F, int64_t D,
+                          int dtype, void* stream);
 
 /* ---- fused attention (reference Attention.forward x_clip.py:201-245; any dim_head up to 128) ----------------------
  * head_dim = the width of a head slot in memory: 64 (the reference default; the head-resident kernels) or 128 (wide heads: two

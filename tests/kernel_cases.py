@@ -117,6 +117,45 @@ def case_layernorm(dev, dtype, rows, dim, geglu, with_res):
     close(dg, g64.grad, dtype, "ln dg", mult=2.0)
 
 
+def case_ffn_dgrad_geglu(dev, M, F, D, seed=41):
+    """csrc/kernels/gemm9.h: net.4's input gradient + net.2's (GEGLU-LayerNorm) backward in one kernel, against fp64 autograd through
+    h = LayerNorm(u gelu(t)) g ; y = h W2^T and against the two-kernel path (xclip_gemm + xclip_layernorm_bwd).  The fused kernel takes its second row
+    statistic from x2 - x1 (the block's output minus its input, both rounded to bf16): x2 is built by the product's own forward"""
+    dt = torch.bfloat16
+    u = rnd((M, 2 * F), dt, seed)
+    g = (1 + 0.1 * rnd((F,), torch.float32, seed + 1)).to(dt)
+    w2 = (rnd((D, F), torch.float32, seed + 2) / math.sqrt(F)).to(dt)
+    x1 = rnd((M, D), dt, seed + 3)
+    dout = rnd((M, D), dt, seed + 4)
+    ud, gd, wd, x1d, dd = u.to(dev), g.to(dev), w2.to(dev), x1.to(dev), dout.to(dev)
+    a, mean, rstd = ops.layernorm_fwd(ud, gd, None, True)
+    x2 = ops.gemm(a, wd, M, D, F, residual=x1d)
+    assert ops.ffn_dgrad_geglu_ok(M, F, D, dt)
+    dx, dg = ops.ffn_dgrad_geglu(dd, wd, ud, gd, mean, rstd, x2, x1d)
+    # the two-kernel path
+    da = ops.gemm(dd, wd, M, F, D, b_kmajor=True)
+    dx2k, dg2k = ops.layernorm_bwd(da, ud, gd, mean, rstd, True)
+    # fp64 reference
+    u64 = ref64(u).requires_grad_(True)
+    g64 = ref64(g).requires_grad_(True)
+    v = O.geglu(u64)
+    mu = v.mean(-1, keepdim=True)
+    var = ((v - mu) ** 2).mean(-1, keepdim=True)
+    h = (v - mu) * torch.rsqrt(var + ops.ln_eps(dt)) * g64
+    (h @ ref64(w2).t()).backward(ref64(dout))
+    ref_dx, ref_dg = u64.grad, g64.grad
+    scale = float(ref_dx.abs().max())
+    e_f = float((dx.double().cpu() - ref_dx).abs().max()) / scale
+    e_2 = float((dx2k.double().cpu() - ref_dx).abs().max()) / scale
+    _record("ffn_dgrad_geglu dx fused (two-kernel path: %.2e)" % e_2, dt, e_f, max(2.0 * e_2, 2.0 ** -7), "of the output scale")
+    # no worse than twice the two-kernel path's own error (it rounds d a to bf16; the fused kernel keeps it in fp32 but takes s2 from bf16 x2 - x1)
+    assert e_f <= max(2.0 * e_2, 2.0 ** -7), (e_f, e_2)
+    gs = float(ref_dg.abs().max())
+    g_f = float((dg.double().cpu() - ref_dg).abs().max()) / gs
+    g_2 = float((dg2k.double().cpu() - ref_dg).abs().max()) / gs
+    assert g_f <= max(2.0 * g_2, 2.0 ** -7), (g_f, g_2)
+
+
 def case_l2norm(dev, dtype, rows, dim):
     x = rnd((rows, dim), dtype, 5)
     dy = rnd((rows, dim), dtype, 6)

@@ -39,6 +39,24 @@ def test_clip_bf16_vs_oracle():
     C.case_vs_oracle(DEV, torch.bfloat16, O.CFG1, 4, bf16_loss=1.4e-3)      # (the dim-64 toy model: measured 6.6e-4)
 
 
+def test_fused_ffn_backward_vs_oracle_and_two_kernel_path():
+    import dataclasses
+    """round 5: the feed-forward block's net.4 input gradient + net.2 backward as one kernel (csrc/kernels/gemm9.h) takes stacks whose rows and
+    hidden width are whole 256-tiles (bf16).  A 128-wide model with 8 x 32 text rows / 8 x 32 image tokens: every non-pooled layer of both towers
+    goes through it; against the fp64 oracle, and against the same step with the fusion off (gradients equal up to the rounding of d a)"""
+    from x_clip_amd import ops
+    cfg = dataclasses.replace(O.CFG1, dim_text=128, dim_image=128, text_seq_len=31, text_enc_depth=3, visual_image_size=128, visual_patch_size=16,
+                              visual_enc_depth=2)                      # image: 64 patches per sample, mean-pooled into the CLS slot: 8 x 64 rows
+    calls = []
+    orig = ops.ffn_dgrad_geglu
+    ops.ffn_dgrad_geglu = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        C.case_vs_oracle(DEV, torch.bfloat16, cfg, 8, bf16_loss=1.4e-3)
+    finally:
+        ops.ffn_dgrad_geglu = orig
+    assert len(calls) >= 3, calls                                      # (the text tower's two dense layers + the vision tower's)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_live_rows_vs_oracle(dtype):
     """the size-independent form of the GPU suite's full-size step test, at emulator size: 7 samples, 3 with a live upstream gradient"""

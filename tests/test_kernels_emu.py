@@ -31,6 +31,11 @@ def test_layernorm(dtype, rows, dim, geglu, res):
     K.case_layernorm(DEV, dtype, rows, dim, geglu, res)
 
 
+@pytest.mark.parametrize("M,F,D", [(256, 256, 128), (512, 512, 192)])
+def test_ffn_dgrad_geglu_fused(M, F, D):
+    K.case_ffn_dgrad_geglu(DEV, M, F, D)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
 def test_l2norm(dtype):
     K.case_l2norm(DEV, dtype, 7, 64)

@@ -117,6 +117,12 @@ def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_, res):
     assert worst <= 2.0, worst
 
 
+@pytest.mark.parametrize("M,F,D", [(2048, 512, 128), (33792, 2048, 512), (263168, 2048, 512)])
+def test_ffn_dgrad_geglu_fused(M, F, D):
+    """gemm9.h: net.4's input gradient + the GEGLU-LayerNorm backward in one kernel, at the vision / text towers' full sizes (every CU streaming)"""
+    K.case_ffn_dgrad_geglu(DEV, M, F, D)
+
+
 @pytest.mark.parametrize("layout,M,N,K_,alpha,in_place", [("nt", 4104, 512, 2048, 1.0, False), ("nn", 1024, 520, 256, 0.5, True), ("nt", 65792, 512, 2048, 1.0, False)])
 def test_gemm_residual_epilogue(layout, M, N, K_, alpha, in_place):
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha, residual_only=True, in_place=in_place)

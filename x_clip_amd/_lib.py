@@ -45,6 +45,9 @@ _SIGNATURES = {
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),
+    "xclip_ffn_dgrad_geglu_ok": (c_int, [L, L, L, I]),
+    "xclip_ffn_dgrad_geglu_workspace_bytes": (c_int64, [L, L, L]),
+    "xclip_ffn_dgrad_geglu": (c_int, [P, L, P, L, P, L, P, P, P, P, L, P, L, P, L, P, P, L, L, L, L, I, P]),
     "xclip_gemm_batched": (c_int, [I, I, P, L, L, P, L, L, P, L, L, L, L, L, L, F, I, P]),
     "xclip_rowdot": (c_int, [P, L, P, L, P, L, L, I, P]),
     "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, L, F, I, F, U, I, P]),
@@ -82,7 +85,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 def _bind(path: str):

@@ -11,6 +11,7 @@
 #include "kernels/gemm3.h"
 #include "kernels/gemm4.h"
 #include "kernels/gemm8.h"
+#include "kernels/gemm9.h"
 #ifdef XCLIP_MEASURE                                             // negative-result experiments, measurement build only
 #include "kernels/measure/gemm6.h"
 #include "kernels/measure/gemm7.h"
@@ -978,6 +979,60 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
             hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace,
                                (float*)C, (long)ldc, (int)M, (int)N, splits, alpha);
     }
+    return check_launch(__func__);
+}
+
+int xclip_ffn_dgrad_geglu_ok(int64_t M, int64_t F, int64_t D, int dtype) {
+    return dtype == XCLIP_BF16 && M > 0 && M % G2_BM == 0 && F % G2_BN == 0 && D % G2_BK == 0 && D >= 2 * G2_BK && D <= 4096 && F < (1L << 20) &&
+           (M / G2_BM) * (F / G2_BN) < (1L << 30);
+}
+int64_t xclip_ffn_dgrad_geglu_workspace_bytes(int64_t M, int64_t F, int64_t D) {
+    return ((D + 3) / 4 * 4 + 2 * M + 2 * (M / G2_BM) * F) * 4;
+}
+int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t ldw, const void* x, int64_t ldx, const void* gamma,
+                          const float* mean, const float* rstd, const void* x2, int64_t ld2, const void* x1, int64_t ld1, void* dx,
+                          int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes, int64_t M, int64_t F, int64_t D,
+                          int dtype, void* stream) {
+    XC_REQUIRE(xclip_ffn_dgrad_geglu_ok(M, F, D, dtype), "shape / dtype not taken by the fused kernel (xclip_ffn_dgrad_geglu_ok)");
+    XC_REQUIRE(dout && w2 && x && gamma && mean && rstd && x2 && x1 && dx && dg_accum, "null pointer");
+    XC_REQUIRE(aligned16(dout) && aligned16(w2) && aligned16(x) && aligned16(gamma) && aligned16(x2) && aligned16(x1) && aligned16(dx) && aligned16(workspace),
+               "pointers must be 16-byte aligned");
+    XC_REQUIRE(ldd % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && ld2 % 8 == 0 && ld1 % 8 == 0 && lddx % 8 == 0, "leading dimensions must be multiples of the 16-byte chunk");
+    XC_REQUIRE(ldd >= D && ld2 >= D && ld1 >= D && ldw >= F && ldx >= 2 * F && lddx >= 2 * F, "leading dimension too small");
+    XC_REQUIRE(ldd < (1L << 22) && ldw < (1L << 22) && ldx < (1L << 22) && lddx < (1L << 22), "leading dimensions beyond the 32-bit tile offsets");
+    XC_REQUIRE(workspace != nullptr && workspace_bytes >= xclip_ffn_dgrad_geglu_workspace_bytes(M, F, D), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* wg = (float*)workspace;
+    float* s1 = wg + (D + 3) / 4 * 4;
+    float* s2 = s1 + M;
+    float* slab = s2 + M;
+    hipLaunchKernelGGL(ffn_wgamma_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, (const bf16_t*)w2, (long)ldw, (const bf16_t*)gamma, wg, (int)D, (int)F);
+    hipLaunchKernelGGL(ffn_rowstats_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout, (long)ldd, (const bf16_t*)x2, (long)ld2,
+                       (const bf16_t*)x1, (long)ld1, (const float*)wg, s1, s2, (int)M, (int)D);
+    Gemm2Params q{};
+    q.A = (const bf16_t*)dout; q.B = (const bf16_t*)w2; q.C = nullptr; q.lda = ldd; q.ldb = ldw; q.ldc = F;
+    q.M = (int)M; q.N = (int)F; q.K = (int)D; q.alpha = 1.f;
+    q.bias = nullptr; q.residual = nullptr; q.ldr = 0; q.addrows = nullptr; q.rowidx = nullptr; q.ld_add = 0; q.partial = nullptr;
+    q.k_per_split = (int)D;
+    q.tiles_m = (int)(M / G2_BM); q.tiles_n = (int)(F / G2_BN);
+    q.band_n = 0;
+    if (q.tiles_n > 8)
+        for (int b = 8; b >= 4 && q.band_n == 0; --b)
+            if (q.tiles_n % b == 0) q.band_n = b;
+    q.stream_out = 1;
+    GegluBwdArgs e;
+    e.x = (const bf16_t*)x; e.ldx = ldx; e.dx = (bf16_t*)dx; e.lddx = lddx; e.gamma = (const bf16_t*)gamma;
+    e.mean = mean; e.rstd = rstd; e.s1 = s1; e.s2 = s2; e.dg_partial = slab; e.F = (int)F;
+    int gx = q.tiles_m * q.tiles_n;
+    const int cus = xc_num_cus();
+    if (gx > cus) gx = cus;
+    XC_ALLOW_LDS(gemm9_geglu_bwd_kernel, G5_LDS_BYTES);
+    hipLaunchKernelGGL(gemm9_geglu_bwd_kernel, dim3((unsigned)gx, 1), dim3(G2_THREADS), G5_LDS_BYTES, st, q, e);
+    const int nrows = 2 * q.tiles_m;
+    int slices = nrows / 64;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((F + 63) / 64), (unsigned)slices), dim3(256), 1024, st, (const float*)slab, (long)F, dg_accum,
+                       nrows, (int)F);
     return check_launch(__func__);
 }
 

@@ -192,8 +192,9 @@ def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, m
 
 def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
                     gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm", rotary: Optional[Tensor] = None,
-                    causal: bool = False, scale: float = 0.125, hs: int = 64, drop=(0.0, 0.0, 0)):
-    """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2])"""
+                    causal: bool = False, scale: float = 0.125, hs: int = 64, drop=(0.0, 0.0, 0), x2: Optional[Tensor] = None):
+    """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2]).
+    x2 = the layer's output (the next layer's saved input): with it the feed-forward block's first two backward steps run as one kernel"""
     p_attn, p_ff, seed = drop
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     dg_attn, dg_out, dg_ff, dg_inner = gain_acc
@@ -203,12 +204,17 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     F2 = w_ff1.shape[0]
     Fh = F2 // 2
     # feed-forward block
-    da = ops.gemm(dx2, w_ff2, M, Fh, D, b_kmajor=True)
-    d_ff2 = sg.wgrad(dx2, a, D, Fh, M, w_ff2) if need_w[3] else None      # (`a` is the dropped activation: what net.4 saw)
-    if p_ff > 0.0:
-        ops.dropout(da, p_ff, seed + 1, out=da)                                         # the same mask on the gradient
-    du, _ = ops.layernorm_bwd(da, u, g_inner, m4, r4, geglu=True, dg=dg_inner)
-    del da
+    if x2 is not None and p_ff == 0.0 and ops.ffn_dgrad_geglu_ok(M, Fh, D, dx2.dtype):
+        # net.4's input gradient and net.2's (GEGLU-LayerNorm) backward in one kernel: d a never reaches memory (csrc/kernels/gemm9.h)
+        du, _ = ops.ffn_dgrad_geglu(dx2, w_ff2, u, g_inner, m4, r4, x2, x1, dg=dg_inner)
+        d_ff2 = sg.wgrad(dx2, a, D, Fh, M, w_ff2) if need_w[3] else None
+    else:
+        da = ops.gemm(dx2, w_ff2, M, Fh, D, b_kmajor=True)
+        d_ff2 = sg.wgrad(dx2, a, D, Fh, M, w_ff2) if need_w[3] else None      # (`a` is the dropped activation: what net.4 saw)
+        if p_ff > 0.0:
+            ops.dropout(da, p_ff, seed + 1, out=da)                                         # the same mask on the gradient
+        du, _ = ops.layernorm_bwd(da, u, g_inner, m4, r4, geglu=True, dg=dg_inner)
+        del da
     dh2 = ops.gemm(du, w_ff1, M, D, F2, b_kmajor=True)
     d_ff1 = sg.wgrad(du, h2, F2, D, M, w_ff1) if need_w[2] else None
     del du
@@ -374,6 +380,7 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
     grads: List[Optional[Tensor]] = [None] * len(params)
     sg = _SideGemm(dy.device)
     dx, _ = ops.layernorm_bwd(dy, x_last, params[-1], m_out, r_out, dg=gg.views[-1])
+    x_out = x_last if pool_row is None else None             # the output of the layer being walked (= the saved input of the one above it)
     for l in reversed(range(spec.depth)):
         base = 1 + LAYER_PARAMS * l
         W = params[base: base + LAYER_PARAMS]
@@ -391,7 +398,8 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
                                              spec.dim_head ** -0.5, spec.head_slot, pool_row)
         else:
             dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
-                                      (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l))
+                                      (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l), x2=x_out)
+        x_out = saved[0]
         layers[l] = None                         # release this layer's activations
         sg.layer_done()
         grads[base + 1], grads[base + 2], grads[base + 5], grads[base + 7] = dws

@@ -136,6 +136,40 @@ def layernorm_bwd(dy: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, 
     return dx, dg
 
 
+FUSE_FFN_DGRAD = True      # the FF2 input gradient with the GEGLU-LayerNorm backward in its epilogue (csrc/kernels/gemm9.h); False = the two-kernel path
+
+
+def ffn_dgrad_geglu_ok(M: int, F: int, D: int, dtype) -> bool:
+    return FUSE_FFN_DGRAD and dtype == torch.bfloat16 and bool(_lib.lib().xclip_ffn_dgrad_geglu_ok(M, F, D, 1))
+
+
+def ffn_dgrad_geglu(dout: Tensor, w2: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, x2: Tensor, x1: Tensor,
+                    dg: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """d(u | t) of the feed-forward block from the gradient `dout` [M, D] of its output: the product dout w2 ([D, F] = net.4's weight) and
+    the GEGLU-LayerNorm backward in ONE kernel (gemm9.h).  x [M, 2F] = net.0's output, g / mean / rstd = net.2's gain and saved statistics,
+    x1 / x2 [M, D] = the block's input / output (x2 = x1 + net.4(...): the second row statistic is dout . (x2 - x1)).
+    -> (dx [M, 2F], dg fp32 [F], accumulated into `dg` when passed)"""
+    _dev_check(dout, w2, x, g, x2, x1)
+    M, D = dout.shape
+    F = w2.shape[1]
+    assert tuple(w2.shape) == (D, F) and tuple(x.shape) == (M, 2 * F) and tuple(x2.shape) == (M, D) and tuple(x1.shape) == (M, D)
+    assert all(t.stride(-1) == 1 for t in (dout, w2, x, x2, x1)) and mean.dtype == torch.float32 and rstd.dtype == torch.float32
+    dx = torch.empty_like(x)
+    if dg is None:
+        dg = torch.zeros(F, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = workspace(x.device, L.xclip_ffn_dgrad_geglu_workspace_bytes(M, F, D))
+    probe = _probe(x)
+    ev0 = probe.begin(x, "fused_ffn_bwd") if probe is not None else None
+    _lib.check(L.xclip_ffn_dgrad_geglu(dout.data_ptr(), dout.stride(0), w2.data_ptr(), w2.stride(0), x.data_ptr(), x.stride(0), _c(g).data_ptr(),
+                                       mean.data_ptr(), rstd.data_ptr(), x2.data_ptr(), x2.stride(0), x1.data_ptr(), x1.stride(0), dx.data_ptr(),
+                                       dx.stride(0), dg.data_ptr(), ws.data_ptr(), ws.numel(), M, F, D, dtype_code(x), _stream(x)),
+               "xclip_ffn_dgrad_geglu")
+    if probe is not None:      # the product's flops; reads dout, w2, x, x1, x2, writes dx
+        probe.end(x, ev0, "fused_ffn_bwd", 2.0 * M * F * D, (M * D * 3 + D * F + 4 * M * F) * 2, (M, F, D, "NN+geglu_ln_bwd", False))
+    return dx, dg
+
+
 def l2norm_fwd(x: Tensor) -> Tuple[Tensor, Tensor]:
     _dev_check(x)
     x = _c(x)
