@@ -422,6 +422,8 @@ inline void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
 }
 template <int IMM>
 inline void buf_st16_nt(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) { buf_st16<IMM>(r, voff, soff, v); }
+template <int IMM>
+inline u32x4 buf_ld16_nt(BufRsrc r, uint32_t voff, uint32_t soff) { return buf_ld16<IMM>(r, voff, soff); }
 inline u32x4 ld16_nt(const void* p) { u32x4 v; memcpy(&v, p, 16); return v; }
 inline void st16_nt(void* p, u32x4 v) { memcpy(p, &v, 16); }
 inline void wait_vmem() {}

@@ -164,6 +164,11 @@ template <int IMM>
 XC_DEV u32x4 buf_ld16(BufRsrc r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff + IMM, (int)soff, 0));
 }
+// the same load with the non-temporal hint (a line read once: it need not displace what the L2 holds)
+template <int IMM>
+XC_DEV u32x4 buf_ld16_nt(BufRsrc r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff + IMM, (int)soff, 2));
+}
 // 16-byte store at base + voff + soff + IMM (IMM: the instruction's 12-bit immediate offset), as one asm unit WITH two wait states
 // behind it (so the store is not part of the compiler's vmcnt bookkeeping: every wait around it is explicit or only ever too long).
 // The wait states are load-bearing: a 128-bit buffer store reads its four data VGPRs a little after it issues, and a

@@ -25,8 +25,8 @@ struct GegluBwdArgs {
     const bf16_t* x; long ldx;        // [M, 2 F]: value | gate, FF1's output
     bf16_t* dx; long lddx;            // [M, 2 F]: its gradient
     const bf16_t* gamma;              // [F] LayerNorm gain
-    const float* mean; const float* rstd;   // [M] statistics of the forward LayerNorm over a = u gelu(t)
-    const float* s1; const float* s2;       // [M] ffn_rowstats_kernel
+    const float* rowc;                // [M, 4] per row {rstd, -mean rstd, s1 / F rstd, s2 / F rstd} (ffn_rowstats_kernel; mean / rstd = the
+                                      // forward LayerNorm's statistics over a = u gelu(t))
     float* dg_partial;                // [2 tiles_m, F] per (row tile, wave row) column sums of dh ahat
     int F;
 };
@@ -44,7 +44,6 @@ struct G4GegluBwdEpilogue {
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
         const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
-        const float invF = 1.0f / (float)e.F;
         // whole-line descriptors of the tile's u, t, du, dt blocks
         const BufRsrc ru = make_rsrc(e.x + (long)m0 * e.ldx + n0, 255u * (uint32_t)e.ldx * 2u + 512u);
         const BufRsrc rt = make_rsrc(e.x + (long)m0 * e.ldx + e.F + n0, 255u * (uint32_t)e.ldx * 2u + 512u);
@@ -66,12 +65,15 @@ struct G4GegluBwdEpilogue {
         // gate quads; the next group's lines are requested once this group's have been consumed.
         u32x4 ul[4], tl[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { tl[k] = buf_ld16<0>(rt, vx, x8 * (uint32_t)k); ul[k] = buf_ld16<0>(ru, vx, x8 * (uint32_t)k); }
+        for (int k = 0; k < 4; ++k) { tl[k] = buf_ld16_nt<0>(rt, vx, x8 * (uint32_t)k); ul[k] = buf_ld16_nt<0>(ru, vx, x8 * (uint32_t)k); }
+        // a row's four constants {rstd, -mean rstd, s1 / F rstd, s2 / F rstd} (ffn_rowstats_kernel) as one 16-byte load, one group ahead
+        const float* const rs = e.rowc + ((long)m0 + wm * 128 + r) * 4;
+        u32x4 rc_next = ld16(rs);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wm * 128 + 32 * i + r;
-            const float rstd = e.rstd[row], shift = -e.mean[row] * rstd;
-            const float k1 = e.s1[row] * invF * rstd, k2 = e.s2[row] * invF * rstd;
+            const u32x4 rc = rc_next;
+            if (i < 3) rc_next = ld16(rs + (long)(i + 1) * 32 * 4);
+            const float rstd = u2f(rc[0]), shift = u2f(rc[1]), k1 = u2f(rc[2]), k2 = u2f(rc[3]);
             u32x2 tq[2][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(line + k * 1024) = tl[k];
@@ -87,8 +89,8 @@ struct G4GegluBwdEpilogue {
             if (i < 3) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    tl[k] = buf_ld16<0>(rt, vx, x8 * (uint32_t)(4 * (i + 1) + k));
-                    ul[k] = buf_ld16<0>(ru, vx, x8 * (uint32_t)(4 * (i + 1) + k));
+                    tl[k] = buf_ld16_nt<0>(rt, vx, x8 * (uint32_t)(4 * (i + 1) + k));
+                    ul[k] = buf_ld16_nt<0>(ru, vx, x8 * (uint32_t)(4 * (i + 1) + k));
                 }
             }
 #pragma unroll
@@ -184,10 +186,12 @@ __global__ __launch_bounds__(256) void ffn_wgamma_kernel(const bf16_t* __restric
     if (lane == 0) wg[row] = s;
 }
 
-// s1[r] = dOut[r, :] . wg,  s2[r] = dOut[r, :] . (x2[r, :] - x1[r, :]): one wave per row (D <= 4096 features)
+// the four per-row constants of the fused epilogue: with s1 = dOut[r, :] . wg and s2 = dOut[r, :] . (x2[r, :] - x1[r, :]),
+// rowc[r] = {rstd, -mean rstd, s1 / F rstd, s2 / F rstd}.  One wave per row (D <= 4096 features)
 __global__ __launch_bounds__(256) void ffn_rowstats_kernel(const bf16_t* __restrict__ dout, long ldd, const bf16_t* __restrict__ x2, long ld2,
                                                            const bf16_t* __restrict__ x1, long ld1, const float* __restrict__ wg,
-                                                           float* __restrict__ s1, float* __restrict__ s2, int rows, int D) {
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ rowc, int rows, int D, float invF) {
     const int lane = lane_id();
     const long row = (long)blockIdx.x * 4 + wave_id();
     if (row >= rows) return;
@@ -204,7 +208,11 @@ __global__ __launch_bounds__(256) void ffn_rowstats_kernel(const bf16_t* __restr
     }
     a1 = wave_sum(a1);
     a2 = wave_sum(a2);
-    if (lane == 0) { s1[row] = a1; s2[row] = a2; }
+    if (lane == 0) {
+        const float rs = rstd[row];
+        const u32x4 v = {f2u(rs), f2u(-mean[row] * rs), f2u(a1 * invF * rs), f2u(a2 * invF * rs)};
+        st16(rowc + row * 4, v);
+    }
 }
 
 }  // namespace xc

@@ -987,7 +987,7 @@ int xclip_ffn_dgrad_geglu_ok(int64_t M, int64_t F, int64_t D, int dtype) {
            (M / G2_BM) * (F / G2_BN) < (1L << 30);
 }
 int64_t xclip_ffn_dgrad_geglu_workspace_bytes(int64_t M, int64_t F, int64_t D) {
-    return ((D + 3) / 4 * 4 + 2 * M + 2 * (M / G2_BM) * F) * 4;
+    return ((D + 3) / 4 * 4 + 4 * M + 2 * (M / G2_BM) * F) * 4;
 }
 int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t ldw, const void* x, int64_t ldx, const void* gamma,
                           const float* mean, const float* rstd, const void* x2, int64_t ld2, const void* x1, int64_t ld1, void* dx,
@@ -1003,12 +1003,11 @@ int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t
     XC_REQUIRE(workspace != nullptr && workspace_bytes >= xclip_ffn_dgrad_geglu_workspace_bytes(M, F, D), "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* wg = (float*)workspace;
-    float* s1 = wg + (D + 3) / 4 * 4;
-    float* s2 = s1 + M;
-    float* slab = s2 + M;
+    float* rowc = wg + (D + 3) / 4 * 4;
+    float* slab = rowc + 4 * M;
     hipLaunchKernelGGL(ffn_wgamma_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, (const bf16_t*)w2, (long)ldw, (const bf16_t*)gamma, wg, (int)D, (int)F);
     hipLaunchKernelGGL(ffn_rowstats_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout, (long)ldd, (const bf16_t*)x2, (long)ld2,
-                       (const bf16_t*)x1, (long)ld1, (const float*)wg, s1, s2, (int)M, (int)D);
+                       (const bf16_t*)x1, (long)ld1, (const float*)wg, mean, rstd, rowc, (int)M, (int)D, 1.0f / (float)F);
     Gemm2Params q{};
     q.A = (const bf16_t*)dout; q.B = (const bf16_t*)w2; q.C = nullptr; q.lda = ldd; q.ldb = ldw; q.ldc = F;
     q.M = (int)M; q.N = (int)F; q.K = (int)D; q.alpha = 1.f;
@@ -1022,7 +1021,7 @@ int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t
     q.stream_out = 1;
     GegluBwdArgs e;
     e.x = (const bf16_t*)x; e.ldx = ldx; e.dx = (bf16_t*)dx; e.lddx = lddx; e.gamma = (const bf16_t*)gamma;
-    e.mean = mean; e.rstd = rstd; e.s1 = s1; e.s2 = s2; e.dg_partial = slab; e.F = (int)F;
+    e.rowc = rowc; e.dg_partial = slab; e.F = (int)F;
     int gx = q.tiles_m * q.tiles_n;
     const int cus = xc_num_cus();
     if (gx > cus) gx = cus;
