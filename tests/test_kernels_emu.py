@@ -102,6 +102,12 @@ def test_attention_causal_long_bf16(n):
     K.case_attention(DEV, torch.bfloat16, 1, n, 1, True, causal=True)
 
 
+@pytest.mark.parametrize("n,heads,masked", [(64, 2, False), (96, 1, True), (129, 2, True), (256, 1, True), (257, 1, False)])
+def test_attention_single_pass_backward(n, heads, masked):
+    """attention5.h: the backward as one pass over the (query block, key block) pairs (whole 32-blocks, or whole blocks + one tail row)"""
+    K.case_attention(DEV, torch.bfloat16, 2, n, heads, masked)
+
+
 def test_attention_single_tail_row():
     """257 = 8 x 32 + 1 tokens, not causal: the tail key / query as the accumulators' initial values (no 33rd block), with and without masks"""
     K.case_attention_single_tail(DEV, torch.bfloat16)

@@ -1,0 +1,250 @@
+// attention5.h -- the head-resident attention backward as ONE pass over the (query block, key block) pairs.
+//
+// attention3.h's backward visits every pair twice: phase A (dQ for the wave's queries) and phase B (dK, dV for the wave's keys) each
+// recompute S and dP and their exponentials -- 28 MFMAs and two rounds of score arithmetic per 32 x 32 pair.  Here a pair is computed
+// once, by the wave that owns its KEY block (dK, dV in registers as in phase B: 16 MFMAs), and its dS goes -- rounded to bf16, as the
+// dK product uses it -- through a 4 KiB LDS tile to the wave that owns its QUERY block, which adds dS K to its dQ accumulators
+// (4 MFMAs): 20 MFMAs and one round of score arithmetic per pair.  The schedule is a rotation: in step s wave w computes the pair
+// (query block (w + s) mod nb, key block w), so the nb waves work on nb different query blocks and every query-block owner finds exactly
+// one new tile behind the step's barrier -- no atomics, no fp32 dQ tile in LDS, deterministic.
+//
+// One work-group of nb = n / 32 <= 8 waves per head: Q, dO and K images (the K image is the A operand of the dQ product) + nb exchange
+// tiles = 146 KiB at n = 257.  Sequences of 32 nb + 1 tokens (the text encoder's CLS + 256) keep the tail row out of the MFMA blocks the way
+// attention3.h does (a3_tail_dot / a3_tail_outer: the tail row's contribution is the accumulators' initial value); the sums over a wave's 32
+// lanes that the tail's own gradients need (dQ_tail = sum_k dS k, dK_tail = sum_q dS q, dV_tail = sum_q P dO) are MFMAs whose B operand has
+// one live column.  Non-causal, no dropout, 64-wide head slots; everything else stays on attention3.h.
+#pragma once
+#include "attention3.h"
+
+namespace xc {
+
+XC_HOST_DEV bool a5_takes(int n, int causal) { return !causal && ((n & 31) == 0 || (n & 31) == 1) && (n >> 5) >= 2 && (n >> 5) <= 8; }
+inline int attn5_bwd_lds_bytes(int n) {
+    const int npad = (n + 31) & ~31, nb = n >> 5;
+    return 3 * npad * 128 + nb * 4096 + npad + 2 * npad * 4 + nb * 192 * 4 + nb * 64 * 4 + 64;
+}
+
+// <f (this lane's row fragments: 8 features per k-block for its half), row>: `rowp` = a row of 64 features in global memory (a
+// broadcast load: every lane of a half-wave reads the same 16 bytes)
+XC_DEV float a5_row_dot(const bf16_t* rowp, const u32x4 (&f)[4], int lane) {
+    const int h = lane >> 5;
+    float acc = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const u32x4 g = ld16(rowp + kb * 16 + h * 8);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc = dot2_bf16(f[kb][w], g[w], acc);
+    }
+    return acc + shfl_xor(acc, 32);
+}
+// the MFMA B operand whose column 0 holds v[k] (k = the 32 contraction slots of a 32-row block, one value per lane c31 = k in `mine`)
+// and whose other 31 columns are zero: the lanes exchange their values through 32 floats of LDS (`sc`, this wave's own)
+XC_DEV void a5_column_operand(float* sc, float mine, int lane, u32x4 (&bf)[2]) {
+    const int c31 = lane & 31, h = lane >> 5;
+    wave_sync();
+    if (h == 0) sc[c31] = mine;
+    wave_sync();
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const u32x4 lo = ld16(sc + 16 * blk + 4 * h), hi = ld16(sc + 16 * blk + 8 + 4 * h);
+        const u32x4 v = {f2bf_pk(u2f(lo[0]), u2f(lo[1])), f2bf_pk(u2f(lo[2]), u2f(lo[3])), f2bf_pk(u2f(hi[0]), u2f(hi[1])), f2bf_pk(u2f(hi[2]), u2f(hi[3]))};
+        bf[blk] = c31 == 0 ? v : zero16();
+    }
+    wave_sync();
+}
+// out[d] (64 floats, lane c31 = 0 of both halves writes) = sum_k X^T[d, k] v[k] over the 32 rows of sub-tile t of image X
+XC_DEV void a5_weighted_row_sum(const unsigned char* X, int t, float* sc, float mine, int lane, float* out) {
+    u32x4 bf[2];
+    a5_column_operand(sc, mine, lane, bf);
+    f32x16 acc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) acc[db] = mma_kblock(a3_col_frag(X, t, blk, db, lane), bf[blk], acc[db], (bf16_t*)nullptr);
+    if ((lane & 31) == 0) a3_put_col(out, acc, lane);
+}
+
+__global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
+    XC_LDS_DYNAMIC(lds);
+    const int n = p.n, nb = n >> 5, tail = n & 31, npad = (n + 31) & ~31, nsub = npad >> 5;
+    const int img = npad * 128;
+    unsigned char* Qs = lds;
+    unsigned char* dOs = Qs + img;
+    unsigned char* Ks = dOs + img;
+    unsigned char* Xs = Ks + img;                              // [nb] dS exchange tiles, image format (32 key rows x 128-byte pitch)
+    unsigned char* Ms = Xs + nb * 4096;                        // [npad] key validity
+    float* Ls = reinterpret_cast<float*>(Ms + npad);           // [npad] lse log2(e) per query
+    float* Ds = Ls + npad;                                     // [npad] delta per query
+    float* Tp = Ds + npad;                                     // [nb][3][64] the waves' partials of the tail row's dQ | dK | dV
+    float* Sc = Tp + nb * 192;                                 // [nb][64] per-wave scratch of a5_column_operand
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c31 = lane & 31;
+    const int wave = uniform(tid >> 6), nwaves = nb;
+    const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
+    const int hh = bh % p.heads, bi = bh / p.heads;
+    const long ldq = 3L * p.heads * ATT_DH, ldo = (long)p.heads * ATT_DH;
+    const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.qkv) + (long)bi * n * ldq + hh * ATT_DH;
+    const bf16_t* Kb = Qb + (long)p.heads * ATT_DH;
+    const bf16_t* Vb = Kb + (long)p.heads * ATT_DH;
+    const bf16_t* dOb = reinterpret_cast<const bf16_t*>(p.dout) + (long)bi * n * ldo + hh * ATT_DH;
+    const bf16_t* Ob = reinterpret_cast<const bf16_t*>(p.out) + (long)bi * n * ldo + hh * ATT_DH;
+    bf16_t* dQ = reinterpret_cast<bf16_t*>(p.dqkv) + (long)bi * n * ldq + hh * ATT_DH;
+    bf16_t* dK = dQ + (long)p.heads * ATT_DH;
+    bf16_t* dV = dK + (long)p.heads * ATT_DH;
+    a3_dma_image(Qs, Qb, ldq, n, npad, wave, nwaves, lane);
+    a3_dma_image(dOs, dOb, ldo, n, npad, wave, nwaves, lane);
+    a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
+    a3_key_validity(Ms, p.mask, (long)bi * n, n, npad);
+    const float scale2 = p.scale * 1.4426950408889634f;
+    // delta_i = sum_d dO[i, d] O[i, d] and lse_i log2(e) (as attention3.h)
+    for (int blk = wave; blk < nsub; blk += nwaves) {
+        const int row_ = blk * 32 + c31;
+        const int rl = row_ < n ? row_ : n - 1;
+        const float lse_r = p.lse[((long)bi * p.heads + hh) * n + rl];
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a[8], b[8];
+            load_vec<bf16_t>(Ob + (long)rl * ldo + h * 32 + c * 8, a);
+            load_vec<bf16_t>(dOb + (long)rl * ldo + h * 32 + c * 8, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += a[k] * b[k];
+        }
+        acc += shfl_xor(acc, 32);
+        if (h == 0) {
+            Ds[row_] = row_ < n ? acc : 0.f;
+            Ls[row_] = row_ < n ? lse_r * 1.4426950408889634f : 0.f;
+        }
+    }
+    // the wave's own key block: K, V rows straight from global memory (L2 hits: the image DMA asks for the same lines)
+    const int row = wave * 32 + c31;                           // (< n: the wave's block is a full one)
+    u32x4 kf[4], vf[4];
+    a3_row_frags(Kb, ldq, row, lane, kf);
+    a3_row_frags(Vb, ldq, row, lane, vf);
+    wait_vmem();
+    sync();
+    const bool kvalid = Ms[row] != 0;
+    const bool masked = !wave_all(kvalid);                     // (uniform) padding among this block's keys
+    f32x16 dk[2], dv[2], dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; dq[db][r] = 0.f; }
+    float* const sc = Sc + wave * 64;
+    if (tail) {                                                // (uniform) n = 32 nb + 1: the tail row, sub-tile nb row 0 of the images
+        const int trow = 32 * nb;
+        // the tail QUERY against this wave's keys (a lane owns a key): dK, dV start at its contribution; dQ_tail's partial sum
+        {
+            const float st = a3_tail_dot(Qs, nb, 0, kf, lane), dpt = a3_tail_dot(dOs, nb, 0, vf, lane);
+            const float pt = kvalid ? fast_exp2(st * scale2 - Ls[trow]) : 0.f;
+            const float ds = pt * (dpt - Ds[trow]);            // dS / scale
+            a3_tail_outer(Qs, nb, 0, ds, lane, dk);
+            a3_tail_outer(dOs, nb, 0, pt, lane, dv);
+            a5_weighted_row_sum(Ks, wave, sc, ds, lane, Tp + (wave * 3 + 0) * 64);          // sum_k dS[k] K[k]
+        }
+        // the tail KEY against this wave's queries (a lane owns a query): dQ starts at its contribution; dK_tail / dV_tail partial sums
+        {
+            u32x4 qf[4], dof[4];
+            a3_row_frags(Qb, ldq, row, lane, qf);
+            a3_row_frags(dOb, ldo, row, lane, dof);
+            const float st = a3_tail_dot(Ks, nb, 0, qf, lane), dpt = a5_row_dot(Vb + (long)trow * ldq, dof, lane);
+            const float pt = Ms[trow] != 0 ? fast_exp2(st * scale2 - Ls[row]) : 0.f;
+            const float ds = pt * (dpt - Ds[row]);
+            a3_tail_outer(Ks, nb, 0, ds, lane, dq);
+            a5_weighted_row_sum(Qs, wave, sc, ds, lane, Tp + (wave * 3 + 1) * 64);          // sum_q dS[q] Q[q]
+            a5_weighted_row_sum(dOs, wave, sc, pt, lane, Tp + (wave * 3 + 2) * 64);         // sum_q P[q] dO[q]
+        }
+    }
+    unsigned char* const myX = Xs + wave * 4096;
+    for (int s = 0; s < nb; ++s) {
+        const int t = wave + s < nb ? wave + s : wave + s - nb;         // the query block of this step's pair (uniform)
+        {
+            u32x4 qa[4], da[4];
+            a3_tile_rows(Qs, t, lane, qa);
+            a3_tile_rows(dOs, t, lane, da);
+            f32x16 sv, dp;
+            float l2[16], dl[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 a = ld16(Ls + t * 32 + 8 * q + 4 * h), b = ld16(Ds + t * 32 + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { l2[4 * q + e] = u2f(a[e]); dl[4 * q + e] = u2f(b[e]); }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sv[r] = 0.f; dp[r] = -dl[r]; }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                sv = mma_kblock(qa[kb], kf[kb], sv, (bf16_t*)nullptr);
+                dp = mma_kblock(da[kb], vf[kb], dp, (bf16_t*)nullptr);
+            }
+            if (masked) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = kvalid ? fast_exp2(sv[r] * scale2 - l2[r]) : 0.f;
+                    sv[r] = pv;
+                    dp[r] = pv * dp[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sv[r] = fast_exp2(sv[r] * scale2 - l2[r]);
+                    dp[r] = sv[r] * dp[r];
+                }
+            }
+            u32x4 df[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const u32x4 pf = a2_pack_acc(sv, blk);
+                df[blk] = a2_pack_acc(dp, blk);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = mma_kblock(a3_col_frag(dOs, t, blk, db, lane), pf, dv[db], (bf16_t*)nullptr);
+                    dk[db] = mma_kblock(a3_col_frag(Qs, t, blk, db, lane), df[blk], dk[db], (bf16_t*)nullptr);
+                }
+            }
+            // dS (bf16, as the dK product used it) to the owner of query block t: row = this lane's key, quad g = queries 8 g + 4 h + 0..3
+            // (the packed operand df[blk] holds exactly those quads: registers 8 blk + 0..7 = quads 2 blk, 2 blk + 1)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x2 v = {df[g >> 1][2 * (g & 1)], df[g >> 1][2 * (g & 1) + 1]};
+                *reinterpret_cast<u32x2*>(myX + c31 * 128 + a2_slot(c31, g) * 16 + 8 * h) = v;
+            }
+        }
+        sync();                                                // every tile of this step is in place
+        {
+            const int pw = wave - s >= 0 ? wave - s : wave - s + nb;    // who computed (query block `wave`, key block pw)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const u32x4 dsf = a3_col_frag(Xs, pw, blk, 0, lane);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) dq[db] = mma_kblock(a3_col_frag(Ks, pw, blk, db, lane), dsf, dq[db], (bf16_t*)nullptr);
+            }
+        }
+        sync();                                                // ... and has been consumed: the tiles may be overwritten
+    }
+    a3_store_rows_direct(dq, dQ, ldq, wave * 32, n, lane, p.scale);
+    a3_store_rows_direct(dk, dK, ldq, wave * 32, n, lane, p.scale);
+    a3_store_rows_direct(dv, dV, ldq, wave * 32, n, lane);
+    if (tail && wave == 0) {                                   // the tail row's own gradients; lane = feature d (the partials are in: the loop's barriers)
+        const int trow = 32 * nb;
+        const float qv = bf2f(Qb[(long)trow * ldq + lane]), kv = bf2f(Kb[(long)trow * ldq + lane]), vv = bf2f(Vb[(long)trow * ldq + lane]);
+        const float dov = bf2f(dOb[(long)trow * ldo + lane]);
+        const float st = wave_sum(qv * kv), dpt = wave_sum(dov * vv);           // tail query x tail key
+        const float pt = Ms[trow] != 0 ? fast_exp2(st * scale2 - Ls[trow]) : 0.f;
+        const float ds = pt * (dpt - Ds[trow]);
+        float aq = ds * kv, ak = ds * qv, av = pt * dov;
+        for (int w = 0; w < nb; ++w) {
+            aq += Tp[(w * 3 + 0) * 64 + lane];
+            ak += Tp[(w * 3 + 1) * 64 + lane];
+            av += Tp[(w * 3 + 2) * 64 + lane];
+        }
+        dQ[(long)trow * ldq + lane] = f2bf(aq * p.scale);
+        dK[(long)trow * ldq + lane] = f2bf(ak * p.scale);
+        dV[(long)trow * ldq + lane] = f2bf(av);
+    }
+}
+
+}  // namespace xc

@@ -9,6 +9,7 @@
 #include "kernels/attention2.h"
 #include "kernels/attention3.h"
 #include "kernels/attention4.h"
+#include "kernels/attention5.h"
 #include "kernels/attention_pool.h"
 
 using namespace xc;
@@ -187,6 +188,13 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     }
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N && !tiled_only) {               // merged head-resident backward (computes delta itself)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
+        // the single-pass form (attention5.h) for the sequences it takes; XCLIP_ATTN_BWD=3 (measurement build) keeps the two-phase kernel for the A/B
+        static const int bwd_gen = measure_env("XCLIP_ATTN_BWD", 5);
+        if (bwd_gen == 5 && a5_takes((int)n, causal) && attn5_bwd_lds_bytes((int)n) <= 160 * 1024) {
+            XC_ALLOW_LDS(attn5_bwd_kernel, 160 * 1024);
+            hipLaunchKernelGGL(attn5_bwd_kernel, dim3((unsigned)(batch * heads)), dim3((unsigned)((n >> 5) * 64)), attn5_bwd_lds_bytes((int)n), st, p);
+            return check_launch(__func__);
+        }
         const int nwq = a3_bwd_waves((int)n);
         static const int abl = measure_env("XCLIP_ATTN_ABL", 0);   // measurement build only
         p.chunks = abl;
