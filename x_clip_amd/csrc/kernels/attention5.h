@@ -18,10 +18,35 @@
 
 namespace xc {
 
+constexpr int A5_MIN_BLOCKS = 7;
+constexpr int A5_TILE = 32 * 64;                               // a dS exchange tile: 32 key rows x 32 queries, bf16
+
+// The exchange tile: row = key (64-byte pitch), 16-byte chunk c (queries 8 c .. 8 c + 7) at chunk position c ^ ((row >> 2) & 3) -- the
+// 8-byte writes of a half-wave's 32 rows then spread over all banks.  The writer owns a key row; the reader wants the MFMA operand whose
+// contraction index runs over the KEYS and whose lane index is the query: a transposing read, as a3_col_frag does on the operand images.
+XC_DEV void a5_tile_put(unsigned char* tile, int c31, int h, int g, u32x2 v) {
+    *reinterpret_cast<u32x2*>(tile + c31 * 64 + ((g ^ ((c31 >> 2) & 3)) << 4) + 8 * h) = v;
+}
+XC_DEV u32x4 a5_tile_frag(const unsigned char* tile, int blk, int lane) {
+    const int g = lane >> 4, tt = lane & 15;
+    const int r0 = 16 * blk + 4 * (g >> 1) + (tt >> 2);        // + 8 for the second half of the k-block
+    const int col = 16 * (g & 1) + (tt & 3) * 4;               // query column (a multiple of 4)
+    const int lo_off = r0 * 64 + (((col >> 3) ^ ((r0 >> 2) & 3)) << 4) + (col & 7) * 2;
+    const int hi_off = (r0 + 8) * 64 + (((col >> 3) ^ (((r0 + 8) >> 2) & 3)) << 4) + (col & 7) * 2;
+    const s16x4 lo = lds_read_tr16(tile + lo_off);
+    const s16x4 hi = lds_read_tr16(tile + hi_off);
+    const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+    u32x4 f = {a[0], a[1], b[0], b[1]};
+    return f;
+}
+
+// (measured, b = 1024, 8 heads: n = 256 755 against 783 us, n = 257 899 against 907; n = 129 508 against 413 -- four waves in one work-group
+//  leave every SIMD with one wave: only the eight-block sequences go this way; profiles/r05_l_attn_bwd_*.log)
 XC_HOST_DEV bool a5_takes(int n, int causal) { return !causal && ((n & 31) == 0 || (n & 31) == 1) && (n >> 5) >= 2 && (n >> 5) <= 8; }
+XC_HOST_DEV bool a5_prefers(int n) { return (n >> 5) >= A5_MIN_BLOCKS; }
 inline int attn5_bwd_lds_bytes(int n) {
     const int npad = (n + 31) & ~31, nb = n >> 5;
-    return 3 * npad * 128 + nb * 4096 + npad + 2 * npad * 4 + nb * 192 * 4 + nb * 64 * 4 + 64;
+    return 3 * npad * 128 + 2 * nb * A5_TILE + npad + 2 * npad * 4 + nb * 192 * 4 + nb * 64 * 4 + 64;
 }
 
 // <f (this lane's row fragments: 8 features per k-block for its half), row>: `rowp` = a row of 64 features in global memory (a
@@ -75,8 +100,8 @@ __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
     unsigned char* Qs = lds;
     unsigned char* dOs = Qs + img;
     unsigned char* Ks = dOs + img;
-    unsigned char* Xs = Ks + img;                              // [nb] dS exchange tiles, image format (32 key rows x 128-byte pitch)
-    unsigned char* Ms = Xs + nb * 4096;                        // [npad] key validity
+    unsigned char* Xs = Ks + img;                              // [2][nb] dS exchange tiles (a5_tile_put / a5_tile_frag), two steps deep
+    unsigned char* Ms = Xs + 2 * nb * A5_TILE;                 // [npad] key validity
     float* Ls = reinterpret_cast<float*>(Ms + npad);           // [npad] lse log2(e) per query
     float* Ds = Ls + npad;                                     // [npad] delta per query
     float* Tp = Ds + npad;                                     // [nb][3][64] the waves' partials of the tail row's dQ | dK | dV
@@ -86,6 +111,14 @@ __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
     const int bh = xcd_remap(blockIdx.x, p.batch * p.heads);
     const int hh = bh % p.heads, bi = bh / p.heads;
     const long ldq = 3L * p.heads * ATT_DH, ldo = (long)p.heads * ATT_DH;
+    const float scale2 = p.scale * 1.4426950408889634f;
+    const int row = wave * 32 + c31;                           // this lane's key (and query) of the wave's block (< n: a full block)
+    // (A persistent form -- one work-group per CU walking heads, the next head's Q / dO images requested once the last pair is through, its K
+    //  image behind the last dQ product, its delta pass under this head's stores -- was built and measured SLOWER, 958 against 899 us at
+    //  n = 257: the prefetch can only start at the very end of a head, and the next prologue then waits for this head's stores too
+    //  (profiles/r05_m_attn_bwd_single_pass_v3_persistent_prefetch.log).  What a head costs beside its pairs -- three image DMAs, the delta
+    //  pass, 36 stores per lane: 0.41 ms of the launch -- stays exposed with ONE resident work-group of 146 KiB per CU; attention3.h's two
+    //  80 KiB work-groups per CU overlap some of it, which is why 29 % fewer MFMAs buy only 1 - 4 %.)
     const bf16_t* Qb = reinterpret_cast<const bf16_t*>(p.qkv) + (long)bi * n * ldq + hh * ATT_DH;
     const bf16_t* Kb = Qb + (long)p.heads * ATT_DH;
     const bf16_t* Vb = Kb + (long)p.heads * ATT_DH;
@@ -94,16 +127,16 @@ __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
     bf16_t* dQ = reinterpret_cast<bf16_t*>(p.dqkv) + (long)bi * n * ldq + hh * ATT_DH;
     bf16_t* dK = dQ + (long)p.heads * ATT_DH;
     bf16_t* dV = dK + (long)p.heads * ATT_DH;
+    const float* const lse_h = p.lse + ((long)bi * p.heads + hh) * n;
     a3_dma_image(Qs, Qb, ldq, n, npad, wave, nwaves, lane);
     a3_dma_image(dOs, dOb, ldo, n, npad, wave, nwaves, lane);
     a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
     a3_key_validity(Ms, p.mask, (long)bi * n, n, npad);
-    const float scale2 = p.scale * 1.4426950408889634f;
     // delta_i = sum_d dO[i, d] O[i, d] and lse_i log2(e) (as attention3.h)
     for (int blk = wave; blk < nsub; blk += nwaves) {
         const int row_ = blk * 32 + c31;
         const int rl = row_ < n ? row_ : n - 1;
-        const float lse_r = p.lse[((long)bi * p.heads + hh) * n + rl];
+        const float lse_r = lse_h[rl];
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -120,7 +153,6 @@ __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
         }
     }
     // the wave's own key block: K, V rows straight from global memory (L2 hits: the image DMA asks for the same lines)
-    const int row = wave * 32 + c31;                           // (< n: the wave's block is a full one)
     u32x4 kf[4], vf[4];
     a3_row_frags(Kb, ldq, row, lane, kf);
     a3_row_frags(Vb, ldq, row, lane, vf);
@@ -158,72 +190,75 @@ __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
             a5_weighted_row_sum(dOs, wave, sc, pt, lane, Tp + (wave * 3 + 2) * 64);         // sum_q P[q] dO[q]
         }
     }
-    unsigned char* const myX = Xs + wave * 4096;
-    for (int s = 0; s < nb; ++s) {
+    // step s: wave w computes the pair (query block (w + s) mod nb, key block w) -- dK, dV, and dS into buffer s & 1 -- and, one barrier
+    // later and in the same stretch of code as the NEXT pair's chains, adds the tile the owner of key block (w - s) mod nb left for its
+    // own query block to dQ.  One barrier per step: the tiles of step s - 1 were consumed before it, so step s + 1 may overwrite them.
+    auto produce = [&](int s) {
         const int t = wave + s < nb ? wave + s : wave + s - nb;         // the query block of this step's pair (uniform)
-        {
-            u32x4 qa[4], da[4];
-            a3_tile_rows(Qs, t, lane, qa);
-            a3_tile_rows(dOs, t, lane, da);
-            f32x16 sv, dp;
-            float l2[16], dl[16];
+        unsigned char* const myX = Xs + ((s & 1) * nb + wave) * A5_TILE;
+        u32x4 qa[4], da[4];
+        a3_tile_rows(Qs, t, lane, qa);
+        a3_tile_rows(dOs, t, lane, da);
+        f32x16 sv, dp;
+        float l2[16], dl[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const u32x4 a = ld16(Ls + t * 32 + 8 * q + 4 * h), b = ld16(Ds + t * 32 + 8 * q + 4 * h);
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 a = ld16(Ls + t * 32 + 8 * q + 4 * h), b = ld16(Ds + t * 32 + 8 * q + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { l2[4 * q + e] = u2f(a[e]); dl[4 * q + e] = u2f(b[e]); }
+            for (int e = 0; e < 4; ++e) { l2[4 * q + e] = u2f(a[e]); dl[4 * q + e] = u2f(b[e]); }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sv[r] = 0.f; dp[r] = -dl[r]; }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            sv = mma_kblock(qa[kb], kf[kb], sv, (bf16_t*)nullptr);
+            dp = mma_kblock(da[kb], vf[kb], dp, (bf16_t*)nullptr);
+        }
+        if (masked) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = kvalid ? fast_exp2(sv[r] * scale2 - l2[r]) : 0.f;
+                sv[r] = pv;
+                dp[r] = pv * dp[r];
             }
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sv[r] = 0.f; dp[r] = -dl[r]; }
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                sv = mma_kblock(qa[kb], kf[kb], sv, (bf16_t*)nullptr);
-                dp = mma_kblock(da[kb], vf[kb], dp, (bf16_t*)nullptr);
-            }
-            if (masked) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = kvalid ? fast_exp2(sv[r] * scale2 - l2[r]) : 0.f;
-                    sv[r] = pv;
-                    dp[r] = pv * dp[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sv[r] = fast_exp2(sv[r] * scale2 - l2[r]);
-                    dp[r] = sv[r] * dp[r];
-                }
-            }
-            u32x4 df[2];
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const u32x4 pf = a2_pack_acc(sv, blk);
-                df[blk] = a2_pack_acc(dp, blk);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    dv[db] = mma_kblock(a3_col_frag(dOs, t, blk, db, lane), pf, dv[db], (bf16_t*)nullptr);
-                    dk[db] = mma_kblock(a3_col_frag(Qs, t, blk, db, lane), df[blk], dk[db], (bf16_t*)nullptr);
-                }
-            }
-            // dS (bf16, as the dK product used it) to the owner of query block t: row = this lane's key, quad g = queries 8 g + 4 h + 0..3
-            // (the packed operand df[blk] holds exactly those quads: registers 8 blk + 0..7 = quads 2 blk, 2 blk + 1)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const u32x2 v = {df[g >> 1][2 * (g & 1)], df[g >> 1][2 * (g & 1) + 1]};
-                *reinterpret_cast<u32x2*>(myX + c31 * 128 + a2_slot(c31, g) * 16 + 8 * h) = v;
+            for (int r = 0; r < 16; ++r) {
+                sv[r] = fast_exp2(sv[r] * scale2 - l2[r]);
+                dp[r] = sv[r] * dp[r];
             }
         }
-        sync();                                                // every tile of this step is in place
-        {
-            const int pw = wave - s >= 0 ? wave - s : wave - s + nb;    // who computed (query block `wave`, key block pw)
+        u32x4 df[2];
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const u32x4 dsf = a3_col_frag(Xs, pw, blk, 0, lane);
+        for (int blk = 0; blk < 2; ++blk) {
+            const u32x4 pf = a2_pack_acc(sv, blk);
+            df[blk] = a2_pack_acc(dp, blk);
+            // dS (bf16, as the dK product uses it) to the owner of query block t: row = this lane's key, quad g = queries 8 g + 4 h + 0..3
+            // (the packed operand df[blk] holds exactly the quads 2 blk, 2 blk + 1)
+            a5_tile_put(myX, c31, h, 2 * blk, u32x2{df[blk][0], df[blk][1]});
+            a5_tile_put(myX, c31, h, 2 * blk + 1, u32x2{df[blk][2], df[blk][3]});
 #pragma unroll
-                for (int db = 0; db < 2; ++db) dq[db] = mma_kblock(a3_col_frag(Ks, pw, blk, db, lane), dsf, dq[db], (bf16_t*)nullptr);
+            for (int db = 0; db < 2; ++db) {
+                dv[db] = mma_kblock(a3_col_frag(dOs, t, blk, db, lane), pf, dv[db], (bf16_t*)nullptr);
+                dk[db] = mma_kblock(a3_col_frag(Qs, t, blk, db, lane), df[blk], dk[db], (bf16_t*)nullptr);
             }
         }
-        sync();                                                // ... and has been consumed: the tiles may be overwritten
+    };
+    auto consume = [&](int s) {
+        const int pw = wave - s >= 0 ? wave - s : wave - s + nb;        // who computed (query block `wave`, key block pw)
+        const unsigned char* const X = Xs + ((s & 1) * nb + pw) * A5_TILE;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const u32x4 dsf = a5_tile_frag(X, blk, lane);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) dq[db] = mma_kblock(a3_col_frag(Ks, pw, blk, db, lane), dsf, dq[db], (bf16_t*)nullptr);
+        }
+    };
+    produce(0);
+    for (int s = 0; s < nb; ++s) {
+        sync();                                                // the tiles of step s are in place; those of step s - 1 have been consumed
+        if (s + 1 < nb) produce(s + 1);
+        consume(s);
     }
     a3_store_rows_direct(dq, dQ, ldq, wave * 32, n, lane, p.scale);
     a3_store_rows_direct(dk, dK, ldq, wave * 32, n, lane, p.scale);

@@ -189,10 +189,12 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
     if (dtype == XCLIP_BF16 && n <= A3_MAX_N && !tiled_only) {               // merged head-resident backward (computes delta itself)
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         // the single-pass form (attention5.h) for the sequences it takes; XCLIP_ATTN_BWD=3 (measurement build) keeps the two-phase kernel for the A/B
-        static const int bwd_gen = measure_env("XCLIP_ATTN_BWD", 5);
-        if (bwd_gen == 5 && a5_takes((int)n, causal) && attn5_bwd_lds_bytes((int)n) <= 160 * 1024) {
+        // (XCLIP_ATTN5_MIN=2: every sequence it can take, for the record of where it loses)
+        static const int bwd_gen = measure_env("XCLIP_ATTN_BWD", 5), min5 = measure_env("XCLIP_ATTN5_MIN", A5_MIN_BLOCKS);
+        if (bwd_gen == 5 && a5_takes((int)n, causal) && (n >> 5) >= min5 && attn5_bwd_lds_bytes((int)n) <= 160 * 1024) {
             XC_ALLOW_LDS(attn5_bwd_kernel, 160 * 1024);
-            hipLaunchKernelGGL(attn5_bwd_kernel, dim3((unsigned)(batch * heads)), dim3((unsigned)((n >> 5) * 64)), attn5_bwd_lds_bytes((int)n), st, p);
+            const int64_t g5 = batch * heads;
+            hipLaunchKernelGGL(attn5_bwd_kernel, dim3((unsigned)g5), dim3((unsigned)((n >> 5) * 64)), attn5_bwd_lds_bytes((int)n), st, p);
             return check_launch(__func__);
         }
         const int nwq = a3_bwd_waves((int)n);
