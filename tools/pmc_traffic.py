@@ -42,7 +42,8 @@ def main():
     for r in rows[:24]:
         print(f"{r[0]:60s} {r[1]:8d} {r[2]:18.0f} {r[3]:14.1f} {r[4]:12.1f} {r[5]:11.1f}")
     fam = sys.argv[4] if len(sys.argv) > 4 else "gemm3"
-    g = [r for r in rows if r[0].startswith(fam) and "_kernel" in r[0]]          # "gemm" = gemm4_kernel + gemm5_kernel + ...
+    # "gemm" = gemm4_kernel + gemm5_kernel + gemm8_kernel ...; gemm9_geglu_bwd_kernel (the product + LayerNorm backward, its own family in bench.py) is not a plain product
+    g = [r for r in rows if r[0].startswith(fam) and "_kernel" in r[0] and not r[0].startswith("gemm9")]
     n = sum(r[1] for r in g)
     per = sum(r[5] * r[1] for r in g) / max(n, 1)
     print(f"# {fam} family: {n} launches, {per:.1f} MB per launch (reads x2 + writes)")

@@ -398,7 +398,7 @@ def cast_from_f32(src: Tensor, dtype, scale: float = 1.0) -> Tensor:
 # ---- GEMM -----------------------------------------------------------------------------------------------------------
 # which production bf16 GEMM kernel the library carries: measurements that cannot be taken inside a run (the PMC traffic figure of
 # profiles/gemm_traffic.json) are tagged with it and ignored by bench.py when they belong to an older kernel
-GEMM_GENERATION = "gemm5b"   # (b: whole-line epilogue stores through LDS)
+GEMM_GENERATION = "gemm8a"   # (gemm8.h for the plain interior NT / NN products, gemm4.h for the rest; gemm9.h is a family of its own)
 
 # True: forward / input-gradient products never get a split-K workspace, so the library cannot cut the row tail of a persistent launch off as
 # a split-K problem (xclip_api.hip gemm2_tail_cut).  Which rows form that tail depends on the batch size; without the cut a sample's
