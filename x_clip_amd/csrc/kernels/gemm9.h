@@ -86,6 +86,14 @@ struct G4GegluBwdEpilogue {
 #pragma unroll
             for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(line + k * 1024) = ul[k];
             lds_fence();
+            // this lane's 32 columns of gamma, requested BEFORE the next group's lines: the memory counter retires in order, so a load issued
+            // behind the prefetch could only be used once the prefetch had landed -- every group waited for its successor's lines (the first
+            // version).  (Once per tile, in front of everything, would also keep it ahead of the previous group's stores: 82 spilled registers.)
+            u32x2 gq[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gq[j][q] = *reinterpret_cast<const u32x2*>(e.gamma + n0 + wn * 64 + 32 * j + 8 * q + 4 * h);
             if (i < 3) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -99,7 +107,7 @@ struct G4GegluBwdEpilogue {
                 for (int q = 0; q < 4; ++q) {
                     unsigned char* const at = quad + (((4 * j + q) ^ (r & 7)) << 4);
                     const u32x2 uv = *reinterpret_cast<const u32x2*>(at);
-                    const u32x2 gv = *reinterpret_cast<const u32x2*>(e.gamma + n0 + wn * 64 + 32 * j + 8 * q + 4 * h);
+                    const u32x2 gv = gq[j][q];
                     const float uu[4] = {u2f(uv[0] << 16), u2f(uv[0] & 0xffff0000u), u2f(uv[1] << 16), u2f(uv[1] & 0xffff0000u)};
                     const float tt[4] = {u2f(tq[j][q][0] << 16), u2f(tq[j][q][0] & 0xffff0000u), u2f(tq[j][q][1] << 16), u2f(tq[j][q][1] & 0xffff0000u)};
                     const float gg[4] = {u2f(gv[0] << 16), u2f(gv[0] & 0xffff0000u), u2f(gv[1] << 16), u2f(gv[1] & 0xffff0000u)};
