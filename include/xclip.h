@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 20
+#define XCLIP_ABI_VERSION 21
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -127,6 +127,11 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
                int64_t M, int64_t N, int64_t K, float alpha, const void* bias, const void* residual, int64_t ldr,
                const void* addrows, const int32_t* rowidx, int64_t ld_add, void* workspace, int64_t workspace_bytes,
                int dtype, void* stream);
+/* bf16 products with M, N, K multiples of 64, no bias / gathered rows, an output of at most 64 tiles of 256 x 256 and at most `max_flop`
+ * (2 M N K; default 6e9) go to a 64 x 64-tile kernel built for latency (the [batch, d] rows of a pooled last layer and of the latent
+ * projections, x_clip.py:713-715): one launch, no split-K.  Sets the bound (0 = never; < 0 = only ask) and returns the previous one.
+ * Process-wide; results do not depend on it beyond the summation order of the contraction. */
+int64_t xclip_gemm_small_limit(int64_t max_flop);
 
 /* ---- the inference returns (reference CLIP.forward with return_loss = False, x_clip.py:740-746) --------------------------------
  * xclip_gemm_batched: `batch` independent products C_z[M,N] = alpha * op(A_z) op(B_z) with xclip_gemm's operand layouts, problem z at

@@ -72,7 +72,7 @@ def test_gemm_layouts(dtype, layout):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
-def test_gemm_epilogue_and_splitk(dtype):
+def test_gemm_epilogue_and_splitk(dtype, big_gemm_kernels):
     K.case_gemm(DEV, dtype, 40, 136, 64, "nt", epilogue=True, alpha=0.5)
     K.case_gemm(DEV, dtype, 64, 64, 1536, "tn")             # long contraction -> split-K slabs + reduce
 
@@ -149,6 +149,44 @@ def test_simloss_chunked(dtype, dcl):
     K.case_simloss_chunked(DEV, dtype, dcl)
 
 
+@pytest.fixture
+def big_gemm_kernels():
+    """shapes that gemm_small.h would take stay on the 256 x 256 kernels these tests are about"""
+    was = K.ops.gemm_small_limit(0)
+    yield
+    K.ops.gemm_small_limit(was)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K_", [(128, 64, 64), (64, 192, 512), (192, 128, 640), (64, 64, 1536)])
+def test_gemm_small_layouts(layout, M, N, K_):
+    """gemm_small.h: one K step (two stages), the whole contraction requested up front (eight steps: the ring does not wrap), a ring that
+    wraps twice, and a long one (24 steps through eight stages); every layout"""
+    assert K.ops.gemm_small_limit() > 2 * M * N * K_
+    K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout)
+
+
+@pytest.mark.parametrize("layout,alpha,in_place", [("nt", 1.0, False), ("nn", 0.5, True), ("tn", 0.25, False)])
+def test_gemm_small_residual_and_alpha(layout, alpha, in_place):
+    K.case_gemm(DEV, torch.bfloat16, 128, 128, 256, layout, alpha=alpha, residual_only=True, in_place=in_place)
+    K.case_gemm(DEV, torch.bfloat16, 64, 128, 128, layout, alpha=alpha)
+
+
+def test_gemm_small_many_tiles_four_stages():
+    """more than 256 tiles: four stages (two work-groups per CU on the part), the ring wraps"""
+    K.case_gemm(DEV, torch.bfloat16, 1088, 1024, 384, "nt")
+
+
+def test_gemm_small_limit_is_honoured():
+    was = K.ops.gemm_small_limit(0)
+    try:
+        assert K.ops.gemm_small_limit() == 0
+        K.case_gemm(DEV, torch.bfloat16, 128, 64, 128, "nt")           # (the same product through the other kernels)
+    finally:
+        K.ops.gemm_small_limit(was)
+    assert K.ops.gemm_small_limit() == was
+
+
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm2_layouts(layout):
     """256x256 DMA-staged bf16 kernel (gemm2.h): ragged M and N tiles, two K steps"""
@@ -162,14 +200,14 @@ def test_gemm3_persistent_wraparound(layout):
 
 
 @pytest.mark.parametrize("layout,M,N,K_,alpha", [("nt", 1024, 512, 128, 1.0), ("nn", 768, 512, 64, 0.5), ("nt", 776, 512, 64, 1.0)])
-def test_gemm4_interior_tiles_in_a_row(layout, M, N, K_, alpha):
+def test_gemm4_interior_tiles_in_a_row(layout, M, N, K_, alpha, big_gemm_kernels):
     """interior tiles in a row on one work-group (3 emulated CUs, 6-8 tiles): the straight-line descriptor epilogue, the C = 0 first
     k-block of every tile, a single K step per tile (the three-stage A ring wraps inside the prologue), a ragged last row of tiles"""
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha)
 
 
 @pytest.mark.parametrize("layout,M,N,K_,alpha,in_place", [("nt", 776, 512, 128, 1.0, False), ("nn", 512, 264, 64, 0.5, True), ("nt", 264, 136, 64, 1.0, False)])
-def test_gemm4_residual_epilogue(layout, M, N, K_, alpha, in_place):
+def test_gemm4_residual_epilogue(layout, M, N, K_, alpha, in_place, big_gemm_kernels):
     """C = alpha A B + R through the straight-line residual epilogue (interior tiles) and the general one (ragged tiles); in place too"""
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha, residual_only=True, in_place=in_place)
 
@@ -179,7 +217,7 @@ def test_gemm5_banded_tile_order():
     K.case_gemm(DEV, torch.bfloat16, 264, 4096, 64, "nt")
 
 
-def test_gemm4_slab_epilogue_interior_tiles():
+def test_gemm4_slab_epilogue_interior_tiles(big_gemm_kernels):
     """split-K weight-gradient shape whose tiles are all interior: the fp32 slab leaves through the wave-private LDS transposition
     (whole-line stores) -- only the LOGIC can be checked here; the store hazard this path once hit exists on the hardware only
     (tests/test_kernels_gpu.py::test_gemm_layouts[520-512-2048-tn], tools/debug/slab_epilogue_check.py)"""
@@ -294,7 +332,7 @@ def test_nt_xent(dtype, rows, dim, temperature):
     K.case_nt_xent(DEV, dtype, rows, dim, temperature)
 
 
-def test_gemm_splitk_uneven_slices():
+def test_gemm_splitk_uneven_slices(big_gemm_kernels):
     K.case_gemm_splitk_uneven(DEV, M=256, N=256, K=2880)
 
 
@@ -371,7 +409,8 @@ def test_gemm_row_tail_as_split_k():
     """xclip_api.hip gemm2_tail_cut: a persistent launch whose last round would fill only a few CUs cuts its rows at the last whole round and
     runs the row tail as a split-K problem (fp32 slabs + the reduction, which also applies alpha and the skip term).  The policy plans for
     the device's CU count, so the emulator is told it has 4 (its own interpreter: the count is read once): 1280 rows = 5 row tiles x 2
-    column tiles = 2 rounds + 2 tiles -> 4 row tiles in the main launch, 1 as slabs; NT / NN, with and without a skip term, in place"""
+    column tiles = 2 rounds + 2 tiles -> 4 row tiles in the main launch, 1 as slabs; NT / NN, with and without a skip term, in place.
+    Products of fewer than 16 K steps hand the same tail to gemm_small.h instead (gemm_small_tail_cut)"""
     import subprocess
     import sys
     code = (
@@ -384,7 +423,9 @@ def test_gemm_row_tail_as_split_k():
         "L = _lib.lib()\n"
         "assert L.xclip_gemm_workspace_bytes(1280, 512, 1536, 1) == 2 * 256 * 512 * 4        # the tail: 2 tiles x 2 K slices fill the 4 CUs\n"
         "assert L.xclip_gemm_workspace_bytes(1280, 512, 512, 1) == 0                         # short K: a tile is not worth cutting\n"
-        "for (M, N, K, bk, res, inplace) in [(1280, 512, 1536, False, False, False), (1280, 512, 2048, False, True, False), (1280, 512, 2048, True, True, True), (1416, 256, 1024, True, False, False)]:\n"
+        "for (M, N, K, bk, res, inplace) in [(1280, 512, 1536, False, False, False), (1280, 512, 2048, False, True, False), (1280, 512, 2048, True, True, True), (1416, 256, 1024, True, False, False),\n"
+        "                                    # short K (gemm_small_tail_cut): the tail as one launch of the 64 x 64 kernel, skip term and in place too\n"
+        "                                    (1280, 512, 512, False, False, False), (1280, 512, 256, True, True, True), (1216, 256, 128, False, True, False)]:\n"
         "    a = torch.randn(M, K).bfloat16(); b = (torch.randn(K, N) if bk else torch.randn(N, K)).bfloat16()\n"
         "    r = torch.randn(M, N).bfloat16() if res else None\n"
         "    want = 0.5 * (a.float() @ (b.float() if bk else b.float().t())) + (r.float() if res else 0)\n"

@@ -117,6 +117,38 @@ def test_gemm_full_size_every_element_and_repeatable(layout, M, N, K_, res):
     assert worst <= 2.0, worst
 
 
+@pytest.mark.parametrize("layout,M,N,K_,res", [("nt", 1024, 512, 512, False), ("nn", 1024, 512, 512, False), ("tn", 512, 512, 1024, False),
+                                               ("nt", 1024, 512, 2048, True), ("nt", 1024, 4096, 512, False), ("nn", 1024, 512, 2048, False),
+                                               ("tn", 4096, 512, 1024, False), ("tn", 512, 2048, 1024, False), ("nn", 1024, 2048, 512, False),
+                                               ("nt", 64, 64, 64, False), ("tn", 1024, 512, 1024, True)])
+def test_gemm_small_products_every_element_and_repeatable(layout, M, N, K_, res):
+    """gemm_small.h at the shapes of the pooled last layer / latent projections (b = 1024): counted waits on a ring of LDS-DMA stages that
+    the emulator cannot see (it lands every piece at once) -- every element against an fp32 product, ten launches bit-identical, and the same
+    product through the 256 x 256 kernels (xclip_gemm_small_limit(0)) within the bf16 rounding of the two summation orders"""
+    from x_clip_amd import ops
+    assert ops.gemm_small_limit() >= 2 * M * N * K_
+    a_k, b_k = layout == "tn", layout in ("nn", "tn")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn((K_, M) if a_k else (M, K_), generator=g).to(torch.bfloat16).to(DEV)
+    b = torch.randn((K_, N) if b_k else (N, K_), generator=g).to(torch.bfloat16).to(DEV)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV) if res else None
+    outs = [ops.gemm(a, b, M, N, K_, a_k, b_k, residual=r) for _ in range(10)]
+    was = ops.gemm_small_limit(0)
+    try:
+        big = ops.gemm(a, b, M, N, K_, a_k, b_k, residual=r)
+    finally:
+        ops.gemm_small_limit(was)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "the same launch must give the same bits"
+    ref = (a.t() if a_k else a).float() @ (b if b_k else b.t()).float()
+    if res:
+        ref = ref + r.float()
+    scale = float(ref.abs().max())
+    assert float((outs[0].float() - ref.to(torch.bfloat16).float()).abs().max()) <= 2.0 * scale * 2.0 ** -8
+    assert float((outs[0].float() - big.float()).abs().max()) <= 2.0 * scale * 2.0 ** -8
+
+
 @pytest.mark.parametrize("M,F,D", [(2048, 512, 128), (33792, 2048, 512), (263168, 2048, 512)])
 def test_ffn_dgrad_geglu_fused(M, F, D):
     """gemm9.h: net.4's input gradient + the GEGLU-LayerNorm backward in one kernel, at the vision / text towers' full sizes (every CU streaming)"""

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "xclip_scatter_add_sorted": (c_int, [P, L, P, P, P, L, L, L, L, L, L, I, P]),
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
+    "xclip_gemm_small_limit": (c_int64, [L]),
     "xclip_gemm": (c_int, [I, I, P, L, P, L, P, L, L, L, L, F, P, P, L, P, P, L, P, L, I, P]),
     "xclip_ffn_dgrad_geglu_ok": (c_int, [L, L, L, I]),
     "xclip_ffn_dgrad_geglu_workspace_bytes": (c_int64, [L, L, L]),
@@ -85,7 +86,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 def _bind(path: str):

@@ -12,6 +12,7 @@
 #include "kernels/gemm4.h"
 #include "kernels/gemm8.h"
 #include "kernels/gemm9.h"
+#include "kernels/gemm_small.h"
 #ifdef XCLIP_MEASURE                                             // negative-result experiments, measurement build only
 #include "kernels/measure/gemm6.h"
 #include "kernels/measure/gemm7.h"
@@ -884,6 +885,50 @@ static int gemm2_run(int a_kmajor, int b_kmajor, const void* A, int64_t lda, con
     return check_launch(__func__);
 }
 
+// the latency-built 64 x 64 kernel (gemm_small.h) for outputs of a few tiles and a few GFLOP
+static int64_t g_small_flop = GS_MAX_FLOP;
+int64_t xclip_gemm_small_limit(int64_t max_flop) {
+    const int64_t was = g_small_flop;
+    if (max_flop >= 0) g_small_flop = max_flop;
+    return was;
+}
+static int gemm_small_run(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                          int64_t N, int64_t K, float alpha, const void* residual, int64_t ldr, hipStream_t st) {
+    GemmSmallParams q;
+    q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = (bf16_t*)C; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
+    q.M = (int)M; q.N = (int)N; q.K = (int)K; q.alpha = alpha; q.residual = (const bf16_t*)residual; q.ldr = ldr;
+    q.tiles_m = (int)(M / GS_BM); q.tiles_n = (int)(N / GS_BN);
+    const int64_t tiles = (int64_t)q.tiles_m * q.tiles_n;
+    q.stages = gs_stages(tiles, K / GS_BK);
+    const int lds = q.stages * GS_STAGE_BYTES;
+#define XC_GS(AK, BK_, RES) do { XC_ALLOW_LDS((gemm_small_kernel<AK, BK_, RES>), GS_MAX_STAGES * GS_STAGE_BYTES); \
+        hipLaunchKernelGGL((gemm_small_kernel<AK, BK_, RES>), dim3((unsigned)tiles), dim3(GS_THREADS), lds, st, q); } while (0)
+    if (residual != nullptr) {
+        if (!a_kmajor && !b_kmajor) XC_GS(false, false, true); else if (!a_kmajor) XC_GS(false, true, true); else XC_GS(true, true, true);
+    } else {
+        if (!a_kmajor && !b_kmajor) XC_GS(false, false, false); else if (!a_kmajor) XC_GS(false, true, false); else XC_GS(true, true, false);
+    }
+#undef XC_GS
+    return check_launch(__func__);
+}
+
+// The row tail of a SHORT-K persistent product (fewer than 16 K steps: gemm2_tail_cut leaves those whole, a split-K tail of a few K steps
+// per slice would be all reduction).  The same arithmetic -- 263,168 text rows x N = 512 are 8 rounds + 8 tiles, the vision tower's 33,792
+// rows x N = 512 are 264 tiles: TWO rounds for 1.03 -- but the tail (1024 rows here) is exactly the kind of product gemm_small.h was built
+// for: the main launch takes the whole rounds, the tail follows as one 64 x 64-tile launch.  -> rows of the main launch, 0 = no cut
+static int64_t gemm_small_tail_cut(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    static const int on = measure_env("XCLIP_GEMM_SMALL_TAIL", 1);   // (measurement build: 0 = the uncut launch, for the A/B)
+    if (!on) return 0;
+    const int64_t cus = xc_policy_cus();
+    const int64_t tm = (M + G2_BM - 1) / G2_BM, tn = (N + G2_BN - 1) / G2_BN, tiles = tm * tn;
+    const int64_t rounds = tiles / cus;
+    if (rounds < 1 || tiles % cus == 0 || K / G2_BK >= 16) return 0;
+    const int64_t tm_main = rounds * cus / tn;
+    const int64_t tail_tiles = tiles - tm_main * tn;
+    if (tm_main < 1 || tail_tiles * 2 > cus) return 0;
+    return gs_takes(M - tm_main * G2_BM, N, K, false, lda, ldb, g_small_flop) ? tm_main * G2_BM : 0;
+}
+
 #ifdef XCLIP_MEASURE
 // measurement build: gemm8.h on / off at run time (same-process A/B); -> the previous setting
 extern "C" int xclip_measure_gemm8(int on) { const int was = gemm8_on() ? 1 : 0; g_gemm8 = on; return was; }
@@ -920,9 +965,21 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
     if (M == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bool plain = (bias == nullptr && residual == nullptr && addrows == nullptr);
+    if (dtype == XCLIP_BF16 && gs_takes(M, N, K, bias != nullptr || addrows != nullptr, lda, ldb, g_small_flop))
+        return gemm_small_run(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, M, N, K, alpha, residual, ldr, st);
     if (use_gemm2(M, N, K, dtype)) {
         // the row tail as a split-K problem of its own (gemm2_tail_cut): the main rows, then the tail's slabs, then the reduction that also
         // applies alpha and the skip term
+        // (no workspace needed, and no change of the summation order: the 64 x 64 kernel adds the same MFMA k-blocks in the same order as the
+        //  256 x 256 ones, so a row's result does not depend on which launch computed it -- tests/test_clip_gpu.py::test_full_size_properties_bf16)
+        const int64_t scut = (!a_kmajor && bias == nullptr && addrows == nullptr) ? gemm_small_tail_cut(M, N, K, lda, ldb) : 0;
+        if (scut > 0) {
+            const int rc = gemm2_run(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, scut, N, K, alpha, nullptr, residual, ldr, nullptr, nullptr, 0, nullptr, 0,
+                                     st, true, nullptr);
+            if (rc != 0) return rc;
+            return gemm_small_run(a_kmajor, b_kmajor, (const char*)A + scut * lda * 2, lda, B, ldb, (char*)C + scut * ldc * 2, ldc, M - scut, N, K, alpha,
+                                  residual != nullptr ? (const char*)residual + scut * ldr * 2 : nullptr, ldr, st);
+        }
         const int64_t cut = (!a_kmajor && bias == nullptr && addrows == nullptr && workspace != nullptr) ? gemm2_tail_cut(M, N, K) : 0;
         const int64_t mt = M - cut;
         if (cut > 0 && gemm2_splits(mt, N, K) > 1 && workspace_bytes >= (int64_t)gemm2_splits(mt, N, K) * mt * N * 4) {

@@ -543,6 +543,13 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b
     return out
 
 
+def gemm_small_limit(max_flop: int = -1) -> int:
+    """the FLOP bound (2 M N K) under which a bf16 product with a small output takes the latency-built 64 x 64 kernel (gemm_small.h);
+    0 = never, < 0 = only ask.  -> the previous bound.  Process-wide (a tuning knob; the tests use it to reach the 256 x 256 kernels
+    with small shapes)"""
+    return int(_lib.lib().xclip_gemm_small_limit(int(max_flop)))
+
+
 def bmm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kmajor: bool = False, b_kmajor: bool = False, alpha: float = 1.0) -> Tensor:
     """one launch of B independent products out[z] = alpha * op(a[z]) op(b[z]) -> [B, M, N], gemm()'s operand layouts per problem (normal
     a[z] [M, K] / b[z] [N, K]; k-major a[z] [K, M] / b[z] [K, N]); a, b 3-D with unit inner stride, N a multiple of the 16-byte chunk.  The
