@@ -409,8 +409,7 @@ def test_gemm_row_tail_as_split_k():
     """xclip_api.hip gemm2_tail_cut: a persistent launch whose last round would fill only a few CUs cuts its rows at the last whole round and
     runs the row tail as a split-K problem (fp32 slabs + the reduction, which also applies alpha and the skip term).  The policy plans for
     the device's CU count, so the emulator is told it has 4 (its own interpreter: the count is read once): 1280 rows = 5 row tiles x 2
-    column tiles = 2 rounds + 2 tiles -> 4 row tiles in the main launch, 1 as slabs; NT / NN, with and without a skip term, in place.
-    Products of fewer than 16 K steps hand the same tail to gemm_small.h instead (gemm_small_tail_cut)"""
+    column tiles = 2 rounds + 2 tiles -> 4 row tiles in the main launch, 1 as slabs; NT / NN, with and without a skip term, in place"""
     import subprocess
     import sys
     code = (
@@ -423,9 +422,7 @@ def test_gemm_row_tail_as_split_k():
         "L = _lib.lib()\n"
         "assert L.xclip_gemm_workspace_bytes(1280, 512, 1536, 1) == 2 * 256 * 512 * 4        # the tail: 2 tiles x 2 K slices fill the 4 CUs\n"
         "assert L.xclip_gemm_workspace_bytes(1280, 512, 512, 1) == 0                         # short K: a tile is not worth cutting\n"
-        "for (M, N, K, bk, res, inplace) in [(1280, 512, 1536, False, False, False), (1280, 512, 2048, False, True, False), (1280, 512, 2048, True, True, True), (1416, 256, 1024, True, False, False),\n"
-        "                                    # short K (gemm_small_tail_cut): the tail as one launch of the 64 x 64 kernel, skip term and in place too\n"
-        "                                    (1280, 512, 512, False, False, False), (1280, 512, 256, True, True, True), (1216, 256, 128, False, True, False)]:\n"
+        "for (M, N, K, bk, res, inplace) in [(1280, 512, 1536, False, False, False), (1280, 512, 2048, False, True, False), (1280, 512, 2048, True, True, True), (1416, 256, 1024, True, False, False)]:\n"
         "    a = torch.randn(M, K).bfloat16(); b = (torch.randn(K, N) if bk else torch.randn(N, K)).bfloat16()\n"
         "    r = torch.randn(M, N).bfloat16() if res else None\n"
         "    want = 0.5 * (a.float() @ (b.float() if bk else b.float().t())) + (r.float() if res else 0)\n"

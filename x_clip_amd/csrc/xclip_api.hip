@@ -912,22 +912,10 @@ static int gemm_small_run(int a_kmajor, int b_kmajor, const void* A, int64_t lda
     return check_launch(__func__);
 }
 
-// The row tail of a SHORT-K persistent product (fewer than 16 K steps: gemm2_tail_cut leaves those whole, a split-K tail of a few K steps
-// per slice would be all reduction).  The same arithmetic -- 263,168 text rows x N = 512 are 8 rounds + 8 tiles, the vision tower's 33,792
-// rows x N = 512 are 264 tiles: TWO rounds for 1.03 -- but the tail (1024 rows here) is exactly the kind of product gemm_small.h was built
-// for: the main launch takes the whole rounds, the tail follows as one 64 x 64-tile launch.  -> rows of the main launch, 0 = no cut
-static int64_t gemm_small_tail_cut(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
-    static const int on = measure_env("XCLIP_GEMM_SMALL_TAIL", 1);   // (measurement build: 0 = the uncut launch, for the A/B)
-    if (!on) return 0;
-    const int64_t cus = xc_policy_cus();
-    const int64_t tm = (M + G2_BM - 1) / G2_BM, tn = (N + G2_BN - 1) / G2_BN, tiles = tm * tn;
-    const int64_t rounds = tiles / cus;
-    if (rounds < 1 || tiles % cus == 0 || K / G2_BK >= 16) return 0;
-    const int64_t tm_main = rounds * cus / tn;
-    const int64_t tail_tiles = tiles - tm_main * tn;
-    if (tm_main < 1 || tail_tiles * 2 > cus) return 0;
-    return gs_takes(M - tm_main * G2_BM, N, K, false, lda, ldb, g_small_flop) ? tm_main * G2_BM : 0;
-}
+// (Measured and not kept: the row tail of a SHORT-K persistent product -- fewer than 16 K steps, which gemm2_tail_cut leaves whole -- as a
+//  second launch of the 64 x 64 kernel behind the whole rounds.  Bit-identical results (the same MFMA k-blocks in the same order), and the
+//  round it saves is worth about what the dependent launch costs: text out-projection 153.8 -> 152.0 us, QKV 406 -> 403, FF1 1101 -> 1102
+//  (profiles/r05_s_bench_shapes_short_k_tail_on_small_kernel.log against r05_r_bench_shapes_small_kernel.log).)
 
 #ifdef XCLIP_MEASURE
 // measurement build: gemm8.h on / off at run time (same-process A/B); -> the previous setting
@@ -970,16 +958,6 @@ int xclip_gemm(int a_kmajor, int b_kmajor, const void* A, int64_t lda, const voi
     if (use_gemm2(M, N, K, dtype)) {
         // the row tail as a split-K problem of its own (gemm2_tail_cut): the main rows, then the tail's slabs, then the reduction that also
         // applies alpha and the skip term
-        // (no workspace needed, and no change of the summation order: the 64 x 64 kernel adds the same MFMA k-blocks in the same order as the
-        //  256 x 256 ones, so a row's result does not depend on which launch computed it -- tests/test_clip_gpu.py::test_full_size_properties_bf16)
-        const int64_t scut = (!a_kmajor && bias == nullptr && addrows == nullptr) ? gemm_small_tail_cut(M, N, K, lda, ldb) : 0;
-        if (scut > 0) {
-            const int rc = gemm2_run(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, scut, N, K, alpha, nullptr, residual, ldr, nullptr, nullptr, 0, nullptr, 0,
-                                     st, true, nullptr);
-            if (rc != 0) return rc;
-            return gemm_small_run(a_kmajor, b_kmajor, (const char*)A + scut * lda * 2, lda, B, ldb, (char*)C + scut * ldc * 2, ldc, M - scut, N, K, alpha,
-                                  residual != nullptr ? (const char*)residual + scut * ldr * 2 : nullptr, ldr, st);
-        }
         const int64_t cut = (!a_kmajor && bias == nullptr && addrows == nullptr && workspace != nullptr) ? gemm2_tail_cut(M, N, K) : 0;
         const int64_t mt = M - cut;
         if (cut > 0 && gemm2_splits(mt, N, K) > 1 && workspace_bytes >= (int64_t)gemm2_splits(mt, N, K) * mt * N * 4) {
