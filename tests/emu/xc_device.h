@@ -422,6 +422,7 @@ inline void buf_st16(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
 }
 template <int IMM>
 inline void buf_st16_nt(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) { buf_st16<IMM>(r, voff, soff, v); }
+inline void buf_st16_nt_tracked(BufRsrc r, uint32_t voff, u32x4 v) { buf_st16<0>(r, voff, 0u, v); }
 template <int IMM>
 inline u32x4 buf_ld16_nt(BufRsrc r, uint32_t voff, uint32_t soff) { return buf_ld16<IMM>(r, voff, soff); }
 inline u32x4 ld16_nt(const void* p) { u32x4 v; memcpy(&v, p, 16); return v; }
@@ -448,6 +449,7 @@ inline uint64_t shader_cycles() { return 0; }
 inline uint32_t lds_base_granule() { return 0; }
 inline void nap() {}
 template <class T> inline void reg_keep(T&) {}
+inline uint32_t opaque(uint32_t v) { return v; }
 
 template <int OFF>
 inline u32x4 lds_read16_async(const void* p) { return *reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(p) + OFF); }

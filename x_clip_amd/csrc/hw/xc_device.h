@@ -189,6 +189,12 @@ template <int IMM>
 XC_DEV void buf_st16_nt(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) {
     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4 nt\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
 }
+// The same non-temporal store as a BUILTIN with an immediate-zero scalar offset (the form the compiler's own hazard table covers), i.e. one
+// the compiler's wait-count pass KNOWS about.  For code that mixes such stores with compiler-tracked loads (buf_ld16 / plain loads): behind
+// an asm store the pass under-counts -- it waits with vmcnt(#its own younger loads), and since the counter retires in order that drains the
+// asm stores issued in between as well: every use of a prefetched load then waits for the previous batch of stores to be ACKNOWLEDGED
+// (gemm9.h's epilogue: one store round trip per 32-row group).  With the builtin the pass counts the stores and leaves them in flight.
+XC_DEV void buf_st16_nt_tracked(BufRsrc r, uint32_t voff, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 2); }
 // plain 16-byte global accesses with the non-temporal hint (streamed once: first use is last use)
 XC_DEV u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 XC_DEV void st16_nt(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
@@ -238,6 +244,9 @@ XC_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 XC_DEV void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // measurement builds: keep a register value alive / opaque to the optimiser
 template <class T> XC_DEV void reg_keep(T& v) { asm volatile("" : "+v"(v)); }
+// the value, as something the optimiser cannot see through: what is computed from it is recomputed where it is used instead of being
+// hoisted out of a loop and carried in registers (store addresses of an epilogue that has none to spare)
+XC_DEV uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 // constant-rate (100 MHz) timestamp
 XC_DEV uint64_t realtime_10ns() { return __builtin_amdgcn_s_memrealtime(); }
 XC_DEV uint64_t shader_cycles() { return __builtin_amdgcn_s_memtime(); }

@@ -31,6 +31,36 @@ struct GegluBwdArgs {
     int F;
 };
 
+// The epilogue below is bound by the vector ALU, not by memory: ~45 instruction issues per element (gelu_parts: 16 + a reciprocal + an
+// exponential at quarter rate; the LayerNorm / GEGLU chain rule: ~20) x 65,536 elements per tile over a CU's 64 lanes per clock = 23 us of
+// the tile's 25 us of epilogue, with the tile's 512 KB of lines moving underneath (profiles/r05_t_*: leaving the line stores in flight
+// changed nothing).  So the arithmetic runs on PAIRS of elements -- a lane's two neighbours of a bf16 dword -- in ext_vector float2, which
+// hipcc selects as v_pk_mul / v_pk_add / v_pk_fma_f32 (two fp32 operations per issue on gfx950); only the reciprocal, the exponential, the
+// absolute value and the sign transfer stay per element.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+XC_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
+XC_DEV f32x2 bf16x2_unpack(uint32_t w) { return f32x2{u2f(w << 16), u2f(w & 0xffff0000u)}; }
+// common.h's gelu_parts on a pair (the same Abramowitz-Stegun 7.1.26 polynomial, its coefficients halved so that
+// Phi(x) = 0.5 + sign(x) (0.5 - (0.5 poly) exp(-x^2 / 2)) comes out of one more fma)
+XC_DEV void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 den = ax * splat2(0.3275911f * 0.70710678118654752f) + splat2(1.0f);
+    const f32x2 t = {fast_rcp(den[0]), fast_rcp(den[1])};
+    const f32x2 ea = (x * x) * splat2(-0.5f * 1.4426950408889634f);
+    const f32x2 e = {fast_exp2(ea[0]), fast_exp2(ea[1])};                             // exp(-x^2 / 2)
+    f32x2 hp = t * splat2(0.5f * 1.061405429f) + splat2(0.5f * -1.453152027f);
+    hp = hp * t + splat2(0.5f * 1.421413741f);
+    hp = hp * t + splat2(0.5f * -0.284496736f);
+    hp = hp * t + splat2(0.5f * 0.254829592f);
+    hp = hp * t;
+    const f32x2 he = splat2(0.5f) - hp * e;                                           // 0.5 erf(|x| / sqrt 2)
+    cdf = splat2(0.5f) + f32x2{copysignf(he[0], x[0]), copysignf(he[1], x[1])};
+    pdf = e * splat2(0.39894228040143268f);
+}
+
+// ABL (measurement build only, XCLIP_GEMM9_ABL; results are garbage except for 1): 1 the line stores as the untracked asm form (what the first
+// version did), 2 no GELU arithmetic (constants for cdf / pdf), 4 no line loads behind the first group's, 8 no line stores
+template <int ABL = 0>
 struct G4GegluBwdEpilogue {
     const Gemm2Params& p;
     const GegluBwdArgs& e;
@@ -40,6 +70,16 @@ struct G4GegluBwdEpilogue {
     XC_DEV void pack_lines(f32x16 (&)[4][2], unsigned char*, u32x4 (&)[4][4], int = 0, int = 0) const {}
     template <bool NT = false> XC_DEV void store_lines(const u32x4 (&)[4][4], int, int) const {}
     template <bool NT, int NG> XC_DEV void store_line_groups(const u32x4 (&)[NG][4], int, int, int) const {}
+
+    // A line store the compiler's wait-count pass can see (xc_device.h buf_st16_nt_tracked): the epilogue's loads are compiler-tracked, and
+    // behind untracked asm stores every use of the prefetched lines waited for the previous group's eight stores to be acknowledged --
+    // one store round trip per 32-row group.  The address is recomputed per store (opaque: not hoisted into 16 registers the epilogue
+    // does not have).
+    XC_DEV void store_line(BufRsrc r, uint32_t voff, uint32_t soff, u32x4 v) const {
+        if (ABL & 8) return;
+        if (ABL & 1) { buf_st16_nt<0>(r, voff, soff, v); return; }
+        buf_st16_nt_tracked(r, opaque(voff) + soff, v);
+    }
 
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
         const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -54,11 +94,11 @@ struct G4GegluBwdEpilogue {
         const uint32_t x8 = (uint32_t)e.ldx * 16u, d8 = (uint32_t)e.lddx * 16u;        // 8 rows
         unsigned char* const quad = scratch + r * 128 + 8 * h;                        // accumulator layout: + chunk position * 16
         unsigned char* const line = scratch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // line layout: + 1024 per 8 rows
-        float dg[2][16];
+        f32x2 dg[2][8];                                        // column sums of dh ahat: pairs (2 c, 2 c + 1) of the lane's 16 columns per j
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) dg[j][c] = 0.f;
+            for (int c = 0; c < 8; ++c) dg[j][c] = splat2(0.f);
 
         // Register budget (128 accumulators + 32 column sums live throughout): per 32-row group the gate quads are held (16 registers), the
         // value quads are read from the LDS slice one at a time and overwritten IN PLACE by du (a lane's own 8 bytes), dt replaces the
@@ -94,7 +134,7 @@ struct G4GegluBwdEpilogue {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) gq[j][q] = *reinterpret_cast<const u32x2*>(e.gamma + n0 + wn * 64 + 32 * j + 8 * q + 4 * h);
-            if (i < 3) {
+            if (i < 3 && !(ABL & 4)) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     tl[k] = buf_ld16_nt<0>(rt, vx, x8 * (uint32_t)(4 * (i + 1) + k));
@@ -108,25 +148,25 @@ struct G4GegluBwdEpilogue {
                     unsigned char* const at = quad + (((4 * j + q) ^ (r & 7)) << 4);
                     const u32x2 uv = *reinterpret_cast<const u32x2*>(at);
                     const u32x2 gv = gq[j][q];
-                    const float uu[4] = {u2f(uv[0] << 16), u2f(uv[0] & 0xffff0000u), u2f(uv[1] << 16), u2f(uv[1] & 0xffff0000u)};
-                    const float tt[4] = {u2f(tq[j][q][0] << 16), u2f(tq[j][q][0] & 0xffff0000u), u2f(tq[j][q][1] << 16), u2f(tq[j][q][1] & 0xffff0000u)};
-                    const float gg[4] = {u2f(gv[0] << 16), u2f(gv[0] & 0xffff0000u), u2f(gv[1] << 16), u2f(gv[1] & 0xffff0000u)};
-                    float du[4], dt[4];
+                    const f32x2 rstd2 = splat2(rstd), shift2 = splat2(shift), k12 = splat2(k1), k22 = splat2(k2);
+                    u32x2 duw, dtw;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float cdf, pdf;
-                        gelu_parts(tt[c], cdf, pdf);
-                        const float ge = tt[c] * cdf;                                  // gelu(t)
-                        const float udge = uu[c] * (cdf + tt[c] * pdf);                // u gelu'(t)
-                        const float ah = uu[c] * ge * rstd + shift;                    // normalised a
-                        const float dh = acc[i][j][4 * q + c];
-                        dg[j][4 * q + c] += dh * ah;
-                        const float da = dh * gg[c] * rstd - k1 - ah * k2;
-                        du[c] = da * ge;
-                        dt[c] = da * udge;
+                    for (int cp = 0; cp < 2; ++cp) {                                  // columns (2 cp, 2 cp + 1) of the quad: one bf16 dword
+                        const f32x2 uu = bf16x2_unpack(uv[cp]), tt = bf16x2_unpack(tq[j][q][cp]), gg = bf16x2_unpack(gv[cp]);
+                        f32x2 cdf, pdf;
+                        if (ABL & 2) { cdf = splat2(0.5f); pdf = splat2(0.4f); } else gelu_parts2(tt, cdf, pdf);
+                        const f32x2 ge = tt * cdf;                                     // gelu(t)
+                        const f32x2 udge = uu * (cdf + tt * pdf);                      // u gelu'(t)
+                        const f32x2 ah = (uu * ge) * rstd2 + shift2;                   // normalised a
+                        const f32x2 dh = {acc[i][j][4 * q + 2 * cp], acc[i][j][4 * q + 2 * cp + 1]};
+                        dg[j][2 * q + cp] += dh * ah;
+                        const f32x2 da = (dh * gg) * rstd2 - k12 - ah * k22;
+                        const f32x2 du = da * ge, dt = da * udge;
+                        duw[cp] = f2bf_pk(du[0], du[1]);
+                        dtw[cp] = f2bf_pk(dt[0], dt[1]);
                     }
-                    *reinterpret_cast<u32x2*>(at) = u32x2{f2bf_pk(du[0], du[1]), f2bf_pk(du[2], du[3])};     // (this lane's own 8 bytes: read, then overwritten)
-                    tq[j][q] = u32x2{f2bf_pk(dt[0], dt[1]), f2bf_pk(dt[2], dt[3])};
+                    *reinterpret_cast<u32x2*>(at) = duw;                              // (this lane's own 8 bytes: read, then overwritten)
+                    tq[j][q] = dtw;
                 }
             }
             lds_fence();
@@ -136,7 +176,7 @@ struct G4GegluBwdEpilogue {
             for (int k = 0; k < 4; ++k) o[k] = *reinterpret_cast<const u32x4*>(line + k * 1024);
             lds_fence();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) buf_st16_nt<0>(rdu, vd, d8 * (uint32_t)(4 * i + k), o[k]);
+            for (int k = 0; k < 4; ++k) store_line(rdu, vd, d8 * (uint32_t)(4 * i + k), o[k]);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -146,16 +186,16 @@ struct G4GegluBwdEpilogue {
             for (int k = 0; k < 4; ++k) o[k] = *reinterpret_cast<const u32x4*>(line + k * 1024);
             lds_fence();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) buf_st16_nt<0>(rdt, vd, d8 * (uint32_t)(4 * i + k), o[k]);
+            for (int k = 0; k < 4; ++k) store_line(rdt, vd, d8 * (uint32_t)(4 * i + k), o[k]);
         }
         // the gain gradient's partial sums: over the 32 rows (lanes) of each half-wave, then one slab row per (row tile, wave row)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                float v = dg[j][c];
+                float v = dg[j][c >> 1][c & 1];
                 v += shfl_xor(v, 16); v += shfl_xor(v, 8); v += shfl_xor(v, 4); v += shfl_xor(v, 2); v += shfl_xor(v, 1);
-                dg[j][c] = v;
+                dg[j][c >> 1][c & 1] = v;
             }
         if (r == 0) {
             float* out = e.dg_partial + ((long)(m0 / G2_BM) * 2 + wm) * e.F + n0 + wn * 64 + 4 * h;
@@ -163,17 +203,20 @@ struct G4GegluBwdEpilogue {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const u32x4 v = {f2u(dg[j][4 * q]), f2u(dg[j][4 * q + 1]), f2u(dg[j][4 * q + 2]), f2u(dg[j][4 * q + 3])};
+                    const u32x4 v = {f2u(dg[j][2 * q][0]), f2u(dg[j][2 * q][1]), f2u(dg[j][2 * q + 1][0]), f2u(dg[j][2 * q + 1][1])};
                     st16(out + 32 * j + 8 * q, v);
                 }
         }
-        return 0;                                              // (loads and stores mixed: the next wait drains them)
+        // the last group's 4 + 4 line stores and the 8 stores of the column sums (issued by every wave: the lane mask only empties them) are
+        // the wave's 16 youngest memory operations; the next tile's first counted wait may leave them in flight (g5_run: in_flight == 16)
+        return (ABL & (1 | 8)) ? 0 : 16;
     }
 };
 
+template <int ABL = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm9_geglu_bwd_kernel(Gemm2Params p, GegluBwdArgs e) {
     XC_LDS_DYNAMIC(lds);
-    g5_run<false, true, G4GegluBwdEpilogue>(p, lds, G4GegluBwdEpilogue{p, e});
+    g5_run<false, true, G4GegluBwdEpilogue<ABL>>(p, lds, G4GegluBwdEpilogue<ABL>{p, e});
 }
 
 // wg[c] = sum_j W[c, j] gamma[j] (fp32): the weight-only vector of s1.  One wave per row of W.

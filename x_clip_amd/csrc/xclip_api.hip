@@ -1057,11 +1057,26 @@ int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t
     GegluBwdArgs e;
     e.x = (const bf16_t*)x; e.ldx = ldx; e.dx = (bf16_t*)dx; e.lddx = lddx; e.gamma = (const bf16_t*)gamma;
     e.rowc = rowc; e.dg_partial = slab; e.F = (int)F;
+
     int gx = q.tiles_m * q.tiles_n;
     const int cus = xc_num_cus();
     if (gx > cus) gx = cus;
-    XC_ALLOW_LDS(gemm9_geglu_bwd_kernel, G5_LDS_BYTES);
-    hipLaunchKernelGGL(gemm9_geglu_bwd_kernel, dim3((unsigned)gx, 1), dim3(G2_THREADS), G5_LDS_BYTES, st, q, e);
+#define XC_G9(N) do { XC_ALLOW_LDS(gemm9_geglu_bwd_kernel<N>, G5_LDS_BYTES); \
+        hipLaunchKernelGGL(gemm9_geglu_bwd_kernel<N>, dim3((unsigned)gx, 1), dim3(G2_THREADS), G5_LDS_BYTES, st, q, e); } while (0)
+#ifdef XCLIP_MEASURE
+    static const int abl = measure_env("XCLIP_GEMM9_ABL", 0);
+    switch (abl) {
+        case 1: XC_G9(1); break;
+        case 2: XC_G9(2); break;
+        case 4: XC_G9(4); break;
+        case 8: XC_G9(8); break;
+        case 14: XC_G9(14); break;
+        default: XC_G9(0); break;
+    }
+#else
+    XC_G9(0);
+#endif
+#undef XC_G9
     const int nrows = 2 * q.tiles_m;
     int slices = nrows / 64;
     if (slices < 1) slices = 1;
