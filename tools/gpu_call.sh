@@ -23,7 +23,7 @@ for TASK in "$@"; do
   case $KIND in
     tests)
       if [ -n "$ARG" ]; then ( time timeout 1500 python -m pytest tests -m gpu -q -k "$ARG" --durations=8 ) > gpurun_out/${TAG}_pytest_gpu_subset.log 2>&1; tail -12 gpurun_out/${TAG}_pytest_gpu_subset.log
-      else ( time timeout 1700 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -22 gpurun_out/${TAG}_pytest_gpu.log; fi
+      else ( time timeout ${TESTS_TIMEOUT:-1700} python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -22 gpurun_out/${TAG}_pytest_gpu.log; fi
       cp gpurun_out/parity_report_gpu.txt gpurun_out/${TAG}_parity_report_gpu.txt 2>/dev/null;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/${TAG}_smoke.log;;
