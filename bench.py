@@ -406,7 +406,7 @@ def main():
                 traffic_src = tj.get("source")
         except Exception:
             pass
-        out["roofline"] = {"kernel": "xclip_gemm (gemm8_kernel<bf16> plain interior NT/NN, gemm5_kernel<bf16> other NT/NN, gemm4_kernel<bf16> TN incl. split-K reduce): every nn.Linear fwd/dgrad/wgrad "
+        out["roofline"] = {"kernel": "xclip_gemm (gemm8_kernel<bf16> plain interior NT/NN, gemm5_kernel<bf16> other NT/NN, gemm4_kernel<bf16> TN incl. split-K reduce, gemm_small_kernel<bf16> the products with a few tiles of output): every nn.Linear fwd/dgrad/wgrad "
                                      "except net.4's input gradient (fused with the GEGLU-LayerNorm backward: families.fused_ffn_bwd)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 4),
