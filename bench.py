@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--no-dense-compare", action="store_true", help="skip the extra steps that time the dense last text layer beside the line "
                     "(rocprofv3 runs: every step of the process should be the same step)")
     ap.add_argument("--dense-last-layer", action="store_true", help="CLIP.prune_unused_rows = False: the text tower's last layer runs every token row, "
-                    "as the reference computes it (default: only the CLS row the head reads; same loss, same gradients)")
+                    "as the reference computes it (default: only the CLS row the head reads; the same loss and gradients up to bf16 rounding order)")
     ap.add_argument("--text-slices", type=int, default=1, help="CLIP.text_micro_batches: slices of the text batch on separate streams")
     ap.add_argument("--image-slices", type=int, default=None, help="CLIP.image_micro_batches: sequential slices of the image batch through the "
                     "vision tower (bounds the recompute transient; default 2 for --config vitl, else 1)")
@@ -310,7 +310,7 @@ def main():
                                 "default CLIP dim 512 depth 6/6 image 256 patch 32 text seq 256 (own measurement, not a BASELINE configuration as run), ") +
                                "patch dropout 0.5, " + ("DCL" if args.dcl else "InfoNCE") + ("" if not args.simsiam else " + SimSiam side loss") +
                                ("" if not args.causal else ", causal text encoder") + ", fwd+bwd" +
-                               ("; the last text layer computes only the CLS row the head reads (identical loss and gradients; "
+                               ("; the last text layer computes only the CLS row the head reads (the same loss and gradients up to bf16 rounding order; "
                                 "the dense layer is timed in `dense_last_layer`)" if text_pooled else ""),
                    "workload_tag": workload_tag, "local_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                    # the CLS head reads one row of the text encoding: the last text layer's row-wise part (to_out, feed-forward, norm_out) runs on
@@ -491,7 +491,7 @@ def main():
             dense_s = float(t.item())
         model.prune_unused_rows = True
         out["dense_last_layer"] = {"ms_per_step": round(dense_s / nd * 1e3, 3), "value": round(b * world * nd / dense_s, 2), "steps": nd,
-                                   "note": "CLIP.prune_unused_rows = False (bench.py --dense-last-layer): identical loss and gradients"}
+                                   "note": "CLIP.prune_unused_rows = False (bench.py --dense-last-layer): the same loss and gradients up to bf16 rounding order"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -370,14 +370,14 @@ def test_full_size_properties_bf16():
     ulp = float(tl.float().abs().max()) * 2.0 ** -7
     assert moved <= 16 and float(d.max()) <= 8 * ulp, (moved, float(d.max()), ulp)
     # ... and with ops.BATCH_INVARIANT_GEMM the round-3 property holds again: no product is cut, every sample bit for bit
-    from x_clip_amd import ops
-    ops.BATCH_INVARIANT_GEMM = True
+    import x_clip_amd
+    was = x_clip_amd.set_batch_invariant(True)
     try:
         with torch.no_grad():
             tl3, _ = m(text, image, return_latents=True)
             tl4 = torch.cat([m(text[i: i + 512], image[i: i + 512], return_latents=True)[0] for i in (0, 512)])
     finally:
-        ops.BATCH_INVARIANT_GEMM = False
+        x_clip_amd.set_batch_invariant(was)
     assert torch.equal(tl3, tl4), "with BATCH_INVARIANT_GEMM text latents must not depend on which other rows share the batch"
     loss = m(text, image, return_loss=True)
     loss.backward()

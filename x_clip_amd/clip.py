@@ -561,7 +561,7 @@ class CLIP(nn.Module):
         if not self.text_encode_without_mask:
             text_args = (*text_args, text_mask)
         # x_clip.py:708: the CLS path reads `enc_text[:, 0]` and nothing else -- the text tower is then asked for that row only and runs the
-        # row-wise part of its last layer on it (functional.stack_forward `pool_row`; same loss, same gradients: the other rows of that part
+        # row-wise part of its last layer on it (functional.stack_forward `pool_row`; the same loss and gradients up to bf16 rounding order: the other rows of that part
         # are dead in the forward and their gradient is exactly zero in the backward).  `prune_unused_rows = False` keeps the dense last layer.
         text_kwargs = None
         if (self.prune_unused_rows and isinstance(self.text_transformer, TextTransformer) and self.text_has_cls_token

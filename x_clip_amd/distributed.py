@@ -293,6 +293,7 @@ class GradSync:
         self._last_fire = [0] * nb                           # sequence number of a bucket's latest hook firing in this step
         self._events = [[] for _ in self.buckets]
         self._claimed = set()
+        self._missed = set()                                 # addresses claim() has looked for in a fresh index this step and not found
         self._cast_back = []                                 # (param, slice view) whose .grad has another dtype than the flat buffer
         self._step_open = False
         self.stats = {"in_place": 0, "copied": 0, "unused": 0}     # of the last step: gradients written straight into their slice / copied / absent
@@ -322,10 +323,15 @@ class GradSync:
         p = self._by_ptr.get(ptr)
         if p is None or p.data_ptr() != ptr:
             # the map is keyed by storage address: after model.to(...) / a .data swap the addresses are stale (and an old address may
-            # since belong to another tensor) -- rebuild from the live parameters and look again
+            # since belong to another tensor) -- rebuild from the live parameters and look again.  A weight this sink does not own (a
+            # padded copy, another model's parameter, a frozen tensor) misses on every backward GEMM: one rebuild per step and address,
+            # not one per call
+            if p is None and ptr in self._missed:
+                return None
             self._index_params()
             p = self._by_ptr.get(ptr)
             if p is None:
+                self._missed.add(ptr)
                 return None
         if tuple(p.shape) != tuple(shape) or p.dtype != dtype or p.grad is not None or id(p) in self._claimed:
             return None
@@ -451,6 +457,7 @@ class GradSync:
         self._works = []
         self._cast_back = []
         self._claimed.clear()
+        self._missed.clear()
         self._ready.clear()
         self._next = 0
         self._fire_seq = 0
