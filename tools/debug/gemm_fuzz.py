@@ -1,5 +1,7 @@
 """random GEMM shapes / layouts / epilogue terms against torch on the GPU (hardware-only hazards do not show on the emulator):
-    python tools/debug/gemm_fuzz.py [cases] [seed] [--large]
+    python tools/debug/gemm_fuzz.py [cases] [seed] [--large | --small]
+--small: shapes gemm_small.h takes (M, N, K multiples of 64, at most 32 K steps, a few tiles of output; any layout, alpha, the skip term with any
+layout, in place): counted waits on a ring of 2 ... 8 LDS-DMA stages, which the emulator cannot see
 --large: shapes of more than one round of tiles (the row-tail cut of persistent launches, xclip_api.hip gemm2_tail_cut: 257 ... 1100 tiles, ragged
 last row tile, with / without the skip term, in place) and weight-gradient shapes with long contractions (4 ... 48 output tiles x up to 64 K slices on
 the 1-D split-K grid, gemm2.h g2_where)"""
@@ -9,6 +11,7 @@ import torch
 from x_clip_amd import ops
 dev = torch.device("cuda:0")
 large = "--large" in sys.argv
+small = "--small" in sys.argv
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 cases = int(argv[0]) if len(argv) > 0 else 300
 seed = int(argv[1]) if len(argv) > 1 else 0
@@ -28,7 +31,12 @@ for it in range(cases):
     elif large:
         M, N = 256 * ri(1, 8) if ri(0, 1) else 8 * ri(32, 250), 256 * ri(1, 6) if ri(0, 1) else 8 * ri(32, 190)
         K = 64 * ri(300, 4200)
-    res = lay == "nt" and ri(0, 2) == 0
+    if small:
+        M, N, K = 64 * ri(1, 24), 64 * ri(1, 24), 64 * ri(1, 32)
+        if ri(0, 5) == 0:
+            M, N = 64 * ri(17, 40), 64 * ri(17, 40)                    # more than 256 tiles: four stages, two work-groups per CU
+            K = 64 * ri(1, 8)
+    res = (lay == "nt" or small) and ri(0, 2) == 0
     alpha = [1.0, 0.5, 0.125][ri(0, 2)] if not res else 1.0
     ak, bk = lay[0] == "t", lay[1] == "n"
     a = torch.randn((K, M) if ak else (M, K), device=dev, dtype=torch.bfloat16)
@@ -46,4 +54,6 @@ for it in range(cases):
     if not ok:
         bad += 1
         print(f"FAIL {lay} M={M} N={N} K={K} res={res} alpha={alpha}: err {err:.3e} scale {scale:.3e}", flush=True)
-print(f"{cases} cases, {bad} failures")
+if small:
+    assert ops.gemm_small_limit() > 0
+print(f"{cases} cases, {bad} failures" + (" (gemm_small.h shapes)" if small else ""))
