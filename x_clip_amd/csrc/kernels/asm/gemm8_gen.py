@@ -712,9 +712,13 @@ def main():
     parts.append("#define G8_RPL_VARIANTS(V) ((V) == 2)")
     parts.append(f"#define G8_VARIANTS {len(VARIANTS)}")
     parts.append("")
-    with open(os.path.join(HERE, "gemm8_body.inc"), "w") as f:
-        f.write("\n".join(parts))
-    print("wrote", os.path.join(HERE, "gemm8_body.inc"))
+    path, text = os.path.join(HERE, "gemm8_body.inc"), "\n".join(parts)
+    if os.path.exists(path) and open(path).read() == text:     # (untouched when nothing changed: the libraries are rebuilt by file time)
+        print("unchanged", path)
+        return
+    with open(path, "w") as f:
+        f.write(text)
+    print("wrote", path)
 
 
 if __name__ == "__main__":
