@@ -1246,7 +1246,7 @@ int64_t xclip_simloss_workspace_bytes(int64_t nq, int64_t nk) { return 2 * ((nk 
 inline bool use_sim3(int64_t nq, int64_t nk, int64_t d, int dtype) {
     return dtype == XCLIP_BF16 && d % G2_BK == 0 && nq >= 128 && nk >= 128;
 }
-inline dim3 sim3_grid(int64_t nq, int64_t nk) {
+extern "C++" inline dim3 sim3_grid(int64_t nq, int64_t nk) {
     int64_t tiles = ((nq + G2_BM - 1) / G2_BM) * ((nk + G2_BN - 1) / G2_BN);
     const int cus = xc_num_cus();
     return dim3((unsigned)(tiles < cus ? tiles : cus));
