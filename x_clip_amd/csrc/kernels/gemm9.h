@@ -60,7 +60,8 @@ XC_DEV void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
 
 // ABL (measurement build only, XCLIP_GEMM9_ABL; results are garbage except for 1): 1 the line stores as the untracked asm form (what the first
 // version did), 2 no GELU arithmetic (constants for cdf / pdf), 4 no line loads behind the first group's, 8 no line stores
-template <int ABL = 0>
+// WN: waves along N of the work-group's tile (4: g5_run's 2 x 4 waves on 256 x 256; 2: gemm10.h's 2 x 2 waves on 256 x 128)
+template <int ABL = 0, int WN = 4>
 struct G4GegluBwdEpilogue {
     const Gemm2Params& p;
     const GegluBwdArgs& e;
@@ -83,7 +84,7 @@ struct G4GegluBwdEpilogue {
 
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) const {
         const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-        const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+        const int wave = uniform(threadIdx.x >> 6), wm = wave >> (WN == 4 ? 2 : 1), wn = wave & (WN - 1);
         // whole-line descriptors of the tile's u, t, du, dt blocks
         const BufRsrc ru = make_rsrc(e.x + (long)m0 * e.ldx + n0, 255u * (uint32_t)e.ldx * 2u + 512u);
         const BufRsrc rt = make_rsrc(e.x + (long)m0 * e.ldx + e.F + n0, 255u * (uint32_t)e.ldx * 2u + 512u);
