@@ -4,7 +4,7 @@ operations lucidrains/x-clip uses -- nn.Linear, an einsum attention with an fp32
 GEGLU with a LayerNorm inside the feed-forward, pre-norm residual blocks (x_clip.py:111-121,180-199,201-245,274-291) -- forward + backward, bf16,
 b = 1024, beside this repository's step on the same box.  It is NOT the reference (which is absent from the GPU box) and not the oracle: an independent
 few-line model of the same shapes, a yardstick for "the same architecture through the framework's stock kernels".
-    python tools/probe_eager_torch_step.py [batch]"""
+    python tools/probe_eager_torch_step.py [batch] [--fused]      (--fused: F.layer_norm and scaled_dot_product_attention in place of the elementwise forms)"""
 import os
 import sys
 import time
@@ -17,12 +17,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dev = torch.device("cuda:0")
 
 
+STOCK_FUSED = False        # --fused: the framework's fused kernels where it has them (F.layer_norm, scaled_dot_product_attention) instead of the
+                           # reference's elementwise formulations: the best a user gets from stock PyTorch-ROCm without writing kernels
+
+
 class Norm(nn.Module):
     def __init__(self, dim):
         super().__init__()
         self.g = nn.Parameter(torch.ones(dim))
 
     def forward(self, x):
+        if STOCK_FUSED:
+            return F.layer_norm(x, x.shape[-1:], self.g, None, 1e-3)
         var = torch.var(x, dim=-1, unbiased=False, keepdim=True)
         mean = torch.mean(x, dim=-1, keepdim=True)
         return (x - mean) * (var + 1e-3).rsqrt() * self.g
@@ -40,6 +46,10 @@ class Attn(nn.Module):
     def forward(self, x, mask=None):
         b, n, _ = x.shape
         q, k, v = self.qkv(self.norm(x)).view(b, n, 3, self.h, -1).permute(2, 0, 3, 1, 4)
+        if STOCK_FUSED:
+            am = None if mask is None else mask[:, None, None, :]
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=am, scale=self.scale).permute(0, 2, 1, 3).reshape(b, n, -1)
+            return self.out_norm(self.out(o))
         sim = torch.einsum("bhid,bhjd->bhij", q * self.scale, k)
         if mask is not None:
             sim = sim.masked_fill(~mask[:, None, None, :], -torch.finfo(sim.dtype).max)
@@ -110,7 +120,10 @@ class EagerCLIP(nn.Module):
 
 
 def main():
-    b = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    global STOCK_FUSED
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    STOCK_FUSED = "--fused" in sys.argv
+    b = int(argv[0]) if argv else 1024
     torch.manual_seed(0)
     text = torch.randint(1, 10000, (b, 256), device=dev)
     image = torch.randn(b, 3, 256, 256, device=dev, dtype=torch.bfloat16)
@@ -132,7 +145,7 @@ def main():
     def eager_step():
         m.zero_grad(set_to_none=True)
         m(text, image).backward()
-    e = timed(eager_step, f"eager PyTorch-ROCm modules, b = {b}, bf16")
+    e = timed(eager_step, f"eager PyTorch-ROCm modules{' (F.layer_norm + SDPA)' if STOCK_FUSED else ' (the reference`s formulations)'}, b = {b}, bf16")
     del m
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
