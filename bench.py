@@ -134,6 +134,131 @@ def cpu_baseline(budget_s=45.0):
                       f"5.7 fp32 b=32, 18.2 bf16 b=32"}
 
 
+def reference_cpu_baseline(budget_s=40.0, path="/root/reference"):
+    """the REFERENCE ITSELF (lucidrains/x-clip imported from `path`, torchvision stubbed as SURVEY.md Appendix D prescribes) timed on this
+    host's cores on the same bounded sample as the port: default CLIP, patch dropout 0.5, forward + backward, bf16 batch 32 and fp32 batch 8.
+    Returns None where the reference is not importable (the GPU boxes of the pool do not hold /root/reference: the port is timed there)."""
+    import types
+    if not os.path.isdir(os.path.join(path, "x_clip")):
+        return None
+    saved_mods = {k: sys.modules.get(k) for k in ("x_clip", "x_clip.x_clip", "x_clip.distributed", "x_clip.mlm", "x_clip.visual_ssl", "x_clip.tokenizer",
+                                                  "torchvision", "torchvision.transforms")}
+    saved_path = list(sys.path)
+    try:
+        for k in list(sys.modules):
+            if k == "x_clip" or k.startswith("x_clip."):
+                del sys.modules[k]
+        if "torchvision" not in sys.modules:
+            tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+            tv.transforms = tvt
+            sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
+        sys.path.insert(0, path)
+        import x_clip as ref
+        if not os.path.abspath(ref.__file__).startswith(os.path.abspath(path)):
+            return None                                               # this repository's alias package answered: not the reference
+        ncpu = os.cpu_count() or 1
+        threads = min(ncpu, 16)                                       # (the port's sweep on the 256-thread host of the GPU box peaks at 16)
+        before = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        t_start = time.perf_counter()
+        runs = []
+        for name, dt, b, steps in (("bf16", torch.bfloat16, 32, 3), ("fp32", torch.float32, 8, 3)):
+            if time.perf_counter() - t_start > budget_s:
+                break
+            torch.manual_seed(0)
+            clip = ref.CLIP().to(dt).train()
+            g = torch.Generator().manual_seed(1234)
+            text = torch.randint(0, 10000, (b, 256), generator=g)
+            image = torch.randn(b, 3, 256, 256, generator=g).to(dt)
+
+            def step():
+                clip.zero_grad(set_to_none=True)
+                clip(text, image, return_loss=True).backward()
+            step()
+            rates = []
+            for _ in range(steps):
+                t0 = time.perf_counter()
+                step()
+                rates.append(b / (time.perf_counter() - t0))
+            rates.sort()
+            runs.append((name, b, threads, rates[len(rates) // 2], rates[0], rates[-1]))
+            del clip
+        torch.set_num_threads(before)
+        if not runs:
+            return None
+        best = max(runs, key=lambda r: r[3])
+        return {"value": round(best[3], 3), "unit": "pairs/s", "cores": best[2], "kind": "reference", "dtype": best[0], "batch": best[1], "host_cpus": ncpu,
+                "sweep": [{"dtype": d, "batch": b, "threads": t, "pairs_per_s": round(v, 3), "min": round(lo, 3), "max": round(hi, 3)} for d, b, t, v, lo, hi in runs],
+                "sample": f"x_clip.CLIP() of {path} (torchvision stubbed), loss = clip(text, image, return_loss=True); loss.backward(), default CLIP, patch dropout 0.5, "
+                          f"3 timed steps per setting after a warm-up (median); best = {best[0]} batch {best[1]} on {best[2]} of {ncpu} host threads "
+                          f"({time.perf_counter() - t_start:.0f} s of CPU work)"}
+    except Exception as e:                                            # noqa: BLE001  (a baseline must never cost the line)
+        print(f"bench.py: reference CPU baseline unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+        return None
+    finally:
+        sys.path[:] = saved_path
+        for k in list(sys.modules):
+            if k == "x_clip" or k.startswith("x_clip."):
+                del sys.modules[k]
+        for k, v in saved_mods.items():
+            if v is not None:
+                sys.modules[k] = v
+            elif k.startswith("torchvision"):
+                sys.modules.pop(k, None)
+
+
+def head_32k_probe(dev, iters=10, warm=3):
+    """The north star's sim-matrix kernel at the shape it names (BASELINE configs[2]: global batch 32768 = 8 ranks x 4096): ONE rank's row
+    block -- 4096 local latents against the 32768 gathered ones, d = 512, bf16 -- on synthetic l2-normalised latents, outside the timed region.
+    Four kernels, each timed alone with HIP events on the launch stream: the fused similarity + online log-sum-exp forward (no logits stored),
+    the softmax-gradient factor G (written once, bf16), and the two gradient products that read it.  Every kernel is reported against BOTH
+    roofs: the forward moves (b + B) d e = 37.7 MB for 137 GFLOP (3,600 FLOP/B: it is judged against the MFMA peak); G writes
+    b B e = 268 MB (512 FLOP/B, past the machine balance of 312: MFMA-bound in principle, its HBM floor of 34 us is 0.6 of its 55 us MFMA floor,
+    so both fractions are quoted)."""
+    from x_clip_amd import ops
+    b, B, d = 4096, 32768, 512
+    T = torch.nn.functional.normalize(torch.randn(b, d, device=dev), dim=-1).bfloat16()
+    I = torch.nn.functional.normalize(torch.randn(B, d, device=dev), dim=-1).bfloat16()
+    tau = torch.tensor([1.0], device=dev)
+    loss = torch.zeros(1, device=dev)
+    dtau = torch.zeros(1, device=dev)
+
+    def timeit(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / iters * 1e-3
+
+    fl = 2.0 * b * B * d
+    lse, _ = ops.simloss_fwd(T, I, 1.0, 0, True, 1.0 / (2 * B), loss, log_scale=tau)
+    lk = torch.full((B,), float(lse.mean()), device=dev)
+    G = torch.empty(b, B, dtype=torch.bfloat16, device=dev)
+    rows = {}
+    t = timeit(lambda: ops.simloss_fwd(T, I, 1.0, 0, True, 1.0 / (2 * B), loss, log_scale=tau))
+    rows["forward_sim_lse"] = (t, fl, (b + B) * d * 2 + 2 * b * 4)
+    t = timeit(lambda: ops.simloss_grad(T, I, 1.0, 0, True, 0.5 / B, 0.5 / B, 1.0 / B, lse, lk, dtau, log_scale=tau, times_scale=True, out=G))
+    rows["G"] = (t, fl, (b + B) * d * 2 + b * B * 2)
+    t = timeit(lambda: ops.gemm(G, I, b, d, B, b_kmajor=True))
+    rows["dT_eq_G_I"] = (t, fl, b * B * 2 + (b + B) * d * 2)
+    t = timeit(lambda: ops.gemm(G, T, B, d, b, a_kmajor=True, b_kmajor=True))
+    rows["dI_eq_Gt_T"] = (t, fl, b * B * 2 + (b + B) * d * 2)
+    out = {"shape": {"local_rows": b, "gathered_cols": B, "d": d, "dtype": "bf16"}, "kernels": {}}
+    for k, (t, f, by) in rows.items():
+        out["kernels"][k] = {"us": round(t * 1e6, 1), "mfma_frac": round(f / t / MFMA_PEAK_BF16, 4), "hbm_frac": round(by / t / HBM_PEAK, 4),
+                             "tflops": round(f / t / 1e12, 1), "algorithmic_gb_s": round(by / t / 1e9, 1)}
+    bwd = sum(rows[k][0] for k in ("G", "dT_eq_G_I", "dI_eq_Gt_T"))
+    out["backward_total_us"] = round(bwd * 1e6, 1)
+    out["bound"] = "mfma (forward: 3,600 FLOP/B; G: 512 FLOP/B against a machine balance of 312 -- both fractions per kernel)"
+    out["measured"] = f"HIP events on the launch stream, {iters} launches per kernel after {warm} warm-up launches, kernels alone on the chip, synthetic l2-normalised latents"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +266,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-head-probe", action="store_true", help="skip roofline.families.head_32k (the contrastive head's kernels at the 4096 x 32768 x 512 rank block)")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-launch GEMM event probe pass after the timed region")
     ap.add_argument("--overlap", default="both", choices=["both", "towers", "wgrad"], help="which side streams to use (diagnostics)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side streams for the vision tower / weight gradients "
@@ -357,6 +483,30 @@ def main():
             "measured": "HIP events on the compute stream around every wait for a collective (max over ranks), " + str(args.steps) + " extra steps; "
                         "exposed = what the step pays, 0 when the collective finished under the kernels issued meanwhile",
         }
+        # Self-verification of the multi-rank step: every rank evaluates the SAME global-batch loss (its partial sums are
+        # all-reduced) and, after GradSync, holds the SAME averaged gradients -- bit for bit, they come out of one all-reduce.  The last
+        # step's loss and a checksum of three gradients (first text layer's to_qkv, the patch embedding, the temperature: one from each
+        # end of the bucket order) are gathered from all ranks; a disagreement means the collectives paired wrong buffers or a rank missed an
+        # edge, and the line is marked invalid (exit status 1) instead of reporting a throughput for wrong numbers.
+        names = ["text_transformer.transformer.layers.0.0.fn.to_qkv.weight", "visual_transformer.to_tokens.1.weight", "temperature"]
+        params = dict(model.named_parameters())
+        mine = [loss_val]
+        for nme in names:
+            gr = params[nme].grad if nme in params else None
+            mine += [float(gr.double().abs().sum()), float(gr.double().sum())] if gr is not None else [float("nan"), float("nan")]
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        cols = list(zip(*every))
+        finite = all(v == v and abs(v) != float("inf") for row in every for v in row)
+        loss_spread = max(cols[0]) - min(cols[0])
+        grads_equal = all(max(c) == min(c) for c in cols[1:])
+        out["comm"]["cross_rank"] = {"loss_per_rank": [round(v, 6) for v in cols[0]], "loss_spread": loss_spread, "grad_checksum_equal": bool(grads_equal),
+                                     "finite": bool(finite), "checked": names,
+                                     "how": "last step run: loss and (sum |g|, sum g) in fp64 of the named gradients, all_gather_object over the ranks; equal = the same bits"}
+        out["comm"]["loss_spread"] = loss_spread
+        out["comm"]["grad_checksum_equal"] = bool(grads_equal)
+        if not (finite and grads_equal and loss_spread <= 1e-6 * max(1.0, abs(loss_val))):
+            out["invalid"] = "the ranks disagree on the loss or on the averaged gradients (comm.cross_rank): no throughput is claimed for this run"
         n1 = os.environ.get("XCLIP_BENCH_N1_PAIRS_PER_S")
         if n1:
             out["comm"]["scaling_efficiency"] = round(value / (world * float(n1)), 4)
@@ -455,8 +605,19 @@ def main():
                                     "frac": round(b_f / s_f / HBM_PEAK, 4), "mfma_frac": round(f_f / s_f / MFMA_PEAK_BF16, 4),
                                     "avg_launch_us": round(s_f / len(recs) * 1e6, 2),
                                     "ms_per_step": round(s_f / max(args.steps, 1) * 1e3, 3), "launches_per_step": len(recs) // max(args.steps, 1)}
+        if not args.no_head_probe and world == 1:
+            try:                                                       # (an auxiliary figure must never cost the line)
+                fam_head = head_32k_probe(dev)
+                out["roofline"]["families_head_32k_note"] = ("head_32k is NOT part of the step at b = 1024 (its head kernels are head_forward / head_G above, launch-bound): "
+                                                             "it is the north star's sim-matrix kernel at global batch 32768, one rank's row block, probed outside the timed region")
+            except Exception as e:                                     # noqa: BLE001
+                fam_head = {"error": f"{type(e).__name__}: {e}"}
+        else:
+            fam_head = None
         out["roofline"]["families"] = fam
         out["roofline"]["families_ms_per_step"] = round(sum(v["ms_per_step"] for v in fam.values()), 3)
+        if fam_head is not None:
+            fam["head_32k"] = fam_head
         out["roofline"]["probe_pass_ms_per_step"] = round(probe_elapsed / max(args.steps, 1) * 1e3, 3)
         # The shader clock UNDER the load: two more steps in which a one-wave sampler is started on a side stream in front of every 8th GEMM
         # launch and counts shader cycles (s_memtime) over 200 us of the constant 100 MHz counter while that GEMM -- and whatever follows it --
@@ -480,7 +641,7 @@ def main():
             step()
         fence()
         td = time.perf_counter()
-        nd = max(2, min(5, args.steps))
+        nd = max(2, args.steps)                                  # (the same number of timed steps as the headline: VERDICT r5 item 8a)
         for _ in range(nd):
             step()
         fence()
@@ -493,11 +654,20 @@ def main():
         out["dense_last_layer"] = {"ms_per_step": round(dense_s / nd * 1e3, 3), "value": round(b * world * nd / dense_s, 2), "steps": nd,
                                    "note": "CLIP.prune_unused_rows = False (bench.py --dense-last-layer): the same loss and gradients up to bf16 rounding order"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        # the reference itself where it can be imported (north_star: "the reference CPU forward+backward timed on the host cores of the same
+        # box"), kind "reference"; the GPU boxes hold no /root/reference: there the oracle port is timed, kind "port" 
+        ref_line = reference_cpu_baseline()
+        if ref_line is not None:
+            out["cpu_baseline"] = ref_line
+            out["cpu_baseline"]["port"] = "not timed (the reference itself was importable)"
+        else:
+            out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if out.get("invalid"):
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

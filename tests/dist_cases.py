@@ -1,6 +1,9 @@
-"""Workers of the 2-rank runs of the product, shared by the CPU suite (tests/test_distributed_gloo.py: gloo backend, kernels from the
-wave64 emulator build) and the GPU suite (tests/test_distributed_gpu.py: two processes on cuda:0, libxclip_hip.so, real HIP streams;
-gloo carries the collectives because RCCL does not accept two ranks on one device).  `kind` = "cpu" | "cuda"."""
+"""Workers of the multi-rank runs of the product, shared by the CPU suite (tests/test_distributed_gloo.py: gloo backend, kernels from the
+wave64 emulator build) and the GPU suite (tests/test_distributed_gpu.py: libxclip_hip.so, real HIP streams).  `kind` =
+  "cpu"  -- emulator kernels, gloo;
+  "cuda" -- every rank on cuda:0 of a one-GPU box, gloo carrying the collectives (RCCL does not accept two ranks on one device);
+  "rccl" -- rank r on cuda:r, the `nccl` backend (= RCCL over xGMI): what `bench.py --gpus N` runs on a multi-GPU node.  The tests that
+            use it skip where torch.cuda.device_count() < world."""
 import json
 import os
 import sys
@@ -38,9 +41,13 @@ def setup(rank, world, port, kind, backend="gloo"):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from x_clip_amd import _lib
-    if kind == "cuda":
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
+    if kind in ("cuda", "rccl"):
+        index = rank if kind == "rccl" else 0
+        if kind == "rccl":
+            assert torch.cuda.device_count() >= world, (torch.cuda.device_count(), world)
+            backend = "nccl"
+        torch.cuda.set_device(index)
+        dev = torch.device("cuda", index)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -88,7 +95,7 @@ def worker_fixture(rank, world, port, name, sizes, tmp, kind="cpu"):
 
 
 def worker_even(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", dtype_name="float32", patch_keep=None, backend="gloo", steps=1,
-                force_gather=False, reduce_dtype_name=None, second_sink=False):
+                force_gather=False, reduce_dtype_name=None, second_sink=False, bucket_bytes=None):
     """backend="nccl" with world = 1: RCCL itself on the one GPU of the box -- its collectives run on the process group's own stream and
     Work.wait() has real stream semantics (force_gather: CLIP latches requires_all_gather only for world > 1, x_clip.py:591)"""
     dev = setup(rank, world, port, kind, backend)
@@ -115,7 +122,10 @@ def worker_even(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", dtype_nam
     other = None
     if second_sink:                                           # a second GradSync (another model) must not displace the first
         other = GradSync(torch.nn.Linear(8, 8).to(dev))
-    sync = GradSync(model, reduce_dtype=getattr(torch, reduce_dtype_name) if reduce_dtype_name else None)
+    sync = GradSync(model, reduce_dtype=getattr(torch, reduce_dtype_name) if reduce_dtype_name else None,
+                    **({"bucket_bytes": bucket_bytes} if bucket_bytes else {}))
+    if bucket_bytes:                                          # the towers cut into several buckets (toy models: ask for small ones)
+        assert len(sync.buckets) >= 5, [sum(p.numel() for p in b) for b in sync.buckets]
     if second_sink:
         other2 = GradSync(torch.nn.Linear(8, 8).to(dev))      # ... whichever was registered last
     for step in range(steps):                                 # steps > 1: the later steps launch buckets from the hooks, in the frozen order
@@ -127,12 +137,13 @@ def worker_even(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", dtype_nam
             assert sync.stats["in_place"] >= 4 * (cfg.text_enc_depth + cfg.visual_enc_depth), sync.stats     # the weight-gradient GEMMs wrote into the bucket slices
         if step > 0:
             assert sync._agreed and all(e is not None for e in sync._expected)
-    if kind == "cuda":
+    if kind != "cpu":
         torch.cuda.synchronize()
     grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
     for p in model.parameters():
         assert p.grad is None or p.grad.dtype == p.dtype
-    torch.save({"loss": float(loss.detach()), "grads": grads, "overlap": sync.overlap}, os.path.join(tmp, f"rank{rank}.pt"))
+    torch.save({"loss": float(loss.detach()), "grads": grads, "overlap": sync.overlap, "buckets": len(sync.buckets), "launched": sync.launched,
+                "order": list(sync._order)}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -170,6 +181,55 @@ def worker_disagreeing_ranks(rank, world, port, cfg_kwargs, batch, tmp, kind="cp
     dist.destroy_process_group()
 
 
+def worker_unfreeze(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", bucket_bytes=None):
+    """LiT-style unlock: the text tower is frozen for two steps and trained from the third.  Without rearm() the third step's
+    finish() raises on every rank (gradients for buckets no rank reduced in the first step) and leaves a usable object; after rearm() the
+    step is a first step again and the averaged gradients of BOTH towers are the oracle's (data and checks of worker_even)."""
+    dev = setup(rank, world, port, kind)
+    from x_clip_amd import CLIP
+    from x_clip_amd.distributed import GradSync
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig(**cfg_kwargs)
+    sd = O.make_state_dict(cfg, 5, torch.float32)
+    text, image, aug_t, _ = O.make_inputs(cfg, batch * world, 6, 1, 0)
+    sl = slice(rank * batch, (rank + 1) * batch)
+    model = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    model.assume_equal_batch = True
+    sync = GradSync(model, **({"bucket_bytes": bucket_bytes} if bucket_bytes else {}))
+
+    def step(freeze):
+        model.zero_grad(set_to_none=True)
+        loss = model(text[sl].to(dev), image[sl].float().to(dev), return_loss=True, aug_text=[aug_t[0][sl].to(dev)], freeze_text_encoder=freeze)
+        loss.backward()
+        return loss
+
+    for _ in range(2):
+        step(True)
+        sync.finish()
+    step(False)
+    raised = False
+    try:
+        sync.finish()
+    except RuntimeError as e:
+        raised = "rearm" in str(e)
+    assert raised
+    assert sync._works == [] and all(c == 0 for c in sync._count) and not sync._claimed      # the step's state was reset before the raise
+    sync.rearm()
+    launched0 = sync.launched
+    for _ in range(2):                                        # a first step again, then one launched from the hooks
+        loss = step(False)
+        sync.finish()
+    assert sync._agreed and all((e or 0) > 0 for e in sync._expected), sync._expected
+    assert sync.launched - launched0 == 2 * len(sync.buckets)
+    if kind != "cpu":
+        torch.cuda.synchronize()
+    grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
 def worker_filip(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu"):
     dev = setup(rank, world, port, kind)
     from x_clip_amd import CLIP
@@ -189,7 +249,7 @@ def worker_filip(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu"):
 
 
 def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_text=0, n_aug_image=0, gradsync=False, dtype_name="float32",
-                  freeze_text=False, image_slices=1):
+                  freeze_text=False, image_slices=1, bucket_bytes=None):
     """any world size, any per-rank batch sizes, any head: rank r holds rows sum(sizes[:r]) ... of the global batch of every view"""
     dev = setup(rank, world, port, kind)
     from x_clip_amd import CLIP
@@ -205,7 +265,7 @@ def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_t
     model = CLIP(**cfg.ctor_kwargs(), visual_patch_dropout=0.0)
     model.load_state_dict(sd)
     model = model.to(dtype).to(dev).train()
-    sync = GradSync(model) if gradsync else None
+    sync = GradSync(model, **({"bucket_bytes": bucket_bytes} if bucket_bytes else {})) if gradsync else None
     model.image_micro_batches = image_slices              # > 1: the vision tower's parameters see that many backward passes per step
     kw = {}
     if n_aug_text:
@@ -229,7 +289,7 @@ def worker_ragged(rank, world, port, cfg_kwargs, sizes, tmp, kind="cpu", n_aug_t
             for p in model.parameters():
                 if p.grad is not None:
                     assert p.grad.data_ptr() == sync._view(p).data_ptr()
-    if kind == "cuda":
+    if kind != "cpu":
         torch.cuda.synchronize()
     grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
     torch.save({"loss": float(loss.detach()), "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))

@@ -117,7 +117,7 @@ def case_layernorm(dev, dtype, rows, dim, geglu, with_res):
     close(dg, g64.grad, dtype, "ln dg", mult=2.0)
 
 
-def case_ffn_dgrad_geglu(dev, M, F, D, seed=41):
+def case_ffn_dgrad_geglu(dev, M, F, D, seed=41, resid_scale=1.0):
     """csrc/kernels/gemm9.h: net.4's input gradient + net.2's (GEGLU-LayerNorm) backward in one kernel, against fp64 autograd through
     h = LayerNorm(u gelu(t)) g ; y = h W2^T and against the two-kernel path (xclip_gemm + xclip_layernorm_bwd).  The fused kernel takes its second row
     statistic from x2 - x1 (the block's output minus its input, both rounded to bf16): x2 is built by the product's own forward"""
@@ -125,7 +125,10 @@ def case_ffn_dgrad_geglu(dev, M, F, D, seed=41):
     u = rnd((M, 2 * F), dt, seed)
     g = (1 + 0.1 * rnd((F,), torch.float32, seed + 1)).to(dt)
     w2 = (rnd((D, F), torch.float32, seed + 2) / math.sqrt(F)).to(dt)
-    x1 = rnd((M, D), dt, seed + 3)
+    # resid_scale: the residual stream |x1| that many times the block's own output |y| ~ 1 (deep pre-norm layers): x2 = bf16(x1 + y)
+    # then carries ulp(x2) / 2 of absolute error per element, i.e. x2 - x1 knows y only to resid_scale x 2^-9 of ITS scale -- the cancellation
+    # the fused kernel's s2 = dOut . (x2 - x1) inherits and the two-kernel path (which reads the bf16-rounded d a instead) does not have
+    x1 = (resid_scale * rnd((M, D), torch.float32, seed + 3)).to(dt)
     dout = rnd((M, D), dt, seed + 4)
     ud, gd, wd, x1d, dd = u.to(dev), g.to(dev), w2.to(dev), x1.to(dev), dout.to(dev)
     a, mean, rstd = ops.layernorm_fwd(ud, gd, None, True)
@@ -147,13 +150,17 @@ def case_ffn_dgrad_geglu(dev, M, F, D, seed=41):
     scale = float(ref_dx.abs().max())
     e_f = float((dx.double().cpu() - ref_dx).abs().max()) / scale
     e_2 = float((dx2k.double().cpu() - ref_dx).abs().max()) / scale
-    _record("ffn_dgrad_geglu dx fused (two-kernel path: %.2e)" % e_2, dt, e_f, max(2.0 * e_2, 2.0 ** -7), "of the output scale")
     # no worse than twice the two-kernel path's own error (it rounds d a to bf16; the fused kernel keeps it in fp32 but takes s2 from bf16 x2 - x1)
-    assert e_f <= max(2.0 * e_2, 2.0 ** -7), (e_f, e_2)
+    # -- plus, for a residual stream R = |x1| / |y| > 1, the cancellation term of s2 (ops.FUSE_FFN_DGRAD's comment): x2 - x1 carries
+    # R 2^-9 |y| of rounding per element, s2 / F moves by that x sqrt(D) / F x |dOut|, and the largest element of dx sees it amplified by
+    # max |ahat| max |u| (~ 30 for Gaussian inputs; calibrated on the emulator: 4.2e-2 at R = 16, D = 128, F = 256) -- held to twice that
+    bound = max(2.0 * e_2, 2.0 ** -7) + (0.0 if resid_scale == 1.0 else 60.0 * resid_scale * 2.0 ** -9 * math.sqrt(D) / F)
+    _record("ffn_dgrad_geglu dx fused%s (two-kernel path: %.2e)" % ("" if resid_scale == 1.0 else " |x1|/|y| = %g" % resid_scale, e_2), dt, e_f, bound, "of the output scale")
+    assert e_f <= bound, (e_f, e_2, bound)
     gs = float(ref_dg.abs().max())
     g_f = float((dg.double().cpu() - ref_dg).abs().max()) / gs
     g_2 = float((dg2k.double().cpu() - ref_dg).abs().max()) / gs
-    assert g_f <= max(2.0 * g_2, 2.0 ** -7), (g_f, g_2)
+    assert g_f <= max(2.0 * g_2, 2.0 ** -7) + (0.0 if resid_scale == 1.0 else 60.0 * resid_scale * 2.0 ** -9 * math.sqrt(D) / F), (g_f, g_2)
 
 
 def case_l2norm(dev, dtype, rows, dim):

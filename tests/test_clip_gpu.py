@@ -379,6 +379,24 @@ def test_full_size_properties_bf16():
     finally:
         x_clip_amd.set_batch_invariant(was)
     assert torch.equal(tl3, tl4), "with BATCH_INVARIANT_GEMM text latents must not depend on which other rows share the batch"
+    # batch sizes on BOTH sides of the small-kernel boundary (gemm_small.h takes the pooled layer's / the latent products by their
+    # row count: B = 1024 yes, B = 1000 (not a multiple of 64) and B = 2048 (beyond its FLOP limit for the 4096-wide products) no)
+    from x_clip_amd import ops
+    limit = ops.gemm_small_limit()
+    was = x_clip_amd.set_batch_invariant(True)
+    try:
+        assert ops.gemm_small_limit() == 0
+        with torch.no_grad():
+            a1000 = m(text[:1000], image[:1000], return_latents=True)
+            a1024 = m(text, image, return_latents=True)
+            t2, i2 = torch.cat([text, text.flip(0)]), torch.cat([image, image.flip(0)])
+            a2048 = m(t2, i2, return_latents=True)
+    finally:
+        x_clip_amd.set_batch_invariant(was)
+    assert ops.gemm_small_limit() == limit
+    for k in (0, 1):
+        assert torch.equal(a1000[k], a1024[k][:1000]), ("1000 vs 1024", k)
+        assert torch.equal(a1024[k], a2048[k][:1024]), ("1024 vs 2048", k)
     loss = m(text, image, return_loss=True)
     loss.backward()
     S = math.e * tl.double() @ il.double().t()

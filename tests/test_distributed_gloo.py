@@ -56,6 +56,7 @@ def test_two_ranks_filip_vs_oracle(tmp_path, dcl):
 # the padded-on-the-wire gathers carry different sizes per rank, one rank holds a single sample ----------------------------------------
 RAGGED = {
     # name: (world sizes, config overrides, augmented text views, augmented image views, GradSync)
+    "w2_dcl_gradsync": ([5, 3], dict(decoupled_contrastive_learning=True), 1, 0, True),
     "w4_dcl": ([3, 1, 4, 2], dict(decoupled_contrastive_learning=True), 0, 0, False),
     "w4_simreg_extra_dcl": ([3, 1, 4, 2], dict(decoupled_contrastive_learning=True, extra_latent_projection=True, sim_reg_loss_weight=0.5), 0, 0, False),
     "w4_multiview_m3n2": ([2, 3, 1, 2], dict(), 2, 1, False),
@@ -148,3 +149,59 @@ def test_gradsync_ranks_that_disagree_fall_back_together(tmp_path):
     mp.spawn(D.worker_disagreeing_ranks, args=(2, port, dataclasses.asdict(cfg), 4, str(tmp_path)), nprocs=2, join=True)
     # (rank 1's frozen text tower contributed zeros: the vision side of the model is what both ranks differentiated)
     D.check_even(str(tmp_path), cfg, 4, 2, only_prefix=("visual_transformer.", "to_visual_latent", "temperature"))
+
+
+# ---- round 6: layer-sized gradient buckets and the announced unfreeze ---------------------------------
+@pytest.mark.parametrize("steps", [3])
+def test_gradsync_layer_sized_buckets_two_ranks(tmp_path, steps):
+    """the toy towers cut into many small buckets (bucket_bytes = 48 KB: embeddings, each layer, the projections): three steps, the later
+    ones launch every bucket from the hook that completes it in the agreed order (last layer first); gradients = (1 / W) x the oracle's,
+    the same bits on both ranks; both ranks agreed on one launch order and issued the same number of collectives"""
+    from oracle import clip_oracle as O
+    import torch
+    cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True, extra_latent_projection=True)
+    port = D.free_port()
+    mp.spawn(D.worker_even, args=(2, port, dataclasses.asdict(cfg), 8, str(tmp_path), "cpu", "float32", None, "gloo", steps, False, None, False, 48 << 10),
+             nprocs=2, join=True)
+    D.check_even(str(tmp_path), cfg, 8, 2)
+    outs = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(2)]
+    assert outs[0]["buckets"] == outs[1]["buckets"] >= 5
+    assert outs[0]["order"] == outs[1]["order"] and outs[0]["launched"] == outs[1]["launched"] == steps * outs[0]["buckets"]
+    assert outs[0]["overlap"] and outs[1]["overlap"]
+
+
+def test_gradsync_layer_sized_buckets_eight_ragged_ranks(tmp_path):
+    """eight ragged ranks, DCL + extra projections + multiview, small buckets, GradSync over three steps"""
+    from oracle import clip_oracle as O
+    sizes, over, n_t, n_i, gs = RAGGED["w8_dcl_extra_multiview_m2n2_gradsync"]
+    cfg = dataclasses.replace(O.CFG1, **over)
+    port = D.free_port()
+    mp.spawn(D.worker_ragged, args=(8, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "cpu", n_t, n_i, True, "float32", False, 1, 48 << 10),
+             nprocs=8, join=True)
+    D.check_ragged(str(tmp_path), cfg, sizes, n_t, n_i, True)
+
+
+def test_gradsync_partition_of_the_default_model():
+    """the default architecture in bf16 at the default bucket size: one bucket per transformer layer (8.4 MB), the embeddings apart, the
+    small top-level parameters last; every trainable parameter exactly once; nothing above 2 x bucket_bytes"""
+    import torch
+    from x_clip_amd import CLIP
+    from x_clip_amd.distributed import GradSync
+    model = CLIP().to(torch.bfloat16)
+    buckets = GradSync._partition(model, 12 << 20)
+    ids = [id(p) for b in buckets for p in b]
+    want = [id(p) for p in model.parameters() if p.requires_grad]
+    assert len(ids) == len(set(ids)) and set(ids) == set(want)
+    sizes = [sum(p.numel() * 2 for p in b) for b in buckets]
+    assert max(sizes) <= 24 << 20, sizes
+    assert len(buckets) >= 14, sizes                      # 6 + 6 layers, the embeddings / patch embedding, the projections
+    layer_sized = [s for s in sizes if 8 << 20 <= s <= 9 << 20]
+    assert len(layer_sized) >= 10, sizes
+
+
+def test_gradsync_unfreeze_needs_rearm(tmp_path):
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(O.CFG1, decoupled_contrastive_learning=True)
+    port = D.free_port()
+    mp.spawn(D.worker_unfreeze, args=(2, port, dataclasses.asdict(cfg), 4, str(tmp_path), "cpu", 48 << 10), nprocs=2, join=True)
+    D.check_even(str(tmp_path), cfg, 4, 2)

@@ -136,6 +136,55 @@ def test_eight_ranks_on_gpu_mid_bf16_gradsync_wire_dtype(tmp_path, wire):
     print("worst gradient relative error (8 ranks, bf16 model, wire", wire or "bfloat16", "):", worst)
 
 
+# ---- RCCL on DISTINCT devices: rank r on cuda:r, the `nccl` backend.  On the one-GPU boxes of the pool these SKIP
+# (and say so in the report); on a multi-GPU node they are the parity check of exactly what `bench.py --gpus N` runs: the latents' RCCL
+# all-gather consumed per rank chunk, the log-sum-exp gather, the scalar all-reduces and GradSync's bucketed all-reduces launched from the
+# hooks, all against the fp64 oracle of the concatenated global batch. ---------------------------------------------------------------------
+def _need_devices(world):
+    have = torch.cuda.device_count()
+    if have < world:
+        pytest.skip(f"RCCL on distinct devices needs {world} GPUs, this box has {have}")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_ranks_vs_oracle_even_mid_bf16_gradsync(tmp_path, world):
+    """the dim-512 bf16 model, DCL + one augmented text view, aligned per-rank batches, three steps (the later ones launch the gradient
+    buckets from the hooks in the agreed order): every rank's loss = the oracle's on the global batch, every rank's averaged gradients =
+    (1 / W) x the oracle's and the same bits on every rank"""
+    _need_devices(world)
+    from oracle import clip_oracle as O
+    cfg = O.ClipConfig(**MID)
+    batch = 32 // world if world > 2 else 8
+    port = D.free_port()
+    mp.spawn(D.worker_even, args=(world, port, dataclasses.asdict(cfg), batch, str(tmp_path), "rccl", "bfloat16", 8, "nccl", 3), nprocs=world, join=True)
+    worst = D.check_even(str(tmp_path), cfg, batch, world, dtype=torch.bfloat16, patch_keep=8, rel_bar=0.08, loss_bar=3e-4, cos_bar=0.995)
+    print(f"worst gradient relative error ({world} ranks over RCCL, bf16):", worst)
+
+
+@pytest.mark.parametrize("world,name", [(2, "w2_dcl_gradsync"), (4, "w4_dcl"), (4, "w4_simreg_extra_dcl"), (4, "w4_multiview_m3n2"), (4, "w4_filip_dcl"),
+                                        (8, "w8_infonce_gradsync"), (8, "w8_dcl_extra_multiview_m2n2_gradsync"), (8, "w8_filip")])
+def test_rccl_ranks_vs_oracle_ragged(tmp_path, world, name):
+    """ragged per-rank batches (padded on the wire, one rank with a single sample), every head: fp32, the oracle's bars of the gloo suite"""
+    _need_devices(world)
+    from oracle import clip_oracle as O
+    from test_distributed_gloo import RAGGED
+    sizes, over, n_t, n_i, gs = RAGGED[name]
+    assert len(sizes) == world
+    cfg = dataclasses.replace(O.CFG1, **over)
+    port = D.free_port()
+    mp.spawn(D.worker_ragged, args=(world, port, dataclasses.asdict(cfg), sizes, str(tmp_path), "rccl", n_t, n_i, gs), nprocs=world, join=True)
+    D.check_ragged(str(tmp_path), cfg, sizes, n_t, n_i, gs)
+
+
+@pytest.mark.parametrize("name,sizes", [("dist2_infonce", [5, 3]), ("dist2_dcl", [5, 3]), ("dist2_simreg_extra", [5, 3])])
+def test_rccl_two_ranks_match_reference_semantics(name, sizes, tmp_path):
+    """the reference's own distributed semantics (fixtures generated from the reference under gloo) over RCCL on two devices"""
+    _need_devices(2)
+    port = D.free_port()
+    mp.spawn(D.worker_fixture, args=(2, port, name, sizes, str(tmp_path), "rccl"), nprocs=2, join=True)
+    D.check_fixture(str(tmp_path), name)
+
+
 def test_rccl_two_ranks_one_device_probe(tmp_path):
     """RCCL (`nccl` backend) with both ranks on cuda:0: recorded, not required -- the single-GPU box cannot give each rank its own
     device; the driver's multi-GPU scaling run is where RCCL itself executes"""

@@ -36,6 +36,13 @@ def test_ffn_dgrad_geglu_fused(M, F, D):
     K.case_ffn_dgrad_geglu(DEV, M, F, D)
 
 
+@pytest.mark.parametrize("resid_scale", [16.0, 100.0])
+def test_ffn_dgrad_geglu_fused_large_residual_stream(resid_scale):
+    """|x1| = 16 x / 100 x the block's output (the second row statistic comes from the bf16 difference x2 - x1); the fused kernel
+    must stay within the bound the two-kernel path defines"""
+    K.case_ffn_dgrad_geglu(DEV, 256, 256, 128, resid_scale=resid_scale)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
 def test_l2norm(dtype):
     K.case_l2norm(DEV, dtype, 7, 64)

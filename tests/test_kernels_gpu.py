@@ -155,6 +155,12 @@ def test_ffn_dgrad_geglu_fused(M, F, D):
     K.case_ffn_dgrad_geglu(DEV, M, F, D)
 
 
+@pytest.mark.parametrize("resid_scale", [16.0, 100.0])
+def test_ffn_dgrad_geglu_fused_large_residual_stream(resid_scale):
+    """the residual stream 16 x / 100 x the feed-forward block's own output, at the vision tower's size"""
+    K.case_ffn_dgrad_geglu(DEV, 33792, 2048, 512, resid_scale=resid_scale)
+
+
 @pytest.mark.parametrize("layout,M,N,K_,alpha,in_place", [("nt", 4104, 512, 2048, 1.0, False), ("nn", 1024, 520, 256, 0.5, True), ("nt", 65792, 512, 2048, 1.0, False)])
 def test_gemm_residual_epilogue(layout, M, N, K_, alpha, in_place):
     K.case_gemm(DEV, torch.bfloat16, M, N, K_, layout, alpha=alpha, residual_only=True, in_place=in_place)

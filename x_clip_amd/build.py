@@ -34,17 +34,32 @@ def _sources():
     mdir = os.path.join(kdir, "measure")
     out += [os.path.join(mdir, f) for f in sorted(os.listdir(mdir)) if f.endswith(".h")]
     adir = os.path.join(kdir, "asm")
-    out += [os.path.join(adir, f) for f in sorted(os.listdir(adir)) if f.endswith((".inc", ".py"))]
+    out += [os.path.join(adir, f) for f in sorted(os.listdir(adir)) if f.endswith(".inc")]       # (the generated body is the dependency, not its generator)
     return out
 
 
 def _generate():
-    """the hand-scheduled kernel bodies (csrc/kernels/asm/*_gen.py -> *_body.inc): regenerated when the generator is newer"""
+    """the hand-scheduled kernel bodies (csrc/kernels/asm/*_gen.py -> *_body.inc): regenerated when the generator's CONTENT differs from
+    the one that wrote the body (its SHA-256 is kept beside the objects).  File times say nothing here: the generator leaves an unchanged
+    body untouched, so after a fresh checkout -- or an edit of the generator that does not change its output -- the body stays older than
+    its generator for ever and a time comparison would run the subprocess on every build()."""
+    import hashlib
     adir = os.path.join(CSRC, "kernels", "asm")
+    stamps = os.path.join(HERE, "_obj")
     for gen in sorted(f for f in os.listdir(adir) if f.endswith("_gen.py")):
         inc = os.path.join(adir, gen.replace("_gen.py", "_body.inc"))
-        if not os.path.exists(inc) or os.path.getmtime(inc) < os.path.getmtime(os.path.join(adir, gen)):
-            subprocess.run([sys.executable, os.path.join(adir, gen)], check=True, stdout=subprocess.DEVNULL)
+        with open(os.path.join(adir, gen), "rb") as f:
+            digest = hashlib.sha256(f.read()).hexdigest()
+        stamp = os.path.join(stamps, gen + ".sha256")
+        if os.path.exists(inc) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+            continue
+        subprocess.run([sys.executable, os.path.join(adir, gen)], check=True, stdout=subprocess.DEVNULL)
+        try:
+            os.makedirs(stamps, exist_ok=True)
+            with open(stamp, "w") as f:
+                f.write(digest + "\n")
+        except OSError:                                         # a read-only tree: the generator simply runs again next time
+            pass
 
 
 def build(force: bool = False, verbose: bool = False, measure: bool = False) -> str:

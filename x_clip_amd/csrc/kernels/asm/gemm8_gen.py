@@ -665,7 +665,10 @@ class Body:
 
 
 def clobbers(bk):
-    return [f"v{i}" for i in range(NV(bk))] + [f"s{i}" for i in range(S_LO, S_HI + 1)] + ["vcc", "memory"]
+    # scc (every s_add / s_cmp of the body) is named so that the unit stays safe if code is ever placed behind it.  m0 (the
+    # LDS-DMA base) cannot be named: it is a RESERVED register to the compiler ("inline asm clobber list contains reserved registers: m0"),
+    # which never keeps a value in it across statements and re-materialises it in front of every instruction of its own that reads it
+    return [f"v{i}" for i in range(NV(bk))] + [f"s{i}" for i in range(S_LO, S_HI + 1)] + ["vcc", "scc", "memory"]
 
 
 def c_string(lines):

@@ -60,7 +60,7 @@ XC_DEV void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
 
 // ABL (measurement build only, XCLIP_GEMM9_ABL; results are garbage except for 1): 1 the line stores as the untracked asm form (what the first
 // version did), 2 no GELU arithmetic (constants for cdf / pdf), 4 no line loads behind the first group's, 8 no line stores
-// WN: waves along N of the work-group's tile (4: g5_run's 2 x 4 waves on 256 x 256; 2: gemm10.h's 2 x 2 waves on 256 x 128)
+// WN: waves along N of the work-group's tile (4: g5_run's 2 x 4 waves on 256 x 256; 2: two waves along N (a 256 x 128 tile; round 5 experiment, removed))
 template <int ABL = 0, int WN = 4>
 struct G4GegluBwdEpilogue {
     const Gemm2Params& p;

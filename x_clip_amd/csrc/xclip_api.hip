@@ -12,9 +12,6 @@
 #include "kernels/gemm4.h"
 #include "kernels/gemm8.h"
 #include "kernels/gemm9.h"
-#ifdef XCLIP_MEASURE
-#include "kernels/measure/gemm10.h"
-#endif
 #include "kernels/gemm_small.h"
 #ifdef XCLIP_MEASURE                                             // negative-result experiments, measurement build only
 #include "kernels/measure/gemm6.h"
@@ -1064,20 +1061,8 @@ int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t
     int gx = q.tiles_m * q.tiles_n;
     const int cus = xc_num_cus();
     if (gx > cus) gx = cus;
-#ifdef XCLIP_MEASURE
-    // (measurement build, XCLIP_GEMM9_GROUPS=2: two four-wave work-groups per CU on 256 x 128 tiles, measure/gemm10.h -- slower, and not correct
-    //  on the hardware beyond one tile per work-group: see its header)
-    static const int groups = measure_env("XCLIP_GEMM9_GROUPS", G9_GROUPS_DEFAULT);
-    if (groups == 2 && D % G10_BK == 0 && D / G10_BK >= 4 && F % G10_BN == 0) {
-        static const int stagger = measure_env("XCLIP_GEMM10_STAGGER", G10_STAGGER_10NS);
-        Gemm2Params q2 = q;
-        q2.tiles_n = (int)(F / G10_BN);
-        int gx2 = q2.tiles_m * q2.tiles_n;
-        if (gx2 > 2 * cus) gx2 = 2 * cus;
-        XC_ALLOW_LDS(gemm10_geglu_bwd_kernel<0>, G10_LDS_BYTES);
-        hipLaunchKernelGGL(gemm10_geglu_bwd_kernel<0>, dim3((unsigned)gx2, 1), dim3(G10_THREADS), G10_LDS_BYTES, st, q2, e, stagger);
-    } else
-#endif
+    // (round 5's two-work-groups-per-CU form of this kernel -- 256 x 128 tiles, four waves each -- measured slower, 1457 against 1277 us, and
+    //  was not correct beyond one tile per work-group on the hardware; removed in round 6, log: profiles/r05_aa_gemm10_two_groups_ab.log)
     {
 #define XC_G9(N) do { XC_ALLOW_LDS(gemm9_geglu_bwd_kernel<N>, G5_LDS_BYTES); \
         hipLaunchKernelGGL(gemm9_geglu_bwd_kernel<N>, dim3((unsigned)gx, 1), dim3(G2_THREADS), G5_LDS_BYTES, st, q, e); } while (0)
