@@ -408,6 +408,8 @@ inline void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_b
     unsigned char* dst = (unsigned char*)lds_wave_base + 16 * lane_id();
     if (off + 16 <= r.bytes) memcpy(dst, r.base + off, 16); else memset(dst, 0, 16);
 }
+inline const void* uniform_ptr(const void* p) { return p; }
+inline void buf_glds16_raw(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) { buf_glds16(r, voff, soff, lds_wave_base); }
 template <int IMM>
 inline u32x4 buf_ld16(BufRsrc r, uint32_t voff, uint32_t soff) {
     const uint64_t off = (uint64_t)voff + soff + IMM;
@@ -477,6 +479,8 @@ constexpr bool XC_ASM_UNITS = false;
 inline uint32_t lds_addr(const void*) { return 0; }        // (only feeds asm units)
 
 inline void atomic_add(float* p, float v) { *p += v; }
+inline void lds_atomic_add(float* p, float v) { *p += v; }      // (fibres switch only at collectives / barriers)
+inline void lds_atomic_add(int* p, int v) { *p = (int)((unsigned)*p + (unsigned)v); }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }

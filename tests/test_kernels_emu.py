@@ -398,6 +398,34 @@ def test_gemm6_gemm7_experimental_kernels():
         assert out.returncode == 0 and "gemm6 ok" in out.stdout, (gen, out.stderr[-2000:])
 
 
+def test_attention_streaming_backward_measurement_build():
+    """attention6.h (round 6: the attention backward as a stream through a three-slot LDS ring, one persistent work-group per CU, dQ summed in
+    fixed point with integer LDS atomics; MEASUREMENT build only, XCLIP_ATTN_BWD=6 -- measured slower than attention5.h) against the fp64
+    reference: n = 256 / 257, masks incl. a padded tail key, more heads than emulated CUs (a work-group walks several heads: the ring, the K / V
+    image hand-over and the lse / mask registers cross head boundaries); its dQ is bit-reproducible (integer adds commute)"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from x_clip_amd import _lib, ops\n"
+        "from emu.build_emu import build\n"
+        "_lib._use_library_for_tests(build(measure=True))\n"
+        "import kernel_cases as K\n"
+        "dev = torch.device('cpu')\n"
+        "K.case_attention(dev, torch.bfloat16, 2, 256, 1, True)\n"
+        "K.case_attention(dev, torch.bfloat16, 5, 257, 2, True)\n"
+        "K.case_attention_single_tail(dev, torch.bfloat16)\n"
+        "torch.manual_seed(0)\n"
+        "qkv = torch.randn(4, 257, 3 * 64).bfloat16(); do = torch.randn(4, 257, 64).bfloat16()\n"
+        "out, lse = ops.attention_fwd(qkv, None, 1, 0.125)\n"
+        "a = ops.attention_bwd(qkv, None, out, do, lse, 1, 0.125); b = ops.attention_bwd(qkv, None, out, do, lse, 1, 0.125)\n"
+        "assert torch.equal(a, b)\n"
+        "print('attn6 ok')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XCLIP_ATTN_BWD="6"), capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0 and "attn6 ok" in out.stdout, out.stderr[-3000:]
+
+
 def test_gemm_split_k_whole_slices_per_xcd():
     """weight-gradient (TN) split-K launches run on a 1-D grid whose work-groups place themselves: the (slice, tile) pairs slice-major, one
     contiguous eighth per XCD (gemm2.h g2_where: the work-groups that read the same K range share an L2).  16 slices x 2 tiles, 8 x 8, 16 x 4

@@ -193,6 +193,34 @@ def test_attention_wide_heads(dtype, n, heads, masked, causal):
     K.case_attention(DEV, dtype, 3, n, heads, masked, causal=causal, hd=128)
 
 
+def test_attention_streaming_backward_measurement_build():
+    """attention6.h on the hardware (round 6; MEASUREMENT build, XCLIP_ATTN_BWD=6: slower than attention5.h, kept as a measured alternative):
+    the streamed ring, the counted waits that leave a step's requests in flight, the K / V image hand-over across heads and the integer
+    LDS atomics against the fp64 reference -- 8192 heads on 256 persistent work-groups (32 heads each) -- and bit-reproducible dQ"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from x_clip_amd import _lib, ops\n"
+        "_lib.use_measurement_build()\n"
+        "import kernel_cases as K\n"
+        "dev = torch.device('cuda:0')\n"
+        "K.case_attention(dev, torch.bfloat16, 3, 256, 2, True)\n"
+        "K.case_attention_single_tail(dev, torch.bfloat16, n=257, heads=8)\n"
+        "K.case_attention(dev, torch.bfloat16, 1024, 257, 8, True)\n"
+        "torch.manual_seed(0)\n"
+        "qkv = torch.randn(300, 257, 3 * 8 * 64, device=dev).bfloat16(); do = torch.randn(300, 257, 8 * 64, device=dev).bfloat16()\n"
+        "out, lse = ops.attention_fwd(qkv, None, 8, 0.125)\n"
+        "a = ops.attention_bwd(qkv, None, out, do, lse, 8, 0.125); b = ops.attention_bwd(qkv, None, out, do, lse, 8, 0.125)\n"
+        "assert torch.equal(a, b) and torch.isfinite(a.float()).all()\n"
+        "print('attn6 ok')\n") % (here, os.path.dirname(here))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XCLIP_ATTN_BWD="6"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "attn6 ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
 def test_attention_single_tail_row():
     """257 = 8 x 32 + 1 tokens, not causal: the tail key / query as the accumulators' initial values (no 33rd block), with and without masks"""
     K.case_attention_single_tail(DEV, torch.bfloat16)

@@ -158,6 +158,22 @@ XC_DEV BufRsrc make_rsrc(const void* base, uint32_t bytes) {
 XC_DEV void buf_glds16(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
+// The same LDS DMA as ONE asm unit, i.e. invisible to the compiler's wait-count pass: behind the builtin form the pass treats every later
+// LDS read that might alias the landing zone as dependent and inserts s_waitcnt vmcnt(0) in front of it -- a prefetch issued at the top of
+// a step was waited for in the middle of the same step (attention6.h, round 6: the streamed ring ran at the DMA's latency).  With this
+// form EVERY wait for the piece is the caller's (wait_vmem / XC_WAIT_VMEM_LE + a barrier before another wave reads the landing zone).
+// `lds_wave_base` must be wave-uniform (it goes to M0 through an SGPR).
+// (a wave-uniform pointer the compiler cannot prove uniform, forced into scalar registers: the asm's descriptor operand must be one)
+XC_DEV const void* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const void*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+XC_DEV void buf_glds16_raw(BufRsrc r, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)soff);
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(r), "s"(so), "s"(m) : "memory");
+}
 // 16-byte store at base + voff + soff + IMM (IMM: the instruction's 12-bit immediate offset)
 // 16-byte load from base + voff + soff + IMM (zero past the descriptor's extent); counted by the compiler's own vmcnt bookkeeping
 template <int IMM>
@@ -281,6 +297,11 @@ constexpr bool XC_ASM_UNITS = true;
 #define XC_ASM_UNIT(TEXT, OPERANDS, CLOBBERS) asm volatile(TEXT : : OPERANDS : CLOBBERS)
 
 XC_DEV void atomic_add(float* p, float v) { atomicAdd(p, v); }
+// adds into LDS without a return value (counted by lgkmcnt).  Measured on MI355X (tools/probes/lds_atomic_rate_probe.hip, 8 waves per CU issuing,
+// conflict-free addresses): ds_add_u32 4.1 cycles per wave-instruction (= ds_write_b32), ds_add_u64 8.0, ds_add_f32 192 -- the fp32 form
+// is served one lane at a time (3 cycles per lane) and is 47 x slower than the integer form: accumulate in fixed point (attention6.h)
+XC_DEV void lds_atomic_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+XC_DEV void lds_atomic_add(int* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 XC_DEV float fast_exp(float x) { return __expf(x); }
 XC_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }        // bare v_exp_f32

@@ -10,6 +10,7 @@
 #include "kernels/attention3.h"
 #include "kernels/attention4.h"
 #include "kernels/attention5.h"
+#include "kernels/attention6.h"
 #include "kernels/attention_pool.h"
 
 using namespace xc;
@@ -190,8 +191,22 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
         XC_REQUIRE(scale > 0.f, "the head-resident kernels take the score maximum before scaling: scale must be positive");
         // the single-pass form (attention5.h) for the sequences it takes; XCLIP_ATTN_BWD=3 (measurement build) keeps the two-phase kernel for the A/B
         // (XCLIP_ATTN5_MIN=2: every sequence it can take, for the record of where it loses)
+        // round 6: the streaming persistent form (attention6.h) for n = 256 / 257, XCLIP_ATTN_BWD=6 on the measurement build: correct on the
+        // hardware and SLOWER than the single pass -- 975 against 813 us at n = 256, 1305 against 937 at n = 257 (b = 1024, 8 heads;
+        // profiles/r06_f_attn_bwd_ab.log, ablations profiles/r06_g_attn6_abl.log) -- the product keeps attention5.h
         static const int bwd_gen = measure_env("XCLIP_ATTN_BWD", 5), min5 = measure_env("XCLIP_ATTN5_MIN", A5_MIN_BLOCKS);
-        if (bwd_gen == 5 && a5_takes((int)n, causal) && (n >> 5) >= min5 && attn5_bwd_lds_bytes((int)n) <= 160 * 1024) {
+        if (bwd_gen == 6 && a6_takes((int)n, causal)) {
+            XC_ALLOW_LDS(attn6_bwd_kernel, 160 * 1024);
+            const int64_t heads_total = batch * heads;
+            const int cus = xc_num_cus();
+            int64_t g6 = heads_total < cus ? heads_total : cus;
+            static const int abl6 = measure_env("XCLIP_ATTN6_ABL", 0);    // measurement build only: attention6.h's ablation mask
+            p.chunks = abl6;
+            if (g6 >= 8) g6 &= ~(int64_t)7;                     // whole XCD rounds: a work-group's heads stay on one XCD's slice of the order
+            hipLaunchKernelGGL(attn6_bwd_kernel, dim3((unsigned)g6), dim3(512), A6_LDS_BYTES, st, p);
+            return check_launch(__func__);
+        }
+        if (bwd_gen >= 5 && a5_takes((int)n, causal) && (n >> 5) >= min5 && attn5_bwd_lds_bytes((int)n) <= 160 * 1024) {
             XC_ALLOW_LDS(attn5_bwd_kernel, 160 * 1024);
             const int64_t g5 = batch * heads;
             hipLaunchKernelGGL(attn5_bwd_kernel, dim3((unsigned)g5), dim3((unsigned)((n >> 5) * 64)), attn5_bwd_lds_bytes((int)n), st, p);
