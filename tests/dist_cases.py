@@ -122,28 +122,38 @@ def worker_even(rank, world, port, cfg_kwargs, batch, tmp, kind="cpu", dtype_nam
     other = None
     if second_sink:                                           # a second GradSync (another model) must not displace the first
         other = GradSync(torch.nn.Linear(8, 8).to(dev))
-    sync = GradSync(model, reduce_dtype=getattr(torch, reduce_dtype_name) if reduce_dtype_name else None,
-                    **({"bucket_bytes": bucket_bytes} if bucket_bytes else {}))
-    if bucket_bytes:                                          # the towers cut into several buckets (toy models: ask for small ones)
-        assert len(sync.buckets) >= 5, [sum(p.numel() for p in b) for b in sync.buckets]
-    if second_sink:
-        other2 = GradSync(torch.nn.Linear(8, 8).to(dev))      # ... whichever was registered last
-    for step in range(steps):                                 # steps > 1: the later steps launch buckets from the hooks, in the frozen order
-        model.zero_grad(set_to_none=True)
-        loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, aug_text=[aug_t[0][sl].to(dev)])
-        loss.backward()
-        sync.finish()
-        if reduce_dtype_name is None:
-            assert sync.stats["in_place"] >= 4 * (cfg.text_enc_depth + cfg.visual_enc_depth), sync.stats     # the weight-gradient GEMMs wrote into the bucket slices
-        if step > 0:
-            assert sync._agreed and all(e is not None for e in sync._expected)
-    if kind != "cpu":
-        torch.cuda.synchronize()
-    grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
-    for p in model.parameters():
-        assert p.grad is None or p.grad.dtype == p.dtype
-    torch.save({"loss": float(loss.detach()), "grads": grads, "overlap": sync.overlap, "buckets": len(sync.buckets), "launched": sync.launched,
-                "order": list(sync._order)}, os.path.join(tmp, f"rank{rank}.pt"))
+    # reduce_dtype_name may name SEVERAL wire dtypes ("bfloat16+float32"): the same processes then run the steps once per wire (a GradSync
+    # each) and save rank{r}_{wire}.pt -- one spawn of eight interpreters instead of two (the GPU suite's two slowest tests)
+    wires = [None] if reduce_dtype_name is None else reduce_dtype_name.split("+")
+    for wire in wires:
+        wire_dtype = None if wire in (None, "model") else getattr(torch, wire)
+        for p_ in model.parameters():
+            p_.grad = None
+        sync = GradSync(model, reduce_dtype=wire_dtype, **({"bucket_bytes": bucket_bytes} if bucket_bytes else {}))
+        if bucket_bytes:                                          # the towers cut into several buckets (toy models: ask for small ones)
+            assert len(sync.buckets) >= 5, [sum(p.numel() for p in b) for b in sync.buckets]
+        if second_sink:
+            other2 = GradSync(torch.nn.Linear(8, 8).to(dev))      # ... whichever was registered last
+        for step in range(steps):                                 # steps > 1: the later steps launch buckets from the hooks, in the frozen order
+            model.zero_grad(set_to_none=True)
+            loss = model(text[sl].to(dev), image[sl].to(dtype).to(dev), return_loss=True, aug_text=[aug_t[0][sl].to(dev)])
+            loss.backward()
+            sync.finish()
+            if wire_dtype is None:
+                assert sync.stats["in_place"] >= 4 * (cfg.text_enc_depth + cfg.visual_enc_depth), sync.stats     # the weight-gradient GEMMs wrote into the bucket slices
+            if step > 0:
+                assert sync._agreed and all(e is not None for e in sync._expected)
+        if kind != "cpu":
+            torch.cuda.synchronize()
+        grads = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+        for p in model.parameters():
+            assert p.grad is None or p.grad.dtype == p.dtype
+        suffix = "" if len(wires) == 1 else "_" + str(wire)
+        torch.save({"loss": float(loss.detach()), "grads": grads, "overlap": sync.overlap, "buckets": len(sync.buckets), "launched": sync.launched,
+                    "order": list(sync._order)}, os.path.join(tmp, f"rank{rank}{suffix}.pt"))
+        sync.remove()
+        if second_sink:
+            other2.remove()
     dist.destroy_process_group()
 
 
@@ -331,19 +341,34 @@ def check_fixture(tmp, name, world=2):
         assert abs(float(tot) - ref_norm) <= 5e-4 * ref_norm + 1e-7, (k, float(tot), ref_norm)
 
 
-def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, rel_bar=3e-4, loss_bar=1e-5, cos_bar=None, measured=None, only_prefix=None):
+_EVEN_ORACLE = {}                                             # (config, global batch, dtype, kept patches) -> (fp64 loss, fp64 gradients): the session's cache
+
+
+def _even_oracle(cfg, total, dtype, patch_keep):
+    """the fp64 oracle of worker_even's global batch -- evaluated once per (configuration, global batch) and session: the 2 / 4 / 8-rank runs of
+    the dim-512 model share a global batch of 32, and the wire-dtype variants share everything"""
+    import dataclasses
     from oracle import clip_oracle as O
-    outs = [torch.load(os.path.join(tmp, f"rank{r}.pt"), weights_only=False) for r in range(world)]
-    sd = O.make_state_dict(cfg, 5, torch.float32)
-    sd = {k: (v.to(dtype).double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-    text, image, aug_t, _ = O.make_inputs(cfg, batch * world, 6, 1, 0)
-    keep = None
-    if patch_keep:
-        g = torch.Generator().manual_seed(8)
-        keep = torch.randn(batch * world * 2, cfg.num_patches, generator=g).topk(patch_keep, dim=-1).indices[: batch * world]
-    with O.layer_norm_eps(1e-5 if dtype == torch.float32 else 1e-3):
-        ref = O.clip_forward(sd, cfg, text, image.to(dtype).double(), aug_t, [], keep)
-        ref.backward()
+    key = (tuple(sorted(dataclasses.asdict(cfg).items())), total, str(dtype), patch_keep)
+    if key not in _EVEN_ORACLE:
+        sd = O.make_state_dict(cfg, 5, torch.float32)
+        sd = {k: (v.to(dtype).double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        text, image, aug_t, _ = O.make_inputs(cfg, total, 6, 1, 0)
+        keep = None
+        if patch_keep:
+            g = torch.Generator().manual_seed(8)
+            keep = torch.randn(total * 2, cfg.num_patches, generator=g).topk(patch_keep, dim=-1).indices[:total]
+        with O.layer_norm_eps(1e-5 if dtype == torch.float32 else 1e-3):
+            ref = O.clip_forward(sd, cfg, text, image.to(dtype).double(), aug_t, [], keep)
+            ref.backward()
+        _EVEN_ORACLE[key] = (ref.detach(), sd)
+    return _EVEN_ORACLE[key]
+
+
+def check_even(tmp, cfg, batch, world=2, dtype=torch.float32, patch_keep=None, rel_bar=3e-4, loss_bar=1e-5, cos_bar=None, measured=None, only_prefix=None,
+               suffix=""):
+    outs = [torch.load(os.path.join(tmp, f"rank{r}{suffix}.pt"), weights_only=False) for r in range(world)]
+    ref, sd = _even_oracle(cfg, batch * world, dtype, patch_keep)
     for o in outs:
         assert abs(o["loss"] - float(ref.detach())) < loss_bar * max(1.0, abs(float(ref.detach()))), (o["loss"], float(ref.detach()))
     worst = (0.0, "")
