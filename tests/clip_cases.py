@@ -29,7 +29,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 class poisoned_empty:
     """NaN-poisons every torch.empty / empty_like allocation made inside the block (0xFF bytes for uint8 scratch = fp32 NaN): a kernel
     that reads memory it was supposed to write first -- an unwritten split-K slab, a skipped padding row -- then fails a parity check
-    even when the allocator happens to hand out zeroed pages (which is what hid such a bug on the CPU)"""
+    even when the allocator happens to hand out zeroed pages (which is what hid such a bug on the CPU, see DESIGN_APPENDIX.md section 6c)"""
 
     def __enter__(self):
         self.saved = (torch.empty, torch.empty_like)

@@ -35,7 +35,7 @@ def ref64(t):
 
 
 # name -> [largest measured error, the bound it was held to, unit]: written out by tests/conftest.py at session end (the GPU run's
-# table is committed under profiles/ and quoted in DESIGN.md section 7 -- measured errors, not bounds)
+# table is committed under profiles/ and quoted in DESIGN_APPENDIX.md section 7 -- measured errors, not bounds)
 REPORT = {}
 
 
@@ -806,7 +806,7 @@ def case_gemm_splitk_uneven(dev, M=1248, N=768, K=6144):
 
 def case_gemm_fuzz(dev, cases=150, seed=1):
     """random shapes / layouts / epilogue terms of xclip_gemm against fp32 torch: interior and ragged tiles, split-K slabs, the residual
-    form, alpha -- the paths whose hardware-only store hazards neither the emulator nor a fixed shape list shows"""
+    form, alpha -- the paths whose hardware-only store hazards (DESIGN_APPENDIX.md section 6d) neither the emulator nor a fixed shape list shows"""
     g = torch.Generator().manual_seed(seed)
 
     def ri(lo, hi):

@@ -374,7 +374,7 @@ def test_edge_cases_of_the_row_kernels():
 
 
 def test_gemm6_gemm7_experimental_kernels():
-    """measure/gemm6.h / gemm7.h (MEASUREMENT build only, XCLIP_GEMM=6 / 7; measured slower than the ring kernel: DESIGN.md section 6b) still
+    """measure/gemm6.h / gemm7.h (MEASUREMENT build only, XCLIP_GEMM=6 / 7; measured slower than the ring kernel: DESIGN_APPENDIX.md section 6b) still
     compute the product -- the switch is read once per process, so the check runs in its own interpreter; and the PRODUCT build ignores the
     switch altogether"""
     import subprocess
@@ -400,7 +400,7 @@ def test_gemm6_gemm7_experimental_kernels():
 
 def test_attention_streaming_backward_measurement_build():
     """attention6.h (round 6: the attention backward as a stream through a three-slot LDS ring, one persistent work-group per CU, dQ summed in
-    fixed point with integer LDS atomics; MEASUREMENT build only, XCLIP_ATTN_BWD=6 -- measured slower than attention5.h, DESIGN.md) against the fp64
+    fixed point with integer LDS atomics; MEASUREMENT build only, XCLIP_ATTN_BWD=6 -- measured slower than attention5.h, DESIGN.md section 8) against the fp64
     reference: n = 256 / 257, masks incl. a padded tail key, more heads than emulated CUs (a work-group walks several heads: the ring, the K / V
     image hand-over and the lse / mask registers cross head boundaries); its dQ is bit-reproducible (integer adds commute)"""
     import subprocess

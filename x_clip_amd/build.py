@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, measure: bool = False) -> 
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # the toolchain goes into the library (xclip_build_info): the wait states around the asm buffer stores were validated against ROCm 7.2's
-    # code generation -- another compiler means: run the GPU gate tests before trusting the GEMM epilogues
+    # code generation (DESIGN_APPENDIX.md 6d) -- another compiler means: run the GPU gate tests before trusting the GEMM epilogues
     try:
         ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True, check=True).stdout.splitlines()[0].strip()
     except Exception:                                           # noqa: BLE001

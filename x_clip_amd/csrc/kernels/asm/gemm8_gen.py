@@ -3,7 +3,7 @@
 
     python x_clip_amd/csrc/kernels/asm/gemm8_gen.py          # rewrites gemm8_body.inc next to this file
 
-Why a generator and not HIP: what gemm4.h's g5_run loses on the K = 512 products is the tile boundary (the epilogue of a tile is
+Why a generator and not HIP: what gemm4.h's g5_run loses on the K = 512 products is the tile boundary (DESIGN_APPENDIX.md 6b: the epilogue of a tile is
 not overlapped with matrix work, 15 % of such a launch), and the form that hides it -- a finished tile's packed output held in 64 registers and
 stored two instructions per K step UNDER the next tile's MFMAs -- needs 128 accumulator + 48 fragment + 64 held registers live at once.  hipcc
 spills that (profiles/r04_gemm_stage_i_iii_compile_evidence.txt); with every register named by hand it fits 246 of the 256.

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void filip_reduce_rows_kernel(const T* __restr
 // History (configs[3], 1 GB chunk; profiles/r03_d / r03_h / r03_i_kernel_stats_filip.txt): a flat (row, chunk) index with two 64-bit
 // divisions and ~14 narrow global loads per 16 bytes written: 0.64 ms = 1.5 TB/s; divisions gone: 0.67 ms (not the arithmetic);
 // one work-group per (row, slice) with the per-image factors in LDS and one wide tmax load: 0.52 ms (276 k work-groups living ~4 us
-// each: launch- and latency-bound); this form: see DESIGN.md.  Rows of padding tokens and the padding columns are written as zeros.
+// each: launch- and latency-bound); this form: see DESIGN_APPENDIX.md section 3.  Rows of padding tokens and the padding columns are written as zeros.
 constexpr int ROUTE_MAX_IMG = 2050;                             // images a 2048-column slice can touch (ni >= 1)
 constexpr int ROUTE_KM_ENTRIES = 16384;                         // staged kmax entries per batch of rows (32 KiB)
 constexpr int ROUTE_LDS_BYTES = ROUTE_MAX_IMG * 8 + ROUTE_KM_ENTRIES * 2 + 16;

@@ -124,6 +124,9 @@ XC_DEV void g4_run(const Gemm2Params& p, unsigned char* lds, Epilogue epi) {
     };
     d.a = oa.rsrc();
     d.b = ob.rsrc();
+    // (round 6, measured and not kept: these pieces as asm units the compiler's wait-count pass does not see (xc_device.h buf_glds16_raw) --
+    //  the weight gradients of configs[1] 2737 / 2720 us with the builtin against 2739 / 2751 us, profiles/r06_j_wgrad_raw_ab.log: the slab
+    //  epilogue's compiler-inserted waits sit in the ragged-tile path only)
     auto piece_a = [&](int q, unsigned char* stage) { buf_glds16(d.a, va[q & 1], (q >> 1) ? sa : 0u, stage + (my0 - lds) + q * 1024); };
     auto piece_b = [&](int q, unsigned char* stage) { buf_glds16(d.b, vb[q & 1], (q >> 1) ? sb : 0u, stage + G2_OPER_BYTES + (my0 - lds) + q * 1024); };
 
@@ -599,7 +602,15 @@ struct G4GemmEpilogue {
     // one 32-row group: the wave's accumulator blocks acc_i[j] -> the four line pieces o_i[k] (rows 8 k + lane / 8 of the group)
     template <bool UNIT_ALPHA>
     XC_DEV void pack_lines_i(f32x16 (&acc_i)[2], unsigned char* scratch, u32x4 (&o_i)[4]) const {
-        const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+        pack_lines_i<UNIT_ALPHA>(acc_i, scratch, o_i, (int)(threadIdx.x & 63));
+    }
+    // (`lane` as an argument: an epilogue that has no registers to spare passes an OPAQUE copy of it, so that the nine per-lane exchange
+    //  addresses below are recomputed per tile -- a handful of VALU -- instead of being hoisted out of the tile loop and spilled: the G
+    //  kernel of simloss5.h reloaded them from scratch in front of every tile's exchange, 13 spilled registers -> 1; the launch time did
+    //  not move, profiles/r06_j_sim_g_*.log)
+    template <bool UNIT_ALPHA>
+    XC_DEV void pack_lines_i(f32x16 (&acc_i)[2], unsigned char* scratch, u32x4 (&o_i)[4], int lane) const {
+        const int r = lane & 31, h = lane >> 5;
         unsigned char* const wr = scratch + r * 128 + 8 * h;                        // + chunk position * 16
         const unsigned char* const rd = scratch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + 1024 per 8 rows
         const float al = p.alpha;

@@ -1,6 +1,6 @@
 // gemm7.h -- EXPERIMENTAL (XCLIP_GEMM=7): the ring kernel of gemm4.h (g5_run) with FOUR waves of 128 x 128 per 256 x 256 tile instead of
 // eight of 128 x 64: one wave per SIMD, 256 accumulator registers per lane (the unified 512-entry file), 8 fragment reads per 16 MFMAs
-// instead of 6 per 8 -- a third fewer LDS bytes per MFMA on a part that is power-limited under this kernel.  Same LDS
+// instead of 6 per 8 -- a third fewer LDS bytes per MFMA on a part that is power-limited under this kernel (DESIGN_APPENDIX.md section 3).  Same LDS
 // images, same A-ring-of-three / B-ring-of-two, same whole-line epilogue; every wave stages 8 + 8 DMA pieces per K step instead of 4 + 4.
 //
 // Scope of the experiment: bf16 C = alpha * A[M, K] B[N, K]^T, both operands row-major, M and N multiples of 256, K a multiple of 64 with

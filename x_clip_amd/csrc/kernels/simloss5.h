@@ -3,7 +3,7 @@
 // the one that streams, K's column panel is re-read from L2 by every tile of its column -- in a ring of three LDS stages, descriptor-
 // addressed LDS DMA, the counted waits.  At the configs[2] per-rank block 4096 x 32768 x 512 (the same-shape plain GEMM that WRITES the
 // logits: 144 - 151 us): forward (log-sum-exp partials, nothing stored) 177 -> 154 - 158 us = 893 TFLOP/s; G 362 -> 170 us
-// (profiles/r03_b_*, r03_o_* ... r03_u_*; DESIGN.md section 3 has the steps).  The first ring form of G (whole-line epilogue with the
+// (profiles/r03_b_*, r03_o_* ... r03_u_*; DESIGN_APPENDIX.md section 3 has the steps).  The first ring form of G (whole-line epilogue with the
 // general tile in the same function: 423 us) lives on in the measurement build.
 #pragma once
 #include "gemm4.h"
@@ -45,7 +45,8 @@ XC_DEV bool sim5_off_diagonal(const SimParams& p, int m0, int n0) { return m0 + 
 
 // (STREAM -- non-temporal stores for a G the L2s cannot hold anyway -- is a template parameter: as a run-time branch around the 16
 //  stores it cost this kernel 102 spilled registers)
-// (VAR: measurement build only, XCLIP_SIMG -- 1 = without DEFER_FRAGS, 2 = without the spread vote / exact form (round-3 arithmetic), 3 = both)
+// (VAR: measurement build only, XCLIP_SIMG -- 1 = without DEFER_FRAGS, 2 = without the spread vote / exact form (round-3 arithmetic), 3 = both,
+//  4 = the exchange addresses hoisted and spilled as before round 6)
 template <bool STREAM, int VAR = 0>
 struct Sim5FastGradEpilogue {
     const SimParams& p;
@@ -66,7 +67,10 @@ struct Sim5FastGradEpilogue {
     XC_DEV int with_scratch(f32x16 (&acc)[4][2], int m0, int n0, unsigned char* scratch) {
         if (!sim5_full_tile(p, m0, n0)) return 0;                   // (uniform) the edge launch's tile
         to_g(acc, m0, n0);
-        const int lane = threadIdx.x & 63;
+        // (an opaque lane id: what is derived from it below is recomputed per tile, not carried across the K loop in spilled registers --
+        //  round 6: twelve scratch reloads per tile, each behind s_waitcnt vmcnt(0), i.e. a drain of the next tile's DMA pieces and of the
+        //  previous group's stores; profiles/r06_k_*)
+        const int lane = (VAR & 4) ? (int)(threadIdx.x & 63) : (int)opaque((uint32_t)(threadIdx.x & 63));      // (VAR 4: the round-5 form, for the A/B)
         const int wave = uniform(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
         const G4GemmEpilogue<G4_PLAIN> lines{gp};
         const BufRsrc rc = make_rsrc(gp.C + (long)m0 * gp.ldc + n0, 255u * (uint32_t)gp.ldc * 2u + 512u);
@@ -75,7 +79,7 @@ struct Sim5FastGradEpilogue {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x4 o[4];
-            lines.template pack_lines_i<true>(acc[i], scratch, o);
+            lines.template pack_lines_i<true>(acc[i], scratch, o, lane);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (STREAM) buf_st16_nt<0>(rc, vc, s8 * (uint32_t)(4 * i + k), o[k]);

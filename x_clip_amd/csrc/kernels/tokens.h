@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(T* __restrict__ x, long ld,
 // One wave reads the shader-cycle counter (s_memtime) against the constant 100 MHz counter (s_memrealtime) over `ticks` ticks of 10 ns:
 // out[0] = shader cycles, out[1] = 10 ns ticks elapsed.  Launched between the kernels of a step it reads the clock the power management
 // holds the part at under that load (DVFS reacts in milliseconds, the sample takes microseconds): bench.py reports it so that a slow
-// box and a slow kernel can be told apart (1.55 - 1.68 GHz under the GEMMs, 2.0 - 2.15 GHz with the MFMA loop alone).
+// box and a slow kernel can be told apart (DESIGN_APPENDIX.md section 5: 1.55 - 1.68 GHz under the GEMMs, 2.0 - 2.15 GHz with the MFMA loop alone).
 __global__ void clock_sample_kernel(uint64_t* out, long ticks) {
     if (threadIdx.x != 0) return;
     const uint64_t c0 = shader_cycles(), r0 = realtime_10ns();

@@ -13,7 +13,7 @@
 #include "kernels/gemm8.h"
 #include "kernels/gemm9.h"
 #include "kernels/gemm_small.h"
-#ifdef XCLIP_MEASURE                                             // negative-result experiments, measurement build only
+#ifdef XCLIP_MEASURE                                             // negative-result experiments, measurement build only (DESIGN_APPENDIX.md 6b)
 #include "kernels/measure/gemm6.h"
 #include "kernels/measure/gemm7.h"
 #endif
@@ -1348,9 +1348,9 @@ int xclip_simloss_grad(const void* Q, const void* K, int64_t nq, int64_t nk, int
 #endif
 #ifdef XCLIP_MEASURE
         static const int simg = measure_env("XCLIP_SIMG", 0);      // A/B of this round's additions to the G kernel (simloss5.h VAR), streamed form only
-        if (!skip_fast && simg >= 1 && simg <= 3 && nq * ldg * 2 > (48LL << 20)) {
+        if (!skip_fast && simg >= 1 && simg <= 4 && nq * ldg * 2 > (48LL << 20)) {
 #define XC_SIMG(V) case V: XC_ALLOW_LDS((sim5_grad_fast_kernel<true, V>), G5_LDS_BYTES); hipLaunchKernelGGL((sim5_grad_fast_kernel<true, V>), sim3_grid(nq, nk), dim3(G2_THREADS), G5_LDS_BYTES, st, p); break;
-            switch (simg) { XC_SIMG(1) XC_SIMG(2) XC_SIMG(3) }
+            switch (simg) { XC_SIMG(1) XC_SIMG(2) XC_SIMG(3) XC_SIMG(4) }
 #undef XC_SIMG
         } else
 #endif
