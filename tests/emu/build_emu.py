@@ -32,8 +32,16 @@ def build(force=False, measure=False):
     if not os.path.exists(cxx):
         cxx = "clang++"
     cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi",
-           *(["-DXCLIP_MEASURE"] if measure else []), "-I", HERE, "-I", CSRC, *[os.path.join(CSRC, u) for u in UNITS], "-o", OUT]
-    subprocess.run(cmd, check=True)
+           *(["-DXCLIP_MEASURE"] if measure else []), "-I", HERE, "-I", CSRC, *[os.path.join(CSRC, u) for u in UNITS]]
+    # (into a private file, then renamed: the workers of a multi-rank test may find the library stale at the same moment -- two compilers
+    #  writing one path left a rank loading a file that did not exist for an instant)
+    tmp = f"{OUT}.{os.getpid()}.tmp"
+    try:
+        subprocess.run(cmd + ["-o", tmp], check=True)
+        os.replace(tmp, OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return OUT
 
 

@@ -414,10 +414,9 @@ def test_attention_streaming_backward_measurement_build():
         "import kernel_cases as K\n"
         "dev = torch.device('cpu')\n"
         "K.case_attention(dev, torch.bfloat16, 2, 256, 1, True)\n"
-        "K.case_attention(dev, torch.bfloat16, 5, 257, 2, True)\n"
         "K.case_attention_single_tail(dev, torch.bfloat16)\n"
         "torch.manual_seed(0)\n"
-        "qkv = torch.randn(4, 257, 3 * 64).bfloat16(); do = torch.randn(4, 257, 64).bfloat16()\n"
+        "qkv = torch.randn(2, 257, 3 * 64).bfloat16(); do = torch.randn(2, 257, 64).bfloat16()\n"
         "out, lse = ops.attention_fwd(qkv, None, 1, 0.125)\n"
         "a = ops.attention_bwd(qkv, None, out, do, lse, 1, 0.125); b = ops.attention_bwd(qkv, None, out, do, lse, 1, 0.125)\n"
         "assert torch.equal(a, b)\n"

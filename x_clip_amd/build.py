@@ -92,7 +92,13 @@ def build(force: bool = False, verbose: bool = False, measure: bool = False) -> 
         procs.append(subprocess.Popen([hipcc, *common, *extra, "-c", os.path.join(CSRC, unit), "-o", obj]))
     if any(p.wait() != 0 for p in procs):
         raise RuntimeError("hipcc failed")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], check=True)
+    tmp = f"{LIB}.{os.getpid()}.tmp"                             # (linked beside the target, then renamed: a concurrent loader never sees half a file)
+    try:
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp], check=True)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

@@ -93,6 +93,9 @@ struct G4GegluBwdEpilogue {
         const uint32_t vx = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)e.ldx + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
         const uint32_t vd = ((uint32_t)(wm * 128 + (lane >> 3)) * (uint32_t)e.lddx + (uint32_t)(wn * 64 + 8 * (lane & 7))) * 2u;
         const uint32_t x8 = (uint32_t)e.ldx * 16u, d8 = (uint32_t)e.lddx * 16u;        // 8 rows
+        // (round 6, measured and not kept: the two 8-byte halves of a chunk swapped in rows whose bit 3 is set -- the quad accesses of rows r
+        //  and r + 8 then use different bank pairs, 4-way -> 2-way conflicts (22.7 % of the kernel's LDS cycles, profiles/r05_w_sq_gemm9.txt):
+        //  1280 - 1296 us against 1266 - 1284 without, profiles/r06_k_gemm9_exchange_half_swap_ab.log: the epilogue is bound by its vector ALU)
         unsigned char* const quad = scratch + r * 128 + 8 * h;                        // accumulator layout: + chunk position * 16
         unsigned char* const line = scratch + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // line layout: + 1024 per 8 rows
         f32x2 dg[2][8];                                        // column sums of dh ahat: pairs (2 c, 2 c + 1) of the lane's 16 columns per j
