@@ -317,6 +317,8 @@ def main():
         _lib.use_measurement_build()
     if os.environ.get("XCLIP_BENCH_FFN_FUSED") == "0":        # own A/B: the feed-forward backward as xclip_gemm + xclip_layernorm_bwd (two kernels)
         ops.FUSE_FFN_DGRAD = False
+    if os.environ.get("XCLIP_BENCH_FFN_ROWSTATS") == "0":    # own A/B: the fused feed-forward backward's row pass as its own kernel (round 5)
+        ops.FUSE_FFN_ROWSTATS = False
     if os.environ.get("XCLIP_FILIP_FUSED") == "0":           # own A/B: the chunked FILIP forward (materialised similarities + reduction passes)
         losses.FILIP_FUSED = False
     if os.environ.get("XCLIP_FILIP_CHUNK_MB"):                 # own A/B: size of the backward's routing-matrix chunks

@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 21
+#define XCLIP_ABI_VERSION 22
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -154,6 +154,20 @@ int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t
                           const float* mean, const float* rstd, const void* x2, int64_t ld2, const void* x1, int64_t ld1, void* dx,
                           int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes, int64_t M, int64_t F, int64_t D,
                           int dtype, void* stream);
+/* Round 6 (ABI 22): the row pass of that backward folded into the kernel that PRODUCES dout.  In a pre-norm stack (x_clip.py:285-289) the
+ * gradient of a block's output is written by the LayerNorm backward of the block above it (or of norm_out), whose own input row IS the lower
+ * block's output x2: xclip_layernorm_bwd_ffnstats = xclip_layernorm_bwd (no geglu) that also writes the lower block's four per-row constants
+ * rowc [rows, 4] = {rstd4, -mean4 rstd4, (dx . wg) rstd4 / F, (dx . (x - x1_below)) rstd4 / F} from the row it holds (dx as stored), given
+ * wg = xclip_ffn_wgamma(w2, gamma) [D] fp32, the lower block's input x1_below and its inner LayerNorm's statistics mean4 / rstd4, inv_f = 1 / F;
+ * xclip_ffn_dgrad_geglu_rowc then runs the product with those constants (no x1 / x2 pass).  Same results as xclip_ffn_dgrad_geglu. */
+int xclip_ffn_wgamma(const void* w2, int64_t ldw, const void* gamma, float* wg, int64_t D, int64_t F, int dtype, void* stream);
+int xclip_layernorm_bwd_ffnstats(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes,
+                                 int64_t rows, int64_t dim, const void* x1_below, int64_t ld1, const float* wg, const float* mean4,
+                                 const float* rstd4, float inv_f, float* rowc, int dtype, void* stream);
+int xclip_ffn_dgrad_geglu_rowc(const void* dout, int64_t ldd, const void* w2, int64_t ldw, const void* x, int64_t ldx, const void* gamma,
+                               const float* rowc, void* dx, int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes,
+                               int64_t M, int64_t F, int64_t D, int dtype, void* stream);
 
 /* ---- fused attention (reference Attention.forward x_clip.py:201-245; any dim_head up to 128) ----------------------
  * head_dim = the width of a head slot in memory: 64 (the reference default; the head-resident kernels) or 128 (wide heads: two

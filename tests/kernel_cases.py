@@ -166,6 +166,44 @@ def case_ffn_dgrad_geglu(dev, M, F, D, seed=41, resid_scale=1.0):
     assert g_f <= max(2.0 * g_2, 2.0 ** -7) + (0.0 if resid_scale == 1.0 else 60.0 * resid_scale * 2.0 ** -9 * math.sqrt(D) / F), (g_f, g_2)
 
 
+def case_ffn_rowstats_in_layernorm_bwd(dev, M, F, D, seed=47):
+    """round 6: the fused feed-forward backward's row pass inside the LayerNorm backward that writes its dOut (rows.h ln_bwd_kernel FFN,
+    xclip_layernorm_bwd_ffnstats + xclip_ffn_dgrad_geglu_rowc) against the separate row pass: the same dx from the LayerNorm backward, the
+    same row constants (dOut enters as stored, chunk for chunk as ffn_rowstats_kernel sums it), hence the same d(u | t) and gain gradient"""
+    dt = torch.bfloat16
+    u = rnd((M, 2 * F), dt, seed).to(dev)
+    gi = (1 + 0.1 * rnd((F,), torch.float32, seed + 1)).to(dt).to(dev)
+    w2 = (rnd((D, F), torch.float32, seed + 2) / math.sqrt(F)).to(dt).to(dev)
+    x1 = rnd((M, D), dt, seed + 3).to(dev)
+    a, m4, r4 = ops.layernorm_fwd(u, gi, None, True)
+    x2 = ops.gemm(a, w2, M, D, F, residual=x1)                       # the block's output = the input row of the LayerNorm above it
+    g = (1 + 0.1 * rnd((D,), torch.float32, seed + 4)).to(dt).to(dev)
+    _, mean, rstd = ops.layernorm_fwd(x2, g)
+    dy, dres = rnd((M, D), dt, seed + 5).to(dev), rnd((M, D), dt, seed + 6).to(dev)
+    def same(a, b, what, frac=2e-3):
+        """the two instantiations of one kernel: identical on the emulator; on the GPU the compiler contracts their fused multiply-adds
+        differently, so a few elements may round the other way -- at most one bf16 ulp of the scale, on at most `frac` of the elements"""
+        a, b = a.float(), b.float()
+        scale = float(b.abs().max())
+        bad = float((a != b).float().mean())
+        err = float((a - b).abs().max())
+        assert err <= scale * 2.0 ** -7 and bad <= frac, (what, err, scale, bad)
+
+    for res in (dres, None):
+        dx_ref, dg_ref = ops.layernorm_bwd(dy, x2, g, mean, rstd, dres=res)
+        req = ops.ffn_stats_request(w2, gi, x1, m4, r4)
+        assert req is not None
+        dx, dg = ops.layernorm_bwd(dy, x2, g, mean, rstd, dres=res, ffn_stats=req)
+        same(dx, dx_ref, "dx")
+        assert float((dg - dg_ref).abs().max()) <= 1e-4 * float(dg_ref.abs().max())
+        # the same dOut through both forms of the row pass
+        du_ref, dgi_ref = ops.ffn_dgrad_geglu(dx, w2, u, gi, m4, r4, x2, x1)
+        du, dgi = ops.ffn_dgrad_geglu(dx, w2, u, gi, m4, r4, None, None, rowc=req[5])
+        assert torch.isfinite(du.float()).all()
+        same(du, du_ref, "du", frac=2e-2)
+        assert float((dgi - dgi_ref).abs().max()) <= 1e-3 * float(dgi_ref.abs().max())
+
+
 def case_l2norm(dev, dtype, rows, dim):
     x = rnd((rows, dim), dtype, 5)
     dy = rnd((rows, dim), dtype, 6)

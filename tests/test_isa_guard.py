@@ -25,7 +25,9 @@ HOT = {
     "attn3_fwd_kernel<false>": (3, 0), "attn3_bwd_kernel<false>": (6, 0), "attn3_bwd_kernel<true>": (6, 0),
     # (last template argument: the non-temporal hint on the streamed rows, xclip_api.hip ROWS_NT)
     "ln_geglu_bwd_kernel<bf16, 2, 2, true>": (0, 0), "ln_fwd_kernel<bf16, 4, true, true>": (4, 0), "ln_fwd_kernel<bf16, 1, false, true>": (2, 0),
-    "ln_bwd_kernel<bf16, 1, false, true>": (3, 0), "ln_chain_fwd_kernel<bf16, 1, false>": (2, 0), "ln_chain_bwd_kernel<bf16, 1, true>": (1, 0),
+    "ln_bwd_kernel<bf16, 1, false, true, false>": (3, 0), "ln_chain_fwd_kernel<bf16, 1, false>": (2, 0), "ln_chain_bwd_kernel<bf16, 1, true>": (1, 0),
+    # (round 6: the same kernel writing the lower block's feed-forward row constants -- one more pair: its W2 gamma vector, once per work-group)
+    "ln_bwd_kernel<bf16, 1, false, true, true>": (4, 0),
     "splitk_reduce_kernel<bf16>": (0, 0),
 }
 # G of the contrastive head: round 4's exact two-exponential form for wave blocks whose lse values spread beyond one reference point

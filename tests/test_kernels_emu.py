@@ -36,6 +36,11 @@ def test_ffn_dgrad_geglu_fused(M, F, D):
     K.case_ffn_dgrad_geglu(DEV, M, F, D)
 
 
+@pytest.mark.parametrize("M,F,D", [(256, 256, 128), (512, 256, 512)])
+def test_ffn_rowstats_in_layernorm_bwd(M, F, D):
+    K.case_ffn_rowstats_in_layernorm_bwd(DEV, M, F, D)
+
+
 @pytest.mark.parametrize("resid_scale", [16.0, 100.0])
 def test_ffn_dgrad_geglu_fused_large_residual_stream(resid_scale):
     """|x1| = 16 x / 100 x the block's output (the second row statistic comes from the bf16 difference x2 - x1); the fused kernel

@@ -155,6 +155,12 @@ def test_ffn_dgrad_geglu_fused(M, F, D):
     K.case_ffn_dgrad_geglu(DEV, M, F, D)
 
 
+@pytest.mark.parametrize("M,F,D", [(2048, 512, 128), (33792, 2048, 512), (263168, 2048, 512)])
+def test_ffn_rowstats_in_layernorm_bwd(M, F, D):
+    """round 6: the fused feed-forward backward's row constants written by the LayerNorm backward above the block, at the towers' sizes"""
+    K.case_ffn_rowstats_in_layernorm_bwd(DEV, M, F, D)
+
+
 @pytest.mark.parametrize("resid_scale", [16.0, 100.0])
 def test_ffn_dgrad_geglu_fused_large_residual_stream(resid_scale):
     """the residual stream 16 x / 100 x the feed-forward block's own output, at the vision tower's size"""

@@ -49,6 +49,9 @@ _SIGNATURES = {
     "xclip_ffn_dgrad_geglu_ok": (c_int, [L, L, L, I]),
     "xclip_ffn_dgrad_geglu_workspace_bytes": (c_int64, [L, L, L]),
     "xclip_ffn_dgrad_geglu": (c_int, [P, L, P, L, P, L, P, P, P, P, L, P, L, P, L, P, P, L, L, L, L, I, P]),
+    "xclip_ffn_wgamma": (c_int, [P, L, P, P, L, L, I, P]),
+    "xclip_layernorm_bwd_ffnstats": (c_int, [P, P, L, P, P, P, P, P, L, P, P, L, L, L, P, L, P, P, P, F, P, I, P]),
+    "xclip_ffn_dgrad_geglu_rowc": (c_int, [P, L, P, L, P, L, P, P, P, L, P, P, L, L, L, L, I, P]),
     "xclip_gemm_batched": (c_int, [I, I, P, L, L, P, L, L, P, L, L, L, L, L, L, F, I, P]),
     "xclip_rowdot": (c_int, [P, L, P, L, P, L, L, I, P]),
     "xclip_attention_fwd": (c_int, [P, P, P, P, L, L, L, L, F, I, F, U, I, P]),
@@ -86,7 +89,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 def _bind(path: str):

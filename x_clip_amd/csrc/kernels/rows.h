@@ -337,12 +337,26 @@ __global__ __launch_bounds__(256) void ln_chain_bwd_kernel(const T* __restrict__
 // [rows, 2D] gradient of the FF1 output.  Waves walk the rows grid-stride and keep their dg partials in
 // registers; one LDS fold + one row of per-work-group partial sums at the end.  `dres` (optional, [rows, D]) is
 // added to dx: the pre-norm residual blocks x + f(LN(x)) hand their skip-path gradient straight to this kernel.
-template <typename T, int MAXC, bool GEGLU, bool NT = false>
+// FFN (round 6; not with GEGLU): the dx this kernel writes is the gradient dOut of the residual block BELOW it, whose fused feed-forward
+// backward (gemm9.h) starts from four per-row constants {rstd, -mean rstd, s1 / F rstd, s2 / F rstd} with s1 = dOut . (W2 gamma) and
+// s2 = dOut . (x2 - x1) -- x2 being THIS kernel's own input row x (the block's output), x1 the block's input.  The row is in registers
+// here: one more row read (x1) and two more reductions replace ffn_rowstats_kernel's pass over dOut, x2 and x1 (0.76 ms per step of
+// configs[1]).  dOut enters the dot products as stored (rounded to T), chunk for chunk as that kernel summed it.
+struct LnFfnStats {
+    const void* x1;              // [rows, D] (ld1) the lower block's input
+    long ld1;
+    const float* wg;             // [D] W2 gamma of the lower block (ffn_wgamma_kernel)
+    const float* mean4;          // [rows] statistics of the lower block's inner LayerNorm
+    const float* rstd4;
+    float inv_f;                 // 1 / F
+    float* rowc;                 // [rows, 4] out
+};
+template <typename T, int MAXC, bool GEGLU, bool NT = false, bool FFN = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long ldx,
                                                      const T* __restrict__ g, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const T* __restrict__ dres,
                                                      T* __restrict__ dx, long lddx, float* __restrict__ dg_partial, int rows,
-                                                     int D) {
+                                                     int D, LnFfnStats fs = LnFfnStats{}) {
     constexpr int VEC = Elem<T>::VEC;
     XC_LDS_DYNAMIC(lds);
     float* red = reinterpret_cast<float*>(lds);            // [3][D]
@@ -356,10 +370,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int j = 0; j < VEC; ++j) { gv[i][j] = 0.f; dgacc[i][j] = 0.f; }
         if (c < nch) load_vec<T>(g + c * VEC, gv[i]);
     }
+    constexpr int FC = (FFN && !GEGLU) ? MAXC : 1;             // (register arrays of the statistics: one dummy chunk without them)
+    float wgv[FC][VEC];
+    if (FFN && !GEGLU) {
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            const int c = lane + 64 * i;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) wgv[i][j] = 0.f;
+            if (c < nch) {
+#pragma unroll
+                for (int j = 0; j < VEC; j += 4) {
+                    const u32x4 w = ld16(fs.wg + c * VEC + j);
+                    wgv[i][j] = u2f(w[0]); wgv[i][j + 1] = u2f(w[1]); wgv[i][j + 2] = u2f(w[2]); wgv[i][j + 3] = u2f(w[3]);
+                }
+            }
+        }
+    }
     for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
         const float mean = mean_in[row], rstd = rstd_in[row];
+        float rs4 = 0.f, m4 = 0.f;                                 // (FFN) requested with the row's own statistics: one round trip
+        if (FFN && !GEGLU) { rs4 = fs.rstd4[row]; m4 = fs.mean4[row]; }
         float xh[MAXC][VEC], dyv[MAXC][VEC];
         load_row<T, MAXC, GEGLU, NT>(x + row * ldx, D, lane, xh);
+        float xr[FC][VEC], x1v[FC][VEC];                           // (FFN) the raw row = the lower block's output, and its input
+        if (FFN && !GEGLU) {
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int c = lane + 64 * i;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { xr[i][j] = xh[i][j]; x1v[i][j] = 0.f; }
+                if (c < nch) load_vec<T, NT>(reinterpret_cast<const T*>(fs.x1) + row * fs.ld1 + c * VEC, x1v[i]);
+            }
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
@@ -378,6 +421,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
         const float c1 = wave_sum(s1) / (float)D;
         const float c2 = wave_sum(s2) / (float)D;
+        float a1 = 0.f, a2 = 0.f;                                  // (FFN) dOut . wg and dOut . (x2 - x1) of this row
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
@@ -406,7 +450,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                         for (int j = 0; j < VEC; ++j) da[j] += rv[j];
                     }
                     store_vec<T, NT>(dx + row * lddx + c * VEC, da);
+                    if (FFN) {
+                        const int fi = i < FC ? i : 0;
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            const float d = to_f32(from_f32<T>(da[j]));            // dOut as stored
+                            a1 += d * wgv[fi][j];
+                            a2 += d * (xr[fi][j] - x1v[fi][j]);
+                        }
+                    }
                 }
+            }
+        }
+        if (FFN && !GEGLU) {
+            a1 = wave_sum(a1);
+            a2 = wave_sum(a2);
+            if (lane == 0) {
+                const u32x4 v = {f2u(rs4), f2u(-m4 * rs4), f2u(a1 * fs.inv_f * rs4), f2u(a2 * fs.inv_f * rs4)};
+                st16(fs.rowc + row * 4, v);
             }
         }
     }

@@ -429,6 +429,39 @@ int xclip_layernorm_bwd(const void* dy, const void* x, int64_t ldx, const void* 
     return check_launch(__func__);
 }
 
+int xclip_layernorm_bwd_ffnstats(const void* dy, const void* x, int64_t ldx, const void* g, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes,
+                                 int64_t rows, int64_t dim, const void* x1_below, int64_t ld1, const float* wg, const float* mean4,
+                                 const float* rstd4, float inv_f, float* rowc, int dtype, void* stream) {
+    XC_REQUIRE(dtype == XCLIP_BF16, "bf16 only (the fused feed-forward backward the row constants feed)");
+    XC_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && ld1 % 8 == 0, "dims must be multiples of the 16-byte chunk");
+    XC_REQUIRE(ldx >= dim && lddx >= dim && ld1 >= dim, "leading dimension too small");
+    XC_REQUIRE(dy && x && g && mean && rstd && dx && dg_accum && x1_below && wg && mean4 && rstd4 && rowc, "null pointer");
+    XC_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(g) && aligned16(dx) && aligned16(dres) && aligned16(x1_below) && aligned16(wg) && aligned16(rowc),
+               "pointers must be 16-byte aligned");
+    XC_REQUIRE(workspace != nullptr && workspace_bytes >= xclip_layernorm_bwd_workspace_bytes(rows, dim) && aligned16(workspace),
+               "workspace of xclip_layernorm_bwd_workspace_bytes(rows, dim) bytes required");
+    if (rows == 0) return 0;
+    const int cpl = chunks_per_lane(dim, 8);
+    XC_REQUIRE(cpl == 1 || cpl == 2 || cpl == 4 || cpl == 8, "row too wide (bf16 rows up to 4096 elements)");
+    float* partial = (float*)workspace;
+    const int blocks = ln_bwd_blocks(rows);
+    const size_t lds = (size_t)3 * dim * sizeof(float);
+    constexpr bool NTP = (ROWS_NT & 8) != 0;
+    const LnFfnStats fs{x1_below, (long)ld1, wg, mean4, rstd4, inv_f, rowc};
+    hipStream_t st = (hipStream_t)stream;
+#define XC_LNF(C) do { XC_ALLOW_LDS((ln_bwd_kernel<bf16_t, C, false, NTP, true>), lds); \
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, C, false, NTP, true>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, (long)ldx, \
+                           (const bf16_t*)g, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (long)lddx, partial, (int)rows, (int)dim, fs); } while (0)
+    switch (cpl) { case 1: XC_LNF(1); break; case 2: XC_LNF(2); break; case 4: XC_LNF(4); break; default: XC_LNF(8); break; }
+#undef XC_LNF
+    int slices = blocks / 64;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((dim + 63) / 64), (unsigned)slices), dim3(256), 1024, st, (const float*)partial, (long)dim, dg_accum,
+                       blocks, (int)dim);
+    return check_launch(__func__);
+}
+
 int xclip_layernorm_chain_fwd(const void* p, const void* g1, const void* res, void* x1, float* mean1, float* rstd1, const void* g2,
                               void* h2, float* mean2, float* rstd2, int64_t rows, int64_t dim, float eps, int dtype, void* stream) {
     XC_REQUIRE(dtype_ok(dtype), "bad dtype");
@@ -1024,25 +1057,34 @@ int xclip_ffn_dgrad_geglu_ok(int64_t M, int64_t F, int64_t D, int dtype) {
 int64_t xclip_ffn_dgrad_geglu_workspace_bytes(int64_t M, int64_t F, int64_t D) {
     return ((D + 3) / 4 * 4 + 4 * M + 2 * (M / G2_BM) * F) * 4;
 }
-int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t ldw, const void* x, int64_t ldx, const void* gamma,
-                          const float* mean, const float* rstd, const void* x2, int64_t ld2, const void* x1, int64_t ld1, void* dx,
-                          int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes, int64_t M, int64_t F, int64_t D,
-                          int dtype, void* stream) {
-    XC_REQUIRE(xclip_ffn_dgrad_geglu_ok(M, F, D, dtype), "shape / dtype not taken by the fused kernel (xclip_ffn_dgrad_geglu_ok)");
-    XC_REQUIRE(dout && w2 && x && gamma && mean && rstd && x2 && x1 && dx && dg_accum, "null pointer");
-    XC_REQUIRE(aligned16(dout) && aligned16(w2) && aligned16(x) && aligned16(gamma) && aligned16(x2) && aligned16(x1) && aligned16(dx) && aligned16(workspace),
-               "pointers must be 16-byte aligned");
-    XC_REQUIRE(ldd % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && ld2 % 8 == 0 && ld1 % 8 == 0 && lddx % 8 == 0, "leading dimensions must be multiples of the 16-byte chunk");
-    XC_REQUIRE(ldd >= D && ld2 >= D && ld1 >= D && ldw >= F && ldx >= 2 * F && lddx >= 2 * F, "leading dimension too small");
-    XC_REQUIRE(ldd < (1L << 22) && ldw < (1L << 22) && ldx < (1L << 22) && lddx < (1L << 22), "leading dimensions beyond the 32-bit tile offsets");
-    XC_REQUIRE(workspace != nullptr && workspace_bytes >= xclip_ffn_dgrad_geglu_workspace_bytes(M, F, D), "workspace too small");
+// rowc_in != nullptr: the rows' constants are already there (written by xclip_layernorm_bwd_ffnstats in the pass that produced dout);
+// otherwise the weight vector and the row pass run here (x2 / x1 required)
+static int ffn_dgrad_geglu_run(const char* fn, const void* dout, int64_t ldd, const void* w2, int64_t ldw, const void* x, int64_t ldx, const void* gamma,
+                               const float* mean, const float* rstd, const void* x2, int64_t ld2, const void* x1, int64_t ld1, const float* rowc_in,
+                               void* dx, int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes, int64_t M, int64_t F, int64_t D,
+                               int dtype, void* stream) {
+#define XC_REQ(cond, msg) do { if (!(cond)) return xcapi::fail(fn, msg); } while (0)
+    XC_REQ(xclip_ffn_dgrad_geglu_ok(M, F, D, dtype), "shape / dtype not taken by the fused kernel (xclip_ffn_dgrad_geglu_ok)");
+    XC_REQ(dout && w2 && x && gamma && dx && dg_accum, "null pointer");
+    XC_REQ(rowc_in != nullptr || (mean && rstd && x2 && x1), "null pointer");
+    XC_REQ(aligned16(dout) && aligned16(w2) && aligned16(x) && aligned16(gamma) && aligned16(x2) && aligned16(x1) && aligned16(dx) && aligned16(workspace) && aligned16(rowc_in),
+           "pointers must be 16-byte aligned");
+    XC_REQ(ldd % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && ld2 % 8 == 0 && ld1 % 8 == 0 && lddx % 8 == 0, "leading dimensions must be multiples of the 16-byte chunk");
+    XC_REQ(ldd >= D && (rowc_in != nullptr || (ld2 >= D && ld1 >= D)) && ldw >= F && ldx >= 2 * F && lddx >= 2 * F, "leading dimension too small");
+    XC_REQ(ldd < (1L << 22) && ldw < (1L << 22) && ldx < (1L << 22) && lddx < (1L << 22), "leading dimensions beyond the 32-bit tile offsets");
+    XC_REQ(workspace != nullptr && workspace_bytes >= xclip_ffn_dgrad_geglu_workspace_bytes(M, F, D), "workspace too small");
+#undef XC_REQ
     hipStream_t st = (hipStream_t)stream;
     float* wg = (float*)workspace;
     float* rowc = wg + (D + 3) / 4 * 4;
     float* slab = rowc + 4 * M;
-    hipLaunchKernelGGL(ffn_wgamma_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, (const bf16_t*)w2, (long)ldw, (const bf16_t*)gamma, wg, (int)D, (int)F);
-    hipLaunchKernelGGL(ffn_rowstats_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout, (long)ldd, (const bf16_t*)x2, (long)ld2,
-                       (const bf16_t*)x1, (long)ld1, (const float*)wg, mean, rstd, rowc, (int)M, (int)D, 1.0f / (float)F);
+    if (rowc_in == nullptr) {
+        hipLaunchKernelGGL(ffn_wgamma_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, (const bf16_t*)w2, (long)ldw, (const bf16_t*)gamma, wg, (int)D, (int)F);
+        hipLaunchKernelGGL(ffn_rowstats_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout, (long)ldd, (const bf16_t*)x2, (long)ld2,
+                           (const bf16_t*)x1, (long)ld1, (const float*)wg, mean, rstd, rowc, (int)M, (int)D, 1.0f / (float)F);
+    } else {
+        rowc = const_cast<float*>(rowc_in);
+    }
     Gemm2Params q{};
     q.A = (const bf16_t*)dout; q.B = (const bf16_t*)w2; q.C = nullptr; q.lda = ldd; q.ldb = ldw; q.ldc = F;
     q.M = (int)M; q.N = (int)F; q.K = (int)D; q.alpha = 1.f;
@@ -1086,6 +1128,28 @@ int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t
     if (slices < 1) slices = 1;
     hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((F + 63) / 64), (unsigned)slices), dim3(256), 1024, st, (const float*)slab, (long)F, dg_accum,
                        nrows, (int)F);
+    return check_launch(fn);
+}
+int xclip_ffn_dgrad_geglu(const void* dout, int64_t ldd, const void* w2, int64_t ldw, const void* x, int64_t ldx, const void* gamma,
+                          const float* mean, const float* rstd, const void* x2, int64_t ld2, const void* x1, int64_t ld1, void* dx,
+                          int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes, int64_t M, int64_t F, int64_t D,
+                          int dtype, void* stream) {
+    XC_REQUIRE(mean && rstd && x2 && x1, "null pointer");
+    return ffn_dgrad_geglu_run(__func__, dout, ldd, w2, ldw, x, ldx, gamma, mean, rstd, x2, ld2, x1, ld1, nullptr, dx, lddx, dg_accum, workspace,
+                               workspace_bytes, M, F, D, dtype, stream);
+}
+int xclip_ffn_dgrad_geglu_rowc(const void* dout, int64_t ldd, const void* w2, int64_t ldw, const void* x, int64_t ldx, const void* gamma,
+                               const float* rowc, void* dx, int64_t lddx, float* dg_accum, void* workspace, int64_t workspace_bytes,
+                               int64_t M, int64_t F, int64_t D, int dtype, void* stream) {
+    XC_REQUIRE(rowc != nullptr, "null pointer");
+    return ffn_dgrad_geglu_run(__func__, dout, ldd, w2, ldw, x, ldx, gamma, nullptr, nullptr, nullptr, 0, nullptr, 0, rowc, dx, lddx, dg_accum, workspace,
+                               workspace_bytes, M, F, D, dtype, stream);
+}
+int xclip_ffn_wgamma(const void* w2, int64_t ldw, const void* gamma, float* wg, int64_t D, int64_t F, int dtype, void* stream) {
+    XC_REQUIRE(dtype == XCLIP_BF16, "bf16 only (the fused feed-forward backward)");
+    XC_REQUIRE(w2 && gamma && wg && aligned16(w2) && aligned16(gamma) && aligned16(wg), "null or misaligned pointer");
+    XC_REQUIRE(D > 0 && F > 0 && F % 8 == 0 && ldw % 8 == 0 && ldw >= F, "bad shape");
+    hipLaunchKernelGGL(ffn_wgamma_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w2, (long)ldw, (const bf16_t*)gamma, wg, (int)D, (int)F);
     return check_launch(__func__);
 }
 

@@ -192,9 +192,12 @@ def _layer_forward(x: Tensor, B: int, n: int, W: Sequence[Tensor], heads: int, m
 
 def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], heads: int, mask: Optional[Tensor],
                     gain_acc: Sequence[Tensor], need_w: Sequence[bool], sg: "_SideGemm", rotary: Optional[Tensor] = None,
-                    causal: bool = False, scale: float = 0.125, hs: int = 64, drop=(0.0, 0.0, 0), x2: Optional[Tensor] = None):
+                    causal: bool = False, scale: float = 0.125, hs: int = 64, drop=(0.0, 0.0, 0), x2: Optional[Tensor] = None,
+                    rowc: Optional[Tensor] = None, below=None):
     """dx2: gradient w.r.t. the layer output [M, D] -> (gradient w.r.t. the layer input, [dWqkv, dWout, dWff1, dWff2]).
-    x2 = the layer's output (the next layer's saved input): with it the feed-forward block's first two backward steps run as one kernel"""
+    x2 = the layer's output (the next layer's saved input): with it the feed-forward block's first two backward steps run as one kernel;
+    rowc = that kernel's per-row constants when the pass that produced dx2 already wrote them (ops.layernorm_bwd(ffn_stats=...));
+    below = the same request for the layer BELOW this one (ops.ffn_stats_request): this layer's last kernel writes its input gradient"""
     p_attn, p_ff, seed = drop
     g_attn, w_qkv, w_out, g_out, g_ff, w_ff1, g_inner, w_ff2 = W
     dg_attn, dg_out, dg_ff, dg_inner = gain_acc
@@ -204,9 +207,9 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     F2 = w_ff1.shape[0]
     Fh = F2 // 2
     # feed-forward block
-    if x2 is not None and p_ff == 0.0 and ops.ffn_dgrad_geglu_ok(M, Fh, D, dx2.dtype):
+    if (x2 is not None or rowc is not None) and p_ff == 0.0 and ops.ffn_dgrad_geglu_ok(M, Fh, D, dx2.dtype):
         # net.4's input gradient and net.2's (GEGLU-LayerNorm) backward in one kernel: d a never reaches memory (csrc/kernels/gemm9.h)
-        du, _ = ops.ffn_dgrad_geglu(dx2, w_ff2, u, g_inner, m4, r4, x2, x1, dg=dg_inner)
+        du, _ = ops.ffn_dgrad_geglu(dx2, w_ff2, u, g_inner, m4, r4, x2, x1, dg=dg_inner, rowc=rowc)
         d_ff2 = sg.wgrad(dx2, a, D, Fh, M, w_ff2) if need_w[3] else None
     else:
         da = ops.gemm(dx2, w_ff2, M, Fh, D, b_kmajor=True)
@@ -231,7 +234,7 @@ def _layer_backward(dx2: Tensor, saved, B: int, n: int, W: Sequence[Tensor], hea
     dh = ops.gemm(dqkv.view(M, 3 * inner), w_qkv, M, D, 3 * inner, b_kmajor=True)
     d_qkv = sg.wgrad(dqkv.view(M, 3 * inner), h, 3 * inner, D, M, w_qkv) if need_w[0] else None
     del dqkv
-    dx, _ = ops.layernorm_bwd(dh, x, g_attn, m1, r1, dres=dx1, dg=dg_attn)
+    dx, _ = ops.layernorm_bwd(dh, x, g_attn, m1, r1, dres=dx1, dg=dg_attn, ffn_stats=below)
     return dx, [d_qkv, d_out, d_ff1, d_ff2]
 
 
@@ -383,7 +386,23 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
     gg = _GainGrads(gains)
     grads: List[Optional[Tensor]] = [None] * len(params)
     sg = _SideGemm(dy.device)
-    dx, _ = ops.layernorm_bwd(dy, x_last, params[-1], m_out, r_out, dg=gg.views[-1])
+    def stats_for(l: int):
+        """the row constants of layer l's fused feed-forward backward can be written by the kernel that produces its output gradient -- the
+        LayerNorm backward of the layer above it, or of norm_out -- whose input row is layer l's output (round 6: one pass over dOut, x2, x1
+        per layer less).  Not with recompute (layer l's tape does not exist yet at that point), dropout, a pooled layer (l itself, or the one
+        above it: its kernel's dx is completed on the pooled rows afterwards) or shapes the fused kernel does not take"""
+        if l < 0 or l >= spec.depth or spec.checkpoint or spec.ff_dropout != 0.0 or layers[l] is None:
+            return None
+        if pool_row is not None and l >= spec.depth - 2:
+            return None
+        sv = layers[l]
+        if len(sv) < 18:
+            return None
+        Wl = params[1 + LAYER_PARAMS * l: 1 + LAYER_PARAMS * (l + 1)]
+        return ops.ffn_stats_request(Wl[7], Wl[6], sv[10], sv[16], sv[17])
+
+    st = stats_for(spec.depth - 1) if pool_row is None else None
+    dx, _ = ops.layernorm_bwd(dy, x_last, params[-1], m_out, r_out, dg=gg.views[-1], ffn_stats=st)
     x_out = x_last if pool_row is None else None             # the output of the layer being walked (= the saved input of the one above it)
     for l in reversed(range(spec.depth)):
         base = 1 + LAYER_PARAMS * l
@@ -400,9 +419,12 @@ def stack_backward(dy: Tensor, tape, B: int, n: int, spec: StackSpec, params: Se
         if pooled:
             dx, dws = _layer_backward_pooled(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal,
                                              spec.dim_head ** -0.5, spec.head_slot, pool_row)
+            st = None
         else:
+            below = stats_for(l - 1)
             dx, dws = _layer_backward(dx, saved, B, n, W, spec.heads, mask, gg.views[1 + 4 * l: 5 + 4 * l], need_w, sg, spec.rotary, spec.causal, spec.dim_head ** -0.5, spec.head_slot,
-                                      (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l), x2=x_out)
+                                      (spec.attn_dropout, spec.ff_dropout, seed0 + 2 * l), x2=x_out, rowc=None if st is None else st[5], below=below)
+            st = below
         x_out = saved[0]
         layers[l] = None                         # release this layer's activations
         sg.layer_done()

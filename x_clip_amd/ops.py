@@ -111,8 +111,11 @@ def layernorm_fwd(x: Tensor, g: Tensor, res: Optional[Tensor] = None, geglu: boo
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, geglu: bool = False,
-                  dres: Optional[Tensor] = None, dg: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-    """-> dx (shape of x; + dres when given), dg (fp32 [D]; accumulated into `dg` when passed)"""
+                  dres: Optional[Tensor] = None, dg: Optional[Tensor] = None, ffn_stats=None) -> Tuple[Tensor, Tensor]:
+    """-> dx (shape of x; + dres when given), dg (fp32 [D]; accumulated into `dg` when passed).
+    ffn_stats = (x1_below, wg, mean4, rstd4, inv_f, rowc) (FfnStats below; bf16, not with geglu): the kernel also writes the four per-row
+    constants of the feed-forward block BELOW this LayerNorm -- whose output is `x` and whose output gradient is the dx written here --
+    into rowc [rows, 4] for ffn_dgrad_geglu(rowc=...) (xclip_layernorm_bwd_ffnstats)"""
     _dev_check(dy, x, g, dres)
     dy, x = _c(dy), _c(x)
     width = x.shape[-1]
@@ -128,11 +131,22 @@ def layernorm_bwd(dy: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, 
     ws = workspace(x.device, L.xclip_layernorm_bwd_workspace_bytes(rows, dim))
     probe = _probe(x)
     ev0 = probe.begin(x) if probe is not None else None
-    _lib.check(L.xclip_layernorm_bwd(dy.data_ptr(), x.data_ptr(), width, _c(g).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                     _ptr(dres), dx.data_ptr(), width, dg.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
-                                     rows, dim, int(geglu), dtype_code(x), _stream(x)), "xclip_layernorm_bwd")
-    if probe is not None:      # reads dy, x (+ dres), writes dx
-        probe.end(x, ev0, "layernorm", 0.0, rows * (dim + 2 * width + (dim if dres is not None else 0)) * x.element_size(), "ln_geglu_bwd" if geglu else "ln_bwd")
+    if ffn_stats is not None:
+        x1b, wg, mean4, rstd4, inv_f, rowc = ffn_stats
+        assert not geglu and x.dtype == torch.bfloat16 and tuple(x1b.shape) == (rows, dim) and x1b.stride(-1) == 1 and x1b.dtype == x.dtype
+        assert wg.dtype == torch.float32 and wg.numel() >= dim and tuple(rowc.shape) == (rows, 4) and rowc.dtype == torch.float32 and rowc.is_contiguous()
+        _dev_check(x1b, wg, mean4, rstd4, rowc)
+        _lib.check(L.xclip_layernorm_bwd_ffnstats(dy.data_ptr(), x.data_ptr(), width, _c(g).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                  _ptr(dres), dx.data_ptr(), width, dg.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
+                                                  rows, dim, x1b.data_ptr(), x1b.stride(0), wg.data_ptr(), mean4.data_ptr(), rstd4.data_ptr(),
+                                                  float(inv_f), rowc.data_ptr(), dtype_code(x), _stream(x)), "xclip_layernorm_bwd_ffnstats")
+    else:
+        _lib.check(L.xclip_layernorm_bwd(dy.data_ptr(), x.data_ptr(), width, _c(g).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         _ptr(dres), dx.data_ptr(), width, dg.data_ptr(), _ptr(ws), 0 if ws is None else ws.numel(),
+                                         rows, dim, int(geglu), dtype_code(x), _stream(x)), "xclip_layernorm_bwd")
+    if probe is not None:      # reads dy, x (+ dres, + the lower block's input), writes dx
+        probe.end(x, ev0, "layernorm", 0.0, rows * (dim + 2 * width + (dim if dres is not None else 0) + (dim if ffn_stats is not None else 0)) * x.element_size(),
+                  "ln_geglu_bwd" if geglu else "ln_bwd")
     return dx, dg
 
 
@@ -150,15 +164,51 @@ def ffn_dgrad_geglu_ok(M: int, F: int, D: int, dtype) -> bool:
     return FUSE_FFN_DGRAD and dtype == torch.bfloat16 and bool(_lib.lib().xclip_ffn_dgrad_geglu_ok(M, F, D, 1))
 
 
-def ffn_dgrad_geglu(dout: Tensor, w2: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, x2: Tensor, x1: Tensor,
-                    dg: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+FUSE_FFN_ROWSTATS = True   # round 6: the fused feed-forward backward's row pass inside the LayerNorm backward that writes its dout (functional.stack_backward)
+
+
+def ffn_stats_request(w2: Tensor, g: Tensor, x1: Tensor, mean4: Tensor, rstd4: Tensor):
+    """what layernorm_bwd(ffn_stats=...) needs to produce the row constants of the feed-forward block (w2 [D, F] = net.4's weight, g = net.2's
+    gain, x1 [M, D] = the block's input, mean4 / rstd4 = net.2's saved statistics) -> (x1, wg, mean4, rstd4, 1 / F, rowc [M, 4] fp32 to be
+    filled), or None when the fused backward does not take the shape"""
+    M, D = x1.shape
+    F = w2.shape[1]
+    if not (FUSE_FFN_ROWSTATS and ffn_dgrad_geglu_ok(M, F, D, x1.dtype) and x1.stride(-1) == 1 and D <= 4096):
+        return None
+    _dev_check(w2, g, x1, mean4, rstd4)
+    wg = torch.empty((D + 3) // 4 * 4, dtype=torch.float32, device=x1.device)
+    _lib.check(_lib.lib().xclip_ffn_wgamma(w2.data_ptr(), w2.stride(0), _c(g).data_ptr(), wg.data_ptr(), D, F, dtype_code(x1), _stream(x1)),
+               "xclip_ffn_wgamma")
+    return (x1, wg, mean4, rstd4, 1.0 / F, torch.empty(M, 4, dtype=torch.float32, device=x1.device))
+
+
+def ffn_dgrad_geglu(dout: Tensor, w2: Tensor, x: Tensor, g: Tensor, mean: Tensor, rstd: Tensor, x2: Optional[Tensor], x1: Optional[Tensor],
+                    dg: Optional[Tensor] = None, rowc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """d(u | t) of the feed-forward block from the gradient `dout` [M, D] of its output: the product dout w2 ([D, F] = net.4's weight) and
     the GEGLU-LayerNorm backward in ONE kernel (gemm9.h).  x [M, 2F] = net.0's output, g / mean / rstd = net.2's gain and saved statistics,
     x1 / x2 [M, D] = the block's input / output (x2 = x1 + net.4(...): the second row statistic is dout . (x2 - x1)).
+    rowc [M, 4] fp32 (optional): the rows' constants as layernorm_bwd(ffn_stats=...) wrote them while producing `dout` -- x2 / x1 are then not read.
     -> (dx [M, 2F], dg fp32 [F], accumulated into `dg` when passed)"""
-    _dev_check(dout, w2, x, g, x2, x1)
     M, D = dout.shape
     F = w2.shape[1]
+    if rowc is not None:
+        _dev_check(dout, w2, x, g, rowc)
+        assert tuple(w2.shape) == (D, F) and tuple(x.shape) == (M, 2 * F) and tuple(rowc.shape) == (M, 4) and rowc.dtype == torch.float32 and rowc.is_contiguous()
+        assert all(t.stride(-1) == 1 for t in (dout, w2, x))
+        dx = torch.empty_like(x)
+        if dg is None:
+            dg = torch.zeros(F, dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        ws = workspace(x.device, L.xclip_ffn_dgrad_geglu_workspace_bytes(M, F, D))
+        probe = _probe(x)
+        ev0 = probe.begin(x, "fused_ffn_bwd") if probe is not None else None
+        _lib.check(L.xclip_ffn_dgrad_geglu_rowc(dout.data_ptr(), dout.stride(0), w2.data_ptr(), w2.stride(0), x.data_ptr(), x.stride(0), _c(g).data_ptr(),
+                                                rowc.data_ptr(), dx.data_ptr(), dx.stride(0), dg.data_ptr(), ws.data_ptr(), ws.numel(), M, F, D,
+                                                dtype_code(x), _stream(x)), "xclip_ffn_dgrad_geglu_rowc")
+        if probe is not None:      # the product's flops; reads dout, w2, x, writes dx
+            probe.end(x, ev0, "fused_ffn_bwd", 2.0 * M * F * D, (M * D + D * F + 4 * M * F) * 2, (M, F, D, "NN+geglu_ln_bwd", False))
+        return dx, dg
+    _dev_check(dout, w2, x, g, x2, x1)
     assert tuple(w2.shape) == (D, F) and tuple(x.shape) == (M, 2 * F) and tuple(x2.shape) == (M, D) and tuple(x1.shape) == (M, D)
     assert all(t.stride(-1) == 1 for t in (dout, w2, x, x2, x1)) and mean.dtype == torch.float32 and rstd.dtype == torch.float32
     dx = torch.empty_like(x)
