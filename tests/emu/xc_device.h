@@ -399,6 +399,7 @@ inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
 inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * lane_id(), gsrc, 16);
 }
+inline void glds16_raw(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
 inline void glds4(const void* gsrc, void* lds_wave_base) { memcpy((unsigned char*)lds_wave_base + 4 * lane_id(), gsrc, 4); }
 // buffer resources (csrc/hw/xc_device.h): base + byte count; out-of-range accesses read zero / are dropped
 struct BufRsrc { const unsigned char* base; uint32_t bytes; };

@@ -430,6 +430,39 @@ def test_attention_streaming_backward_measurement_build():
     assert out.returncode == 0 and "attn6 ok" in out.stdout, out.stderr[-3000:]
 
 
+def test_attention_persistent_single_pass_measurement_build():
+    """attention7.h (round 6, MEASUREMENT build, XCLIP_ATTN_BWD=7: attention5.h as a persistent kernel, the next head's images requested under
+    this head's stores -- measured slower) and attention5.h's round-5 forms (XCLIP_ATTN5_VAR=3: quarter-line stores,
+    images before the delta rows): against the fp64 reference, and the same bits as the product form (delta rows first, whole-line stores
+    through the wave's spent exchange tile) -- n = 256 / 257, masks, more heads than emulated CUs"""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from x_clip_amd import _lib, ops\n"
+        "from emu.build_emu import build\n"
+        "_lib._use_library_for_tests(build(measure=True))\n"
+        "import kernel_cases as K\n"
+        "dev = torch.device('cpu')\n"
+        "K.case_attention(dev, torch.bfloat16, 2, 256, 1, True)\n"
+        "K.case_attention_single_tail(dev, torch.bfloat16)\n"
+        "torch.manual_seed(0)\n"
+        "qkv = torch.randn(3, 257, 3 * 64).bfloat16(); do = torch.randn(3, 257, 64).bfloat16(); mask = torch.rand(3, 257) > 0.2\n"
+        "out, lse = ops.attention_fwd(qkv, mask, 1, 0.125)\n"
+        "torch.save(ops.attention_bwd(qkv, mask, out, do, lse, 1, 0.125), sys.argv[1])\n"
+        "print('attn ok')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    with tempfile.TemporaryDirectory() as tmp:
+        got = {}
+        for name, env in [("product", dict(XCLIP_ATTN_BWD="5")), ("round5", dict(XCLIP_ATTN_BWD="5", XCLIP_ATTN5_VAR="3")), ("persistent", dict(XCLIP_ATTN_BWD="7"))]:
+            path = os.path.join(tmp, name + ".pt")
+            out = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1800)
+            assert out.returncode == 0 and "attn ok" in out.stdout, (name, out.stderr[-3000:])
+            got[name] = torch.load(path)
+        assert torch.equal(got["product"], got["round5"]) and torch.equal(got["product"], got["persistent"])
+
+
 def test_gemm_split_k_whole_slices_per_xcd():
     """weight-gradient (TN) split-K launches run on a 1-D grid whose work-groups place themselves: the (slice, tile) pairs slice-major, one
     contiguous eighth per XCD (gemm2.h g2_where: the work-groups that read the same K range share an L2).  16 slices x 2 tiles, 8 x 8, 16 x 4

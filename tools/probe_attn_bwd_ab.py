@@ -1,5 +1,6 @@
 """round 6: the attention backward's generations side by side on one box, measurement build (XCLIP_ATTN_BWD is read once per process: this
-script re-runs itself per generation): 6 = attention6.h (streaming persistent), 5 = attention5.h (single pass, head resident), 3 =
+script re-runs itself per generation; XCLIP_AB_GENS=5,7,5 picks the order): 7 = attention7.h (attention5.h persistent, the next head's images
+requested by asm-issued DMA under this head's stores), 6 = attention6.h (streaming persistent), 5 = attention5.h (single pass, head resident), 3 =
 attention3.h (two phases).  Text-layer shape of configs[1] (b = 1024, n = 257, 8 heads, masked) and n = 256; results must agree with each
 other to bf16 rounding (checked against generation 5 through a file)."""
 import os
@@ -45,7 +46,7 @@ def child(gen):
         elif os.path.exists(path):
             r = torch.load(path).to(dev).float()
             err = float((d.float() - r).abs().max()) / float(r.abs().max())
-            agree = f"   max |d - d(gen 5)| / scale = {err:.2e}, finite = {bool(torch.isfinite(d.float()).all())}"
+            agree = f"   max |d - d(gen 5)| / scale = {err:.2e}, equal = {bool(torch.equal(d.float(), r))}, finite = {bool(torch.isfinite(d.float()).all())}"
         else:
             agree = ""
         tb = timeit(lambda: ops.attention_bwd(qkv, mask, out, do, lse, h, 0.125))
@@ -59,6 +60,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child(sys.argv[1])
     else:
-        for gen in ("5", "6", "3", "6", "5"):
+        for gen in os.environ.get("XCLIP_AB_GENS", "5,7,6,3,7,5").split(","):
             env = dict(os.environ, XCLIP_ATTN_BWD=gen)
             subprocess.run([sys.executable, os.path.abspath(__file__), gen], env=env, check=False)

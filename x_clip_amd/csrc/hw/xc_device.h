@@ -139,6 +139,12 @@ XC_DEV void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// glds16 as an asm unit the compiler's wait-count pass does not see (see buf_glds16_raw below): for prefetches that must stay in flight
+// across later LDS reads.  Every wait for the piece is the caller's.
+XC_DEV void glds16_raw(const void* gsrc, void* lds_wave_base) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(m) : "memory");
+}
 // glds4: 4 bytes per lane (global_load_lds_dword) -- used as an L2 PREFETCH: one lane per 128-byte line, landing in a
 // scratch LDS area nobody reads; costs no VGPR and is tracked by vmcnt like any other DMA piece
 XC_DEV void glds4(const void* gsrc, void* lds_wave_base) {

@@ -93,6 +93,55 @@ XC_DEV void a5_weighted_row_sum(const unsigned char* X, int t, float* sc, float 
     if ((lane & 31) == 0) a3_put_col(out, acc, lane);
 }
 
+// a wave's 32 x 64 accumulator block to global rows as WHOLE 128-byte lines: a3_store_rows_direct's store instruction carries 32 rows x 32
+// bytes -- a quarter of 32 different lines, 4 requests per line at the L2 -- this one 8 rows x 128 bytes.  The rows go through `tile` (2 KiB of
+// LDS private to the wave: 16 rows x 128 bytes, chunk j of row r at chunk position j ^ (r & 7)) in two halves.
+XC_DEV void a5_store_rows_lines(const f32x16 (&acc)[2], bf16_t* dst, long ldd, int row0, int nrows, int lane, unsigned char* tile, float mul = 1.f) {
+    const int c31 = lane & 31, h = lane >> 5, r16 = c31 & 15;
+    u32x4 ch[2][2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pk[q][0] = f2bf_pk(acc[db][4 * q] * mul, acc[db][4 * q + 1] * mul);
+            pk[q][1] = f2bf_pk(acc[db][4 * q + 2] * mul, acc[db][4 * q + 3] * mul);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; qq += 2) {
+            permlane32_swap(pk[qq][0], pk[qq + 1][0]);
+            permlane32_swap(pk[qq][1], pk[qq + 1][1]);
+            ch[db][qq >> 1] = u32x4{pk[qq][0], pk[qq][1], pk[qq + 1][0], pk[qq + 1][1]};       // chunk 4 db + qq + h of row c31
+        }
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        wave_sync();
+        if ((c31 >> 4) == hf) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int j = 4 * db + 2 * q2 + h;
+                    *reinterpret_cast<u32x4*>(tile + r16 * 128 + ((j ^ (r16 & 7)) << 4)) = ch[db][q2];
+                }
+        }
+        wave_sync();
+#pragma unroll
+        for (int jr = 0; jr < 2; ++jr) {
+            const int r = (lane >> 3) + 8 * jr, j = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tile + r * 128 + ((j ^ (r & 7)) << 4));
+            const int row = row0 + 16 * hf + r;
+            if (row < nrows) st16(dst + (long)row * ldd + j * 8, v);
+        }
+    }
+}
+
+// (One work-group of 146 KiB per CU: a head's phases -- images and rows in, pairs, gradients out -- are serial on its CU.  Measured on the
+//  persistent twin attention7.h by leaving phases out (profiles/r06_o_attn7_abl.log, n = 256, b = 1024: 900 us = loads 250 + delta pass 115 +
+//  pairs 285 + stores 194, additive; 170 us of stores here).  Starting the CUs of the first dispatch round in 2 / 4 / 8 groups a fraction of a
+//  head apart -- so that one group's memory phases meet another's pairs -- changes nothing, 817 ... 835 us at every offset
+//  (profiles/r06_p_attn5_stagger.log): the phases are not queueing behind each other at the memory system, each is its own latency chain.)
 __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
     XC_LDS_DYNAMIC(lds);
     const int n = p.n, nb = n >> 5, tail = n & 31, npad = (n + 31) & ~31, nsub = npad >> 5;
@@ -128,28 +177,57 @@ __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
     bf16_t* dK = dQ + (long)p.heads * ATT_DH;
     bf16_t* dV = dK + (long)p.heads * ATT_DH;
     const float* const lse_h = p.lse + ((long)bi * p.heads + hh) * n;
-    a3_dma_image(Qs, Qb, ldq, n, npad, wave, nwaves, lane);
-    a3_dma_image(dOs, dOb, ldo, n, npad, wave, nwaves, lane);
-    a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
-    a3_key_validity(Ms, p.mask, (long)bi * n, n, npad);
-    // delta_i = sum_d dO[i, d] O[i, d] and lse_i log2(e) (as attention3.h)
-    for (int blk = wave; blk < nsub; blk += nwaves) {
-        const int row_ = blk * 32 + c31;
-        const int rl = row_ < n ? row_ : n - 1;
-        const float lse_r = lse_h[rl];
+    // Round 6, two changes of order that leave the result bit-identical (profiles/r06_q_attn5_var.log, r06_r_attn5_var_lines.log; b = 1024, 8
+    // heads, one box: n = 257 1004 -> 965 us, n = 256 827 -> 803):
+    //   * the delta pass's rows (O, dO of the wave's own block) are requested BEFORE the three images: loads return in order, so the row dots
+    //     run while the images land instead of behind them;
+    //   * dQ / dK / dV leave as whole 128-byte lines (a5_store_rows_lines).
+    // The measurement build keeps the round-5 forms selectable for the A/B: p.chunks = 1 quarter-line stores, 2 images first, 4 no stores
+    // (timing only).  (Also measured: the non-temporal hint on the quarter-line stores, 1005 -> 1143 ... 1200 us -- partial lines written
+    // through to HBM.)
+#ifdef XCLIP_MEASURE
+    const int var = uniform(p.chunks);
+#else
+    constexpr int var = 0;
+#endif
+    auto delta_of = [&](int row_, const u32x4 (&a)[4], const u32x4 (&b)[4], float lse_r) {      // delta_i = sum_d dO[i, d] O[i, d]; lse_i log2(e)
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float a[8], b[8];
-            load_vec<bf16_t>(Ob + (long)rl * ldo + h * 32 + c * 8, a);
-            load_vec<bf16_t>(dOb + (long)rl * ldo + h * 32 + c * 8, b);
+            float fa[8], fb[8];
+            unpack(a[c], fa, (bf16_t*)nullptr);
+            unpack(b[c], fb, (bf16_t*)nullptr);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc += a[k] * b[k];
+            for (int k = 0; k < 8; ++k) acc += fa[k] * fb[k];
         }
         acc += shfl_xor(acc, 32);
         if (h == 0) {
             Ds[row_] = row_ < n ? acc : 0.f;
             Ls[row_] = row_ < n ? lse_r * 1.4426950408889634f : 0.f;
+        }
+    };
+    auto delta_rows = [&](int row_, u32x4 (&a)[4], u32x4 (&b)[4]) {
+        const int rl = row_ < n ? row_ : n - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a[c] = ld16(Ob + (long)rl * ldo + h * 32 + c * 8);
+            b[c] = ld16(dOb + (long)rl * ldo + h * 32 + c * 8);
+        }
+        return lse_h[rl];
+    };
+    {
+        u32x4 a[4], b[4];
+        float lse_r = 0.f;
+        if (!(var & 2)) lse_r = delta_rows(row, a, b);
+        a3_dma_image(Qs, Qb, ldq, n, npad, wave, nwaves, lane);
+        a3_dma_image(dOs, dOb, ldo, n, npad, wave, nwaves, lane);
+        a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
+        a3_key_validity(Ms, p.mask, (long)bi * n, n, npad);
+        if (var & 2) lse_r = delta_rows(row, a, b);
+        delta_of(row, a, b, lse_r);
+        for (int blk = wave + nwaves; blk < nsub; blk += nwaves) {             // (n = 32 nb + 1: the tail row's block, wave 0)
+            const float lse_t = delta_rows(blk * 32 + c31, a, b);
+            delta_of(blk * 32 + c31, a, b, lse_t);
         }
     }
     // the wave's own key block: K, V rows straight from global memory (L2 hits: the image DMA asks for the same lines)
@@ -260,9 +338,23 @@ __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
         if (s + 1 < nb) produce(s + 1);
         consume(s);
     }
-    a3_store_rows_direct(dq, dQ, ldq, wave * 32, n, lane, p.scale);
-    a3_store_rows_direct(dk, dK, ldq, wave * 32, n, lane, p.scale);
-    a3_store_rows_direct(dv, dV, ldq, wave * 32, n, lane);
+    if (var & 4) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { reg_keep(dq[db]); reg_keep(dk[db]); reg_keep(dv[db]); }
+    } else if (var & 1) {
+        a3_store_rows_direct(dq, dQ, ldq, wave * 32, n, lane, p.scale);
+        a3_store_rows_direct(dk, dK, ldq, wave * 32, n, lane, p.scale);
+        a3_store_rows_direct(dv, dV, ldq, wave * 32, n, lane);
+    } else {
+        // through the wave's own exchange tile of the parity no one reads any more: the tiles of step nb - 2 were consumed before the loop's last
+        // barrier, and only this wave ever writes this one
+        // (an opaque lane id: the store addresses are computed here, not ahead of the pair loop and carried through it in spilled registers)
+        unsigned char* const mine = Xs + ((nb & 1) * nb + wave) * A5_TILE;
+        const int lane_s = (int)opaque((uint32_t)lane);
+        a5_store_rows_lines(dq, dQ, ldq, wave * 32, n, lane_s, mine, p.scale);
+        a5_store_rows_lines(dk, dK, ldq, wave * 32, n, lane_s, mine, p.scale);
+        a5_store_rows_lines(dv, dV, ldq, wave * 32, n, lane_s, mine);
+    }
     if (tail && wave == 0) {                                   // the tail row's own gradients; lane = feature d (the partials are in: the loop's barriers)
         const int trow = 32 * nb;
         const float qv = bf2f(Qb[(long)trow * ldq + lane]), kv = bf2f(Kb[(long)trow * ldq + lane]), vv = bf2f(Vb[(long)trow * ldq + lane]);

@@ -11,6 +11,7 @@
 #include "kernels/attention4.h"
 #include "kernels/attention5.h"
 #include "kernels/attention6.h"
+#include "kernels/attention7.h"
 #include "kernels/attention_pool.h"
 
 using namespace xc;
@@ -206,8 +207,24 @@ int xclip_attention_bwd(const void* qkv, const uint8_t* mask, const void* out, c
             hipLaunchKernelGGL(attn6_bwd_kernel, dim3((unsigned)g6), dim3(512), A6_LDS_BYTES, st, p);
             return check_launch(__func__);
         }
+        if (bwd_gen == 7 && a5_takes((int)n, causal) && (n >> 5) >= min5 && attn5_bwd_lds_bytes((int)n) <= 160 * 1024) {
+            // attention7.h (round 6, measurement build): attention5.h persistent, the next head's images requested (asm-issued DMA) under this
+            // head's stores -- bit-identical, and SLOWER: 1018 against 942 us at n = 257, 846 against 808 at n = 256 (profiles/r06_n_attn7_ab.log);
+            // requesting the images at the top of the head instead changes nothing (r06_o_attn7_abl.log, mask 2)
+            XC_ALLOW_LDS(attn7_bwd_kernel, 160 * 1024);
+            const int64_t heads_total = batch * heads;
+            const int cus = xc_num_cus();
+            int64_t g7 = heads_total < cus ? heads_total : cus;
+            if (g7 >= 8) g7 &= ~(int64_t)7;
+            static const int abl7 = measure_env("XCLIP_ATTN7_ABL", 0);    // measurement build only: attention7.h's ablation mask
+            p.chunks = abl7;
+            hipLaunchKernelGGL(attn7_bwd_kernel, dim3((unsigned)g7), dim3((unsigned)((n >> 5) * 64)), attn5_bwd_lds_bytes((int)n), st, p);
+            return check_launch(__func__);
+        }
         if (bwd_gen >= 5 && a5_takes((int)n, causal) && (n >> 5) >= min5 && attn5_bwd_lds_bytes((int)n) <= 160 * 1024) {
             XC_ALLOW_LDS(attn5_bwd_kernel, 160 * 1024);
+            static const int var5 = measure_env("XCLIP_ATTN5_VAR", 0);     // measurement build only: attention5.h's variant mask
+            p.chunks = var5;
             const int64_t g5 = batch * heads;
             hipLaunchKernelGGL(attn5_bwd_kernel, dim3((unsigned)g5), dim3((unsigned)((n >> 5) * 64)), attn5_bwd_lds_bytes((int)n), st, p);
             return check_launch(__func__);
