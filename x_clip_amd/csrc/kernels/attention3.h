@@ -214,24 +214,38 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
     const bf16_t* Vb = Kb + (long)p.heads * ATT_DH;
     bf16_t* out = reinterpret_cast<bf16_t*>(p.out) + (long)bi * n * p.heads * ATT_DH + hh * ATT_DH;
     float* lse_out = p.lse + ((long)bi * p.heads + hh) * n;
-    a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
-    a3_dma_image(Vs, Vb, ldq, n, npad, wave, nwaves, lane);
-    a3_key_validity(Ms, p.mask, (long)bi * n, n, npad);
     const bool coop = a3_coop_tail(n);
     const int tail0 = (n >> 5) << 5, ntail = n & 31;
     const int q0 = wave * 32;
     const int qrow = q0 + c31;
     const int qld = qrow < n ? qrow : n - 1;
+    // (round 6: the first query rows a wave uses -- the tail rows, or its own block where there is no tail -- are requested BEFORE the images:
+    //  loads return in order, so they are there when the images are, instead of one more round trip behind the barrier.  Holding BOTH sets
+    //  across the tail phase spills under this kernel's 128 registers.)
     u32x4 qf[4];
+    const int qfirst = coop ? (tail0 + c31 < n ? tail0 + c31 : n - 1) : qld;
+#ifdef XCLIP_MEASURE
+    const bool q_late = (p.chunks & 8) != 0;                   // (measurement build, XCLIP_ATTN_ABL=8: the round-5 order, for the A/B)
+#else
+    constexpr bool q_late = false;
+#endif
+    if (!q_late) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) qf[kb] = ld16(Qb + (long)qfirst * ldq + kb * 16 + h * 8);
+    }
+    a3_dma_image(Ks, Kb, ldq, n, npad, wave, nwaves, lane);
+    a3_dma_image(Vs, Vb, ldq, n, npad, wave, nwaves, lane);
+    a3_key_validity(Ms, p.mask, (long)bi * n, n, npad);
     f32x16 o[2];
     wait_vmem();
     sync();
+    if (q_late) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) qf[kb] = ld16(Qb + (long)qfirst * ldq + kb * 16 + h * 8);
+    }
     const int nsub = npad >> 5;
     const float scale2 = p.scale * 1.4426950408889634f;
     if (coop) {                                                // tail queries x this wave's share of the key sub-tiles
-        const int trow = tail0 + c31 < n ? tail0 + c31 : n - 1;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) qf[kb] = ld16(Qb + (long)trow * ldq + kb * 16 + h * 8);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -256,8 +270,10 @@ __global__ __launch_bounds__(576) XC_FOUR_WAVES_PER_SIMD void attn3_fwd_kernel(A
                 for (int r = 0; r < 16; ++r) rec[2 + db * 32 + mfma_row(r, lane)] = o[db][r];
         }
     }
+    if (coop) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) qf[kb] = ld16(Qb + (long)qld * ldq + kb * 16 + h * 8);
+        for (int kb = 0; kb < 4; ++kb) qf[kb] = ld16(Qb + (long)qld * ldq + kb * 16 + h * 8);
+    }
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
