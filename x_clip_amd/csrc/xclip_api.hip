@@ -336,6 +336,8 @@ inline bool use_gemm2(int64_t M, int64_t N, int64_t K, int dtype) {
 int gemm2_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + G2_BM - 1) / G2_BM) * ((N + G2_BN - 1) / G2_BN);
     int64_t s = xc_policy_cus() / tiles;                      // one 8-wave work-group per CU: enough K slices to fill the part that runs it
+    static const int force = measure_env("XCLIP_GEMM_SPLITS", 0);     // (measurement build: a fixed slice count, for the sweep)
+    if (force > 0) s = force;
     const int64_t maxs = K / (4 * G2_BK);
     if (s > maxs) s = maxs;
     if (s > 64) s = 64;
