@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 enum { XCLIP_F32 = 0, XCLIP_BF16 = 1 };
-#define XCLIP_ABI_VERSION 22
+#define XCLIP_ABI_VERSION 23
 
 int xclip_abi_version(void);
 const char* xclip_last_error(void);
@@ -113,6 +113,15 @@ int xclip_rows_scatter_add(const void* src, int64_t lds, const int32_t* idx, flo
 int xclip_scatter_add_sorted(const void* src, int64_t lds, const int64_t* sorted_ids, const int64_t* perm, float* table_accum,
                              int64_t table_rows, int64_t count, int64_t dim, int64_t n_in, int64_t n_out, int64_t row_off, int dtype,
                              void* stream);
+
+/* The sort in front of xclip_scatter_add_sorted: sorted_ids = ids ascending, perm[e] = the index entry e had in `ids`; STABLE (equal ids keep
+ * their order: the segment sums of the scatter then add their rows in one fixed order).  Replaces the torch.sort(tokens.flatten()) the
+ * nn.Embedding backward of x_clip.py:320 amounts to.  ids in [0, id_limit), id_limit <= 2^32, count < 2^32 (an id outside that range keeps a
+ * deterministic place decided by its low bits; the scatter drops it).  Least-significant-digit radix passes of 8 bits over (id, position)
+ * pairs: ceil(log2(id_limit) / 8) passes of three launches.  workspace: xclip_sort_ids_workspace_bytes(count) bytes, 16-byte aligned. */
+int64_t xclip_sort_ids_workspace_bytes(int64_t count);
+int xclip_sort_ids(const int64_t* ids, int64_t count, int64_t id_limit, int64_t* sorted_ids, int64_t* perm, void* workspace,
+                   int64_t workspace_bytes, void* stream);
 
 /* dst[i] = (dtype) (src[i] * scale) : fp32 gradient accumulators -> parameter dtype */
 int xclip_cast_from_f32(const float* src, void* dst, int64_t count, float scale, int dtype, void* stream);

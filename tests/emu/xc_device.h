@@ -322,6 +322,12 @@ inline uint32_t wave_ballot32(bool pred) {                 // bit l = the predic
     for (int m = 32; m >= 1; m >>= 1) v |= shfl_xor(v, m);
     return (uint32_t)v;
 }
+inline uint64_t wave_ballot64(bool pred) {
+    int lo = (pred && lane_id() < 32) ? (int)(1u << lane_id()) : 0, hi = (pred && lane_id() >= 32) ? (int)(1u << (lane_id() - 32)) : 0;
+    for (int m = 32; m >= 1; m >>= 1) { lo |= shfl_xor(lo, m); hi |= shfl_xor(hi, m); }
+    return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+}
+inline int popc64(uint64_t v) { return __builtin_popcountll(v); }
 inline bool wave_any(bool pred) {
     int v = pred ? 1 : 0;
     for (int m = 32; m >= 1; m >>= 1) v |= shfl_xor(v, m);

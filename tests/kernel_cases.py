@@ -636,10 +636,32 @@ def case_scatter_sorted(dev, dtype):
     ops.scatter_add_sorted(dout.to(dev).view(b * (n + 1), D), st.values.to(dev), st.indices.to(dev), table, n_in=n, n_out=n + 1, row_off=1)
     want = torch.zeros(vocab, D, dtype=torch.float64).index_add_(0, tok.reshape(-1), ref64(dout)[:, 1:].reshape(-1, D))
     close(table, want, torch.float32, "sorted scatter", mult=8.0)
-    dE, dP, dcls = ops.text_embed_bwd(dout.to(dev), tok.to(dev), vocab, True, True, sorted_tokens=(st.values.to(dev), st.indices.to(dev)))
+    dE, dP, dcls = ops.text_embed_bwd(dout.to(dev), tok.to(dev), vocab, True, True, sorted_tokens=ops.sort_ids(tok.reshape(-1).to(dev), vocab))
     close(dE, want, torch.float32, "dE sorted", mult=8.0)
     close(dP, ref64(dout)[:, 1:].sum(0), torch.float32, "dP", mult=8.0)
     close(dcls, ref64(dout)[:, 0].sum(0), torch.float32, "dcls", mult=8.0)
+
+
+def case_sort_ids(dev, sizes=((1, 2), (63, 5), (64, 256), (1000, 7), (1024, 49408), (1025, 300), (4099, 49408), (5000, 262144), (9000, 1 << 20))):
+    """sort.h against torch.sort(stable=True): one / two / three radix passes (id_limit up to 2^8 / 2^16 / 2^24), counts around the 1024-pair
+    work-group and the 64-lane slice, long runs of one id (a padded batch), ids that differ only in a high digit; the result is the STABLE
+    order -- and running it twice gives the same bits, which is what the segment sums behind it need"""
+    for (n, limit) in sizes:
+        g = torch.Generator().manual_seed(n * 31 + limit)
+        ids = torch.randint(0, limit, (n,), generator=g)
+        if n > 200:
+            ids[n // 3: n // 3 + 150] = limit - 1                # a run crossing slices, rounds and (n > 1024) work-groups
+            ids[::17] = 0
+            if limit > 300:
+                ids[5::19] = 256 * ((limit - 1) // 256)          # equal low digit, different high digit
+        want = torch.sort(ids, stable=True)
+        got, perm = ops.sort_ids(ids.to(dev), limit)
+        assert torch.equal(got.cpu(), want.values), (n, limit, "ids")
+        assert torch.equal(perm.cpu(), want.indices), (n, limit, "perm")
+        again = ops.sort_ids(ids.to(dev), limit)
+        assert torch.equal(again[0], got) and torch.equal(again[1], perm)
+    e = ops.sort_ids(torch.empty(0, dtype=torch.int64, device=dev), 10)
+    assert e[0].numel() == 0 and e[1].numel() == 0
 
 
 def case_gelu_accuracy(dev, dtype):

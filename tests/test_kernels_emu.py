@@ -242,6 +242,12 @@ def test_gemm2_epilogue_and_splitk():
     K.case_gemm(DEV, torch.bfloat16, 128, 136, 1024, "tn")           # split-K slabs + reduce
 
 
+def test_sort_ids_stable_radix():
+    """sort.h (round 6): the stable radix sort of (id, position) pairs in front of the segmented embedding-gradient sums, against
+    torch.sort(stable=True) -- replaces the torch.sort of the reference-shaped backward (nn.Embedding backward, x_clip.py:320)"""
+    K.case_sort_ids(DEV)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=["fp32", "bf16"])
 def test_scatter_sorted_and_gelu(dtype):
     K.case_scatter_sorted(DEV, dtype)

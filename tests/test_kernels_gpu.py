@@ -322,6 +322,13 @@ def test_gemm2_epilogue_and_splitk():
     K.case_gemm(DEV, torch.bfloat16, 4096, 512, 64 * 129, "nn")
 
 
+def test_sort_ids_stable_radix():
+    """sort.h (round 6): the stable radix sort of (id, position) pairs in front of the segmented embedding-gradient sums, against
+    torch.sort(stable=True) -- replaces the torch.sort of the reference-shaped backward (nn.Embedding backward, x_clip.py:320)"""
+    K.case_sort_ids(DEV)
+    K.case_sort_ids(DEV, sizes=((263168, 49408), (32768, 64), (1 << 20, 1 << 18)))                 # the step's two sorts at full size, and a million ids
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES, ids=IDS)
 def test_scatter_sorted_and_gelu(dtype):
     K.case_scatter_sorted(DEV, dtype)

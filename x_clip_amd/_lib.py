@@ -42,6 +42,8 @@ _SIGNATURES = {
     "xclip_rows_scatter_add_workspace_bytes": (c_int64, [L, L]),
     "xclip_rows_scatter_add": (c_int, [P, L, P, P, P, L, L, P, L, I, P]),
     "xclip_scatter_add_sorted": (c_int, [P, L, P, P, P, L, L, L, L, L, L, I, P]),
+    "xclip_sort_ids_workspace_bytes": (L, [L]),
+    "xclip_sort_ids": (c_int, [P, L, L, P, P, P, L, P]),
     "xclip_cast_from_f32": (c_int, [P, P, L, F, I, P]),
     "xclip_gemm_workspace_bytes": (c_int64, [L, L, L, I]),
     "xclip_gemm_small_limit": (c_int64, [L]),
@@ -89,7 +91,7 @@ _SIGNATURES = {
     "xclip_simloss_grad": (c_int, [P, P, L, L, L, F, P, L, I, F, F, F, P, I, P, P, P, L, P, I, P]),
 }
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 def _bind(path: str):

@@ -83,6 +83,9 @@ XC_DEV bool wave_all(bool pred) { return __all(pred) != 0; }
 XC_DEV bool wave_any(bool pred) { return __any(pred) != 0; }
 // bit l = the predicate of lane l, lanes 0..31 (wave-uniform result)
 XC_DEV uint32_t wave_ballot32(bool pred) { return (uint32_t)__ballot(pred); }
+// bit l = the predicate of lane l, all 64 lanes
+XC_DEV uint64_t wave_ballot64(bool pred) { return (uint64_t)__ballot(pred); }
+XC_DEV int popc64(uint64_t v) { return __popcll(v); }
 
 XC_DEV float wave_sum(float v) {
 #pragma unroll

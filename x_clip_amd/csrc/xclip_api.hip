@@ -20,6 +20,7 @@
 #include "kernels/rows.h"
 #include "kernels/simloss.h"
 #include "kernels/simloss5.h"
+#include "kernels/sort.h"
 #include "kernels/tokens.h"
 
 using namespace xc;
@@ -722,6 +723,44 @@ int xclip_scatter_add_sorted(const void* src, int64_t lds, const int64_t* sorted
 #define F(T, C) hipLaunchKernelGGL((scatter_add_sorted_kernel<T, C>), grid, block, staged ? stage_bytes : 0, (hipStream_t)stream, (const T*)src, (long)lds, (const long long*)sorted_ids, (const long long*)perm, table_accum, (long)count, (int)dim, (int)n_in, (int)n_out, (int)row_off, (int)chunk, (long long)table_rows, staged)
     XC_DISPATCH_ROW(dtype, cpl, F);
 #undef F
+    return check_launch(__func__);
+}
+
+int64_t xclip_sort_ids_workspace_bytes(int64_t count) {
+    if (count <= 0) return 0;
+    const int64_t nblk = (count + SORT_BLOCK - 1) / SORT_BLOCK;
+    return 2 * ((count * 8 + 15) & ~(int64_t)15) + 2 * nblk * SORT_BINS * 4;
+}
+
+int xclip_sort_ids(const int64_t* ids, int64_t count, int64_t id_limit, int64_t* sorted_ids, int64_t* perm, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+    XC_REQUIRE(count >= 0 && count < ((int64_t)1 << 32) && id_limit >= 1 && id_limit <= ((int64_t)1 << 32), "count / id_limit out of range");
+    if (count == 0) return 0;
+    XC_REQUIRE(ids != nullptr && sorted_ids != nullptr && perm != nullptr, "bad pointers");
+    XC_REQUIRE(workspace != nullptr && aligned16(workspace) && workspace_bytes >= xclip_sort_ids_workspace_bytes(count), "workspace too small or misaligned");
+    const int64_t nblk = (count + SORT_BLOCK - 1) / SORT_BLOCK, half = (count * 8 + 15) & ~(int64_t)15;
+    uint64_t* bufs[2] = {reinterpret_cast<uint64_t*>(workspace), reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(workspace) + half)};
+    int* const hist = reinterpret_cast<int*>(static_cast<unsigned char*>(workspace) + 2 * half);
+    int* const offs = hist + nblk * SORT_BINS;
+    int bits = 0;
+    while (((int64_t)1 << bits) < id_limit) ++bits;
+    const int passes = bits <= 8 ? 1 : (bits + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)nblk), block(256);
+    const size_t lds = SORT_BINS * sizeof(int);
+    const long long* src_ids = reinterpret_cast<const long long*>(ids);
+    for (int ps = 0; ps < passes; ++ps) {
+        const bool first = ps == 0, last = ps == passes - 1;
+        const uint64_t* in = first ? nullptr : bufs[(ps - 1) & 1];
+        uint64_t* out = last ? nullptr : bufs[ps & 1];
+        const int shift = 8 * ps;
+        if (first) hipLaunchKernelGGL((sort_hist_kernel<true>), grid, block, lds, st, src_ids, in, (long)count, shift, hist);
+        else hipLaunchKernelGGL((sort_hist_kernel<false>), grid, block, lds, st, src_ids, in, (long)count, shift, hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 5 * lds, st, (const int*)hist, offs, (int)nblk);
+#define S(F, L) hipLaunchKernelGGL((sort_scatter_kernel<F, L>), grid, block, lds, st, src_ids, in, out, (long long*)sorted_ids, (long long*)perm, (long)count, shift, (const int*)offs)
+        if (first && last) S(true, true); else if (first) S(true, false); else if (last) S(false, true); else S(false, false);
+#undef S
+    }
     return check_launch(__func__);
 }
 

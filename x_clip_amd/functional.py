@@ -523,9 +523,8 @@ class _TextEncodeFn(torch.autograd.Function):
         dx0, sgrads = stack_backward(dy, _take_tape(ctx), B, npos, ctx.spec, ctx.saved_tensors, ctx.kmask, need[6:])
         dE = dP = dcls = None
         if need[3] or need[4] or need[5]:
-            st = torch.sort(ctx.tokens.reshape(-1))                      # index plumbing: ids ascending + their positions
-            aE, aP, acls = ops.text_embed_bwd(dx0.view(B, npos, D), ctx.tokens, vocab, has_pos, has_cls,
-                                              sorted_tokens=(st.values, st.indices) if need[3] else None)
+            st = ops.sort_ids(ctx.tokens.reshape(-1), vocab) if need[3] else None    # ids ascending + their positions (sort.h)
+            aE, aP, acls = ops.text_embed_bwd(dx0.view(B, npos, D), ctx.tokens, vocab, has_pos, has_cls, sorted_tokens=st)
             dE = ops.cast_from_f32(aE, dtype) if need[3] else None
             dP = ops.cast_from_f32(aP, dtype) if (need[4] and has_pos) else None
             if dP is not None and dP.shape[0] != ctx.pos_rows:           # text shorter than max_seq_len: the unused positions get zero
@@ -610,8 +609,7 @@ class _VisionEncodeFn(torch.autograd.Function):
             if need[5]:
                 ops.rows_scatter_add(dtok, None, None, acc_b)           # bias gradient = column sum
             if need[6]:
-                st = torch.sort(rowidx.to(torch.int64))                 # index plumbing
-                ops.scatter_add_sorted(dtok, st.values, st.indices, acc_p)
+                ops.scatter_add_sorted(dtok, *ops.sort_ids(rowidx.to(torch.int64).reshape(-1), npatch), acc_p)
             db = ops.cast_from_f32(acc_b, dtype) if need[5] else None
             dpos = ops.cast_from_f32(acc_p, dtype) if need[6] else None
         return (None, None, None, None, None, dw_tok, db, dpos, dw_cls, *sgrads)

@@ -355,6 +355,25 @@ def text_embed_bwd(dout: Tensor, tokens: Tensor, vocab: int, has_pos: bool, has_
     return dE, dP, dcls
 
 
+def sort_ids(ids: Tensor, id_limit: int) -> Tuple[Tensor, Tensor]:
+    """(ids ascending, perm) of a flat int64 id vector with values in [0, id_limit): perm[e] = where entry e stood; stable.  What
+    `scatter_add_sorted` wants in front of it (the nn.Embedding backward of x_clip.py:320 as a segmented sum); sort.h's radix passes"""
+    _dev_check(ids)
+    assert ids.dtype == torch.int64 and ids.dim() == 1
+    ids = _c(ids)
+    n = ids.numel()
+    out, perm = torch.empty_like(ids), torch.empty_like(ids)
+    if n == 0:
+        return out, perm
+    L = _lib.lib()
+    ws = workspace(ids.device, L.xclip_sort_ids_workspace_bytes(n) + 16)
+    base = ws.data_ptr()
+    off = (-base) % 16
+    _lib.check(L.xclip_sort_ids(ids.data_ptr(), n, int(id_limit), out.data_ptr(), perm.data_ptr(), base + off, ws.numel() - off, _stream(ids)),
+               "xclip_sort_ids")
+    return out, perm
+
+
 def scatter_add_sorted(src: Tensor, sorted_ids: Tensor, perm: Tensor, table: Tensor, n_in: int = 1, n_out: int = 1, row_off: int = 0):
     """table[sorted_ids[e]] += src[(perm[e] // n_in) * n_out + perm[e] % n_in + row_off]; sorted_ids ascending"""
     _dev_check(src, sorted_ids, perm, table)
