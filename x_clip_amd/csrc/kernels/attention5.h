@@ -184,7 +184,9 @@ __global__ __launch_bounds__(512) void attn5_bwd_kernel(AttnParams p) {
     //   * dQ / dK / dV leave as whole 128-byte lines (a5_store_rows_lines).
     // The measurement build keeps the round-5 forms selectable for the A/B: p.chunks = 1 quarter-line stores, 2 images first, 4 no stores
     // (timing only).  (Also measured: the non-temporal hint on the quarter-line stores, 1005 -> 1143 ... 1200 us -- partial lines written
-    // through to HBM.)
+    // through to HBM; the tail key's rows -- this wave's Q / dO rows in operand layout, V's tail row -- requested with the delta rows instead
+    // of behind the barrier: 961 - 965 against 948 - 958 us, twelve more loads per lane in front of the images cost more than the round trip
+    // they hide, profiles/r06_w_attn5_tail_rows_prefetch_not_kept.log.)
 #ifdef XCLIP_MEASURE
     const int var = uniform(p.chunks);
 #else
