@@ -44,7 +44,10 @@ NO_SPILL = ["gemm8_kernel<false, 0>", "gemm8_kernel<false, 1>", "gemm8_kernel<tr
             # round 5: the fused feed-forward backward (its epilogue has no register to spare: compiler-visible stores with recomputed addresses),
             # the single-pass attention backward, the latency-built small-output GEMM
             "gemm9_geglu_bwd_kernel<0>", "attn5_bwd_kernel", "gemm_small_kernel<false, false, false>", "gemm_small_kernel<false, true, false>",
-            "gemm_small_kernel<true, true, false>", "gemm_small_kernel<false, false, true>"]
+            "gemm_small_kernel<true, true, false>", "gemm_small_kernel<false, false, true>",
+            # round 6: the radix sort in front of the embedding gradient
+            "sort_hist_kernel<true>", "sort_hist_kernel<false>", "sort_scan_kernel", "sort_scatter_kernel<true, false>", "sort_scatter_kernel<false, true>",
+            "sort_scatter_kernel<true, true>", "sort_scatter_kernel<false, false>"]
 
 
 @pytest.fixture(scope="module")
