@@ -601,6 +601,15 @@ int xclip_patchify(const void* image, const int32_t* keep, void* out, int64_t ld
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     dim3 grid((unsigned)blocks), block(256);
+    // three bf16 channels, patch edge and image width multiples of 8, no padding behind a row: whole 16-byte pieces in and out
+    static const int rgb8 = measure_env("XCLIP_PATCHIFY_RGB8", 1);     // (measurement build: 0 = the element-wise kernel, for the A/B)
+    if (rgb8 && dtype == XCLIP_BF16 && channels == 3 && patch % 8 == 0 && width % 8 == 0 && ldo == patch * patch * 3 && aligned16(image)) {
+        int64_t b8 = (batch * nkeep * patch * (patch / 8) + 255) / 256;
+        if (b8 > 16384) b8 = 16384;
+        hipLaunchKernelGGL(patchify_rgb8_kernel, dim3((unsigned)b8), block, 0, (hipStream_t)stream, (const bf16_t*)image, (const int*)keep,
+                           (bf16_t*)out, (long)ldo, (int)batch, (int)height, (int)width, (int)patch, (int)nkeep);
+        return check_launch(__func__);
+    }
     if (dtype == XCLIP_BF16)
         hipLaunchKernelGGL((patchify_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)image, (const int*)keep,
                            (bf16_t*)out, (long)ldo, (int)batch, (int)channels, (int)height, (int)width, (int)patch, (int)nkeep);
